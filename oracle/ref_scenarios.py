@@ -1,0 +1,192 @@
+"""
+ORACLE / TEST INFRASTRUCTURE ONLY -- never imported by the product path.
+
+Deterministic re-statement of the reference's example driver loops (main_min_example.py:77-107,
+main_std_example.py:98-135) on top of oracle/ref_env.py: fake clock advancing a fixed dt per tick, ideal-tracking ego
+simulator ``vdc_dummy(iter_time=dt)`` (vdc_dummy.py:5-9), opponents from the reference's own ``ObjectlistDummy``
+(objectlist_dummy.py:73-189). While the loop runs, recorders wrapped around the two drop-in seams capture every call's
+inputs and outputs:
+
+  seam (1)  graph_ltpl.online_graph.src.main_online_path_gen.main_online_path_gen   (caller OTH.py:416-427)
+  seam (2)  graph_ltpl.online_graph.src.VpForwardBackward.VpForwardBackward methods (callers OTH.py:676-972)
+
+The records are what oracle/gen_golden.py writes to tests/golden/*.npz.
+"""
+
+import copy
+import numpy as np
+
+from . import ref_env
+
+ZONE_EXAMPLE = {'sample_zone': [[64, 64, 64, 64, 64, 64, 64, 65, 65, 65, 65, 65, 65, 65, 66, 66, 66, 66, 66, 66, 66],
+                                [0, 1, 2, 3, 4, 5, 6, 0, 1, 2, 3, 4, 5, 6, 0, 1, 2, 3, 4, 5, 6],
+                                np.array([[-20.54, 227.56], [23.80, 186.64]]),
+                                np.array([[-23.80, 224.06], [20.17, 183.60]])]}   # main_std_example.py:90-93
+
+
+class SeamRecorder(object):
+    """Wraps both seams of the reference in place and stores deep copies of every call."""
+
+    def __init__(self, graph_ltpl, graph_base):
+        self.gl = graph_ltpl
+        self.gb = graph_base
+        self.path_calls = []
+        self.vel_calls = []
+        self.zone_nodes = ([], [])
+        self._orig = {}
+        self._install()
+
+    # ---- seam (1) -------------------------------------------------------------------------------------------------
+    def _install(self):
+        gl = self.gl
+        mod = gl.online_graph.src.main_online_path_gen
+        orig_path = mod.main_online_path_gen
+        self._orig['path'] = (mod, 'main_online_path_gen', orig_path)
+
+        # the zone node list reaches GraphBase only when it changes (gen_local_node_template.py:43,96)
+        gb = self.gb
+        orig_rm = gb.remove_nodes_filter
+        self._orig['rm'] = (gb, 'remove_nodes_filter', orig_rm)
+
+        def rm_wrap(layer_ids, node_ids, applied_filter="default", base=None):
+            if applied_filter == "overtaking_zones":
+                self.zone_nodes = ([int(x) for x in layer_ids], [int(x) for x in node_ids])
+            return orig_rm(layer_ids=layer_ids, node_ids=node_ids, applied_filter=applied_filter, base=base)
+        gb.remove_nodes_filter = rm_wrap
+
+        def path_wrap(graph_base, start_node, obj_veh, obj_zone, action_sets=True, last_action_id=None,
+                      max_solutions=1, const_path_seg=None, pos_est=None, last_solution_nodes=None, w_last_edges=()):
+            rec = {
+                'start_node': [int(start_node[0]), int(start_node[1])],
+                'obj_pos': np.array([v.get_pos() for v in obj_veh], dtype=float).reshape(-1, 2),
+                'obj_radius': np.array([v.get_radius() for v in obj_veh], dtype=float),
+                'obj_vel': np.array([v.get_vel() for v in obj_veh], dtype=float),
+                'obj_pred': [np.array(v.get_prediction(), dtype=float).reshape(-1, 2) for v in obj_veh],
+                'action_sets': bool(action_sets),
+                'last_action_id': last_action_id,
+                'const_path_seg': None if const_path_seg is None else np.array(const_path_seg, dtype=float),
+                'pos_est': None if pos_est is None else np.array(pos_est, dtype=float).reshape(-1),
+                'last_solution_nodes': copy.deepcopy(last_solution_nodes),
+                'w_last_edges': list(w_last_edges),
+            }
+            out = orig_path(graph_base=graph_base, start_node=start_node, obj_veh=obj_veh, obj_zone=obj_zone,
+                            action_sets=action_sets, last_action_id=last_action_id, max_solutions=max_solutions,
+                            const_path_seg=const_path_seg, pos_est=pos_est, last_solution_nodes=last_solution_nodes,
+                            w_last_edges=w_last_edges)
+            rec['zone_layers'], rec['zone_nodes'] = copy.deepcopy(self.zone_nodes)
+            nodes, node_idx, coeff, path_param, red_len, closest = out
+            rec['out'] = {
+                'keys': list(nodes.keys()),
+                'nodes': {k: [[int(a), int(b)] for a, b in nodes[k][0]] for k in nodes},
+                'node_idx': {k: [int(i) for i in node_idx[k][0]] for k in nodes},
+                'coeff': {k: np.array(coeff[k][0], dtype=float) for k in nodes},
+                'path_param': {k: np.array(path_param[k][0], dtype=float) for k in nodes},
+                'red_len': {k: bool(red_len[k][0]) for k in nodes},
+                'closest_obj_index': None if closest is None else int(closest),
+            }
+            self.path_calls.append(rec)
+            return out
+        mod.main_online_path_gen = path_wrap
+
+        # ---- seam (2) ---------------------------------------------------------------------------------------------
+        vp_mod = gl.online_graph.src.VpForwardBackward
+        cls = vp_mod.VpForwardBackward
+        rec_list = self.vel_calls
+        P = '_VpForwardBackward__'
+
+        def state_of(obj):
+            return {'vel_max': float(getattr(obj, P + 'vel_max')),
+                    'gg_scale': float(getattr(obj, P + 'gg_scale')),
+                    'old_gg_scale': float(getattr(obj, P + 'old_gg_scale')),
+                    'ax_max_machines': np.array(getattr(obj, P + 'ax_max_machines'), dtype=float)}
+
+        def wrap_method(name):
+            orig = getattr(cls, name)
+            self._orig['vp_' + name] = (cls, name, orig)
+
+            def wrapped(obj, **kwargs):
+                rec = {'method': name, 'state': state_of(obj),
+                       'args': {k: (np.array(v, dtype=float) if isinstance(v, (np.ndarray, list, tuple))
+                                    else float(v)) for k, v in kwargs.items()}}
+                out = orig(obj, **kwargs)
+                if isinstance(out, tuple):
+                    rec['out'] = [np.array(o, dtype=float) if isinstance(o, (np.ndarray, list)) else o for o in out]
+                else:
+                    rec['out'] = np.array(out, dtype=float)
+                rec_list.append(rec)
+                return out
+            setattr(cls, name, wrapped)
+
+        for name in ('check_brake_prefix', 'calc_vel_profile', 'calc_vel_profile_follow', 'calc_vel_brake_em'):
+            wrap_method(name)
+
+    def uninstall(self):
+        for owner, name, orig in self._orig.values():
+            setattr(owner, name, orig)
+        self._orig = {}
+
+
+def make_planner(cache_dir, clock=None, track="monteblanco"):
+    """Graph_LTPL instance (reference facade) initialised like the example scripts, visualisation / logging off."""
+    graph_ltpl, clock = ref_env.load_reference(clock)
+    path_dict = ref_env.default_path_dict(cache_dir, track)
+    ltpl_obj = graph_ltpl.Graph_LTPL.Graph_LTPL(path_dict=path_dict, visual_mode=False, log_to_file=False)
+    ltpl_obj.graph_init()
+    graph_base = ltpl_obj._Graph_LTPL__graph_base
+    return graph_ltpl, clock, ltpl_obj, graph_base, path_dict
+
+
+def set_start(graph_ltpl, ltpl_obj, path_dict):
+    refline = graph_ltpl.imp_global_traj.src.import_globtraj_csv.\
+        import_globtraj_csv(import_path=path_dict['globtraj_input_path'])[0]
+    pos_est = refline[0, :]
+    heading_est = np.arctan2(np.diff(refline[0:2, 1]), np.diff(refline[0:2, 0])) - np.pi / 2
+    ltpl_obj.set_startpos(pos_est=pos_est, heading_est=heading_est)
+    return pos_est, 0.0
+
+
+def opponents_c2(graph_ltpl, n_opp=8):
+    """C2 opponent set: race-line followers s0_k = 250 + 280 k, vel_scale_k = 0.30 + 0.05 (k mod 4)."""
+    Dummy = graph_ltpl.testing_tools.src.objectlist_dummy.ObjectlistDummy
+    return [Dummy(dynamic=True, vel_scale=0.30 + 0.05 * (k % 4), s0=250.0 + 280.0 * k) for k in range(n_opp)]
+
+
+def get_objects(dummies):
+    obj_list = []
+    for k, d in enumerate(dummies):
+        for o in d.get_objectlist():
+            o = dict(o)
+            o['id'] = k + 1
+            obj_list.append(o)
+    return obj_list
+
+
+def run_loop(graph_ltpl, clock, ltpl_obj, path_dict, n_ticks, dt=0.05, dummies=None, zones=None,
+             action_pref=("right", "left", "straight", "follow"), on_tick=None):
+    """The example drivers' online loop with a fixed time step. Returns per-tick exported trajectory sets."""
+    pos_est, vel_est = set_start(graph_ltpl, ltpl_obj, path_dict)
+    traj_set = {'straight': None}
+    exported = []
+    for tick in range(n_ticks):
+        clock.advance(dt)
+        sel_action = None
+        for sel_action in action_pref:
+            if sel_action in traj_set.keys():
+                break
+        obj_list = get_objects(dummies) if dummies is not None else []
+        ltpl_obj.calc_paths(prev_action_id=sel_action, object_list=obj_list, blocked_zones=zones)
+        if traj_set[sel_action] is not None:
+            pos_est, vel_est = graph_ltpl.testing_tools.src.vdc_dummy.vdc_dummy(
+                pos_est=pos_est,
+                last_s_course=(traj_set[sel_action][0][:, 0]),
+                last_path=(traj_set[sel_action][0][:, 1:3]),
+                last_vel_course=(traj_set[sel_action][0][:, 5]),
+                iter_time=dt)
+        traj_set, traj_id, _ = ltpl_obj.calc_vel_profile(pos_est=pos_est, vel_est=vel_est)
+        exported.append({'sel_action': sel_action, 'pos_est': np.array(pos_est, dtype=float),
+                         'vel_est': float(vel_est),
+                         'traj': {k: np.array(v[0], dtype=float) for k, v in traj_set.items()},
+                         'traj_id': dict(traj_id)})
+        if on_tick is not None:
+            on_tick(tick, exported[-1])
+    return exported
