@@ -1,0 +1,457 @@
+"""
+ctypes binding of the C ABI declared in include/ltpl_hip.h (libltpl_hip.so, hand-written HIP for gfx950).
+
+There is deliberately NO CPU fallback: if the shared library is missing or no HIP device is visible, constructing
+``HipBackend`` raises. The struct layouts below mirror include/ltpl_hip.h field by field.
+"""
+
+import ctypes as C
+import os
+import numpy as np
+
+from .lattice import Lattice
+
+MAX_ACTIONS = 3
+MAX_LAST_NODES = 8
+ACT_STRAIGHT, ACT_FOLLOW, ACT_LEFT, ACT_RIGHT, ACT_NONE = 0, 1, 2, 3, -1
+ACTION_NAMES = {ACT_STRAIGHT: "straight", ACT_FOLLOW: "follow", ACT_LEFT: "left", ACT_RIGHT: "right"}
+ACTION_IDS = {v: k for k, v in ACTION_NAMES.items()}
+FLAG_ACTION_SETS, FLAG_OBJ_IN_CONST, FLAG_OBJ_BESIDES, FLAG_HAS_PSI_S = 1, 2, 4, 8
+VEL_FB, VEL_BRAKE, VEL_FOLLOW = 0, 1, 2
+
+_STATUS = {0: "OK", 1: "invalid argument", 2: "no HIP device", 3: "HIP runtime error", 4: "capacity exceeded",
+           5: "unsupported configuration"}
+
+_pi32 = C.POINTER(C.c_int32)
+_pf64 = C.POINTER(C.c_double)
+
+
+class LatticeDesc(C.Structure):
+    _fields_ = [("num_layers", C.c_int32), ("num_nodes", C.c_int32), ("num_edges", C.c_int32),
+                ("num_samples", C.c_int32), ("num_glob_rl", C.c_int32), ("closed", C.c_int32),
+                ("plan_horizon_mode", C.c_int32), ("reserved0", C.c_int32),
+                ("min_plan_horizon", C.c_double), ("lat_resolution", C.c_double), ("lat_offset", C.c_double),
+                ("veh_width", C.c_double), ("veh_length", C.c_double), ("sampled_resolution", C.c_double),
+                ("vel_decrease_lat", C.c_double),
+                ("layer_node_off", _pi32), ("raceline_index", _pi32), ("s_raceline", _pf64), ("refline_x", _pf64),
+                ("refline_y", _pf64), ("vel_raceline", _pf64),
+                ("node_x", _pf64), ("node_y", _pf64), ("vgoal_cost", _pf64),
+                ("in_ptr", _pi32), ("edge_src", _pi32), ("edge_cost", _pf64), ("edge_len", _pf64),
+                ("samp_ptr", _pi32),
+                ("samp_x", _pf64), ("samp_y", _pf64), ("samp_psi", _pf64), ("samp_len", _pf64),
+                ("glob_rl", _pf64)]
+
+
+class Caps(C.Structure):
+    _fields_ = [("max_path_nodes", C.c_int32), ("max_path_pts", C.c_int32), ("max_horizon_edges", C.c_int32),
+                ("device", C.c_int32), ("num_cus", C.c_int32), ("lds_bytes_paths", C.c_int32)]
+
+
+class PathsIn(C.Structure):
+    _fields_ = [("n_scen", C.c_int32), ("n_w_last", C.c_int32), ("w_last_edges", _pf64),
+                ("start_layer", _pi32), ("start_node", _pi32), ("flags", _pi32), ("last_action", _pi32),
+                ("const_closest", _pi32), ("psi_s", _pf64),
+                ("veh_off", _pi32), ("pos_off", _pi32), ("veh_radius", _pf64), ("pos_x", _pf64), ("pos_y", _pf64),
+                ("zone_off", _pi32), ("zone_gid", _pi32),
+                ("n_last", _pi32), ("last_layer", _pi32), ("last_node", _pi32)]
+
+
+class PathsOut(C.Structure):
+    _fields_ = [("cap_nodes", C.c_int32), ("cap_pts", C.c_int32),
+                ("end_layer", _pi32), ("closest_obj_index", _pi32), ("closest_obj_node", _pi32),
+                ("n_actions", _pi32),
+                ("action_id", _pi32), ("valid", _pi32), ("reduced", _pi32), ("goal_layer", _pi32),
+                ("n_nodes", _pi32), ("n_pts", _pi32), ("n_ties", _pi32), ("nodes", _pi32), ("node_idx", _pi32),
+                ("coeff", _pf64), ("path_param", _pf64)]
+
+
+class VelParams(C.Structure):
+    _fields_ = [("dyn_model_exp", C.c_double), ("drag_coeff", C.c_double), ("m_veh", C.c_double),
+                ("len_veh", C.c_double), ("v_max", C.c_double),
+                ("n_ax_max_machines", C.c_int32), ("follow_control_type", C.c_int32),
+                ("ax_max_machines", _pf64),
+                ("c_p", C.c_double), ("k_p", C.c_double), ("k_d", C.c_double), ("tan_w", C.c_double)]
+
+
+class VelJob(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("n", C.c_int32), ("n_el", C.c_int32), ("has_v_end", C.c_int32),
+                ("kappa", _pf64), ("el_lengths", _pf64), ("loc_gg", _pf64),
+                ("v_start", C.c_double), ("v_end", C.c_double),
+                ("v_ego", C.c_double), ("v_obj", C.c_double), ("safety_d", C.c_double), ("obj_dist", C.c_double),
+                ("obj_x", C.c_double), ("obj_y", C.c_double)]
+
+
+class VelResult(C.Structure):
+    _fields_ = [("vx", _pf64), ("too_close", C.c_int32), ("vel_bound", C.c_int32)]
+
+
+class TickVelIn(C.Structure):
+    _fields_ = [("params", C.POINTER(VelParams)), ("gg_ax", C.c_double), ("gg_ay", C.c_double),
+                ("gg_brake_scale", C.c_double), ("safety_d", C.c_double), ("v_max_offset", C.c_double),
+                ("vel_plan", _pf64), ("vel_est", _pf64), ("pos_est_x", _pf64), ("pos_est_y", _pf64),
+                ("veh_vel", _pf64)]
+
+
+class TickVelOut(C.Structure):
+    _fields_ = [("vx", _pf64), ("ax", _pf64), ("vel_bound", _pi32), ("too_close", _pi32)]
+
+
+def _p(arr, typ):
+    return arr.ctypes.data_as(typ)
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+class LatticeBinding(object):
+    """Keeps the column arrays alive that a ``ltpl_lattice_desc`` points to."""
+
+    def __init__(self, lat: Lattice):
+        if not lat.closed:
+            raise ValueError("only closed tracks are supported by this version of the backend")
+        self.lat = lat
+        k = self.keep = {}
+        k["layer_node_off"] = _i32(lat.layer_off)
+        k["raceline_index"] = _i32(lat.raceline_index)
+        k["s_raceline"] = _f64(lat.s_raceline)
+        k["refline_x"] = _f64(lat.refline[:, 0])
+        k["refline_y"] = _f64(lat.refline[:, 1])
+        k["vel_raceline"] = _f64(lat.vel_raceline)
+        k["node_x"] = _f64(lat.node_pos[:, 0])
+        k["node_y"] = _f64(lat.node_pos[:, 1])
+        k["vgoal_cost"] = _f64(lat.vgoal_cost)
+        k["in_ptr"] = _i32(lat.in_ptr)
+        k["edge_src"] = _i32(lat.edge_src)
+        k["edge_cost"] = _f64(lat.edge_cost)
+        k["edge_len"] = _f64(lat.edge_len)
+        k["samp_ptr"] = _i32(lat.samp_ptr)
+        k["samp_x"] = _f64(lat.samples[:, 0])
+        k["samp_y"] = _f64(lat.samples[:, 1])
+        k["samp_psi"] = _f64(lat.samples[:, 2])
+        k["samp_len"] = _f64(lat.samples[:, 4])
+        k["glob_rl"] = _f64(lat.glob_rl)
+        d = self.desc = LatticeDesc()
+        d.num_layers, d.num_nodes, d.num_edges = lat.num_layers, lat.num_nodes, lat.num_edges
+        d.num_samples, d.num_glob_rl = lat.num_samples, lat.glob_rl.shape[0]
+        d.closed = int(lat.closed)
+        d.plan_horizon_mode = {"distance": 0, "layers": 1}[lat.plan_horizon_mode]
+        d.min_plan_horizon = lat.min_plan_horizon
+        d.lat_resolution, d.lat_offset = lat.lat_resolution, lat.lat_offset
+        d.veh_width, d.veh_length = lat.veh_width, lat.veh_length
+        d.sampled_resolution, d.vel_decrease_lat = lat.sampled_resolution, lat.vel_decrease_lat
+        for name, arr in k.items():
+            setattr(d, name, _p(arr, _pi32 if arr.dtype == np.int32 else _pf64))
+
+
+class VelParamSet(object):
+    """VpForwardBackward constructor + update_dyn_parameters state (VpForwardBackward.py:22-84)."""
+
+    def __init__(self, dyn_model_exp=1.0, drag_coeff=0.85, m_veh=1000.0, len_veh=4.7, v_max=100.0,
+                 ax_max_machines=((100.0, 5.0),), follow_control_type="PD", follow_control_params=None):
+        cp = follow_control_params or {"c_p": 1.25, "k_d": 0.025, "k_p": 0.2}
+        self.axm = _f64(np.atleast_2d(ax_max_machines))
+        if self.axm.ndim != 2 or self.axm.shape[1] != 2:
+            raise RuntimeError("ax_max_machines must consist of the two columns [vx, ax_max_machines]!")
+        s = self.struct = VelParams()
+        s.dyn_model_exp, s.drag_coeff, s.m_veh, s.len_veh, s.v_max = dyn_model_exp, drag_coeff, m_veh, len_veh, v_max
+        s.n_ax_max_machines = self.axm.shape[0]
+        if follow_control_type not in ("PD", "PDtan"):
+            raise ValueError('Unsupported control type "' + str(follow_control_type) + '"!')
+        s.follow_control_type = 0 if follow_control_type == "PD" else 1
+        s.ax_max_machines = _p(self.axm, _pf64)
+        s.c_p, s.k_p, s.k_d = cp["c_p"], cp["k_p"], cp["k_d"]
+        s.tan_w = cp.get("tan_w", 1.0)
+
+
+class PathsBatch(object):
+    """
+    Host-side packing of n scenarios into ``ltpl_paths_in``. A scenario is a dict with keys
+      start_node (layer, node); action_sets (bool); obj_in_const, obj_besides (bool); last_action (name | None);
+      const_closest (int | None); psi_s (float | None); vehicles [(radius, positions (k, 2) own pos first)];
+      zone_gids (iterable of global node ids); last_nodes [[layer, node], ...] | None
+    ``w_last_edges`` is shared by the batch (it is a config value: OnlineTrajectoryHandler.py:109).
+    """
+
+    def __init__(self, scenarios, w_last_edges=()):
+        n = len(scenarios)
+        self.n_scen = n
+        self.w_last = _f64(list(w_last_edges) if len(w_last_edges) else [0.0])
+        self.n_w_last = len(w_last_edges)
+        self.start_layer = np.zeros(n, np.int32)
+        self.start_node = np.zeros(n, np.int32)
+        self.flags = np.zeros(n, np.int32)
+        self.last_action = np.full(n, ACT_NONE, np.int32)
+        self.const_closest = np.full(n, -1, np.int32)
+        self.psi_s = np.zeros(n)
+        self.n_last = np.zeros(n, np.int32)
+        self.last_layer = np.full((n, MAX_LAST_NODES), -1, np.int32)
+        self.last_node = np.full((n, MAX_LAST_NODES), -1, np.int32)
+        veh_off, pos_off, radius, px, py, zone_off, zone = [0], [0], [], [], [], [0], []
+        for i, sc in enumerate(scenarios):
+            self.start_layer[i], self.start_node[i] = int(sc["start_node"][0]), int(sc["start_node"][1])
+            f = 0
+            if sc.get("action_sets", True):
+                f |= FLAG_ACTION_SETS
+            if sc.get("obj_in_const", False):
+                f |= FLAG_OBJ_IN_CONST
+            if sc.get("obj_besides", False):
+                f |= FLAG_OBJ_BESIDES
+            if sc.get("psi_s") is not None:
+                f |= FLAG_HAS_PSI_S
+                self.psi_s[i] = float(sc["psi_s"])
+            self.flags[i] = f
+            la = sc.get("last_action")
+            self.last_action[i] = ACTION_IDS.get(la, ACT_NONE) if isinstance(la, str) else ACT_NONE
+            cc = sc.get("const_closest")
+            self.const_closest[i] = -1 if cc is None else int(cc)
+            for radius_k, positions in sc.get("vehicles", ()):
+                positions = np.asarray(positions, dtype=np.float64).reshape(-1, 2)
+                radius.append(float(radius_k))
+                px.extend(positions[:, 0].tolist())
+                py.extend(positions[:, 1].tolist())
+                pos_off.append(len(px))
+            veh_off.append(len(radius))
+            zone.extend(int(g) for g in sc.get("zone_gids", ()))
+            zone_off.append(len(zone))
+            ln = sc.get("last_nodes")
+            if ln:
+                # only nodes that can take part in a cost discount are shipped (w_last_edges has <= MAX-1 entries)
+                k = 0
+                for node in ln[:MAX_LAST_NODES]:
+                    if node is None or node[0] is None or node[1] is None:
+                        break
+                    self.last_layer[i, k], self.last_node[i, k] = int(node[0]), int(node[1])
+                    k += 1
+                self.n_last[i] = k
+        self.veh_off, self.pos_off = _i32(veh_off), _i32(pos_off)
+        self.veh_radius = _f64(radius if radius else [0.0])
+        self.pos_x, self.pos_y = _f64(px if px else [0.0]), _f64(py if py else [0.0])
+        self.zone_off, self.zone_gid = _i32(zone_off), _i32(zone if zone else [0])
+        self.n_veh_total = len(radius)
+        if self.n_w_last > MAX_LAST_NODES - 1:
+            raise ValueError("w_last_edges longer than %d entries is not supported" % (MAX_LAST_NODES - 1))
+        s = self.struct = PathsIn()
+        s.n_scen, s.n_w_last = n, self.n_w_last
+        s.w_last_edges = _p(self.w_last, _pf64)
+        for name in ("start_layer", "start_node", "flags", "last_action", "const_closest", "veh_off", "pos_off",
+                     "zone_off", "zone_gid", "n_last", "last_layer", "last_node"):
+            setattr(s, name, _p(getattr(self, name), _pi32))
+        for name in ("psi_s", "veh_radius", "pos_x", "pos_y"):
+            setattr(s, name, _p(getattr(self, name), _pf64))
+
+
+class PathsResult(object):
+    """Caller-allocated output buffers of seam (1) plus accessors that rebuild the reference's Python structures."""
+
+    def __init__(self, n_scen, cap_nodes, cap_pts):
+        self.n_scen, self.cap_nodes, self.cap_pts = n_scen, int(cap_nodes), int(cap_pts)
+        A = MAX_ACTIONS
+        self.end_layer = np.zeros(n_scen, np.int32)
+        self.closest_obj_index = np.zeros(n_scen, np.int32)
+        self.closest_obj_node = np.zeros((n_scen, 2), np.int32)
+        self.n_actions = np.zeros(n_scen, np.int32)
+        for name in ("action_id", "valid", "reduced", "goal_layer", "n_nodes", "n_pts", "n_ties"):
+            setattr(self, name, np.zeros((n_scen, A), np.int32))
+        self.nodes = np.zeros((n_scen, A, self.cap_nodes), np.int32)
+        self.node_idx = np.zeros((n_scen, A, self.cap_nodes), np.int32)
+        self.coeff = np.zeros((n_scen, A, self.cap_nodes, 8))
+        self.path_param = np.zeros((n_scen, A, self.cap_pts, 5))
+        s = self.struct = PathsOut()
+        s.cap_nodes, s.cap_pts = self.cap_nodes, self.cap_pts
+        for name in ("end_layer", "closest_obj_index", "closest_obj_node", "n_actions", "action_id", "valid",
+                     "reduced", "goal_layer", "n_nodes", "n_pts", "n_ties", "nodes", "node_idx"):
+            setattr(s, name, _p(getattr(self, name), _pi32))
+        s.coeff, s.path_param = _p(self.coeff, _pf64), _p(self.path_param, _pf64)
+
+    def action_sets(self, s, start_layer, num_layers):
+        """
+        The 6-tuple of main_online_path_gen (main_online_path_gen.py:333-334) for scenario ``s``: dicts keyed by action
+        name in insertion order, each value a one-element list; absent keys = no solution.
+        """
+        nodes, node_idx, coeff, path_param, red_len = {}, {}, {}, {}, {}
+        for a in range(int(self.n_actions[s])):
+            if not self.valid[s, a]:
+                continue
+            name = ACTION_NAMES[int(self.action_id[s, a])]
+            nn, npts = int(self.n_nodes[s, a]), int(self.n_pts[s, a])
+            nodes[name] = [[[int((start_layer + i) % num_layers), int(self.nodes[s, a, i])] for i in range(nn)]]
+            node_idx[name] = [[int(v) for v in self.node_idx[s, a, :nn]]]
+            coeff[name] = [self.coeff[s, a, :nn - 1, :].copy()]
+            path_param[name] = [self.path_param[s, a, :npts, :].copy()]
+            red_len[name] = [bool(self.reduced[s, a])]
+        coi = int(self.closest_obj_index[s])
+        return nodes, node_idx, coeff, path_param, red_len, (None if coi < 0 else coi)
+
+
+class TickVelBatch(object):
+    def __init__(self, params: VelParamSet, n_scen, vel_plan, vel_est, pos_est, veh_vel, gg=(5.0, 5.0),
+                 gg_brake_scale=1.0, safety_d=30.0, v_max_offset=0.1):
+        self.params = params
+        self.vel_plan, self.vel_est = _f64(vel_plan), _f64(vel_est)
+        pos_est = np.asarray(pos_est, dtype=np.float64).reshape(n_scen, 2)
+        self.pos_x, self.pos_y = _f64(pos_est[:, 0]), _f64(pos_est[:, 1])
+        self.veh_vel = _f64(veh_vel if len(veh_vel) else [0.0])
+        s = self.struct = TickVelIn()
+        s.params = C.pointer(params.struct)
+        s.gg_ax, s.gg_ay, s.gg_brake_scale = float(gg[0]), float(gg[1]), float(gg_brake_scale)
+        s.safety_d, s.v_max_offset = float(safety_d), float(v_max_offset)
+        s.vel_plan, s.vel_est = _p(self.vel_plan, _pf64), _p(self.vel_est, _pf64)
+        s.pos_est_x, s.pos_est_y = _p(self.pos_x, _pf64), _p(self.pos_y, _pf64)
+        s.veh_vel = _p(self.veh_vel, _pf64)
+
+
+class TickVelResult(object):
+    def __init__(self, n_scen, cap_pts):
+        A = MAX_ACTIONS
+        self.vx = np.zeros((n_scen, A, cap_pts))
+        self.ax = np.zeros((n_scen, A, cap_pts))
+        self.vel_bound = np.zeros((n_scen, A), np.int32)
+        self.too_close = np.zeros((n_scen, A), np.int32)
+        s = self.struct = TickVelOut()
+        s.vx, s.ax = _p(self.vx, _pf64), _p(self.ax, _pf64)
+        s.vel_bound, s.too_close = _p(self.vel_bound, _pi32), _p(self.too_close, _pi32)
+
+
+def make_vel_jobs(jobs):
+    """
+    jobs: list of dicts {mode, kappa, el_lengths, loc_gg, v_start, v_end(optional), + follow fields}. Returns
+    (ctypes array of VelJob, ctypes array of VelResult, list of output arrays, keep-alive list).
+    """
+    n = len(jobs)
+    jarr = (VelJob * n)()
+    rarr = (VelResult * n)()
+    outs, keep = [], []
+    for i, jb in enumerate(jobs):
+        kappa, el, gg = _f64(jb["kappa"]), _f64(jb["el_lengths"]), _f64(jb["loc_gg"])
+        if gg.ndim != 2 or gg.shape[1] != 2:
+            raise RuntimeError("loc_gg must consist of two columns: [ax_max, ay_max]!")
+        if gg.shape[0] != kappa.size:
+            raise RuntimeError("Length of loc_gg and kappa must be equal!")
+        if el.size == 0:
+            el = _f64([0.0])[:0]
+        out = np.zeros(kappa.size)
+        keep.extend((kappa, el, gg))
+        outs.append(out)
+        j = jarr[i]
+        j.mode, j.n, j.n_el = int(jb["mode"]), kappa.size, int(jb["el_lengths"].size if hasattr(jb["el_lengths"], "size")
+                                                                else len(jb["el_lengths"]))
+        j.has_v_end = int(jb.get("v_end") is not None)
+        j.kappa, j.el_lengths, j.loc_gg = _p(kappa, _pf64), _p(el, _pf64), _p(gg, _pf64)
+        j.v_start = float(jb["v_start"])
+        j.v_end = float(jb["v_end"]) if jb.get("v_end") is not None else 0.0
+        for key in ("v_ego", "v_obj", "safety_d", "obj_dist"):
+            setattr(j, key, float(jb.get(key, 0.0)))
+        op = jb.get("obj_pos", (0.0, 0.0))
+        j.obj_x, j.obj_y = float(op[0]), float(op[1])
+        rarr[i].vx = _p(out, _pf64)
+    return jarr, rarr, outs, keep
+
+
+def default_library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libltpl_hip.so")
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+class HipBackend(object):
+    """One handle = one lattice resident in the HBM of one MI355X. Raises if the HIP library / device is missing."""
+
+    def __init__(self, lattice: Lattice, device: int = -1, lib_path: str = None):
+        path = lib_path or os.environ.get("LTPL_HIP_LIB") or default_library_path()
+        if not os.path.isfile(path):
+            raise BackendError("libltpl_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+                               "g.build()'`; there is no CPU fallback" % path)
+        self.lib = C.CDLL(path)
+        self._declare()
+        self.binding = LatticeBinding(lattice)
+        self.lattice = lattice
+        self.handle = C.c_void_p()
+        rc = self.lib.ltpl_create(C.byref(self.binding.desc), int(device), C.byref(self.handle))
+        if rc != 0:
+            msg = self.lib.ltpl_last_error(None)
+            raise BackendError("ltpl_create failed (%s): %s" % (_STATUS.get(rc, rc), (msg or b"").decode()))
+        caps = Caps()
+        self._check(self.lib.ltpl_get_caps(self.handle, C.byref(caps)))
+        self.caps = caps
+
+    def _declare(self):
+        L = self.lib
+        L.ltpl_create.argtypes = [C.POINTER(LatticeDesc), C.c_int, C.POINTER(C.c_void_p)]
+        L.ltpl_destroy.argtypes = [C.c_void_p]
+        L.ltpl_get_caps.argtypes = [C.c_void_p, C.POINTER(Caps)]
+        L.ltpl_last_error.argtypes = [C.c_void_p]
+        L.ltpl_last_error.restype = C.c_char_p
+        L.ltpl_plan_paths.argtypes = [C.c_void_p, C.POINTER(PathsIn), C.POINTER(PathsOut)]
+        L.ltpl_vel_profile.argtypes = [C.c_void_p, C.POINTER(VelParams), C.c_int, C.POINTER(VelJob),
+                                       C.POINTER(VelResult)]
+        L.ltpl_tick_batch.argtypes = [C.c_void_p, C.POINTER(PathsIn), C.POINTER(TickVelIn), C.POINTER(PathsOut),
+                                      C.POINTER(TickVelOut)]
+        L.ltpl_batch_upload.argtypes = [C.c_void_p, C.POINTER(PathsIn), C.POINTER(TickVelIn), C.c_int32, C.c_int32]
+        L.ltpl_batch_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+        L.ltpl_batch_download.argtypes = [C.c_void_p, C.POINTER(PathsOut), C.POINTER(TickVelOut)]
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.ltpl_last_error(self.handle)
+            raise BackendError("libltpl_hip: %s: %s" % (_STATUS.get(rc, rc), (msg or b"").decode()))
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle:
+            self.lib.ltpl_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- seam (1) ----
+    def new_paths_result(self, n_scen):
+        return PathsResult(n_scen, self.caps.max_path_nodes, self.caps.max_path_pts)
+
+    def plan_paths(self, batch: PathsBatch, result: PathsResult = None) -> PathsResult:
+        if result is None:
+            result = self.new_paths_result(batch.n_scen)
+        self._check(self.lib.ltpl_plan_paths(self.handle, C.byref(batch.struct), C.byref(result.struct)))
+        return result
+
+    # ---- seam (2) ----
+    def vel_profile(self, params: VelParamSet, jobs):
+        jarr, rarr, outs, keep = make_vel_jobs(jobs)
+        self._check(self.lib.ltpl_vel_profile(self.handle, C.byref(params.struct), len(jobs), jarr, rarr))
+        return [(outs[i], bool(rarr[i].too_close), bool(rarr[i].vel_bound)) for i in range(len(jobs))]
+
+    # ---- fused tick ----
+    def tick_batch(self, batch: PathsBatch, vel: TickVelBatch, result: PathsResult = None,
+                   vresult: TickVelResult = None):
+        if result is None:
+            result = self.new_paths_result(batch.n_scen)
+        if vresult is None:
+            vresult = TickVelResult(batch.n_scen, result.cap_pts)
+        self._check(self.lib.ltpl_tick_batch(self.handle, C.byref(batch.struct), C.byref(vel.struct),
+                                             C.byref(result.struct), C.byref(vresult.struct)))
+        return result, vresult
+
+    def batch_upload(self, batch: PathsBatch, vel: TickVelBatch):
+        self._check(self.lib.ltpl_batch_upload(self.handle, C.byref(batch.struct), C.byref(vel.struct),
+                                               self.caps.max_path_nodes, self.caps.max_path_pts))
+        self._resident_n = batch.n_scen
+
+    def batch_run(self, reps=1, timed=True):
+        ms = C.c_float(0.0)
+        self._check(self.lib.ltpl_batch_run(self.handle, int(reps), C.byref(ms) if timed else None))
+        return float(ms.value)
+
+    def batch_download(self):
+        result = self.new_paths_result(self._resident_n)
+        vresult = TickVelResult(self._resident_n, result.cap_pts)
+        self._check(self.lib.ltpl_batch_download(self.handle, C.byref(result.struct), C.byref(vresult.struct)))
+        return result, vresult

@@ -1,0 +1,260 @@
+/*
+ * ltpl_hip.h -- C ABI of libltpl_hip.so, the MI355X (gfx950) backend for the online hot path of graph_ltpl.
+ *
+ * The reference (TUMFTM/GraphBasedLocalTrajectoryPlanner) is pure Python and has no FFI; the natural seams are two
+ * Python call sites that it resolves by fully qualified attribute lookup on every tick:
+ *
+ *   seam (1)  graph_ltpl/online_graph/src/main_online_path_gen.py:11-21,333-334   main_online_path_gen(...)
+ *             called from graph_ltpl/online_graph/src/OnlineTrajectoryHandler.py:416-427
+ *   seam (2)  graph_ltpl/online_graph/src/VpForwardBackward.py:11-255             class VpForwardBackward
+ *             constructed at OnlineTrajectoryHandler.py:137-144, called at :676, :747-752, :789-798, :872-878, :967-972
+ *
+ * Every entry point below names the reference interface it replaces. All functions are extern "C", take plain
+ * pointers / sizes (C-contiguous float64 / int32 host buffers owned by the caller) and return an int status
+ * (LTPL_OK == 0). "No path found" is NOT an error (valid == 0). No C++ exception crosses the ABI. A handle owns its
+ * device memory, pinned staging and one HIP stream; calls on one handle are synchronous on return and must not be
+ * issued concurrently; different handles may be used from different threads / processes.
+ */
+#ifndef LTPL_HIP_H
+#define LTPL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LTPL_ABI_VERSION 1
+
+/* status codes */
+#define LTPL_OK               0
+#define LTPL_ERR_INVALID_ARG  1
+#define LTPL_ERR_NO_DEVICE    2
+#define LTPL_ERR_HIP          3
+#define LTPL_ERR_CAPACITY     4
+#define LTPL_ERR_UNSUPPORTED  5
+
+/* action primitives: ACTION_ID_MAP, OnlineTrajectoryHandler.py:14-17 */
+#define LTPL_ACT_STRAIGHT 0
+#define LTPL_ACT_FOLLOW   1
+#define LTPL_ACT_LEFT     2
+#define LTPL_ACT_RIGHT    3
+#define LTPL_ACT_NONE    (-1)
+
+#define LTPL_MAX_ACTIONS     3   /* at most 3 primitives are offered per tick (main_online_path_gen.py:128-174) */
+#define LTPL_MAX_LAST_NODES  8   /* nodes of the previous solution used for the cost discount (w_last_edges)      */
+
+/* per-scenario flag bits of ltpl_paths_in.flags */
+#define LTPL_FLAG_ACTION_SETS     1   /* action_sets=True                    main_online_path_gen.py:15          */
+#define LTPL_FLAG_OBJ_IN_CONST    2   /* obj_in_const_path                   main_online_path_gen.py:77,118-122  */
+#define LTPL_FLAG_OBJ_BESIDES     4   /* object_besides_const_path           main_online_path_gen.py:78,104-105  */
+#define LTPL_FLAG_HAS_PSI_S       8   /* const_path_seg is not None -> psi_s main_online_path_gen.py:300-303     */
+
+typedef struct ltpl_handle ltpl_handle;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Offline lattice, struct-of-arrays (what GraphBase holds in igraph attributes: GraphBase.py:93-119,163-194,409-439).
+ * Node global id = layer_node_off[layer] + node. Edges are stored CSC by destination node, in-edges sorted by source
+ * node id; an edge always connects layer l to layer (l+1) mod num_layers (gen_edges.py:52-61).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t num_layers;
+    int32_t num_nodes;
+    int32_t num_edges;
+    int32_t num_samples;
+    int32_t num_glob_rl;            /* rows of glob_rl                                                            */
+    int32_t closed;                 /* GraphBase.closed (only closed tracks are supported in this version)        */
+    int32_t plan_horizon_mode;      /* 0 = 'distance', 1 = 'layers'        gen_local_node_template.py:104-133     */
+    int32_t reserved0;
+    double  min_plan_horizon;
+    double  lat_resolution;
+    double  lat_offset;
+    double  veh_width;
+    double  veh_length;
+    double  sampled_resolution;
+    double  vel_decrease_lat;
+    /* per layer [num_layers] */
+    const int32_t* layer_node_off;  /* [num_layers + 1]                                                           */
+    const int32_t* raceline_index;
+    const double*  s_raceline;
+    const double*  refline_x;
+    const double*  refline_y;
+    const double*  vel_raceline;
+    /* per node [num_nodes] */
+    const double*  node_x;
+    const double*  node_y;
+    const double*  vgoal_cost;      /* cost of the virtual goal edge of that node              GraphBase.py:188   */
+    /* per edge [num_edges] */
+    const int32_t* in_ptr;          /* [num_nodes + 1]                                                            */
+    const int32_t* edge_src;        /* source node index inside the previous layer                                */
+    const double*  edge_cost;       /* offline_cost                                                               */
+    const double*  edge_len;        /* spline_length                                                              */
+    const int32_t* samp_ptr;        /* [num_edges + 1]                                                            */
+    /* per sample [num_samples]: columns 0,1,2,4 of spline_param (GraphBase.py:425-436); kappa (col 3) is never read
+     * online because main_online_path_gen.py:318-322 overwrites it                                               */
+    const double*  samp_x;
+    const double*  samp_y;
+    const double*  samp_psi;
+    const double*  samp_len;
+    /* fine global race line, row-major [num_glob_rl][5] = s, x, y, kappa, vel    (GraphBase.glob_rl)             */
+    const double*  glob_rl;
+} ltpl_lattice_desc;
+
+typedef struct {
+    int32_t max_path_nodes;         /* capacity needed per path: nodes                                            */
+    int32_t max_path_pts;           /* capacity needed per path: samples                                          */
+    int32_t max_horizon_edges;
+    int32_t device;
+    int32_t num_cus;
+    int32_t lds_bytes_paths;        /* dynamic LDS of the path kernel                                             */
+} ltpl_caps;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * seam (1): batched main_online_path_gen. One "scenario" = one call of the reference function.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t n_scen;
+    int32_t n_w_last;               /* len(w_last_edges)                                                          */
+    const double*  w_last_edges;    /* [n_w_last]  online cost factors     gen_local_node_template.py:155-162     */
+    const int32_t* start_layer;     /* [n_scen]                                                                   */
+    const int32_t* start_node;      /* [n_scen]                                                                   */
+    const int32_t* flags;           /* [n_scen]  LTPL_FLAG_*                                                      */
+    const int32_t* last_action;     /* [n_scen]  LTPL_ACT_* of last_action_id or LTPL_ACT_NONE                    */
+    const int32_t* const_closest;   /* [n_scen]  object index chosen by the constant-segment test
+                                                 (main_online_path_gen.py:97-115) or -1                           */
+    const double*  psi_s;           /* [n_scen]  const_path_seg[-1, 2] when LTPL_FLAG_HAS_PSI_S                   */
+    /* vehicles: vehicle k of scenario s is v = veh_off[s] + k; its positions are pos_off[v] .. pos_off[v+1]-1,
+     * the first one being VehObject.get_pos(), the others VehObject.get_prediction() rows
+     * (gen_local_node_template.py:169-189)                                                                       */
+    const int32_t* veh_off;         /* [n_scen + 1]                                                               */
+    const int32_t* pos_off;         /* [n_veh_total + 1]                                                          */
+    const double*  veh_radius;      /* [n_veh_total]                                                              */
+    const double*  pos_x;           /* [n_pos_total]                                                              */
+    const double*  pos_y;           /* [n_pos_total]                                                              */
+    /* zone-blocked nodes ("overtaking_zones" filter, gen_local_node_template.py:96): global node ids             */
+    const int32_t* zone_off;        /* [n_scen + 1]                                                               */
+    const int32_t* zone_gid;        /* [n_zone_total]                                                             */
+    /* previous solution (last_solution_nodes): n_last[s] <= LTPL_MAX_LAST_NODES leading nodes                    */
+    const int32_t* n_last;          /* [n_scen]                                                                   */
+    const int32_t* last_layer;      /* [n_scen * LTPL_MAX_LAST_NODES]                                             */
+    const int32_t* last_node;       /* [n_scen * LTPL_MAX_LAST_NODES]                                             */
+} ltpl_paths_in;
+
+typedef struct {
+    int32_t cap_nodes;              /* caller-chosen capacities, >= ltpl_caps.max_path_nodes / max_path_pts       */
+    int32_t cap_pts;
+    /* per scenario */
+    int32_t* end_layer;             /* [n_scen]                                                                   */
+    int32_t* closest_obj_index;     /* [n_scen]     -1 = None                                                     */
+    int32_t* closest_obj_node;      /* [n_scen * 2] layer, node; -1 = None                                        */
+    int32_t* n_actions;             /* [n_scen]     number of action slots used (template length)                 */
+    /* per scenario and action slot a < LTPL_MAX_ACTIONS, index s * LTPL_MAX_ACTIONS + a; slots are in the order the
+     * reference inserts its dict keys (follow / straight first)                                                  */
+    int32_t* action_id;             /* final name (after the follow -> straight rename, :232-237) or NONE         */
+    int32_t* valid;                 /* 1 = key present in the reference's dicts                                   */
+    int32_t* reduced;               /* action_set_red_len                                                         */
+    int32_t* goal_layer;            /* layer the path ends in                                                     */
+    int32_t* n_nodes;
+    int32_t* n_pts;
+    int32_t* n_ties;                /* exact cost ties met while picking predecessors along this sweep            */
+    int32_t* nodes;                 /* [.. * cap_nodes]      node index per layer, layer i = (start + i) mod L    */
+    int32_t* node_idx;              /* [.. * cap_nodes]      row of every node in path_param                      */
+    double*  coeff;                 /* [.. * cap_nodes * 8]  (n_nodes-1) rows [x a0..a3, y a0..a3]                */
+    double*  path_param;            /* [.. * cap_pts * 5]    n_pts rows [x, y, psi, kappa, el_length]             */
+} ltpl_paths_out;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * seam (2): the arithmetic behind class VpForwardBackward.
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define LTPL_VEL_FB      0   /* VpForwardBackward.calc_vel_profile  :194-227 -> tph.calc_vel_profile(closed=False) */
+#define LTPL_VEL_BRAKE   1   /* tph.calc_vel_profile_brake behind check_brake_prefix :115-122, calc_vel_brake_em  */
+#define LTPL_VEL_FOLLOW  2   /* VpForwardBackward.calc_vel_profile_follow :141-192 -> calc_vel_profile_follow.py  */
+
+typedef struct {
+    double  dyn_model_exp;          /* VpForwardBackward.__init__ :22-29                                          */
+    double  drag_coeff;
+    double  m_veh;
+    double  len_veh;
+    double  v_max;                  /* update_dyn_parameters :65-84                                               */
+    int32_t n_ax_max_machines;
+    int32_t follow_control_type;    /* 0 = 'PD', 1 = 'PDtan'          calc_vel_profile_follow.py:65-75            */
+    const double* ax_max_machines;  /* [n_ax_max_machines * 2] rows [v, ax]                                       */
+    double  c_p, k_p, k_d, tan_w;   /* follow controller parameters   params/ltpl_config_online.ini:41-50         */
+} ltpl_vel_params;
+
+typedef struct {
+    int32_t mode;                   /* LTPL_VEL_*                                                                 */
+    int32_t n;                      /* kappa.size                                                                 */
+    int32_t n_el;                   /* el_lengths.size: n-1 (FB, BRAKE) or n (FOLLOW, OTH.py:791 hands over n)    */
+    int32_t has_v_end;
+    const double* kappa;            /* [n]                                                                        */
+    const double* el_lengths;       /* [n_el]                                                                     */
+    const double* loc_gg;           /* [n * 2] rows [ax_max, ay_max], gg_scale already applied                    */
+    double  v_start;
+    double  v_end;
+    /* FOLLOW only (calc_vel_profile_follow.py:78-95) */
+    double  v_ego, v_obj, safety_d, obj_dist, obj_x, obj_y;
+} ltpl_vel_job;
+
+typedef struct {
+    double*  vx;                    /* [n] output profile                                                         */
+    int32_t  too_close;             /* FOLLOW: calc_vel_profile_follow.py:146-149                                 */
+    int32_t  vel_bound;             /* FOLLOW: vel_bound_fulfilled                                                */
+} ltpl_vel_result;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * fused tick: seam (1) followed by the per-primitive velocity stage of OnlineTrajectoryHandler.calc_vel_profile
+ * (OTH.py:688-941) on the freshly planned paths (no constant prefix: cut_index_pos = 0, vel_course empty).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const ltpl_vel_params* params;
+    double  gg_ax, gg_ay;           /* constant local gg (ax, ay) times gg_scale   OTH.py:651-666                 */
+    double  gg_brake_scale;         /* old_gg_scale / gg_scale used by the brake prefix  VpForwardBackward.py:114 */
+    double  safety_d;
+    double  v_max_offset;           /* ACTIONSET.v_max_offset                      OTH.py:102,907                 */
+    const double* vel_plan;         /* [n_scen]                                                                   */
+    const double* vel_est;          /* [n_scen]                                                                   */
+    const double* pos_est_x;        /* [n_scen]                                                                   */
+    const double* pos_est_y;        /* [n_scen]                                                                   */
+    const double* veh_vel;          /* [n_veh_total] VehObject.get_vel()                                          */
+} ltpl_tick_vel_in;
+
+typedef struct {
+    double*  vx;                    /* [n_scen * LTPL_MAX_ACTIONS * cap_pts]                                      */
+    double*  ax;                    /* [n_scen * LTPL_MAX_ACTIONS * cap_pts]                                      */
+    int32_t* vel_bound;             /* [n_scen * LTPL_MAX_ACTIONS]                                                */
+    int32_t* too_close;             /* [n_scen * LTPL_MAX_ACTIONS]                                                */
+} ltpl_tick_vel_out;
+
+/* --- lifecycle ---------------------------------------------------------------------------------------------------- */
+/* Uploads the lattice to HBM once (replaces the pickled GraphBase handed to OnlineTrajectoryHandler,
+ * Graph_LTPL.py:202-229). device < 0 selects the current device. */
+int ltpl_create(const ltpl_lattice_desc* lattice, int device, ltpl_handle** out_handle);
+int ltpl_destroy(ltpl_handle* handle);
+int ltpl_get_caps(const ltpl_handle* handle, ltpl_caps* caps);
+const char* ltpl_last_error(const ltpl_handle* handle);   /* NULL handle -> last create() error */
+int ltpl_version(void);
+
+/* --- seam (1): main_online_path_gen.py:11 ------------------------------------------------------------------------- */
+int ltpl_plan_paths(ltpl_handle* handle, const ltpl_paths_in* in, ltpl_paths_out* out);
+
+/* --- seam (2): VpForwardBackward.py:86,141,194,229 ---------------------------------------------------------------- */
+int ltpl_vel_profile(ltpl_handle* handle, const ltpl_vel_params* params, int n_jobs, const ltpl_vel_job* jobs,
+                     ltpl_vel_result* results);
+
+/* --- fused tick (throughput path): Graph_LTPL.calc_paths + calc_vel_profile arithmetic, Graph_LTPL.py:300,344 ------ */
+int ltpl_tick_batch(ltpl_handle* handle, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin,
+                    ltpl_paths_out* out, ltpl_tick_vel_out* vout);
+
+/* Device-resident variant for benchmarks: upload the batch once, replay the fused kernel, download on demand.
+ * ltpl_batch_run enqueues `reps` launches on the handle's stream and, when ms_total != NULL, brackets them with HIP
+ * events on that stream and waits. */
+int ltpl_batch_upload(ltpl_handle* handle, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin,
+                      int32_t cap_nodes, int32_t cap_pts);
+int ltpl_batch_run(ltpl_handle* handle, int reps, float* ms_total);
+int ltpl_batch_download(ltpl_handle* handle, ltpl_paths_out* out, ltpl_tick_vel_out* vout);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTPL_HIP_H */

@@ -1,0 +1,31 @@
+import os
+import sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+
+
+@pytest.fixture(scope="session")
+def monteblanco():
+    from graphbasedlocaltrajectoryplanner_amd.lattice import Lattice
+    return Lattice.load(os.path.join(ROOT, "tests", "golden", "monteblanco_lattice.npz"))
+
+
+@pytest.fixture(scope="session")
+def oracle_backend(monteblanco):
+    from oracle.oracle_lib import OracleBackend
+    return OracleBackend(monteblanco)
+
+
+@pytest.fixture(scope="session")
+def hip_backend(monteblanco):
+    """The product backend. No fallback: a missing library or device is an error, not a skip."""
+    from graphbasedlocaltrajectoryplanner_amd._capi import HipBackend
+    return HipBackend(monteblanco)

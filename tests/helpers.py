@@ -1,0 +1,76 @@
+"""Shared test helpers: fixture loading, stand-ins for the reference's VehObject, comparison utilities."""
+import os
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+REL_TOL = 1e-5          # north_star: spline coefficients and velocity profiles within 1e-5 relative
+
+
+def load_golden(name):
+    from oracle.fixture_io import load_records
+    return load_records(os.path.join(GOLDEN, name))
+
+
+class Veh(object):
+    """Duck-typed VehObject (ObjectListInterface.py:240-296)."""
+
+    def __init__(self, pos, radius, pred=None, vel=0.0):
+        self._pos, self._radius, self._pred, self._vel = list(pos), float(radius), pred, float(vel)
+
+    def get_pos(self):
+        return self._pos
+
+    def get_radius(self):
+        return self._radius
+
+    def get_prediction(self):
+        return self._pred
+
+    def get_vel(self):
+        return self._vel
+
+
+def vehicles_of(rec):
+    return [Veh(rec['obj_pos'][k], rec['obj_radius'][k], rec['obj_pred'][k], rec['obj_vel'][k])
+            for k in range(len(rec['obj_radius']))]
+
+
+def assert_close_rel(actual, desired, rel=REL_TOL, what=""):
+    """max |a - d| <= rel * max(|d|, scale): relative to the magnitude of the reference array (no element-wise blow-up
+    at zero crossings)."""
+    actual, desired = np.asarray(actual, dtype=float), np.asarray(desired, dtype=float)
+    assert actual.shape == desired.shape, "%s: shape %s vs %s" % (what, actual.shape, desired.shape)
+    if desired.size == 0:
+        return
+    scale = max(float(np.max(np.abs(desired))), 1e-12)
+    err = float(np.max(np.abs(actual - desired)))
+    assert err <= rel * scale, "%s: max abs err %.3e > %.1e * %.3e" % (what, err, rel, scale)
+
+
+def replay_path_call(gen, rec):
+    """Feed one recorded seam-(1) call to an OnlinePathGenerator and return its 6-tuple."""
+    gen.set_zone_nodes(rec['zone_layers'], rec['zone_nodes'])
+    sc = gen.scenario(rec['start_node'], vehicles_of(rec), rec['action_sets'], rec['last_action_id'],
+                      rec['const_path_seg'], rec['pos_est'], rec['last_solution_nodes'])
+    return sc
+
+
+def check_path_output(out6, rec, what=""):
+    nodes, node_idx, coeff, path_param, red_len, closest = out6
+    exp = rec['out']
+    assert list(nodes.keys()) == exp['keys'], "%s: keys %s vs %s" % (what, list(nodes.keys()), exp['keys'])
+    assert closest == exp['closest_obj_index'], "%s: closest_obj_index" % what
+    for k in exp['keys']:
+        assert nodes[k][0] == exp['nodes'][k], "%s/%s: node list differs" % (what, k)            # bit-exact
+        assert list(node_idx[k][0]) == exp['node_idx'][k], "%s/%s: node_idx differs" % (what, k)  # bit-exact
+        assert red_len[k][0] == exp['red_len'][k], "%s/%s: reduced flag" % (what, k)
+        assert_close_rel(coeff[k][0], exp['coeff'][k], what="%s/%s coeff" % (what, k))
+        pp, epp = path_param[k][0], exp['path_param'][k]
+        assert pp.shape == epp.shape
+        assert_close_rel(pp[:, 0:2], epp[:, 0:2], what="%s/%s xy" % (what, k))
+        dpsi = np.abs(np.mod(pp[:, 2] - epp[:, 2] + np.pi, 2 * np.pi) - np.pi)
+        assert float(dpsi.max()) <= REL_TOL * np.pi, "%s/%s psi" % (what, k)
+        assert_close_rel(pp[:, 3], epp[:, 3], what="%s/%s kappa" % (what, k))
+        assert np.array_equal(pp[:, 4], epp[:, 4]), "%s/%s el_length column must be copied bit-exact" % (what, k)
