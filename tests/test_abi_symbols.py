@@ -1,0 +1,47 @@
+"""CPU: the C-ABI library loads (no GPU needed) and exports every symbol include/ltpl_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "ltpl_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ltpl_[a-z_]+)\s*\(", txt)))
+
+
+def test_header_declares_the_expected_entry_points():
+    syms = declared_symbols()
+    for must in ("ltpl_create", "ltpl_destroy", "ltpl_plan_paths", "ltpl_vel_profile", "ltpl_tick_batch",
+                 "ltpl_last_error", "ltpl_version", "ltpl_get_caps", "ltpl_batch_upload", "ltpl_batch_run",
+                 "ltpl_batch_download"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    lib_path = ge.build_hip()
+    lib = ctypes.CDLL(lib_path)
+    for sym in declared_symbols():
+        assert hasattr(lib, sym), "libltpl_hip.so does not export %s" % sym
+    assert lib.ltpl_version() == 1
+
+
+def test_product_fails_loudly_without_library(monteblanco, tmp_path):
+    from graphbasedlocaltrajectoryplanner_amd import _capi
+    with pytest.raises(_capi.BackendError):
+        _capi.HipBackend(monteblanco, lib_path=str(tmp_path / "missing.so"))
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "graphbasedlocaltrajectoryplanner_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("oracle/", "").replace("the oracle", "") or f == "__init__.py", \
+                    "%s mentions the oracle" % f
