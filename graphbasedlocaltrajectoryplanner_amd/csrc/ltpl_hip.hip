@@ -127,7 +127,7 @@ struct TickShared {
     int n_act, filt[LTPL_MAX_ACTIONS], name[LTPL_MAX_ACTIONS];
     int need[NFILT];
     int start_ok[NFILT];
-    int slot_valid[LTPL_MAX_ACTIONS], slot_j[LTPL_MAX_ACTIONS];
+    int slot_valid[LTPL_MAX_ACTIONS], slot_j[LTPL_MAX_ACTIONS], slot_name[LTPL_MAX_ACTIONS], slot_reduced[LTPL_MAX_ACTIONS];
     int n_last; int last_layer[LTPL_MAX_LAST_NODES]; int last_node[LTPL_MAX_LAST_NODES];
 };
 
@@ -147,11 +147,14 @@ __device__ __forceinline__ bool node_removed(const TickShared& ts, const unsigne
 // ---------------------------------------------------------------------------------------------------------------------
 // the path kernel (seam 1)
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG_THREADS) void k_plan_paths(DevLat lat, DevPathsIn in, DevPathsOut out, LdsPlan lp)
+// Result of the path stage for the calling wave (waves 0..2 own one action slot each).
+struct WavePath { int valid; int n_pts; int n_nodes; int name; int reduced; int goal_layer; int end_node; };
+
+__device__ __forceinline__ WavePath plan_paths_body(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out,
+                                                    const LdsPlan& lp, unsigned char* smem, TickShared& ts,
+                                                    int* sh_pos_layer, double* vel_kappa, double* vel_len,
+                                                    double* vel_x = nullptr, double* vel_y = nullptr)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ TickShared ts;
-    __shared__ int sh_pos_layer[MAX_POS];
 
     const int s = blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -431,12 +434,17 @@ __global__ __launch_bounds__(WG_THREADS) void k_plan_paths(DevLat lat, DevPathsI
             out.action_id[slot] = nm; out.reduced[slot] = reduced ? 1 : 0; out.goal_layer[slot] = goal;
             out.valid[slot] = found ? 1 : 0;
             if (!found) { out.n_nodes[slot] = 0; out.n_pts[slot] = 0; out.n_ties[slot] = 0; }
-            ts.slot_valid[a] = found ? 1 : 0; ts.slot_j[a] = mod_j;
+            ts.slot_valid[a] = found ? 1 : 0; ts.slot_j[a] = mod_j; ts.slot_name[a] = nm; ts.slot_reduced[a] = reduced ? 1 : 0;
         }
     }
     __syncthreads();
 
     // ---- phase 6: wave a assembles primitive a (main_online_path_gen.py:250-328) ------------------------------------
+    WavePath wp; wp.valid = 0; wp.n_pts = 0; wp.n_nodes = 0; wp.name = LTPL_ACT_NONE; wp.reduced = 0; wp.goal_layer = -1;
+    wp.end_node = -1;
+    if (wave < LTPL_MAX_ACTIONS && wave < ts.n_act) {
+        wp.name = ts.slot_name[wave]; wp.reduced = ts.slot_reduced[wave];
+    }
     if (wave < LTPL_MAX_ACTIONS && wave < ts.n_act && ts.slot_valid[wave]) {
         const int a = wave, slot = s * LTPL_MAX_ACTIONS + a, f = ts.filt[a], J = ts.slot_j[a], N = J;   // N segments
         unsigned char* pw = smem + lp.off_path + (size_t)a * lp.path_stride;
@@ -566,8 +574,535 @@ __global__ __launch_bounds__(WG_THREADS) void k_plan_paths(DevLat lat, DevPathsI
             row[0] = x; row[1] = y;
             row[2] = normalize_psi_dev(atan2(yd, xd) - D_PI / 2);
             row[3] = (xd * ydd - yd * xdd) / (q * sqrt(q));
-            row[4] = lat.slen[lat.samp_ptr[pedge[i]] + k];
+            const double len_r = lat.slen[lat.samp_ptr[pedge[i]] + k];
+            row[4] = len_r;
+            if (vel_kappa) { vel_kappa[r] = row[3]; vel_len[r] = len_r; }
+            if (vel_x) { vel_x[r] = x; vel_y[r] = y; }
         }
+        wp.valid = 1; wp.n_pts = n_pts; wp.n_nodes = J + 1;
+        { int gl = ts.start_layer + J; if (gl >= L) gl -= L; wp.goal_layer = gl; }
+        wp.end_node = best[f * hm + J] & 0xffff;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    return wp;
+}
+
+__global__ __launch_bounds__(WG_THREADS) void k_plan_paths(DevLat lat, DevPathsIn in, DevPathsOut out, LdsPlan lp)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ TickShared ts;
+    __shared__ int sh_pos_layer[MAX_POS];
+    (void)plan_paths_body(lat, in, out, lp, smem, ts, sh_pos_layer, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// velocity stage (seam 2): tph.calc_vel_profile / calc_vel_profile_brake / calc_vel_profile_follow on the device
+// ---------------------------------------------------------------------------------------------------------------------
+// One wave64 owns one profile. Vectorisable parts (curvature -> lateral-limit speed, run-start detection, final
+// sqrt, acceleration) are spread over the lanes; the forward / backward recurrences are inherently sequential scans
+// and run on lane 0 over LDS-resident arrays. The recurrence state is w = v^2, which removes the sqrt and the
+// divisions from the dependent chain (v_{i+1}^2 = v_i^2 + 2 a_x(v_i) ds_i); comparisons happen in w as well (sqrt is
+// monotone). Differences to the reference's v-state arithmetic are rounding-level (~1e-16 relative).
+struct DevVelParams {
+    double e, inv_e, drag_m, len_veh, v_max;
+    int n_axm, ctrl;
+    const double* axm;          // [n_axm * 2] in device memory
+    double c_p, k_p, k_d, tan_w;
+};
+
+// per-wave LDS scratch of the velocity stage; every array holds cap + 1 doubles
+struct VelScratch {
+    double* w;        // profile state (v^2)
+    double* kabs;     // |kappa|
+    double* el;       // element lengths
+    double* gax;      // per-point longitudinal limit (nullptr -> constant)
+    double* gay;      // per-point lateral limit      (nullptr -> constant)
+    double* s;        // arc length (cap + 1)
+    double* wb;       // ego brake profile (follow)
+    double* wc;       // scratch profile (follow)
+    unsigned char* start;   // run-start flags
+    double* chunk;    // 128 doubles: staging of the global race line for the opponent brake scan
+    int cap;
+};
+
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// np.interp(v, axm[:, 0], axm[:, 1])
+__device__ __forceinline__ double interp_axm(double v, const DevVelParams& p)
+{
+    const double* t = p.axm; const int n = p.n_axm;
+    if (n == 1 || v <= t[0]) return t[1];
+    if (v >= t[2 * (n - 1)]) return t[2 * (n - 1) + 1];
+    int j = 0;
+    while (j + 1 < n && t[2 * (j + 1)] <= v) ++j;
+    const double x0 = t[2 * j], x1 = t[2 * (j + 1)], f0 = t[2 * j + 1], f1 = t[2 * (j + 1) + 1];
+    return (f1 - f0) / (x1 - x0) * (v - x0) + f0;
+}
+
+// tire share of tph calc_ax_poss: ax_max * (1 - (ay_used / ay_max)^e)^(1/e), 0 when the radicand is not positive
+__device__ __forceinline__ double tire_avail(double q, double ax_max, const DevVelParams& p)
+{
+    double rad;
+    if (p.e == 1.0) rad = 1.0 - q;
+    else if (p.e == 2.0) rad = 1.0 - q * q;
+    else rad = 1.0 - pow(q, p.e);
+    if (!(rad > 0.0)) return 0.0;
+    if (p.e == 1.0) return ax_max * rad;
+    if (p.e == 2.0) return ax_max * sqrt(rad);
+    return ax_max * pow(rad, p.inv_e);
+}
+
+#define VMODE_ACCEL_FORW 0
+#define VMODE_DECEL_FORW 1
+#define VMODE_DECEL_BACKW 2
+
+// tph calc_ax_poss in w = v^2; kabs = 1 / radius
+__device__ __forceinline__ double ax_poss_w(double w, double kabs, double ax_max, double ay_max, const DevVelParams& p,
+                                            int mode)
+{
+    const double q = (w * kabs) / ay_max;
+    double ax = tire_avail(q, fabs(ax_max), p);
+    if (mode == VMODE_ACCEL_FORW) {
+        const double axm = (p.n_axm == 1) ? p.axm[1] : interp_axm(sqrt(w), p);
+        ax = ax < axm ? ax : axm;
+        return ax - w * p.drag_m;
+    }
+    if (mode == VMODE_DECEL_FORW) return -ax - w * p.drag_m;
+    return ax + w * p.drag_m;
+}
+
+// one sweep of tph __solver_fb_acc_profile on w[0..n) (lane 0). Backward sweeps address the profile, curvature and
+// element lengths mirrored but -- restated quirk of the reference solver -- the gg limits unmirrored.
+__device__ void fb_sweep(int n, const VelScratch& vs, double cax, double cay, const DevVelParams& p, double vmax2,
+                         bool backwards, int lane)
+{
+    // run starts: first index of every run of positive differences of the (mirrored) profile
+    for (int i = lane; i < n - 1; i += 64) {
+        const int a = backwards ? n - 1 - i : i, b = backwards ? n - 2 - i : i + 1;
+        bool acc = vs.w[b] - vs.w[a] > 0.0;
+        bool prev = false;
+        if (i > 0) { const int a0 = backwards ? n - i : i - 1, b0 = backwards ? n - 1 - i : i; prev = vs.w[b0] - vs.w[a0] > 0.0; }
+        vs.start[i] = (acc && !prev) ? 1 : 0;
+    }
+    wave_sync_lds();
+    if (lane == 0) {
+        bool active = false;
+        const int mode = backwards ? VMODE_DECEL_BACKW : VMODE_ACCEL_FORW;
+        for (int i = 0; i < n - 1; ++i) {
+            if (vs.start[i]) active = true;
+            if (!active) continue;
+            const int pi = backwards ? n - 1 - i : i, pn = backwards ? n - 2 - i : i + 1;
+            const int ei = backwards ? n - 2 - i : i;
+            const double wi = vs.w[pi];
+            const double ax0 = vs.gax ? vs.gax[i] : cax, ay0 = vs.gay ? vs.gay[i] : cay;
+            const double acur = ax_poss_w(wi, vs.kabs[pi], ax0, ay0, p, mode);
+            double wn = wi + 2.0 * acur * vs.el[ei];
+            if (wn < 0.0) wn = 0.0;
+            if (backwards) {
+                const double ax1 = vs.gax ? vs.gax[i + 1] : cax, ay1 = vs.gay ? vs.gay[i + 1] : cay;
+                const double anext = ax_poss_w(wn, vs.kabs[pn], ax1, ay1, p, mode);
+                double wt = wi + 2.0 * anext * vs.el[ei];
+                if (wt < 0.0) wt = 0.0;
+                if (wt < wn) wn = wt;
+            }
+            if (wn < vs.w[pn]) vs.w[pn] = wn;
+            if (wn > vmax2) active = false;
+        }
+    }
+    wave_sync_lds();
+}
+
+// tph.calc_vel_profile(closed=False): vs.kabs / el / (gax, gay) hold the inputs, result in vs.w (as v^2)
+__device__ void fb_profile(int n, const VelScratch& vs, double cax, double cay, const DevVelParams& p, double v_max,
+                           double v_start, bool has_v_end, double v_end, int lane)
+{
+    if (v_start < 0.0) v_start = 0.0;
+    if (has_v_end && v_end < 0.0) v_end = 0.0;
+    const double vmax2 = v_max * v_max;
+    for (int i = lane; i < n; i += 64) {
+        const double ay = vs.gay ? vs.gay[i] : cay;
+        double w = ay / vs.kabs[i];                 // ay * radius; kappa == 0 -> inf
+        if (!(w < vmax2)) w = vmax2;
+        if (i == 0 && w > v_start * v_start) w = v_start * v_start;
+        vs.w[i] = w;
+    }
+    wave_sync_lds();
+    fb_sweep(n, vs, cax, cay, p, vmax2, false, lane);
+    if (lane == 0 && has_v_end && vs.w[n - 1] > v_end * v_end) vs.w[n - 1] = v_end * v_end;
+    wave_sync_lds();
+    fb_sweep(n, vs, cax, cay, p, vmax2, true, lane);
+}
+
+// tph.calc_vel_profile_brake on LDS arrays (lane 0): out[0..n) as v^2, zeros after standstill
+__device__ void brake_profile(int n, double* out, const double* kabs, const double* el, const double* gax,
+                              const double* gay, double cax, double cay, double v_start, const DevVelParams& p, int lane)
+{
+    for (int i = lane; i < n; i += 64) out[i] = 0.0;
+    wave_sync_lds();
+    if (lane == 0) {
+        double w = v_start * v_start;
+        out[0] = w;
+        for (int i = 0; i + 1 < n; ++i) {
+            const double a = ax_poss_w(w, kabs[i], gax ? gax[i] : cax, gay ? gay[i] : cay, p, VMODE_DECEL_FORW);
+            const double r = w + 2.0 * a * el[i];
+            if (r < 0.0) break;
+            w = r; out[i + 1] = w;
+        }
+    }
+    wave_sync_lds();
+}
+
+__device__ __forceinline__ double angle3pt_dev(double ax, double ay, double bx, double by, double cx, double cy)
+{
+    double ang = atan2(cy - by, cx - bx) - atan2(ay - by, ax - bx);
+    if (ang > D_PI) ang -= 2.0 * D_PI;
+    else if (ang <= -D_PI) ang += 2.0 * D_PI;
+    return ang;
+}
+
+// get_s_coord.py:8-99 on a strided polyline in global / LDS memory, all lanes take part; every lane returns s and idx0
+__device__ double get_s_coord_dev(int n, const double* x, const double* y, int stride, const double* s_arr, int s_stride,
+                                  double px, double py, bool closed, int lane, int* idx0)
+{
+    double bd = INFINITY, dummy = 0.0; int nb = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+        const double dx = x[(size_t)i * stride] - px, dy = y[(size_t)i * stride] - py;
+        const double d2 = dx * dx + dy * dy;
+        if (d2 < bd) { bd = d2; nb = i; }
+    }
+    wave_min3(bd, dummy, nb);
+    int i1, i2;
+    if (closed) { i1 = nb - 1; if (i1 < 0) i1 += n; i2 = nb + 1; if (i2 > n - 1) i2 = 0; }
+    else { i1 = nb - 1 > 0 ? nb - 1 : 0; i2 = nb + 1 < n - 1 ? nb + 1 : n - 1; }
+    const double nx = x[(size_t)nb * stride], ny = y[(size_t)nb * stride];
+    const double x1 = x[(size_t)i1 * stride], y1 = y[(size_t)i1 * stride];
+    const double x2 = x[(size_t)i2 * stride], y2 = y[(size_t)i2 * stride];
+    const double ang1 = fabs(angle3pt_dev(nx, ny, px, py, x1, y1));
+    const double ang2 = fabs(angle3pt_dev(nx, ny, px, py, x2, y2));
+    double ax, ay, bx, by;
+    if (ang1 > ang2) { ax = x1; ay = y1; bx = nx; by = ny; } else { ax = nx; ay = ny; bx = x2; by = y2; }
+    const double t = ((px - ax) * (bx - ax) + (py - ay) * (by - ay)) / ((bx - ax) * (bx - ax) + (by - ay) * (by - ay));
+    const double fx = ax + t * (bx - ax), fy = ay + t * (by - ay);
+    const double ds = sqrt((ax - fx) * (ax - fx) + (ay - fy) * (ay - fy));
+    const double s = (ang1 > ang2 ? s_arr[(size_t)i1 * s_stride] : s_arr[(size_t)nb * s_stride]) + ds;
+    if (idx0) *idx0 = (ang1 >= ang2) ? i1 : nb;
+    return s;
+}
+
+struct FollowIn { double v_start, v_ego, v_obj, safety_d, obj_dist, obj_x, obj_y; };
+
+// calc_vel_profile_follow.py:78-313. Inputs: vs.kabs[n], vs.el[n_el >= n] (tailing zero), gg; result vs.w (v^2).
+__device__ void follow_profile(const DevLat& lat, int n, int n_el, const VelScratch& vs, double cax, double cay,
+                               const DevVelParams& p, const FollowIn& fi, int lane, int* too_close, int* vel_bound)
+{
+    int vb = 1;
+    const double control_d = p.c_p * fi.safety_d + p.len_veh;                            // :141
+    const double safety_d = fi.safety_d + p.len_veh;                                     // :144
+    const int tc = (fi.obj_dist - safety_d) < 0.0;                                       // :147-149
+    const double v_max = p.v_max;
+
+    brake_profile(n, vs.wb, vs.kabs, vs.el, vs.gax, vs.gay, cax, cay, fi.v_start, p, lane);   // :152-159
+    // arc length s = [0, cumsum(el[:-1])] (:203) next to the ego stop distance (:162-166)
+    double ego_stop = 0.0;
+    if (lane == 0) {
+        int idb = 0;
+        while (idb < n && vs.wb[idb] > 0.01) ++idb;                                      // v > 0.1
+        double acc = 0.0;
+        for (int i = 0; i < idb && i < n_el; ++i) acc += vs.el[i];
+        ego_stop = acc;
+        vs.s[0] = 0.0;
+        for (int i = 1; i < n_el; ++i) vs.s[i] = vs.s[i - 1] + vs.el[i - 1];
+    }
+    ego_stop = __shfl(ego_stop, 0);
+
+    // opponent: closest point of the global race line (:172-179), brake scan with ggv [100, 14, 14] (:134,185-199)
+    const int G = lat.G - 1;
+    const double* grl = lat.glob_rl;
+    int idx_s_opp = 0;
+    (void)get_s_coord_dev(G, grl + 1, grl + 2, 5, grl, 5, fi.obj_x, fi.obj_y, true, lane, &idx_s_opp);
+    const double vel0 = grl[(size_t)idx_s_opp * 5 + 4];
+    const double vel_start = fi.v_obj < vel0 ? fi.v_obj : vel0;                          // :182
+    double opp_stop = 0.0, wopp = vel_start * vel_start;
+    int stopped = (wopp > 0.01) ? 0 : 1;                                                 // id_brake counts v > 0.1
+    for (int c0 = 0; c0 < G && !stopped; c0 += 64) {
+        const int i = c0 + lane;
+        if (i < G) {
+            int j = i + idx_s_opp; if (j >= G) j -= G;
+            vs.chunk[lane] = fabs(grl[(size_t)j * 5 + 3]);
+            vs.chunk[64 + lane] = grl[(size_t)(j + 1) * 5] - grl[(size_t)j * 5];
+        }
+        wave_sync_lds();
+        if (lane == 0) {
+            const int m = (G - c0) < 64 ? (G - c0) : 64;
+            for (int k = 0; k < m; ++k) {
+                // point c0 + k has v > 0.1: its element length counts towards the stop distance
+                opp_stop += vs.chunk[64 + k];
+                if (c0 + k + 1 >= G) { stopped = 1; break; }
+                const double a = ax_poss_w(wopp, vs.chunk[k], 14.0, 14.0, p, VMODE_DECEL_FORW);
+                const double r = wopp + 2.0 * a * vs.chunk[64 + k];
+                wopp = r < 0.0 ? 0.0 : r;                                                // standstill: profile stays 0
+                if (!(wopp > 0.01)) { stopped = 1; break; }
+            }
+        }
+        stopped = __shfl(stopped, 0);
+        wave_sync_lds();
+    }
+    opp_stop = __shfl(opp_stop, 0);
+
+    // characteristic indices (:201-221)
+    const double s_stop = fi.obj_dist - safety_d + opp_stop;                             // :206
+    int stop_idx = 0; double v_end = 0.0;
+    if (lane == 0) {
+        while (stop_idx < n_el - 1 && vs.s[stop_idx] < s_stop) ++stop_idx;               // :208-209
+        if (s_stop > vs.s[n_el - 1]) {                                                   // :212-221
+            const double s_ends = opp_stop - (s_stop - vs.s[n_el - 1]);
+            int idx = 0; double summed = 0.0;
+            while (summed < s_ends && idx < G) {
+                int j = idx + idx_s_opp; if (j >= G) j -= G;
+                summed += grl[(size_t)(j + 1) * 5] - grl[(size_t)j * 5];
+                ++idx;
+            }
+            int j = (idx % G) + idx_s_opp; if (j >= G) j -= G;
+            v_end = grl[(size_t)j * 5 + 4];
+        }
+    }
+    stop_idx = __shfl(stop_idx, 0); v_end = __shfl(v_end, 0);
+
+    // control velocity (:232-239, get_control_vel :28-75)
+    double v_control;
+    if (p.ctrl == 0) v_control = (fi.v_obj - p.k_p * (control_d - fi.obj_dist) + p.k_d * (fi.v_obj - fi.v_ego));
+    else {
+        double a = (control_d - fi.obj_dist) * D_PI / 2 * 1 / p.tan_w;
+        const double lo = -D_PI / 2 + 1e-5, hi = D_PI / 2 - 1e-5;
+        a = a < lo ? lo : (a > hi ? hi : a);
+        v_control = (fi.v_obj - tan(a) * p.k_p + p.k_d * (fi.v_obj - fi.v_ego));
+    }
+    if (v_control < 0.0) v_control = 0.0;
+    if (v_control > v_max) v_control = v_max;
+
+    // vs.wc <- "vx_profile" (:247-294)
+    if (ego_stop < s_stop) {
+        int idx_c = 0, n_decel = 0; double vcs = fi.v_start;      // vx_control_start
+        if (fi.v_start > v_control && stop_idx >= 2) {                                   // :250-258
+            const double wctl = v_control * v_control;
+            int first = 0x7fffffff;
+            for (int i = lane; i < n; i += 64) if (vs.wb[i] <= wctl) { first = i; break; }
+            double d1 = (double)first, d2 = 0.0; int di = first;
+            wave_min3(d1, d2, di);
+            idx_c = (di == 0x7fffffff) ? 0 : di;                                          // np.argmax of an all-False mask
+            if (idx_c > stop_idx) idx_c = stop_idx;
+            if (idx_c == 0) idx_c = stop_idx;
+            n_decel = idx_c + 1 < n ? idx_c + 1 : n;
+            vcs = sqrt(vs.wb[n_decel - 1]);
+        } else {
+            if (!(stop_idx >= 2)) vb = 0;                                                // :260-261
+        }
+        // SEGMENT 2 (:267-286): FB profile on [idx_c, stop_idx] capped at v_control
+        const int m = (stop_idx + 1 < n ? stop_idx + 1 : n) - idx_c;
+        if (stop_idx - idx_c > 0) {
+            VelScratch sub = vs;
+            sub.w = vs.wc + idx_c; sub.kabs = vs.kabs + idx_c; sub.el = vs.el + idx_c;
+            sub.gax = vs.gax ? vs.gax + idx_c : nullptr; sub.gay = vs.gay ? vs.gay + idx_c : nullptr;
+            fb_profile(m, sub, cax, cay, p, v_control, vcs, true, v_end, lane);
+            if (fabs(sqrt(vs.wc[idx_c]) - vcs) > 1.0) vb = 0;
+        } else if (stop_idx - idx_c == 0) {
+            if (lane == 0) vs.wc[idx_c] = vcs * vcs;
+        }
+        // vx_decel[:-1] in front, zeros behind (:289)
+        for (int i = lane; i < n; i += 64) {
+            if (i < n_decel - 1) vs.wc[i] = vs.wb[i];
+            else if (i > stop_idx) vs.wc[i] = 0.0;
+        }
+        wave_sync_lds();
+        if (fabs(sqrt(vs.wc[0]) - fi.v_start) > 1.0) vb = 0;                             // :291-292
+    } else {
+        for (int i = lane; i < n; i += 64) vs.wc[i] = vs.wb[i];                          // :294
+        wave_sync_lds();
+    }
+    // complete profile (:297-307) and intersection (:310)
+    fb_profile(n, vs, cax, cay, p, v_max, fi.v_start, false, 0.0, lane);
+    for (int i = lane; i < n; i += 64) { const double a = vs.wc[i], b = vs.w[i]; vs.w[i] = a < b ? a : b; }
+    wave_sync_lds();
+    *too_close = tc; *vel_bound = vb;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// kernels of the velocity seam and the fused tick
+// ---------------------------------------------------------------------------------------------------------------------
+struct DevVelJob {
+    int mode, n, n_el, has_v_end;
+    int off_kappa, off_el, off_gg, off_out;       // offsets (in doubles) into the pooled job arrays
+    double v_start, v_end, v_ego, v_obj, safety_d, obj_dist, obj_x, obj_y;
+};
+
+__device__ __forceinline__ VelScratch carve_vel_scratch(unsigned char* base, int cap, bool with_gg, bool with_xy,
+                                                        double** px, double** py)
+{
+    VelScratch vs;
+    double* d = reinterpret_cast<double*>(base);
+    const int c1 = cap + 2;
+    vs.w = d; d += c1; vs.kabs = d; d += c1; vs.el = d; d += c1; vs.s = d; d += c1; vs.wb = d; d += c1; vs.wc = d; d += c1;
+    if (with_gg) { vs.gax = d; d += c1; vs.gay = d; d += c1; } else { vs.gax = nullptr; vs.gay = nullptr; }
+    if (with_xy) { *px = d; d += c1; *py = d; d += c1; }
+    vs.chunk = d; d += 128;
+    vs.start = reinterpret_cast<unsigned char*>(d);
+    vs.cap = cap;
+    return vs;
+}
+
+static size_t vel_scratch_bytes(int cap, bool with_gg, bool with_xy)
+{
+    size_t arrays = 6 + (with_gg ? 2 : 0) + (with_xy ? 2 : 0);
+    size_t b = sizeof(double) * (arrays * (size_t)(cap + 2) + 128) + (size_t)cap + 16;
+    return (b + 15) / 16 * 16;
+}
+
+// seam (2): one wave per job
+__global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p, const DevVelJob* jobs,
+                                                    const double* pool, double* out_pool, int* out_flags, int cap)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const DevVelJob jb = jobs[blockIdx.x];
+    VelScratch vs = carve_vel_scratch(smem, cap, true, false, nullptr, nullptr);
+    const int n = jb.n;
+    for (int i = lane; i < n; i += 64) {
+        vs.kabs[i] = fabs(pool[jb.off_kappa + i]);
+        vs.gax[i] = pool[jb.off_gg + 2 * i];
+        vs.gay[i] = pool[jb.off_gg + 2 * i + 1];
+    }
+    for (int i = lane; i < jb.n_el; i += 64) vs.el[i] = pool[jb.off_el + i];
+    wave_sync_lds();
+    int too_close = 0, vel_bound = 1;
+    if (jb.mode == LTPL_VEL_FB) {
+        fb_profile(n, vs, 0.0, 0.0, p, p.v_max, jb.v_start, jb.has_v_end != 0, jb.v_end, lane);
+    } else if (jb.mode == LTPL_VEL_BRAKE) {
+        brake_profile(n, vs.w, vs.kabs, vs.el, vs.gax, vs.gay, 0.0, 0.0, jb.v_start, p, lane);
+    } else {
+        FollowIn fi; fi.v_start = jb.v_start; fi.v_ego = jb.v_ego; fi.v_obj = jb.v_obj; fi.safety_d = jb.safety_d;
+        fi.obj_dist = jb.obj_dist; fi.obj_x = jb.obj_x; fi.obj_y = jb.obj_y;
+        follow_profile(lat, n, jb.n_el, vs, 0.0, 0.0, p, fi, lane, &too_close, &vel_bound);
+    }
+    for (int i = lane; i < n; i += 64) out_pool[jb.off_out + i] = sqrt(vs.w[i]);
+    if (lane == 0) { out_flags[2 * blockIdx.x] = too_close; out_flags[2 * blockIdx.x + 1] = vel_bound; }
+}
+
+struct DevTickVelIn {
+    double gg_ax, gg_ay, safety_d, v_max_offset;
+    const double* vel_plan; const double* vel_est; const double* pos_est_x; const double* pos_est_y;
+    const double* veh_vel;
+};
+struct DevTickVelOut { double* vx; double* ax; int* vel_bound; int* too_close; };
+
+// per-primitive velocity stage of OnlineTrajectoryHandler.calc_vel_profile (OTH.py:688-941) on a fresh path:
+// cut_index_pos = 0, vel_course empty, no brake prefix (the host rejects vel_plan > v_max + 0.1, for which the
+// reference itself fails at OTH.py:919 because the prefix it computes is never merged back)
+__device__ void tick_vel_stage(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const WavePath& wp,
+                               const VelScratch& vs, const double* px, const double* py, const DevVelParams& p,
+                               const DevTickVelIn& vin, const DevTickVelOut& vout, int s, int slot, int lane)
+{
+    const int n = wp.n_pts;
+    const double vel_plan = vin.vel_plan[s];
+    const double cax = vin.gg_ax, cay = vin.gg_ay;
+    for (int i = lane; i < n; i += 64) vs.kabs[i] = fabs(vs.kabs[i]);
+    if (lane == 0) {
+        // s = [0, cumsum(el[:-1])] (OTH.py:743), one extra entry for get_s_coord's zero-prefixed cumsum (:777)
+        vs.s[0] = 0.0;
+        for (int i = 1; i <= n; ++i) vs.s[i] = vs.s[i - 1] + vs.el[i - 1];
+    }
+    wave_sync_lds();
+    int too_close = 0, vel_bound = 1;
+    bool have_follow = false;
+    if (wp.name == LTPL_ACT_FOLLOW) {                                                    // OTH.py:763-830
+        FollowIn fi; fi.v_start = vel_plan; fi.v_ego = vin.vel_est[s]; fi.safety_d = vin.safety_d;
+        const int ci = out.closest_obj_index[s];
+        const int v0 = in.veh_off[s];
+        if (ci < 0 || ci >= in.veh_off[s + 1] - v0) {
+            fi.obj_dist = 0.0; fi.v_obj = 0.0; fi.obj_x = vin.pos_est_x[s]; fi.obj_y = vin.pos_est_y[s];
+        } else {
+            const int pp = in.pos_off[v0 + ci];
+            fi.obj_x = in.pos_x[pp]; fi.obj_y = in.pos_y[pp]; fi.v_obj = vin.veh_vel[v0 + ci];
+            const double s_obj = get_s_coord_dev(n, px, py, 1, vs.s, 1, fi.obj_x, fi.obj_y, false, lane, nullptr);
+            const double s_sta = get_s_coord_dev(n, px, py, 1, vs.s, 1, vin.pos_est_x[s], vin.pos_est_y[s], false, lane, nullptr);
+            fi.obj_dist = s_obj - s_sta;
+        }
+        // follow_profile rebuilds vs.s as [0, cumsum(el[:-1])] for n_el = n: identical values
+        follow_profile(lat, n, n, vs, cax, cay, p, fi, lane, &too_close, &vel_bound);
+        have_follow = true;
+    }
+    if (wp.name != LTPL_ACT_FOLLOW || wp.reduced) {                                      // OTH.py:834-923
+        if (have_follow) { for (int i = lane; i < n; i += 64) vs.wb[i] = vs.w[i]; wave_sync_lds(); }
+        const int rl = lat.rl_idx[wp.goal_layer];
+        int dn = wp.end_node - rl; if (dn < 0) dn = -dn;
+        const double raceline_offset = (double)dn * lat.lat_offset;
+        double v_end; int v_idx;
+        if (wp.reduced) {
+            v_end = 0.0;
+            const double spl_len = vs.s[n - 1];
+            int first = 0x7fffffff;
+            for (int i = lane; i < n - 1; i += 64) if (!(vs.s[i + 1] < (spl_len - 5.0))) { first = i; break; }
+            double d1 = (double)first, d2 = 0.0; int di = first;
+            wave_min3(d1, d2, di);
+            v_idx = ((di == 0x7fffffff) ? 0 : di) + 1;
+            if (v_idx == 1 && n > 1) v_idx = n;
+        } else {
+            v_end = lat.vel_rl[wp.goal_layer];
+            const double red = v_end * lat.vel_decrease_lat * raceline_offset;
+            v_end -= (red < v_end ? red : v_end);
+            v_idx = n;
+        }
+        if (v_idx > 1) fb_profile(v_idx, vs, cax, cay, p, p.v_max, vel_plan, true, v_end, lane);
+        else { if (lane == 0) vs.w[0] = 0.0; }
+        for (int i = (v_idx > 1 ? v_idx : 1) + lane; i < n; i += 64) vs.w[i] = 0.0;         // OTH.py:901-903
+        wave_sync_lds();
+        vel_bound = fabs(sqrt(vs.w[0]) - vel_plan) < vin.v_max_offset ? 1 : 0;           // OTH.py:906-911
+        if (have_follow && n >= 6) {
+            // OTH.py:923 compares ROW 5 of both arrays; only column 5 (vx) can differ, so the whole profile switches
+            const bool take_follow = sqrt(vs.wb[5]) < sqrt(vs.w[5]);
+            if (take_follow) { for (int i = lane; i < n; i += 64) vs.w[i] = vs.wb[i]; wave_sync_lds(); }
+        }
+    }
+    // finalise (OTH.py:925-941): filt_window == 1 is the identity; ax from neighbouring points, -5 at standstill
+    double* o_vx = vout.vx + (size_t)slot * out.cap_pts;
+    double* o_ax = vout.ax + (size_t)slot * out.cap_pts;
+    for (int i = lane; i < n; i += 64) {
+        const double wi = vs.w[i];
+        const double v = sqrt(wi);
+        o_vx[i] = v;
+        double a = 0.0;
+        if (i < n - 1) {
+            a = (vs.w[i + 1] - wi) / (2.0 * (vs.s[i + 1] - vs.s[i]));
+            if (fabs(v) <= 1e-8 && fabs(a) <= 1e-8) a = -5.0;
+        }
+        o_ax[i] = a;
+    }
+    if (lane == 0) { vout.vel_bound[slot] = vel_bound; vout.too_close[slot] = too_close; }
+}
+
+__global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, DevPathsOut out, LdsPlan lp,
+                                                     DevVelParams p, DevTickVelIn vin, DevTickVelOut vout,
+                                                     int vel_off, int vel_stride, int vel_cap)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ TickShared ts;
+    __shared__ int sh_pos_layer[MAX_POS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    VelScratch vs; double* px = nullptr; double* py = nullptr;
+    if (wave < LTPL_MAX_ACTIONS) vs = carve_vel_scratch(smem + vel_off + (size_t)wave * vel_stride, vel_cap, false, true, &px, &py);
+    WavePath wp = plan_paths_body(lat, in, out, lp, smem, ts, sh_pos_layer, wave < LTPL_MAX_ACTIONS ? vs.kabs : nullptr,
+                                  wave < LTPL_MAX_ACTIONS ? vs.el : nullptr, px, py);
+    const int s = blockIdx.x;
+    if (wave < LTPL_MAX_ACTIONS) {
+        const int slot = s * LTPL_MAX_ACTIONS + wave;
+        if (wp.valid) tick_vel_stage(lat, in, out, wp, vs, px, py, p, vin, vout, s, slot, lane);
+        else if (lane == 0) { vout.vel_bound[slot] = 0; vout.too_close[slot] = 0; }
     }
 }
 
@@ -575,6 +1110,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_plan_paths(DevLat lat, DevPathsI
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 static thread_local std::string g_create_error;
+struct TickLayout;
+static void free_resident(TickLayout* t);
 
 struct ltpl_handle {
     int device = 0;
@@ -589,6 +1126,7 @@ struct ltpl_handle {
     void* d_in = nullptr; size_t d_in_cap = 0;
     void* h_out = nullptr; size_t h_out_cap = 0;
     void* d_out = nullptr; size_t d_out_cap = 0;
+    struct TickLayout* resident = nullptr;   // device-resident batch of ltpl_batch_upload
 };
 
 #define HIP_TRY(h, call)                                                                                              \
@@ -680,6 +1218,7 @@ extern "C" int ltpl_destroy(ltpl_handle* h)
     if (h->h_in) (void)hipHostFree(h->h_in);
     if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    free_resident(h->resident);
     delete h;
     return LTPL_OK;
 }
@@ -943,29 +1482,263 @@ extern "C" int ltpl_plan_paths(ltpl_handle* h, const ltpl_paths_in* in, ltpl_pat
     return LTPL_OK;
 }
 
-// --- velocity seam / fused tick: implemented in the next build step ---------------------------------------------------
-extern "C" int ltpl_vel_profile(ltpl_handle* h, const ltpl_vel_params*, int, const ltpl_vel_job*, ltpl_vel_result*)
+// --- velocity seam / fused tick ---------------------------------------------------------------------------------------
+static int make_vel_params(ltpl_handle* h, const ltpl_vel_params* vp, const double* d_axm, DevVelParams* p)
+{
+    if (!vp || vp->n_ax_max_machines < 1 || !vp->ax_max_machines) { h->err = "ax_max_machines missing"; return LTPL_ERR_INVALID_ARG; }
+    if (!(vp->dyn_model_exp > 0.0) || !(vp->m_veh > 0.0)) { h->err = "invalid vehicle parameters"; return LTPL_ERR_INVALID_ARG; }
+    p->e = vp->dyn_model_exp; p->inv_e = 1.0 / vp->dyn_model_exp; p->drag_m = vp->drag_coeff / vp->m_veh;
+    p->len_veh = vp->len_veh; p->v_max = vp->v_max; p->n_axm = vp->n_ax_max_machines; p->ctrl = vp->follow_control_type;
+    p->axm = d_axm; p->c_p = vp->c_p; p->k_p = vp->k_p; p->k_d = vp->k_d; p->tan_w = vp->tan_w;
+    return LTPL_OK;
+}
+
+extern "C" int ltpl_vel_profile(ltpl_handle* h, const ltpl_vel_params* vp, int n_jobs, const ltpl_vel_job* jobs,
+                                ltpl_vel_result* results)
 {
     if (!h) return LTPL_ERR_INVALID_ARG;
-    h->err = "ltpl_vel_profile: not built yet"; return LTPL_ERR_UNSUPPORTED;
+    if (n_jobs < 1 || !jobs || !results) { h->err = "no jobs"; return LTPL_ERR_INVALID_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    // pooled layout: [axm table][jobs][kappa | el | gg per job] ; outputs: [flags][vx per job]
+    Arena ain, aout;
+    const size_t o_axm = ain.add(sizeof(double) * 2 * (size_t)(vp ? vp->n_ax_max_machines : 1));
+    const size_t o_jobs = ain.add(sizeof(DevVelJob) * (size_t)n_jobs);
+    const size_t o_pool = ain.add(0);
+    size_t pool_doubles = 0, out_doubles = 0; int cap = 0;
+    std::vector<DevVelJob> dj((size_t)n_jobs);
+    for (int j = 0; j < n_jobs; ++j) {
+        const ltpl_vel_job& jb = jobs[j];
+        if (jb.n < 1 || !jb.kappa || !jb.loc_gg || !results[j].vx) { h->err = "job without data"; return LTPL_ERR_INVALID_ARG; }
+        if (jb.mode == LTPL_VEL_FOLLOW) { if (jb.n_el < jb.n) { h->err = "follow: el_lengths shorter than kappa"; return LTPL_ERR_INVALID_ARG; } }
+        else if (jb.mode == LTPL_VEL_FB || jb.mode == LTPL_VEL_BRAKE) {
+            if (jb.n_el != jb.n - 1) { h->err = "kappa must have the length of el_lengths + 1"; return LTPL_ERR_INVALID_ARG; }
+        } else { h->err = "unknown velocity mode"; return LTPL_ERR_INVALID_ARG; }
+        DevVelJob& d = dj[(size_t)j];
+        d.mode = jb.mode; d.n = jb.n; d.n_el = jb.n_el; d.has_v_end = jb.has_v_end;
+        d.off_kappa = (int)pool_doubles; pool_doubles += (size_t)jb.n;
+        d.off_el = (int)pool_doubles; pool_doubles += (size_t)jb.n_el;
+        d.off_gg = (int)pool_doubles; pool_doubles += 2 * (size_t)jb.n;
+        d.off_out = (int)out_doubles; out_doubles += (size_t)jb.n;
+        d.v_start = jb.v_start; d.v_end = jb.v_end; d.v_ego = jb.v_ego; d.v_obj = jb.v_obj; d.safety_d = jb.safety_d;
+        d.obj_dist = jb.obj_dist; d.obj_x = jb.obj_x; d.obj_y = jb.obj_y;
+        const int need = jb.n_el > jb.n ? jb.n_el : jb.n;
+        if (need > cap) cap = need;
+    }
+    ain.add(sizeof(double) * pool_doubles);
+    const size_t o_flags = aout.add(sizeof(int) * 2 * (size_t)n_jobs);
+    const size_t o_vx = aout.add(sizeof(double) * out_doubles);
+    const size_t lds = vel_scratch_bytes(cap, true, false);
+    if (lds > 150 * 1024) { h->err = "velocity profile too long for the LDS-resident solver"; return LTPL_ERR_CAPACITY; }
+    int rc;
+    if ((rc = ensure(h, &h->h_in, &h->h_in_cap, &h->d_in, &h->d_in_cap, ain.size))) return rc;
+    if ((rc = ensure(h, &h->h_out, &h->h_out_cap, &h->d_out, &h->d_out_cap, aout.size))) return rc;
+    unsigned char* hb = static_cast<unsigned char*>(h->h_in);
+    unsigned char* db = static_cast<unsigned char*>(h->d_in);
+    DevVelParams p;
+    if ((rc = make_vel_params(h, vp, reinterpret_cast<const double*>(db + o_axm), &p))) return rc;
+    memcpy(hb + o_axm, vp->ax_max_machines, sizeof(double) * 2 * (size_t)vp->n_ax_max_machines);
+    memcpy(hb + o_jobs, dj.data(), sizeof(DevVelJob) * (size_t)n_jobs);
+    double* pool = reinterpret_cast<double*>(hb + o_pool);
+    for (int j = 0; j < n_jobs; ++j) {
+        const ltpl_vel_job& jb = jobs[j]; const DevVelJob& d = dj[(size_t)j];
+        memcpy(pool + d.off_kappa, jb.kappa, sizeof(double) * (size_t)jb.n);
+        if (jb.n_el > 0) memcpy(pool + d.off_el, jb.el_lengths, sizeof(double) * (size_t)jb.n_el);
+        memcpy(pool + d.off_gg, jb.loc_gg, sizeof(double) * 2 * (size_t)jb.n);
+    }
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_vel_profile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, ain.size, hipMemcpyHostToDevice, h->stream));
+    unsigned char* dob = static_cast<unsigned char*>(h->d_out);
+    hipLaunchKernelGGL(k_vel_profile, dim3(n_jobs), dim3(64), lds, h->stream, h->lat, p,
+                       reinterpret_cast<const DevVelJob*>(db + o_jobs), reinterpret_cast<const double*>(db + o_pool),
+                       reinterpret_cast<double*>(dob + o_vx), reinterpret_cast<int*>(dob + o_flags), cap);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, aout.size, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const unsigned char* ho = static_cast<const unsigned char*>(h->h_out);
+    const int* flags = reinterpret_cast<const int*>(ho + o_flags);
+    const double* vx = reinterpret_cast<const double*>(ho + o_vx);
+    for (int j = 0; j < n_jobs; ++j) {
+        memcpy(results[j].vx, vx + dj[(size_t)j].off_out, sizeof(double) * (size_t)jobs[j].n);
+        results[j].too_close = flags[2 * j]; results[j].vel_bound = flags[2 * j + 1];
+    }
+    return LTPL_OK;
 }
-extern "C" int ltpl_tick_batch(ltpl_handle* h, const ltpl_paths_in*, const ltpl_tick_vel_in*, ltpl_paths_out*, ltpl_tick_vel_out*)
+
+// ---- fused tick ------------------------------------------------------------------------------------------------------
+struct TickLayout {
+    InLayout in; size_t axm, vel_plan, vel_est, pos_x, pos_y, veh_vel, in_total;
+    OutLayout out; size_t vx, ax, vel_bound, too_close, out_total;
+    int n_scen, cap_nodes, cap_pts;
+    DevPathsIn di; DevPathsOut dout; DevVelParams p; DevTickVelIn dvin; DevTickVelOut dvout;
+    int vel_off, vel_stride, vel_cap; size_t lds;
+};
+
+static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin, int cap_nodes, int cap_pts,
+                        TickLayout* t)
+{
+    int rc = validate_and_layout(h, in, &t->in);
+    if (rc) return rc;
+    if (!vin || !vin->params) { h->err = "velocity inputs missing"; return LTPL_ERR_INVALID_ARG; }
+    if (cap_nodes < h->caps.max_path_nodes || cap_pts < h->caps.max_path_pts) { h->err = "output capacity too small"; return LTPL_ERR_CAPACITY; }
+    const int n = in->n_scen;
+    for (int s = 0; s < n; ++s)
+        if (vin->vel_plan[s] > vin->params->v_max + 0.1) {
+            h->err = "vel_plan > v_max + 0.1: the brake-prefix branch is not part of the fused tick (the reference raises at OTH.py:919)";
+            return LTPL_ERR_UNSUPPORTED;
+        }
+    t->n_scen = n; t->cap_nodes = cap_nodes; t->cap_pts = cap_pts;
+    Arena a; a.size = t->in.total;
+    t->axm = a.add(sizeof(double) * 2 * (size_t)vin->params->n_ax_max_machines);
+    t->vel_plan = a.add(sizeof(double) * (size_t)n); t->vel_est = a.add(sizeof(double) * (size_t)n);
+    t->pos_x = a.add(sizeof(double) * (size_t)n); t->pos_y = a.add(sizeof(double) * (size_t)n);
+    t->veh_vel = a.add(sizeof(double) * (size_t)(t->in.n_veh + 1));
+    t->in_total = a.size;
+    layout_out(n, cap_nodes, cap_pts, &t->out);
+    Arena b; b.size = t->out.total;
+    t->vx = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS * (size_t)cap_pts);
+    t->ax = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS * (size_t)cap_pts);
+    t->vel_bound = b.add(sizeof(int) * (size_t)n * LTPL_MAX_ACTIONS);
+    t->too_close = b.add(sizeof(int) * (size_t)n * LTPL_MAX_ACTIONS);
+    t->out_total = b.size;
+    t->vel_cap = h->caps.max_path_pts;
+    t->vel_stride = (int)vel_scratch_bytes(t->vel_cap, false, true);
+    t->vel_off = h->lp.total;
+    t->lds = (size_t)h->lp.total + (size_t)t->vel_stride * LTPL_MAX_ACTIONS;
+    if (t->lds > 150 * 1024) { h->err = "fused tick exceeds the LDS budget"; return LTPL_ERR_CAPACITY; }
+    return LTPL_OK;
+}
+
+static int tick_pack(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin, TickLayout* t,
+                     unsigned char* hb, unsigned char* db, unsigned char* dob)
+{
+    pack_in(in, t->in, hb, db, &t->di);
+    const int n = in->n_scen;
+    memcpy(hb + t->axm, vin->params->ax_max_machines, sizeof(double) * 2 * (size_t)vin->params->n_ax_max_machines);
+    memcpy(hb + t->vel_plan, vin->vel_plan, sizeof(double) * (size_t)n);
+    memcpy(hb + t->vel_est, vin->vel_est, sizeof(double) * (size_t)n);
+    memcpy(hb + t->pos_x, vin->pos_est_x, sizeof(double) * (size_t)n);
+    memcpy(hb + t->pos_y, vin->pos_est_y, sizeof(double) * (size_t)n);
+    if (t->in.n_veh > 0) memcpy(hb + t->veh_vel, vin->veh_vel, sizeof(double) * (size_t)t->in.n_veh);
+    int rc = make_vel_params(h, vin->params, reinterpret_cast<const double*>(db + t->axm), &t->p);
+    if (rc) return rc;
+    t->dvin.gg_ax = vin->gg_ax; t->dvin.gg_ay = vin->gg_ay; t->dvin.safety_d = vin->safety_d;
+    t->dvin.v_max_offset = vin->v_max_offset;
+    t->dvin.vel_plan = reinterpret_cast<const double*>(db + t->vel_plan);
+    t->dvin.vel_est = reinterpret_cast<const double*>(db + t->vel_est);
+    t->dvin.pos_est_x = reinterpret_cast<const double*>(db + t->pos_x);
+    t->dvin.pos_est_y = reinterpret_cast<const double*>(db + t->pos_y);
+    t->dvin.veh_vel = reinterpret_cast<const double*>(db + t->veh_vel);
+    bind_out(dob, t->out, t->cap_nodes, t->cap_pts, &t->dout);
+    t->dvout.vx = reinterpret_cast<double*>(dob + t->vx); t->dvout.ax = reinterpret_cast<double*>(dob + t->ax);
+    t->dvout.vel_bound = reinterpret_cast<int*>(dob + t->vel_bound);
+    t->dvout.too_close = reinterpret_cast<int*>(dob + t->too_close);
+    return LTPL_OK;
+}
+
+static int tick_launch(ltpl_handle* h, const TickLayout& t)
+{
+    hipLaunchKernelGGL(k_tick, dim3(t.n_scen), dim3(WG_THREADS), t.lds, h->stream, h->lat, t.di, t.dout, h->lp, t.p,
+                       t.dvin, t.dvout, t.vel_off, t.vel_stride, t.vel_cap);
+    HIP_TRY(h, hipGetLastError());
+    return LTPL_OK;
+}
+
+static void tick_scatter(const unsigned char* hb, const TickLayout& t, ltpl_paths_out* out, ltpl_tick_vel_out* vout)
+{
+    scatter_out(hb, t.out, t.n_scen, out);
+    const size_t A = LTPL_MAX_ACTIONS, n = (size_t)t.n_scen;
+    if (out->cap_pts == t.cap_pts) {
+        memcpy(vout->vx, hb + t.vx, sizeof(double) * n * A * (size_t)t.cap_pts);
+        memcpy(vout->ax, hb + t.ax, sizeof(double) * n * A * (size_t)t.cap_pts);
+    }
+    memcpy(vout->vel_bound, hb + t.vel_bound, sizeof(int) * n * A);
+    memcpy(vout->too_close, hb + t.too_close, sizeof(int) * n * A);
+}
+
+static int tick_set_lds_limit(ltpl_handle* h, size_t lds)
+{
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return LTPL_OK;
+}
+
+extern "C" int ltpl_tick_batch(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin, ltpl_paths_out* out,
+                               ltpl_tick_vel_out* vout)
 {
     if (!h) return LTPL_ERR_INVALID_ARG;
-    h->err = "ltpl_tick_batch: not built yet"; return LTPL_ERR_UNSUPPORTED;
+    if (!out || !vout) { h->err = "null output"; return LTPL_ERR_INVALID_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    TickLayout t;
+    int rc = tick_prepare(h, in, vin, out->cap_nodes, out->cap_pts, &t);
+    if (rc) return rc;
+    if ((rc = ensure(h, &h->h_in, &h->h_in_cap, &h->d_in, &h->d_in_cap, t.in_total))) return rc;
+    if ((rc = ensure(h, &h->h_out, &h->h_out_cap, &h->d_out, &h->d_out_cap, t.out_total))) return rc;
+    if ((rc = tick_pack(h, in, vin, &t, static_cast<unsigned char*>(h->h_in), static_cast<unsigned char*>(h->d_in),
+                        static_cast<unsigned char*>(h->d_out)))) return rc;
+    if ((rc = tick_set_lds_limit(h, t.lds))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, t.in_total, hipMemcpyHostToDevice, h->stream));
+    if ((rc = tick_launch(h, t))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, t.out_total, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    tick_scatter(static_cast<const unsigned char*>(h->h_out), t, out, vout);
+    return LTPL_OK;
 }
-extern "C" int ltpl_batch_upload(ltpl_handle* h, const ltpl_paths_in*, const ltpl_tick_vel_in*, int32_t, int32_t)
+
+// device-resident batch (benchmarks): inputs stay in HBM, the fused kernel is replayed on the handle's stream
+extern "C" int ltpl_batch_upload(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin, int32_t cap_nodes,
+                                 int32_t cap_pts)
 {
     if (!h) return LTPL_ERR_INVALID_ARG;
-    h->err = "ltpl_batch_upload: not built yet"; return LTPL_ERR_UNSUPPORTED;
+    HIP_TRY(h, hipSetDevice(h->device));
+    delete h->resident; h->resident = nullptr;
+    TickLayout* t = new TickLayout();
+    int rc = tick_prepare(h, in, vin, cap_nodes, cap_pts, t);
+    if (rc) { delete t; return rc; }
+    if ((rc = ensure(h, &h->h_in, &h->h_in_cap, &h->d_in, &h->d_in_cap, t->in_total))) { delete t; return rc; }
+    if ((rc = ensure(h, &h->h_out, &h->h_out_cap, &h->d_out, &h->d_out_cap, t->out_total))) { delete t; return rc; }
+    if ((rc = tick_pack(h, in, vin, t, static_cast<unsigned char*>(h->h_in), static_cast<unsigned char*>(h->d_in),
+                        static_cast<unsigned char*>(h->d_out)))) { delete t; return rc; }
+    if ((rc = tick_set_lds_limit(h, t->lds))) { delete t; return rc; }
+    HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, t->in_total, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->resident = t;
+    return LTPL_OK;
 }
-extern "C" int ltpl_batch_run(ltpl_handle* h, int, float*)
+
+extern "C" int ltpl_batch_run(ltpl_handle* h, int reps, float* ms_total)
 {
     if (!h) return LTPL_ERR_INVALID_ARG;
-    h->err = "ltpl_batch_run: not built yet"; return LTPL_ERR_UNSUPPORTED;
+    if (!h->resident) { h->err = "no resident batch: call ltpl_batch_upload first"; return LTPL_ERR_INVALID_ARG; }
+    if (reps < 1) { h->err = "reps < 1"; return LTPL_ERR_INVALID_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ms_total) {
+        HIP_TRY(h, hipEventCreate(&e0)); HIP_TRY(h, hipEventCreate(&e1));
+        HIP_TRY(h, hipEventRecord(e0, h->stream));
+    }
+    for (int r = 0; r < reps; ++r) { int rc = tick_launch(h, *h->resident); if (rc) return rc; }
+    if (ms_total) {
+        HIP_TRY(h, hipEventRecord(e1, h->stream));
+        HIP_TRY(h, hipEventSynchronize(e1));
+        HIP_TRY(h, hipEventElapsedTime(ms_total, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    return LTPL_OK;
 }
-extern "C" int ltpl_batch_download(ltpl_handle* h, ltpl_paths_out*, ltpl_tick_vel_out*)
+
+extern "C" int ltpl_batch_download(ltpl_handle* h, ltpl_paths_out* out, ltpl_tick_vel_out* vout)
 {
     if (!h) return LTPL_ERR_INVALID_ARG;
-    h->err = "ltpl_batch_download: not built yet"; return LTPL_ERR_UNSUPPORTED;
+    if (!h->resident) { h->err = "no resident batch"; return LTPL_ERR_INVALID_ARG; }
+    if (!out || !vout || out->cap_nodes != h->resident->cap_nodes || out->cap_pts != h->resident->cap_pts) {
+        h->err = "output capacities differ from ltpl_batch_upload"; return LTPL_ERR_INVALID_ARG;
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, h->resident->out_total, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    tick_scatter(static_cast<const unsigned char*>(h->h_out), *h->resident, out, vout);
+    return LTPL_OK;
 }
+
+static void free_resident(TickLayout* t) { delete t; }
