@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""
+bench.py -- planning ticks/s of the fused MI355X tick (seam 1 + per-primitive velocity stage) on the C2 workload.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one launch of the fused tick kernel over one batch of independent C2 scenarios (Monteblanco lattice, 4
+action primitives, 8 dynamic opponents with a 0.2 s prediction each = 16 obstacle positions, sample zone) whose
+inputs are already resident in HBM (ltpl_batch_upload). Every rank owns one GPU and its own shard of scenarios (weak
+scaling, no data-path collective: scenarios are independent); torch.distributed (RCCL) is only used for
+the barrier and the max-over-ranks of the timed region.
+
+The JSON line also carries
+  roofline      algorithmic bytes per launch (graphbasedlocaltrajectoryplanner_amd/roofline.py) divided by
+                the kernel's average duration measured with HIP events on the library's own stream, against the 8 TB/s
+                HBM peak of MI355X; `traffic` = HBM bytes per launch from the rocprofv3 PMC passes, if profiles/ holds them
+  cpu_baseline  the oracle's plain-C restatement (kind "port", 1 core) timed on a bounded sample of the same scenarios
+  latency_us    p50 / p99 of single-scenario ticks through ltpl_tick_batch including all host marshalling and PCIe
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from graphbasedlocaltrajectoryplanner_amd import _capi                       # noqa: E402
+from graphbasedlocaltrajectoryplanner_amd.lattice import Lattice             # noqa: E402
+from graphbasedlocaltrajectoryplanner_amd.roofline import algorithmic_bytes  # noqa: E402
+from graphbasedlocaltrajectoryplanner_amd.scenario_gen import c2_scenarios   # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def make_batch(lat, n, seed):
+    scen, vels = c2_scenarios(lat, n, seed=seed)
+    rng = np.random.default_rng(seed + 77)
+    params = _capi.VelParamSet(len_veh=lat.veh_length)      # Graph_LTPL.calc_vel_profile defaults (Graph_LTPL.py:347-351)
+    vplan = rng.uniform(5.0, 60.0, n)
+    pos = np.array([lat.node_pos[lat.layer_off[s['start_node'][0]] + s['start_node'][1]] for s in scen])
+    batch = _capi.PathsBatch(scen, w_last_edges=[0.0, 0.5, 0.8])       # params/ltpl_config_online.ini:71
+    vel = _capi.TickVelBatch(params, n, vplan, vplan, pos, np.concatenate(vels))
+    return scen, batch, vel
+
+
+def cpu_baseline(lat, scen_batch, vel, n_sample):
+    """Oracle (plain-C restatement, oracle/ltpl_oracle.c) on the first n_sample scenarios of rank 0's shard, 1 core."""
+    from oracle.oracle_lib import OracleBackend
+    orc = OracleBackend(lat)
+    scen = scen_batch[:n_sample]
+    batch = _capi.PathsBatch(scen, w_last_edges=[0.0, 0.5, 0.8])
+    n_veh = int(batch.veh_off[-1])
+    v = _capi.TickVelBatch(vel.params, len(scen), vel.vel_plan[:n_sample], vel.vel_est[:n_sample],
+                           np.column_stack((vel.pos_x[:n_sample], vel.pos_y[:n_sample])), vel.veh_vel[:n_veh])
+    orc.tick_batch(batch, v)                                    # warm caches
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        orc.tick_batch(batch, v)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 200:
+            break
+    return {"value": len(scen) * reps / el, "unit": "ticks/s", "cores": 1, "kind": "port",
+            "sample": "%d C2 scenarios x %d passes through oracle_tick_batch (plain C, -O2, single thread)"
+                      % (len(scen), reps)}
+
+
+def read_traffic():
+    """HBM bytes per launch from a committed rocprofv3 PMC summary, if present (profiles/pmc_traffic.json)."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.isfile(p):
+        try:
+            with open(p) as fh:
+                return json.load(fh).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=8192, help="scenarios per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--latency-ticks", type=int, default=2000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    lat = Lattice.load(os.path.join(ROOT, "tests", "golden", "monteblanco_lattice.npz"))
+    hip = _capi.HipBackend(lat, device=local_rank)
+    scen, batch, vel = make_batch(lat, args.batch, seed=1 + rank)
+    hip.batch_upload(batch, vel)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up (untimed)
+    for _ in range(args.warmup):
+        hip.batch_run(reps=1, timed=False)
+    barrier()
+    t0 = time.perf_counter()
+    ms_kernel = hip.batch_run(reps=args.steps, timed=True)      # HIP events on the library's stream + wait
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    res, vres = hip.batch_download()
+
+    if rank == 0:
+        ab = algorithmic_bytes(lat, batch, res)
+        kern_ms = ms_kernel / args.steps
+        achieved = ab["total"] / (kern_ms * 1e-3) / 1e9
+        n_paths = int(res.valid.sum())
+        # single-scenario latency through the synchronous C call (host marshalling + H2D + kernel + D2H)
+        lat_us = []
+        one_res, one_vres = hip.new_paths_result(1), _capi.TickVelResult(1, hip.caps.max_path_pts)
+        singles = []
+        for i in range(64):
+            b1 = _capi.PathsBatch([scen[i]], w_last_edges=[0.0, 0.5, 0.8])
+            v1 = _capi.TickVelBatch(vel.params, 1, vel.vel_plan[i:i + 1], vel.vel_est[i:i + 1],
+                                    np.array([[vel.pos_x[i], vel.pos_y[i]]]),
+                                    vel.veh_vel[batch.veh_off[i]:batch.veh_off[i + 1]])
+            singles.append((b1, v1))
+        for i in range(100 + args.latency_ticks):
+            b1, v1 = singles[i % 64]
+            t1 = time.perf_counter()
+            hip.tick_batch(b1, v1, one_res, one_vres)
+            if i >= 100:
+                lat_us.append((time.perf_counter() - t1) * 1e6)
+        lat_us = np.array(lat_us)
+        out = {
+            "metric": "planning ticks/s (all action primitives), Monteblanco lattice",
+            "value": world * args.batch * args.steps / elapsed,
+            "unit": "ticks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: Monteblanco lattice (128 layers / 2691 nodes / 14264 edges), 4 action "
+                                   "primitives, 8 dynamic opponents (16 obstacle positions), sample zone; "
+                                   "%d independent scenarios per GPU per step, fused tick (paths + velocity)"
+                                   % args.batch,
+                       "batch_per_gpu": args.batch, "parallelism": "scenario-sharded x%d (no collective)" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": read_traffic(),
+                         "kernel": "k_tick", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": ab["total"],
+                         "algorithmic_bytes_per_tick": ab["total"] / args.batch,
+                         "split": {k: ab[k] / args.batch for k in ("mask", "sweep", "path", "vel")}},
+            "latency_us": {"p50": float(np.percentile(lat_us, 50)), "p99": float(np.percentile(lat_us, 99)),
+                           "mean": float(lat_us.mean()), "ticks": int(lat_us.size),
+                           "what": "one scenario per ltpl_tick_batch call, host wall time incl. marshalling + PCIe"},
+            "paths_per_tick": n_paths / args.batch,
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(lat, scen, vel, min(args.cpu_sample, args.batch))
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
