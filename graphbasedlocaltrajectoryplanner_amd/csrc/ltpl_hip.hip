@@ -81,7 +81,14 @@ struct LdsPlan {
     int path_stride;   // bytes per wave
     int words_blocked, words_zone;
     int total;
+    long long* dbg;    // optional cycle stamps (LTPL_DEBUG_TIMING=1): [block][32], nullptr in production
 };
+
+#define DBG_SLOTS 64
+__device__ __forceinline__ void dbg_stamp(long long* dbg, int k)
+{
+    if (dbg && (threadIdx.x & 63) == 0 && blockIdx.x < 256) dbg[(size_t)blockIdx.x * DBG_SLOTS + (threadIdx.x >> 6) * 16 + k] = clock64();
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // wave helpers (wave64)
@@ -166,6 +173,7 @@ __device__ __forceinline__ WavePath plan_paths_body(const DevLat& lat, const Dev
     uchar2* par = reinterpret_cast<uchar2*>(smem + lp.off_par);
     int* best = reinterpret_cast<int*>(smem + lp.off_best);
 
+    dbg_stamp(lp.dbg, 0);
     // ---- phase 0: scenario scalars, planning range (gen_local_node_template.py:101-147) ----------------------------
     if (wave == 0) {
         const int sl = in.start_layer[s];
@@ -215,6 +223,7 @@ __device__ __forceinline__ WavePath plan_paths_body(const DevLat& lat, const Dev
         if (nl < ts.NH) atomicOr(&zone_bits[nl >> 5], 1u << (nl & 31));
     }
 
+    dbg_stamp(lp.dbg, 1);
     // ---- phase 1: closest reference-line layer per obstacle position (get_intersec_edges.py:40-51) -----------------
     for (int p = wave; p < ts.n_pos; p += NUM_WAVES) {
         const double px = in.pos_x[ts.pos0 + p], py = in.pos_y[ts.pos0 + p];
@@ -233,6 +242,7 @@ __device__ __forceinline__ WavePath plan_paths_body(const DevLat& lat, const Dev
     }
     __syncthreads();
 
+    dbg_stamp(lp.dbg, 2);
     // ---- phase 2: obstacle x edge-sample mask (GraphBase.get_intersec_edges_in_range, GraphBase.py:567-646) --------
     // Work item = (position, window transition); each wave takes items round-robin, lanes stride the contiguous
     // sample arrays of that transition. Window = layers [ol-1, ol+1] with the reference's wrap quirks (:597-600):
@@ -265,6 +275,7 @@ __device__ __forceinline__ WavePath plan_paths_body(const DevLat& lat, const Dev
         }
     }
 
+    dbg_stamp(lp.dbg, 3);
     // ---- phase 3: closest object (gen_local_node_template.py:191-213) and action template (mopg.py:124-174) --------
     if (tid == 0) {
         int ci = -1, cd = -1, cl = -1;
@@ -328,6 +339,7 @@ __device__ __forceinline__ WavePath plan_paths_body(const DevLat& lat, const Dev
     }
     __syncthreads();
 
+    dbg_stamp(lp.dbg, 4);
     // ---- phase 4: layered min-plus sweeps, wave = filter (GraphBase.search_graph_layer, GraphBase.py:854-894) ------
     // dist[v in layer j] = min over in-edges (u, v) of dist[u] + cost(u, v); strict '<' updates; among exact ties the
     // predecessor with the smaller dist[u], then the smaller node id wins (= order in which Dijkstra settles them).
@@ -401,6 +413,7 @@ __device__ __forceinline__ WavePath plan_paths_body(const DevLat& lat, const Dev
         }
     }
 
+    dbg_stamp(lp.dbg, 5);
     // ---- phase 5: search loop with horizon back-off (main_online_path_gen.py:187-248) -------------------------------
     if (tid == 0) {
         const bool in_const = ts.flags & LTPL_FLAG_OBJ_IN_CONST;
@@ -439,6 +452,7 @@ __device__ __forceinline__ WavePath plan_paths_body(const DevLat& lat, const Dev
     }
     __syncthreads();
 
+    dbg_stamp(lp.dbg, 6);
     // ---- phase 6: wave a assembles primitive a (main_online_path_gen.py:250-328) ------------------------------------
     WavePath wp; wp.valid = 0; wp.n_pts = 0; wp.n_nodes = 0; wp.name = LTPL_ACT_NONE; wp.reduced = 0; wp.goal_layer = -1;
     wp.end_node = -1;
@@ -586,6 +600,7 @@ __device__ __forceinline__ WavePath plan_paths_body(const DevLat& lat, const Dev
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    dbg_stamp(lp.dbg, 7);
     return wp;
 }
 
@@ -619,6 +634,9 @@ struct VelScratch {
     double* el;       // element lengths
     double* gax;      // per-point longitudinal limit (nullptr -> constant)
     double* gay;      // per-point lateral limit      (nullptr -> constant)
+    double* igay;     // 1 / gay (division-free recurrence)
+    double* axm;      // LDS copy of ax_max_machines rows [v, ax] (<= 64 rows)
+    long long* dbg;
     double* s;        // arc length (cap + 1)
     double* wb;       // ego brake profile (follow)
     double* wc;       // scratch profile (follow)
@@ -634,10 +652,9 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// np.interp(v, axm[:, 0], axm[:, 1])
-__device__ __forceinline__ double interp_axm(double v, const DevVelParams& p)
+// np.interp(v, axm[:, 0], axm[:, 1]) on the LDS copy of the table
+__device__ __forceinline__ double interp_axm(double v, const double* t, int n)
 {
-    const double* t = p.axm; const int n = p.n_axm;
     if (n == 1 || v <= t[0]) return t[1];
     if (v >= t[2 * (n - 1)]) return t[2 * (n - 1) + 1];
     int j = 0;
@@ -646,80 +663,135 @@ __device__ __forceinline__ double interp_axm(double v, const DevVelParams& p)
     return (f1 - f0) / (x1 - x0) * (v - x0) + f0;
 }
 
-// tire share of tph calc_ax_poss: ax_max * (1 - (ay_used / ay_max)^e)^(1/e), 0 when the radicand is not positive
+// tire share of tph calc_ax_poss: ax_max * (1 - (ay_used / ay_max)^e)^(1/e), 0 when the radicand is not positive.
+// EM selects the exponent at compile time (1: e == 1, 2: e == 2, 0: general pow) so that the recurrences below are
+// straight-line code: with one wave per profile every taken branch is a pipeline refill nobody hides.
+template <int EM>
 __device__ __forceinline__ double tire_avail(double q, double ax_max, const DevVelParams& p)
 {
-    double rad;
-    if (p.e == 1.0) rad = 1.0 - q;
-    else if (p.e == 2.0) rad = 1.0 - q * q;
-    else rad = 1.0 - pow(q, p.e);
-    if (!(rad > 0.0)) return 0.0;
-    if (p.e == 1.0) return ax_max * rad;
-    if (p.e == 2.0) return ax_max * sqrt(rad);
-    return ax_max * pow(rad, p.inv_e);
+    if constexpr (EM == 1) {
+        const double rad = 1.0 - q;
+        return rad > 0.0 ? ax_max * rad : 0.0;
+    } else if constexpr (EM == 2) {
+        const double rad = 1.0 - q * q;
+        return rad > 0.0 ? ax_max * sqrt(rad) : 0.0;
+    } else {
+        const double rad = 1.0 - pow(q, p.e);
+        return rad > 0.0 ? ax_max * pow(rad, p.inv_e) : 0.0;
+    }
 }
 
 #define VMODE_ACCEL_FORW 0
 #define VMODE_DECEL_FORW 1
 #define VMODE_DECEL_BACKW 2
 
-// tph calc_ax_poss in w = v^2; kabs = 1 / radius
-__device__ __forceinline__ double ax_poss_w(double w, double kabs, double ax_max, double ay_max, const DevVelParams& p,
-                                            int mode)
+// tph calc_ax_poss in w = v^2; kq = |kappa| / ay_max (so that ay_used / ay_max = w * kq); axm1 = machine limit when the
+// table has a single row (AXM1), otherwise the LDS copy of the table is interpolated at v = sqrt(w)
+template <int EM, bool AXM1, int MODE>
+__device__ __forceinline__ double ax_poss_w(double w, double kq, double ax_max, const DevVelParams& p,
+                                            const double* axm_tab, double axm1)
 {
-    const double q = (w * kabs) / ay_max;
-    double ax = tire_avail(q, fabs(ax_max), p);
-    if (mode == VMODE_ACCEL_FORW) {
-        const double axm = (p.n_axm == 1) ? p.axm[1] : interp_axm(sqrt(w), p);
+    const double q = w * kq;
+    double ax = tire_avail<EM>(q, fabs(ax_max), p);
+    if constexpr (MODE == VMODE_ACCEL_FORW) {
+        const double axm = AXM1 ? axm1 : interp_axm(sqrt(w), axm_tab, p.n_axm);
         ax = ax < axm ? ax : axm;
         return ax - w * p.drag_m;
+    } else if constexpr (MODE == VMODE_DECEL_FORW) {
+        return -ax - w * p.drag_m;
+    } else {
+        return ax + w * p.drag_m;
     }
-    if (mode == VMODE_DECEL_FORW) return -ax - w * p.drag_m;
-    return ax + w * p.drag_m;
 }
 
 // one sweep of tph __solver_fb_acc_profile on w[0..n) (lane 0). Backward sweeps address the profile, curvature and
 // element lengths mirrored but -- restated quirk of the reference solver -- the gg limits unmirrored.
-__device__ void fb_sweep(int n, const VelScratch& vs, double cax, double cay, const DevVelParams& p, double vmax2,
-                         bool backwards, int lane)
+template <int EM, bool AXM1, bool GGARR, bool BACK>
+__device__ void fb_sweep(int n, const VelScratch& vs, double cax, double cay, const DevVelParams& p, double vmax2, int lane)
 {
     // run starts: first index of every run of positive differences of the (mirrored) profile
     for (int i = lane; i < n - 1; i += 64) {
-        const int a = backwards ? n - 1 - i : i, b = backwards ? n - 2 - i : i + 1;
-        bool acc = vs.w[b] - vs.w[a] > 0.0;
+        const int a = BACK ? n - 1 - i : i, b = BACK ? n - 2 - i : i + 1;
+        const bool acc = vs.w[b] - vs.w[a] > 0.0;
         bool prev = false;
-        if (i > 0) { const int a0 = backwards ? n - i : i - 1, b0 = backwards ? n - 1 - i : i; prev = vs.w[b0] - vs.w[a0] > 0.0; }
+        if (i > 0) { const int a0 = BACK ? n - i : i - 1, b0 = BACK ? n - 1 - i : i; prev = vs.w[b0] - vs.w[a0] > 0.0; }
         vs.start[i] = (acc && !prev) ? 1 : 0;
     }
     wave_sync_lds();
-    if (lane == 0) {
+    if (lane == 0 && n >= 2) {
         bool active = false;
-        const int mode = backwards ? VMODE_DECEL_BACKW : VMODE_ACCEL_FORW;
+        constexpr int MODE = BACK ? VMODE_DECEL_BACKW : VMODE_ACCEL_FORW;
+        const double icay = 1.0 / cay;
+        const double axm1 = vs.axm[1];
+        const double dm = p.drag_m;
+        const double* __restrict__ kabs = vs.kabs; const double* __restrict__ el = vs.el;
+        const double* __restrict__ gax = vs.gax; const double* __restrict__ igay = vs.igay;
+        const unsigned char* __restrict__ st = vs.start;
+        double* w = vs.w;
+        // operands of step i are fetched one step ahead: none of them depends on the recurrence state
+        int pn = BACK ? n - 2 : 1;
+        double wi = w[BACK ? n - 1 : 0];
+        double kq_i = kabs[BACK ? n - 1 : 0] * (GGARR ? igay[0] : icay);
+        double kq_n = kabs[pn] * (GGARR ? igay[1] : icay);
+        double e_i = el[BACK ? n - 2 : 0], wold = w[pn];
+        double ax_i = GGARR ? fabs(gax[0]) : fabs(cax), ax_n = GGARR ? fabs(gax[1]) : fabs(cax);
+        int st_i = st[0];
         for (int i = 0; i < n - 1; ++i) {
-            if (vs.start[i]) active = true;
-            if (!active) continue;
-            const int pi = backwards ? n - 1 - i : i, pn = backwards ? n - 2 - i : i + 1;
-            const int ei = backwards ? n - 2 - i : i;
-            const double wi = vs.w[pi];
-            const double ax0 = vs.gax ? vs.gax[i] : cax, ay0 = vs.gay ? vs.gay[i] : cay;
-            const double acur = ax_poss_w(wi, vs.kabs[pi], ax0, ay0, p, mode);
-            double wn = wi + 2.0 * acur * vs.el[ei];
-            if (wn < 0.0) wn = 0.0;
-            if (backwards) {
-                const double ax1 = vs.gax ? vs.gax[i + 1] : cax, ay1 = vs.gay ? vs.gay[i + 1] : cay;
-                const double anext = ax_poss_w(wn, vs.kabs[pn], ax1, ay1, p, mode);
-                double wt = wi + 2.0 * anext * vs.el[ei];
-                if (wt < 0.0) wt = 0.0;
-                if (wt < wn) wn = wt;
+            const int i2 = (i + 2 < n) ? i + 2 : n - 1;
+            const int pn2 = BACK ? n - 1 - i2 : i2;
+            const int ei2 = BACK ? (n - 3 - i >= 0 ? n - 3 - i : 0) : (i + 1 < n - 1 ? i + 1 : i);
+            const double kq_n2 = kabs[pn2] * (GGARR ? igay[i2] : icay);
+            const double e_i2 = el[ei2], wold2 = w[pn2];
+            const double ax_n2 = GGARR ? fabs(gax[i2]) : fabs(cax);
+            const int st_2 = (i + 1 < n - 1) ? st[i + 1] : 0;
+            active = active || (st_i != 0);
+            double wnext_val = wold;
+            if (active) {
+                double wn;
+                if constexpr (EM == 1 && AXM1) {
+                    // Exponent 1 and a constant machine limit make one step piecewise affine in w = v^2:
+                    //   forward : w' = min(max(T, Z), M),  T = w (1 - 2e (ax kq + dm)) + 2e ax, Z = w (1 - 2e dm),
+                    //             M = Z + 2e axm
+                    //   backward: w' = max(T, Z),          T = w (1 - 2e (ax kq - dm)) + 2e ax, Z = w (1 + 2e dm), then
+                    //             the look-ahead with the limits of the next point (same form, state w').
+                    // All coefficients are independent of the state and leave the dependent fp64 chain.
+                    const double te = 2.0 * e_i;
+                    if constexpr (!BACK) {
+                        const double A0 = 1.0 - te * dm, A1 = A0 - te * (ax_i * kq_i), B1 = te * ax_i, B2 = te * axm1;
+                        const double Z = A0 * wi, T = fma(A1, wi, B1), M = fma(A0, wi, B2);
+                        wn = fmax(fmin(fmax(T, Z), M), 0.0);
+                    } else {
+                        const double A0 = 1.0 + te * dm, A1 = A0 - te * (ax_i * kq_i), B1 = te * ax_i;
+                        const double C0 = te * dm, C1 = C0 - te * (ax_n * kq_n), D1 = te * ax_n;
+                        const double Z = A0 * wi, T = fma(A1, wi, B1);
+                        wn = fmax(fmax(T, Z), 0.0);
+                        const double t0 = fma(C0, wn, wi), t1 = fma(C1, wn, wi + D1);
+                        wn = fmin(fmax(fmax(t1, t0), 0.0), wn);
+                    }
+                } else {
+                    const double acur = ax_poss_w<EM, AXM1, MODE>(wi, kq_i, ax_i, p, vs.axm, axm1);
+                    wn = wi + 2.0 * acur * e_i;
+                    wn = wn < 0.0 ? 0.0 : wn;
+                    if constexpr (BACK) {
+                        const double anext = ax_poss_w<EM, AXM1, MODE>(wn, kq_n, ax_n, p, vs.axm, axm1);
+                        double wt = wi + 2.0 * anext * e_i;
+                        wt = wt < 0.0 ? 0.0 : wt;
+                        wn = wt < wn ? wt : wn;
+                    }
+                }
+                if (wn < wold) { wnext_val = wn; w[pn] = wn; }
+                active = !(wn > vmax2);
             }
-            if (wn < vs.w[pn]) vs.w[pn] = wn;
-            if (wn > vmax2) active = false;
+            wi = wnext_val; pn = pn2;
+            kq_i = kq_n; kq_n = kq_n2; e_i = e_i2; wold = wold2;
+            ax_i = ax_n; ax_n = ax_n2; st_i = st_2;
         }
     }
     wave_sync_lds();
 }
 
 // tph.calc_vel_profile(closed=False): vs.kabs / el / (gax, gay) hold the inputs, result in vs.w (as v^2)
+template <int EM, bool AXM1, bool GGARR>
 __device__ void fb_profile(int n, const VelScratch& vs, double cax, double cay, const DevVelParams& p, double v_max,
                            double v_start, bool has_v_end, double v_end, int lane)
 {
@@ -727,33 +799,52 @@ __device__ void fb_profile(int n, const VelScratch& vs, double cax, double cay, 
     if (has_v_end && v_end < 0.0) v_end = 0.0;
     const double vmax2 = v_max * v_max;
     for (int i = lane; i < n; i += 64) {
-        const double ay = vs.gay ? vs.gay[i] : cay;
+        const double ay = GGARR ? vs.gay[i] : cay;
         double w = ay / vs.kabs[i];                 // ay * radius; kappa == 0 -> inf
         if (!(w < vmax2)) w = vmax2;
         if (i == 0 && w > v_start * v_start) w = v_start * v_start;
         vs.w[i] = w;
     }
     wave_sync_lds();
-    fb_sweep(n, vs, cax, cay, p, vmax2, false, lane);
+    dbg_stamp(vs.dbg, 8);
+    fb_sweep<EM, AXM1, GGARR, false>(n, vs, cax, cay, p, vmax2, lane);
+    dbg_stamp(vs.dbg, 9);
     if (lane == 0 && has_v_end && vs.w[n - 1] > v_end * v_end) vs.w[n - 1] = v_end * v_end;
     wave_sync_lds();
-    fb_sweep(n, vs, cax, cay, p, vmax2, true, lane);
+    fb_sweep<EM, AXM1, GGARR, true>(n, vs, cax, cay, p, vmax2, lane);
+    dbg_stamp(vs.dbg, 10);
 }
 
 // tph.calc_vel_profile_brake on LDS arrays (lane 0): out[0..n) as v^2, zeros after standstill
-__device__ void brake_profile(int n, double* out, const double* kabs, const double* el, const double* gax,
-                              const double* gay, double cax, double cay, double v_start, const DevVelParams& p, int lane)
+template <int EM, bool GGARR>
+__device__ void brake_profile(int n, double* out, const VelScratch& vs, double cax, double cay, double v_start,
+                              const DevVelParams& p, int lane)
 {
     for (int i = lane; i < n; i += 64) out[i] = 0.0;
     wave_sync_lds();
     if (lane == 0) {
+        const double icay = 1.0 / cay;
+        const double* __restrict__ kabs = vs.kabs; const double* __restrict__ el = vs.el;
+        const double* __restrict__ gax = vs.gax; const double* __restrict__ igay = vs.igay;
         double w = v_start * v_start;
         out[0] = w;
+        double kq_i = kabs[0] * (GGARR ? igay[0] : icay), e_i = el[0], ax_i = GGARR ? gax[0] : cax;
         for (int i = 0; i + 1 < n; ++i) {
-            const double a = ax_poss_w(w, kabs[i], gax ? gax[i] : cax, gay ? gay[i] : cay, p, VMODE_DECEL_FORW);
-            const double r = w + 2.0 * a * el[i];
+            const int i1 = i + 1 < n - 1 ? i + 1 : i;
+            const double kq_2 = kabs[i1] * (GGARR ? igay[i1] : icay), e_2 = el[i1], ax_2 = GGARR ? gax[i1] : cax;
+            double r;
+            if constexpr (EM == 1) {
+                const double te = 2.0 * e_i, axa = fabs(ax_i);
+                const double A0 = 1.0 - te * p.drag_m, A1 = A0 + te * (axa * kq_i), B1 = te * axa;
+                const double Z = A0 * w, T = fma(A1, w, -B1);
+                r = fmin(T, Z);
+            } else {
+                const double a = ax_poss_w<EM, true, VMODE_DECEL_FORW>(w, kq_i, ax_i, p, vs.axm, 0.0);
+                r = w + 2.0 * a * e_i;
+            }
             if (r < 0.0) break;
             w = r; out[i + 1] = w;
+            kq_i = kq_2; e_i = e_2; ax_i = ax_2;
         }
     }
     wave_sync_lds();
@@ -799,6 +890,7 @@ __device__ double get_s_coord_dev(int n, const double* x, const double* y, int s
 struct FollowIn { double v_start, v_ego, v_obj, safety_d, obj_dist, obj_x, obj_y; };
 
 // calc_vel_profile_follow.py:78-313. Inputs: vs.kabs[n], vs.el[n_el >= n] (tailing zero), gg; result vs.w (v^2).
+template <int EM, bool AXM1, bool GGARR>
 __device__ void follow_profile(const DevLat& lat, int n, int n_el, const VelScratch& vs, double cax, double cay,
                                const DevVelParams& p, const FollowIn& fi, int lane, int* too_close, int* vel_bound)
 {
@@ -808,7 +900,7 @@ __device__ void follow_profile(const DevLat& lat, int n, int n_el, const VelScra
     const int tc = (fi.obj_dist - safety_d) < 0.0;                                       // :147-149
     const double v_max = p.v_max;
 
-    brake_profile(n, vs.wb, vs.kabs, vs.el, vs.gax, vs.gay, cax, cay, fi.v_start, p, lane);   // :152-159
+    brake_profile<EM, GGARR>(n, vs.wb, vs, cax, cay, fi.v_start, p, lane);   // :152-159
     // arc length s = [0, cumsum(el[:-1])] (:203) next to the ego stop distance (:162-166)
     double ego_stop = 0.0;
     if (lane == 0) {
@@ -845,7 +937,7 @@ __device__ void follow_profile(const DevLat& lat, int n, int n_el, const VelScra
                 // point c0 + k has v > 0.1: its element length counts towards the stop distance
                 opp_stop += vs.chunk[64 + k];
                 if (c0 + k + 1 >= G) { stopped = 1; break; }
-                const double a = ax_poss_w(wopp, vs.chunk[k], 14.0, 14.0, p, VMODE_DECEL_FORW);
+                const double a = ax_poss_w<EM, true, VMODE_DECEL_FORW>(wopp, vs.chunk[k] * (1.0 / 14.0), 14.0, p, vs.axm, 0.0);
                 const double r = wopp + 2.0 * a * vs.chunk[64 + k];
                 wopp = r < 0.0 ? 0.0 : r;                                                // standstill: profile stays 0
                 if (!(wopp > 0.01)) { stopped = 1; break; }
@@ -910,7 +1002,8 @@ __device__ void follow_profile(const DevLat& lat, int n, int n_el, const VelScra
             VelScratch sub = vs;
             sub.w = vs.wc + idx_c; sub.kabs = vs.kabs + idx_c; sub.el = vs.el + idx_c;
             sub.gax = vs.gax ? vs.gax + idx_c : nullptr; sub.gay = vs.gay ? vs.gay + idx_c : nullptr;
-            fb_profile(m, sub, cax, cay, p, v_control, vcs, true, v_end, lane);
+            sub.igay = vs.igay ? vs.igay + idx_c : nullptr;
+            fb_profile<EM, AXM1, GGARR>(m, sub, cax, cay, p, v_control, vcs, true, v_end, lane);
             if (fabs(sqrt(vs.wc[idx_c]) - vcs) > 1.0) vb = 0;
         } else if (stop_idx - idx_c == 0) {
             if (lane == 0) vs.wc[idx_c] = vcs * vcs;
@@ -927,7 +1020,7 @@ __device__ void follow_profile(const DevLat& lat, int n, int n_el, const VelScra
         wave_sync_lds();
     }
     // complete profile (:297-307) and intersection (:310)
-    fb_profile(n, vs, cax, cay, p, v_max, fi.v_start, false, 0.0, lane);
+    fb_profile<EM, AXM1, GGARR>(n, vs, cax, cay, p, v_max, fi.v_start, false, 0.0, lane);
     for (int i = lane; i < n; i += 64) { const double a = vs.wc[i], b = vs.w[i]; vs.w[i] = a < b ? a : b; }
     wave_sync_lds();
     *too_close = tc; *vel_bound = vb;
@@ -949,49 +1042,61 @@ __device__ __forceinline__ VelScratch carve_vel_scratch(unsigned char* base, int
     double* d = reinterpret_cast<double*>(base);
     const int c1 = cap + 2;
     vs.w = d; d += c1; vs.kabs = d; d += c1; vs.el = d; d += c1; vs.s = d; d += c1; vs.wb = d; d += c1; vs.wc = d; d += c1;
-    if (with_gg) { vs.gax = d; d += c1; vs.gay = d; d += c1; } else { vs.gax = nullptr; vs.gay = nullptr; }
+    if (with_gg) { vs.gax = d; d += c1; vs.gay = d; d += c1; vs.igay = d; d += c1; }
+    else { vs.gax = nullptr; vs.gay = nullptr; vs.igay = nullptr; }
     if (with_xy) { *px = d; d += c1; *py = d; d += c1; }
     vs.chunk = d; d += 128;
+    vs.axm = d; d += 128;
     vs.start = reinterpret_cast<unsigned char*>(d);
     vs.cap = cap;
+    vs.dbg = nullptr;
     return vs;
 }
 
 static size_t vel_scratch_bytes(int cap, bool with_gg, bool with_xy)
 {
-    size_t arrays = 6 + (with_gg ? 2 : 0) + (with_xy ? 2 : 0);
-    size_t b = sizeof(double) * (arrays * (size_t)(cap + 2) + 128) + (size_t)cap + 16;
+    size_t arrays = 6 + (with_gg ? 3 : 0) + (with_xy ? 2 : 0);
+    size_t b = sizeof(double) * (arrays * (size_t)(cap + 2) + 256) + (size_t)cap + 16;
     return (b + 15) / 16 * 16;
 }
 
 // seam (2): one wave per job
+template <int EM, bool AXM1>
 __global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p, const DevVelJob* jobs,
-                                                    const double* pool, double* out_pool, int* out_flags, int cap)
+                                                    const double* pool, double* out_pool, int* out_flags, int cap,
+                                                    long long* dbg)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
+    dbg_stamp(dbg, 0);
     const DevVelJob jb = jobs[blockIdx.x];
     VelScratch vs = carve_vel_scratch(smem, cap, true, false, nullptr, nullptr);
+    vs.dbg = dbg;
     const int n = jb.n;
     for (int i = lane; i < n; i += 64) {
         vs.kabs[i] = fabs(pool[jb.off_kappa + i]);
         vs.gax[i] = pool[jb.off_gg + 2 * i];
-        vs.gay[i] = pool[jb.off_gg + 2 * i + 1];
+        const double ay = pool[jb.off_gg + 2 * i + 1];
+        vs.gay[i] = ay; vs.igay[i] = 1.0 / ay;
     }
+    for (int i = lane; i < 2 * p.n_axm; i += 64) vs.axm[i] = p.axm[i];
     for (int i = lane; i < jb.n_el; i += 64) vs.el[i] = pool[jb.off_el + i];
     wave_sync_lds();
+    dbg_stamp(dbg, 1);
     int too_close = 0, vel_bound = 1;
     if (jb.mode == LTPL_VEL_FB) {
-        fb_profile(n, vs, 0.0, 0.0, p, p.v_max, jb.v_start, jb.has_v_end != 0, jb.v_end, lane);
+        fb_profile<EM, AXM1, true>(n, vs, 1.0, 1.0, p, p.v_max, jb.v_start, jb.has_v_end != 0, jb.v_end, lane);
     } else if (jb.mode == LTPL_VEL_BRAKE) {
-        brake_profile(n, vs.w, vs.kabs, vs.el, vs.gax, vs.gay, 0.0, 0.0, jb.v_start, p, lane);
+        brake_profile<EM, true>(n, vs.w, vs, 1.0, 1.0, jb.v_start, p, lane);
     } else {
         FollowIn fi; fi.v_start = jb.v_start; fi.v_ego = jb.v_ego; fi.v_obj = jb.v_obj; fi.safety_d = jb.safety_d;
         fi.obj_dist = jb.obj_dist; fi.obj_x = jb.obj_x; fi.obj_y = jb.obj_y;
-        follow_profile(lat, n, jb.n_el, vs, 0.0, 0.0, p, fi, lane, &too_close, &vel_bound);
+        follow_profile<EM, AXM1, true>(lat, n, jb.n_el, vs, 1.0, 1.0, p, fi, lane, &too_close, &vel_bound);
     }
+    dbg_stamp(dbg, 2);
     for (int i = lane; i < n; i += 64) out_pool[jb.off_out + i] = sqrt(vs.w[i]);
     if (lane == 0) { out_flags[2 * blockIdx.x] = too_close; out_flags[2 * blockIdx.x + 1] = vel_bound; }
+    dbg_stamp(dbg, 3);
 }
 
 struct DevTickVelIn {
@@ -1004,6 +1109,7 @@ struct DevTickVelOut { double* vx; double* ax; int* vel_bound; int* too_close; }
 // per-primitive velocity stage of OnlineTrajectoryHandler.calc_vel_profile (OTH.py:688-941) on a fresh path:
 // cut_index_pos = 0, vel_course empty, no brake prefix (the host rejects vel_plan > v_max + 0.1, for which the
 // reference itself fails at OTH.py:919 because the prefix it computes is never merged back)
+template <int EM, bool AXM1>
 __device__ void tick_vel_stage(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const WavePath& wp,
                                const VelScratch& vs, const double* px, const double* py, const DevVelParams& p,
                                const DevTickVelIn& vin, const DevTickVelOut& vout, int s, int slot, int lane)
@@ -1034,7 +1140,7 @@ __device__ void tick_vel_stage(const DevLat& lat, const DevPathsIn& in, const De
             fi.obj_dist = s_obj - s_sta;
         }
         // follow_profile rebuilds vs.s as [0, cumsum(el[:-1])] for n_el = n: identical values
-        follow_profile(lat, n, n, vs, cax, cay, p, fi, lane, &too_close, &vel_bound);
+        follow_profile<EM, AXM1, false>(lat, n, n, vs, cax, cay, p, fi, lane, &too_close, &vel_bound);
         have_follow = true;
     }
     if (wp.name != LTPL_ACT_FOLLOW || wp.reduced) {                                      // OTH.py:834-923
@@ -1058,7 +1164,7 @@ __device__ void tick_vel_stage(const DevLat& lat, const DevPathsIn& in, const De
             v_end -= (red < v_end ? red : v_end);
             v_idx = n;
         }
-        if (v_idx > 1) fb_profile(v_idx, vs, cax, cay, p, p.v_max, vel_plan, true, v_end, lane);
+        if (v_idx > 1) fb_profile<EM, AXM1, false>(v_idx, vs, cax, cay, p, p.v_max, vel_plan, true, v_end, lane);
         else { if (lane == 0) vs.w[0] = 0.0; }
         for (int i = (v_idx > 1 ? v_idx : 1) + lane; i < n; i += 64) vs.w[i] = 0.0;         // OTH.py:901-903
         wave_sync_lds();
@@ -1086,6 +1192,7 @@ __device__ void tick_vel_stage(const DevLat& lat, const DevPathsIn& in, const De
     if (lane == 0) { vout.vel_bound[slot] = vel_bound; vout.too_close[slot] = too_close; }
 }
 
+template <int EM, bool AXM1>
 __global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, DevPathsOut out, LdsPlan lp,
                                                      DevVelParams p, DevTickVelIn vin, DevTickVelOut vout,
                                                      int vel_off, int vel_stride, int vel_cap)
@@ -1101,9 +1208,408 @@ __global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, 
     const int s = blockIdx.x;
     if (wave < LTPL_MAX_ACTIONS) {
         const int slot = s * LTPL_MAX_ACTIONS + wave;
-        if (wp.valid) tick_vel_stage(lat, in, out, wp, vs, px, py, p, vin, vout, s, slot, lane);
+        for (int i = lane; i < 2 * p.n_axm; i += 64) vs.axm[i] = p.axm[i];
+        wave_sync_lds();
+        vs.dbg = lp.dbg;
+        if (wp.valid) tick_vel_stage<EM, AXM1>(lat, in, out, wp, vs, px, py, p, vin, vout, s, slot, lane);
         else if (lane == 0) { vout.vel_bound[slot] = 0; vout.too_close[slot] = 0; }
+        dbg_stamp(lp.dbg, 11);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// throughput form of the velocity stage: ONE LANE PER PROFILE
+// ---------------------------------------------------------------------------------------------------------------------
+// The recurrences are sequential per profile, so a wave that owns a single profile runs them with 1/64 of its lanes.
+// For batches the velocity stage therefore runs as a second kernel in which every lane of a wave64 integrates its own
+// profile (slot = scenario * 3 + action): 64 independent dependent-chains per instruction stream. Curvature / element
+// length come straight from the path kernel's path_param rows (L1 / L2 resident: 40 B row stride), the profile state
+// lives in three transposed scratch planes [row][slot] so that a wave's accesses to row i are one coalesced line.
+struct DevVelPrep {             // per-slot scalars produced by the path kernel (follow action only)
+    double* obj_dist; double* v_obj; double* obj_x; double* obj_y; int* idx_s_opp;
+};
+
+struct LaneProf {
+    const double* pp;           // path_param rows of this slot [n][5]
+    double* W; double* WB; double* WC;     // transposed planes, element i at [i * P]
+    size_t P;
+};
+
+__device__ __forceinline__ double lp_kabs(const LaneProf& L, int i) { return fabs(L.pp[(size_t)i * 5 + 3]); }
+__device__ __forceinline__ double lp_el(const LaneProf& L, int i) { return L.pp[(size_t)i * 5 + 4]; }
+
+#define LCH 8      // rows per register chunk: all loads of a chunk are issued before the chunk's recurrence steps
+
+// tph.calc_vel_profile(closed=False) for one lane: rows [off, off + n) of the path, result into plane D (as v^2).
+// Rows are processed in register chunks of LCH so that a lane pays one memory latency per chunk, not per step.
+template <int EM, bool AXM1>
+__device__ void lane_fb_profile(const LaneProf& L, double* D, int off, int n, double cax, double cay,
+                                const DevVelParams& p, const double* axm_tab, double v_max, double v_start,
+                                bool has_v_end, double v_end)
+{
+    if (v_start < 0.0) v_start = 0.0;
+    if (has_v_end && v_end < 0.0) v_end = 0.0;
+    const double vmax2 = v_max * v_max, icay = 1.0 / cay, axm1 = axm_tab[1], dm = p.drag_m, axa = fabs(cax);
+    const size_t P = L.P;
+    const double* pp = L.pp + (size_t)off * 5;
+    double* Dp = D + (size_t)off * P;
+    // ---- lateral-limit speed + forward sweep (accel_forw) in one pass -------------------------------------------------
+    double kabs_i = fabs(pp[3]), e_i = pp[4];
+    double wi = cay / kabs_i;
+    if (!(wi < vmax2)) wi = vmax2;
+    if (wi > v_start * v_start) wi = v_start * v_start;
+    Dp[0] = wi;
+    if (n < 2) return;
+    {
+        double orig_i = wi;
+        bool active = false, prev_acc = false;
+        for (int base = 0; base < n - 1; base += LCH) {
+            double kr[LCH], er[LCH];
+#pragma unroll
+            for (int c = 0; c < LCH; ++c) {
+                const int r = base + 1 + c < n ? base + 1 + c : n - 1;
+                kr[c] = fabs(pp[(size_t)r * 5 + 3]); er[c] = pp[(size_t)r * 5 + 4];
+            }
+#pragma unroll
+            for (int c = 0; c < LCH; ++c) {
+                const int i = base + c;
+                if (i < n - 1) {
+                    double w0n = cay / kr[c];
+                    if (!(w0n < vmax2)) w0n = vmax2;
+                    const bool acc = w0n - orig_i > 0.0;
+                    if (acc && !prev_acc) active = true;
+                    prev_acc = acc;
+                    double wnext = w0n;
+                    if (active) {
+                        const double kq_i = kabs_i * icay;
+                        double wn;
+                        if constexpr (EM == 1 && AXM1) {
+                            const double te = 2.0 * e_i;
+                            const double A0 = 1.0 - te * dm, A1 = A0 - te * (axa * kq_i), B1 = te * axa, B2 = te * axm1;
+                            wn = fmax(fmin(fmax(fma(A1, wi, B1), A0 * wi), fma(A0, wi, B2)), 0.0);
+                        } else {
+                            const double a = ax_poss_w<EM, AXM1, VMODE_ACCEL_FORW>(wi, kq_i, cax, p, axm_tab, axm1);
+                            wn = fmax(wi + 2.0 * a * e_i, 0.0);
+                        }
+                        if (wn < w0n) wnext = wn;
+                        active = !(wn > vmax2);
+                    }
+                    if (has_v_end && i + 1 == n - 1 && wnext > v_end * v_end) wnext = v_end * v_end;
+                    Dp[(size_t)(i + 1) * P] = wnext;
+                    orig_i = w0n; wi = wnext; kabs_i = kr[c]; e_i = er[c];
+                }
+            }
+        }
+    }
+    // ---- backward sweep (decel_backw), mirrored indices; with a constant gg the unmirrored-gg quirk is void --------------
+    {
+        // wi = value at row n-1 (still in the register), kabs_i = |kappa| at row n-1
+        double orig_i = wi;
+        bool active = false, prev_acc = false;
+        for (int base = 0; base < n - 1; base += LCH) {
+            double kr[LCH], er[LCH], wr[LCH];
+#pragma unroll
+            for (int c = 0; c < LCH; ++c) {
+                const int r = n - 2 - base - c >= 0 ? n - 2 - base - c : 0;
+                kr[c] = fabs(pp[(size_t)r * 5 + 3]); er[c] = pp[(size_t)r * 5 + 4]; wr[c] = Dp[(size_t)r * P];
+            }
+#pragma unroll
+            for (int c = 0; c < LCH; ++c) {
+                const int i = base + c;
+                if (i < n - 1) {
+                    const double wold = wr[c], e_b = er[c];
+                    const bool acc = wold - orig_i > 0.0;
+                    if (acc && !prev_acc) active = true;
+                    prev_acc = acc;
+                    double wnext = wold;
+                    if (active) {
+                        const double kq_i = kabs_i * icay, kq_n = kr[c] * icay;
+                        double wn;
+                        if constexpr (EM == 1 && AXM1) {
+                            const double te = 2.0 * e_b;
+                            const double A0 = 1.0 + te * dm, A1 = A0 - te * (axa * kq_i), B1 = te * axa;
+                            const double C0 = te * dm, C1 = C0 - te * (axa * kq_n), D1 = te * axa;
+                            wn = fmax(fmax(fma(A1, wi, B1), A0 * wi), 0.0);
+                            const double t0 = fma(C0, wn, wi), t1 = fma(C1, wn, wi + D1);
+                            wn = fmin(fmax(fmax(t1, t0), 0.0), wn);
+                        } else {
+                            const double a = ax_poss_w<EM, AXM1, VMODE_DECEL_BACKW>(wi, kq_i, cax, p, axm_tab, axm1);
+                            wn = fmax(wi + 2.0 * a * e_b, 0.0);
+                            const double a2 = ax_poss_w<EM, AXM1, VMODE_DECEL_BACKW>(wn, kq_n, cax, p, axm_tab, axm1);
+                            wn = fmin(fmax(wi + 2.0 * a2 * e_b, 0.0), wn);
+                        }
+                        if (wn < wold) { wnext = wn; Dp[(size_t)(n - 2 - i) * P] = wn; }
+                        active = !(wn > vmax2);
+                    }
+                    orig_i = wold; wi = wnext; kabs_i = kr[c];
+                }
+            }
+        }
+    }
+}
+
+template <int EM, bool AXM1>
+__global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, DevPathsOut out, DevVelParams p,
+                                                  DevTickVelIn vin, DevTickVelOut vout, DevVelPrep prep,
+                                                  double* planes, int n_slots, long long* dbg)
+{
+    __shared__ double axm_tab[128];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 2 * p.n_axm; i += 64) axm_tab[i] = p.axm[i];
+    __syncthreads();
+    dbg_stamp(dbg, 0);
+    const int slot = blockIdx.x * 64 + lane;
+    if (slot >= n_slots) return;
+    const int s = slot / LTPL_MAX_ACTIONS;
+    if (!out.valid[slot]) { vout.vel_bound[slot] = 0; vout.too_close[slot] = 0; return; }
+    const int n = out.n_pts[slot];
+    const size_t P = (size_t)n_slots;
+    LaneProf L;
+    L.pp = out.path_param + (size_t)slot * out.cap_pts * 5;
+    L.P = P;
+    L.W = planes + slot; L.WB = planes + (size_t)out.cap_pts * P + slot; L.WC = planes + 2 * (size_t)out.cap_pts * P + slot;
+    const double cax = vin.gg_ax, cay = vin.gg_ay, icay = 1.0 / cay;
+    const double vel_plan = vin.vel_plan[s];
+    const int name = out.action_id[slot], reduced = out.reduced[slot];
+    int too_close = 0, vel_bound = 1;
+    bool have_follow = false;
+    const double* pp = L.pp;
+
+    if (name == LTPL_ACT_FOLLOW) {                                                       // OTH.py:763-830
+        // calc_vel_profile_follow.py:78-313 for this lane
+        const double v_start = vel_plan, v_ego = vin.vel_est[s], v_obj = prep.v_obj[slot], obj_dist = prep.obj_dist[slot];
+        const double control_d = p.c_p * vin.safety_d + p.len_veh, safety_d = vin.safety_d + p.len_veh;
+        too_close = (obj_dist - safety_d) < 0.0;
+        const double v_max = p.v_max;
+        double v_control;
+        if (p.ctrl == 0) v_control = (v_obj - p.k_p * (control_d - obj_dist) + p.k_d * (v_obj - v_ego));
+        else {
+            double a = (control_d - obj_dist) * D_PI / 2 * 1 / p.tan_w;
+            const double lo = -D_PI / 2 + 1e-5, hi = D_PI / 2 - 1e-5;
+            a = a < lo ? lo : (a > hi ? hi : a);
+            v_control = (v_obj - tan(a) * p.k_p + p.k_d * (v_obj - v_ego));
+        }
+        if (v_control < 0.0) v_control = 0.0;
+        if (v_control > v_max) v_control = v_max;
+        const double wctl = v_control * v_control;
+
+        // opponent brake distance on the global race line (:169-199); rows are gathered in chunks
+        const int G = lat.G - 1;
+        const double* grl = lat.glob_rl;
+        const int idx_s_opp = prep.idx_s_opp[slot];
+        const double vel0 = grl[(size_t)idx_s_opp * 5 + 4];
+        double wopp = fmin(v_obj, vel0); wopp *= wopp;
+        double opp_stop = 0.0;
+        for (int base = 0; base < G && wopp > 0.01; base += LCH) {
+            double kr[LCH], lr[LCH];
+#pragma unroll
+            for (int c = 0; c < LCH; ++c) {
+                int j = base + c + idx_s_opp; j = j % G;
+                kr[c] = fabs(grl[(size_t)j * 5 + 3]); lr[c] = grl[(size_t)(j + 1) * 5] - grl[(size_t)j * 5];
+            }
+#pragma unroll
+            for (int c = 0; c < LCH; ++c) {
+                const int k = base + c;
+                if (k < G && wopp > 0.01) {
+                    opp_stop += lr[c];
+                    if (k + 1 >= G) wopp = 0.0;
+                    else {
+                        const double a = ax_poss_w<EM, true, VMODE_DECEL_FORW>(wopp, kr[c] * (1.0 / 14.0), 14.0, p, axm_tab, 0.0);
+                        const double r = wopp + 2.0 * a * lr[c];
+                        wopp = r < 0.0 ? 0.0 : r;
+                    }
+                }
+            }
+        }
+        // one pass over the path rows: ego brake profile -> WB (:152-159), ego stop distance (:162-166), first index at
+        // or below the control speed (:254), arc length and stop index (:203-209)
+        const double s_stop = obj_dist - safety_d + opp_stop;                            // :206
+        double ego_stop = 0.0, s_run = 0.0, s_last = 0.0; int first_le = -1, stop_idx = 0;
+        {
+            double w = v_start * v_start; bool braking = true, counting = true, searching = true;
+            for (int base = 0; base < n; base += LCH) {
+                double kr[LCH], er[LCH];
+#pragma unroll
+                for (int c = 0; c < LCH; ++c) {
+                    const int r = base + c < n ? base + c : n - 1;
+                    kr[c] = fabs(pp[(size_t)r * 5 + 3]); er[c] = pp[(size_t)r * 5 + 4];
+                }
+#pragma unroll
+                for (int c = 0; c < LCH; ++c) {
+                    const int i = base + c;
+                    if (i < n) {
+                        const double wv = braking ? w : 0.0;
+                        L.WB[(size_t)i * P] = wv;
+                        if (first_le < 0 && wv <= wctl) first_le = i;
+                        if (counting) { if (wv > 0.01) ego_stop += er[c]; else counting = false; }
+                        if (searching) { if (i < n - 1 && s_run < s_stop) stop_idx = i + 1; else searching = false; }
+                        if (i == n - 1) s_last = s_run; // s[n - 1]
+                        s_run += er[c];                 // s[i + 1]
+                        if (braking && i + 1 < n) {
+                            const double kq = kr[c] * icay, e = er[c];
+                            double r;
+                            if constexpr (EM == 1) {
+                                const double te = 2.0 * e, axa = fabs(cax);
+                                const double A0 = 1.0 - te * p.drag_m, A1 = A0 + te * (axa * kq);
+                                r = fmin(fma(A1, w, -te * axa), A0 * w);
+                            } else {
+                                r = w + 2.0 * ax_poss_w<EM, true, VMODE_DECEL_FORW>(w, kq, cax, p, axm_tab, 0.0) * e;
+                            }
+                            if (r < 0.0) braking = false; else w = r;
+                        }
+                    }
+                }
+            }
+        }
+        double v_end = 0.0;
+        if (s_stop > s_last) {                                                           // :212-221
+            const double s_ends = opp_stop - (s_stop - s_last);
+            int idx = 0; double summed = 0.0;
+            while (summed < s_ends && idx < G) {
+                int j = idx + idx_s_opp; if (j >= G) j -= G;
+                summed += grl[(size_t)(j + 1) * 5] - grl[(size_t)j * 5];
+                ++idx;
+            }
+            int j = (idx % G) + idx_s_opp; if (j >= G) j -= G;
+            v_end = grl[(size_t)j * 5 + 4];
+        }
+        int idx_c = 0, n_decel = 0; bool two_seg = ego_stop < s_stop;
+        if (two_seg) {                                                                   // :247-292
+            double vcs = v_start;
+            if (v_start > v_control && stop_idx >= 2) {
+                idx_c = first_le < 0 ? 0 : first_le;
+                if (idx_c > stop_idx) idx_c = stop_idx;
+                if (idx_c == 0) idx_c = stop_idx;
+                n_decel = idx_c + 1 < n ? idx_c + 1 : n;
+                vcs = sqrt(L.WB[(size_t)(n_decel - 1) * P]);
+            } else if (!(stop_idx >= 2)) vel_bound = 0;
+            const int m = (stop_idx + 1 < n ? stop_idx + 1 : n) - idx_c;
+            if (stop_idx - idx_c > 0) {
+                lane_fb_profile<EM, AXM1>(L, L.WC, idx_c, m, cax, cay, p, axm_tab, v_control, vcs, true, v_end);
+                if (fabs(sqrt(L.WC[(size_t)idx_c * P]) - vcs) > 1.0) vel_bound = 0;
+            } else if (stop_idx - idx_c == 0) L.WC[(size_t)idx_c * P] = vcs * vcs;
+            const double first_v = (n_decel - 1 > 0) ? sqrt(L.WB[0]) : sqrt(L.WC[0]);
+            if (fabs(first_v - v_start) > 1.0) vel_bound = 0;
+        }
+        lane_fb_profile<EM, AXM1>(L, L.W, 0, n, cax, cay, p, axm_tab, v_max, v_start, false, 0.0);
+        // vx_profile (:289 / :294) intersected with the complete profile (:310), chunked
+        for (int base = 0; base < n; base += LCH) {
+            double a[LCH], b[LCH];
+#pragma unroll
+            for (int c = 0; c < LCH; ++c) {
+                const int i = base + c < n ? base + c : n - 1;
+                const bool from_b = !two_seg || i < n_decel - 1;
+                a[c] = from_b ? L.WB[(size_t)i * P] : ((i > stop_idx) ? 0.0 : L.WC[(size_t)i * P]);
+                b[c] = L.W[(size_t)i * P];
+            }
+#pragma unroll
+            for (int c = 0; c < LCH; ++c) if (base + c < n) L.W[(size_t)(base + c) * P] = a[c] < b[c] ? a[c] : b[c];
+        }
+        have_follow = true;
+    }
+    if (name != LTPL_ACT_FOLLOW || reduced) {                                            // OTH.py:834-923
+        if (have_follow) for (int i = 0; i < n; ++i) L.WB[(size_t)i * P] = L.W[(size_t)i * P];
+        const int goal = out.goal_layer[slot];
+        const int end_node = out.nodes[(size_t)slot * out.cap_nodes + out.n_nodes[slot] - 1];
+        int dn = end_node - lat.rl_idx[goal]; if (dn < 0) dn = -dn;
+        const double raceline_offset = (double)dn * lat.lat_offset;
+        double v_end; int v_idx;
+        if (reduced) {
+            v_end = 0.0;
+            double spl_len = 0.0;
+            for (int i = 0; i < n - 1; ++i) spl_len += lp_el(L, i);
+            int first = -1; double c = 0.0;
+            for (int i = 0; i < n - 1; ++i) { c += lp_el(L, i); if (first < 0 && !(c < (spl_len - 5.0))) first = i; }
+            v_idx = (first < 0 ? 0 : first) + 1;
+            if (v_idx == 1 && n > 1) v_idx = n;
+        } else {
+            v_end = lat.vel_rl[goal];
+            const double red = v_end * lat.vel_decrease_lat * raceline_offset;
+            v_end -= (red < v_end ? red : v_end);
+            v_idx = n;
+        }
+        if (v_idx > 1) lane_fb_profile<EM, AXM1>(L, L.W, 0, v_idx, cax, cay, p, axm_tab, p.v_max, vel_plan, true, v_end);
+        else L.W[0] = 0.0;
+        for (int i = (v_idx > 1 ? v_idx : 1); i < n; ++i) L.W[(size_t)i * P] = 0.0;
+        vel_bound = fabs(sqrt(L.W[0]) - vel_plan) < vin.v_max_offset ? 1 : 0;
+        if (have_follow && n >= 6) {
+            if (sqrt(L.WB[5 * P]) < sqrt(L.W[5 * P])) for (int i = 0; i < n; ++i) L.W[(size_t)i * P] = L.WB[(size_t)i * P];
+        }
+    }
+    // finalise (OTH.py:925-941), chunked
+    double* o_vx = vout.vx + (size_t)slot * out.cap_pts;
+    double* o_ax = vout.ax + (size_t)slot * out.cap_pts;
+    double s_i = 0.0, w_i = L.W[0];
+    for (int base = 0; base < n; base += LCH) {
+        double wr[LCH], er[LCH];
+#pragma unroll
+        for (int c = 0; c < LCH; ++c) {
+            const int r = base + c + 1 < n ? base + c + 1 : n - 1;
+            wr[c] = L.W[(size_t)r * P]; er[c] = pp[(size_t)(base + c < n ? base + c : n - 1) * 5 + 4];
+        }
+#pragma unroll
+        for (int c = 0; c < LCH; ++c) {
+            const int i = base + c;
+            if (i < n) {
+                const double v = sqrt(w_i);
+                o_vx[i] = v;
+                double a = 0.0, w_n = 0.0;
+                if (i < n - 1) {
+                    const double s_n = s_i + er[c];
+                    w_n = wr[c];
+                    a = (w_n - w_i) / (2.0 * (s_n - s_i));
+                    if (fabs(v) <= 1e-8 && fabs(a) <= 1e-8) a = -5.0;
+                    s_i = s_n;
+                }
+                o_ax[i] = a;
+                w_i = w_n;
+            }
+        }
+    }
+    vout.vel_bound[slot] = vel_bound; vout.too_close[slot] = too_close;
+    dbg_stamp(dbg, 1);
+}
+
+// follow preparation executed by the path kernel's wave that owns a "follow" action: the wave-parallel reductions
+// (projection of the object and of the ego position on the path, OTH.py:774-784; projection of the object on the
+// global race line, calc_vel_profile_follow.py:172-176) so that the lane kernel only runs recurrences
+__device__ void follow_prep(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const DevTickVelIn& vin,
+                            const DevVelPrep& prep, int n, double* s_arr, const double* el, const double* px,
+                            const double* py, int s, int slot, int lane)
+{
+    if (lane == 0) { s_arr[0] = 0.0; for (int i = 1; i <= n; ++i) s_arr[i] = s_arr[i - 1] + el[i - 1]; }
+    wave_sync_lds();
+    const int ci = out.closest_obj_index[s], v0 = in.veh_off[s];
+    double ox, oy, vobj, odist;
+    if (ci < 0 || ci >= in.veh_off[s + 1] - v0) { odist = 0.0; vobj = 0.0; ox = vin.pos_est_x[s]; oy = vin.pos_est_y[s]; }
+    else {
+        const int pp = in.pos_off[v0 + ci];
+        ox = in.pos_x[pp]; oy = in.pos_y[pp]; vobj = vin.veh_vel[v0 + ci];
+        const double s_obj = get_s_coord_dev(n, px, py, 1, s_arr, 1, ox, oy, false, lane, nullptr);
+        const double s_sta = get_s_coord_dev(n, px, py, 1, s_arr, 1, vin.pos_est_x[s], vin.pos_est_y[s], false, lane, nullptr);
+        odist = s_obj - s_sta;
+    }
+    int idx = 0;
+    (void)get_s_coord_dev(lat.G - 1, lat.glob_rl + 1, lat.glob_rl + 2, 5, lat.glob_rl, 5, ox, oy, true, lane, &idx);
+    if (lane == 0) { prep.obj_dist[slot] = odist; prep.v_obj[slot] = vobj; prep.obj_x[slot] = ox; prep.obj_y[slot] = oy; prep.idx_s_opp[slot] = idx; }
+}
+
+// path kernel + follow preparation (first kernel of the two-kernel batch pipeline)
+__global__ __launch_bounds__(WG_THREADS) void k_plan_paths_prep(DevLat lat, DevPathsIn in, DevPathsOut out, LdsPlan lp,
+                                                                DevTickVelIn vin, DevVelPrep prep, int prep_off, int prep_stride)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ TickShared ts;
+    __shared__ int sh_pos_layer[MAX_POS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* base = reinterpret_cast<double*>(smem + prep_off + (size_t)(wave < LTPL_MAX_ACTIONS ? wave : 0) * prep_stride);
+    const int c1 = out.cap_pts + 2;
+    double* sk = base; double* sel = base + c1; double* sx = base + 2 * c1; double* sy = base + 3 * c1; double* ss = base + 4 * c1;
+    const bool w3 = wave < LTPL_MAX_ACTIONS;
+    WavePath wp = plan_paths_body(lat, in, out, lp, smem, ts, sh_pos_layer, w3 ? sk : nullptr, w3 ? sel : nullptr,
+                                  w3 ? sx : nullptr, w3 ? sy : nullptr);
+    if (w3 && wp.valid && wp.name == LTPL_ACT_FOLLOW)
+        follow_prep(lat, in, out, vin, prep, wp.n_pts, ss, sel, sx, sy, blockIdx.x, blockIdx.x * LTPL_MAX_ACTIONS + wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1127,7 +1633,31 @@ struct ltpl_handle {
     void* h_out = nullptr; size_t h_out_cap = 0;
     void* d_out = nullptr; size_t d_out_cap = 0;
     struct TickLayout* resident = nullptr;   // device-resident batch of ltpl_batch_upload
+    long long* d_dbg = nullptr;              // LTPL_DEBUG_TIMING=1: cycle stamps
+    void* d_planes = nullptr; size_t d_planes_cap = 0;   // transposed profile planes of the lane kernel
 };
+
+static void dbg_report(ltpl_handle* h, const char* what, int n_blocks)
+{
+    if (!h->d_dbg) return;
+    std::vector<long long> v((size_t)256 * DBG_SLOTS);
+    if (hipMemcpy(v.data(), h->d_dbg, v.size() * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+    int nb = n_blocks < 256 ? n_blocks : 256;
+    fprintf(stderr, "[ltpl dbg] %s: mean cycles between stamps over %d blocks (wave: d01 d12 ...)\n", what, nb);
+    for (int w = 0; w < 4; ++w) {
+        fprintf(stderr, "[ltpl dbg]   wave %d:", w);
+        for (int k = 0; k + 1 < 16; ++k) {
+            double acc = 0; int cnt = 0;
+            for (int b = 0; b < nb; ++b) {
+                long long a = v[(size_t)b * DBG_SLOTS + w * 16 + k], c = v[(size_t)b * DBG_SLOTS + w * 16 + k + 1];
+                if (a > 0 && c > a) { acc += (double)(c - a); ++cnt; }
+            }
+            fprintf(stderr, " %9.0f", cnt ? acc / cnt : 0.0);
+        }
+        fprintf(stderr, "\n");
+    }
+    (void)hipMemset(h->d_dbg, 0, v.size() * sizeof(long long));
+}
 
 #define HIP_TRY(h, call)                                                                                              \
     do {                                                                                                              \
@@ -1215,6 +1745,8 @@ extern "C" int ltpl_destroy(ltpl_handle* h)
     for (void* p : h->dev_allocs) (void)hipFree(p);
     if (h->d_in) (void)hipFree(h->d_in);
     if (h->d_out) (void)hipFree(h->d_out);
+    if (h->d_dbg) (void)hipFree(h->d_dbg);
+    if (h->d_planes) (void)hipFree(h->d_planes);
     if (h->h_in) (void)hipHostFree(h->h_in);
     if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1275,6 +1807,13 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
     lp.off_zone = (int)off; off += sizeof(unsigned) * lp.words_zone; off = align_up(off, 16);
     lp.off_par = (int)off; off += sizeof(uchar2) * NFILT * (size_t)lp.hmax * lp.kpad; off = align_up(off, 16);
     lp.total = (int)off;
+    lp.dbg = nullptr;
+    if (getenv("LTPL_DEBUG_TIMING")) {
+        if (hipMalloc(reinterpret_cast<void**>(&h->d_dbg), sizeof(long long) * 256 * DBG_SLOTS) == hipSuccess) {
+            (void)hipMemset(h->d_dbg, 0, sizeof(long long) * 256 * DBG_SLOTS);
+            lp.dbg = h->d_dbg;
+        }
+    }
     if (off > 150 * 1024) {
         h->err = "planning horizon too large for the LDS-resident sweep (" + std::to_string(off) + " B > 150 KiB)";
         return fail(LTPL_ERR_CAPACITY);
@@ -1478,14 +2017,50 @@ extern "C" int ltpl_plan_paths(ltpl_handle* h, const ltpl_paths_in* in, ltpl_pat
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, lo.total, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    dbg_report(h, "k_plan_paths", in->n_scen);
     scatter_out(static_cast<const unsigned char*>(h->h_out), lo, in->n_scen, out);
     return LTPL_OK;
 }
 
 // --- velocity seam / fused tick ---------------------------------------------------------------------------------------
+// kernel variant = (exponent mode, single-row machine table): compile-time specialisations of the recurrences
+static int vel_variant(const ltpl_vel_params* vp)
+{
+    const int em = vp->dyn_model_exp == 1.0 ? 1 : (vp->dyn_model_exp == 2.0 ? 2 : 0);
+    return em * 2 + (vp->n_ax_max_machines == 1 ? 1 : 0);
+}
+typedef void (*vel_kernel_t)(DevLat, DevVelParams, const DevVelJob*, const double*, double*, int*, int, long long*);
+typedef void (*tick_kernel_t)(DevLat, DevPathsIn, DevPathsOut, LdsPlan, DevVelParams, DevTickVelIn, DevTickVelOut, int, int, int);
+typedef void (*lanes_kernel_t)(DevLat, DevPathsIn, DevPathsOut, DevVelParams, DevTickVelIn, DevTickVelOut, DevVelPrep, double*, int, long long*);
+static lanes_kernel_t lanes_kernel_of(int v)
+{
+    switch (v) {
+        case 0: return k_vel_lanes<0, false>; case 1: return k_vel_lanes<0, true>;
+        case 2: return k_vel_lanes<1, false>; case 3: return k_vel_lanes<1, true>;
+        case 4: return k_vel_lanes<2, false>; default: return k_vel_lanes<2, true>;
+    }
+}
+static vel_kernel_t vel_kernel_of(int v)
+{
+    switch (v) {
+        case 0: return k_vel_profile<0, false>; case 1: return k_vel_profile<0, true>;
+        case 2: return k_vel_profile<1, false>; case 3: return k_vel_profile<1, true>;
+        case 4: return k_vel_profile<2, false>; default: return k_vel_profile<2, true>;
+    }
+}
+static tick_kernel_t tick_kernel_of(int v)
+{
+    switch (v) {
+        case 0: return k_tick<0, false>; case 1: return k_tick<0, true>;
+        case 2: return k_tick<1, false>; case 3: return k_tick<1, true>;
+        case 4: return k_tick<2, false>; default: return k_tick<2, true>;
+    }
+}
+
 static int make_vel_params(ltpl_handle* h, const ltpl_vel_params* vp, const double* d_axm, DevVelParams* p)
 {
     if (!vp || vp->n_ax_max_machines < 1 || !vp->ax_max_machines) { h->err = "ax_max_machines missing"; return LTPL_ERR_INVALID_ARG; }
+    if (vp->n_ax_max_machines > 64) { h->err = "ax_max_machines with more than 64 rows"; return LTPL_ERR_CAPACITY; }
     if (!(vp->dyn_model_exp > 0.0) || !(vp->m_veh > 0.0)) { h->err = "invalid vehicle parameters"; return LTPL_ERR_INVALID_ARG; }
     p->e = vp->dyn_model_exp; p->inv_e = 1.0 / vp->dyn_model_exp; p->drag_m = vp->drag_coeff / vp->m_veh;
     p->len_veh = vp->len_veh; p->v_max = vp->v_max; p->n_axm = vp->n_ax_max_machines; p->ctrl = vp->follow_control_type;
@@ -1545,16 +2120,18 @@ extern "C" int ltpl_vel_profile(ltpl_handle* h, const ltpl_vel_params* vp, int n
         if (jb.n_el > 0) memcpy(pool + d.off_el, jb.el_lengths, sizeof(double) * (size_t)jb.n_el);
         memcpy(pool + d.off_gg, jb.loc_gg, sizeof(double) * 2 * (size_t)jb.n);
     }
+    vel_kernel_t kern = vel_kernel_of(vel_variant(vp));
     if (lds > 48 * 1024)
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_vel_profile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, ain.size, hipMemcpyHostToDevice, h->stream));
     unsigned char* dob = static_cast<unsigned char*>(h->d_out);
-    hipLaunchKernelGGL(k_vel_profile, dim3(n_jobs), dim3(64), lds, h->stream, h->lat, p,
+    hipLaunchKernelGGL(kern, dim3(n_jobs), dim3(64), lds, h->stream, h->lat, p,
                        reinterpret_cast<const DevVelJob*>(db + o_jobs), reinterpret_cast<const double*>(db + o_pool),
-                       reinterpret_cast<double*>(dob + o_vx), reinterpret_cast<int*>(dob + o_flags), cap);
+                       reinterpret_cast<double*>(dob + o_vx), reinterpret_cast<int*>(dob + o_flags), cap, h->lp.dbg);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, aout.size, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    dbg_report(h, "k_vel_profile", n_jobs);
     const unsigned char* ho = static_cast<const unsigned char*>(h->h_out);
     const int* flags = reinterpret_cast<const int*>(ho + o_flags);
     const double* vx = reinterpret_cast<const double*>(ho + o_vx);
@@ -1572,7 +2149,12 @@ struct TickLayout {
     int n_scen, cap_nodes, cap_pts;
     DevPathsIn di; DevPathsOut dout; DevVelParams p; DevTickVelIn dvin; DevTickVelOut dvout;
     int vel_off, vel_stride, vel_cap; size_t lds;
+    int variant;
+    // two-kernel batch pipeline (n_scen >= PIPELINE_MIN_SCEN)
+    bool pipeline; size_t prep_odist, prep_vobj, prep_ox, prep_oy, prep_idx; size_t planes_bytes;
+    DevVelPrep dprep; int prep_off, prep_stride; size_t lds_prep;
 };
+#define PIPELINE_MIN_SCEN 64
 
 static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin, int cap_nodes, int cap_pts,
                         TickLayout* t)
@@ -1588,6 +2170,7 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
             return LTPL_ERR_UNSUPPORTED;
         }
     t->n_scen = n; t->cap_nodes = cap_nodes; t->cap_pts = cap_pts;
+    t->variant = vel_variant(vin->params);
     Arena a; a.size = t->in.total;
     t->axm = a.add(sizeof(double) * 2 * (size_t)vin->params->n_ax_max_machines);
     t->vel_plan = a.add(sizeof(double) * (size_t)n); t->vel_est = a.add(sizeof(double) * (size_t)n);
@@ -1600,7 +2183,17 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
     t->ax = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS * (size_t)cap_pts);
     t->vel_bound = b.add(sizeof(int) * (size_t)n * LTPL_MAX_ACTIONS);
     t->too_close = b.add(sizeof(int) * (size_t)n * LTPL_MAX_ACTIONS);
+    t->pipeline = n >= PIPELINE_MIN_SCEN && !getenv("LTPL_FORCE_FUSED");
+    t->prep_odist = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS);
+    t->prep_vobj = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS);
+    t->prep_ox = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS);
+    t->prep_oy = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS);
+    t->prep_idx = b.add(sizeof(int) * (size_t)n * LTPL_MAX_ACTIONS);
     t->out_total = b.size;
+    t->planes_bytes = t->pipeline ? sizeof(double) * 3 * (size_t)cap_pts * (size_t)n * LTPL_MAX_ACTIONS : 0;
+    t->prep_off = h->lp.total;
+    t->prep_stride = (int)align_up(sizeof(double) * 5 * (size_t)(cap_pts + 2), 16);
+    t->lds_prep = (size_t)h->lp.total + (size_t)t->prep_stride * LTPL_MAX_ACTIONS;
     t->vel_cap = h->caps.max_path_pts;
     t->vel_stride = (int)vel_scratch_bytes(t->vel_cap, false, true);
     t->vel_off = h->lp.total;
@@ -1633,12 +2226,33 @@ static int tick_pack(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_ve
     t->dvout.vx = reinterpret_cast<double*>(dob + t->vx); t->dvout.ax = reinterpret_cast<double*>(dob + t->ax);
     t->dvout.vel_bound = reinterpret_cast<int*>(dob + t->vel_bound);
     t->dvout.too_close = reinterpret_cast<int*>(dob + t->too_close);
+    t->dprep.obj_dist = reinterpret_cast<double*>(dob + t->prep_odist);
+    t->dprep.v_obj = reinterpret_cast<double*>(dob + t->prep_vobj);
+    t->dprep.obj_x = reinterpret_cast<double*>(dob + t->prep_ox);
+    t->dprep.obj_y = reinterpret_cast<double*>(dob + t->prep_oy);
+    t->dprep.idx_s_opp = reinterpret_cast<int*>(dob + t->prep_idx);
+    if (t->pipeline && t->planes_bytes > h->d_planes_cap) {
+        if (h->d_planes) (void)hipFree(h->d_planes);
+        h->d_planes = nullptr; h->d_planes_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->d_planes, t->planes_bytes));
+        h->d_planes_cap = t->planes_bytes;
+    }
     return LTPL_OK;
 }
 
 static int tick_launch(ltpl_handle* h, const TickLayout& t)
 {
-    hipLaunchKernelGGL(k_tick, dim3(t.n_scen), dim3(WG_THREADS), t.lds, h->stream, h->lat, t.di, t.dout, h->lp, t.p,
+    if (t.pipeline) {
+        hipLaunchKernelGGL(k_plan_paths_prep, dim3(t.n_scen), dim3(WG_THREADS), t.lds_prep, h->stream, h->lat, t.di, t.dout,
+                           h->lp, t.dvin, t.dprep, t.prep_off, t.prep_stride);
+        HIP_TRY(h, hipGetLastError());
+        const int n_slots = t.n_scen * LTPL_MAX_ACTIONS;
+        hipLaunchKernelGGL(lanes_kernel_of(t.variant), dim3((n_slots + 63) / 64), dim3(64), 0, h->stream, h->lat, t.di, t.dout,
+                           t.p, t.dvin, t.dvout, t.dprep, static_cast<double*>(h->d_planes), n_slots, h->lp.dbg);
+        HIP_TRY(h, hipGetLastError());
+        return LTPL_OK;
+    }
+    hipLaunchKernelGGL(tick_kernel_of(t.variant), dim3(t.n_scen), dim3(WG_THREADS), t.lds, h->stream, h->lat, t.di, t.dout, h->lp, t.p,
                        t.dvin, t.dvout, t.vel_off, t.vel_stride, t.vel_cap);
     HIP_TRY(h, hipGetLastError());
     return LTPL_OK;
@@ -1656,10 +2270,13 @@ static void tick_scatter(const unsigned char* hb, const TickLayout& t, ltpl_path
     memcpy(vout->too_close, hb + t.too_close, sizeof(int) * n * A);
 }
 
-static int tick_set_lds_limit(ltpl_handle* h, size_t lds)
+static int tick_set_lds_limit(ltpl_handle* h, size_t lds, int variant)
 {
+    if (h->lp.total + 5 * 8 * (h->caps.max_path_pts + 4) * LTPL_MAX_ACTIONS > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan_paths_prep), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       h->lp.total + 5 * 8 * (h->caps.max_path_pts + 4) * LTPL_MAX_ACTIONS));
     if (lds > 48 * 1024)
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(tick_kernel_of(variant)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return LTPL_OK;
 }
 
@@ -1676,11 +2293,12 @@ extern "C" int ltpl_tick_batch(ltpl_handle* h, const ltpl_paths_in* in, const lt
     if ((rc = ensure(h, &h->h_out, &h->h_out_cap, &h->d_out, &h->d_out_cap, t.out_total))) return rc;
     if ((rc = tick_pack(h, in, vin, &t, static_cast<unsigned char*>(h->h_in), static_cast<unsigned char*>(h->d_in),
                         static_cast<unsigned char*>(h->d_out)))) return rc;
-    if ((rc = tick_set_lds_limit(h, t.lds))) return rc;
+    if ((rc = tick_set_lds_limit(h, t.lds, t.variant))) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, t.in_total, hipMemcpyHostToDevice, h->stream));
     if ((rc = tick_launch(h, t))) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, t.out_total, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    dbg_report(h, "k_tick", in->n_scen);
     tick_scatter(static_cast<const unsigned char*>(h->h_out), t, out, vout);
     return LTPL_OK;
 }
@@ -1699,7 +2317,7 @@ extern "C" int ltpl_batch_upload(ltpl_handle* h, const ltpl_paths_in* in, const 
     if ((rc = ensure(h, &h->h_out, &h->h_out_cap, &h->d_out, &h->d_out_cap, t->out_total))) { delete t; return rc; }
     if ((rc = tick_pack(h, in, vin, t, static_cast<unsigned char*>(h->h_in), static_cast<unsigned char*>(h->d_in),
                         static_cast<unsigned char*>(h->d_out)))) { delete t; return rc; }
-    if ((rc = tick_set_lds_limit(h, t->lds))) { delete t; return rc; }
+    if ((rc = tick_set_lds_limit(h, t->lds, t->variant))) { delete t; return rc; }
     HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, t->in_total, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->resident = t;
