@@ -1,20 +1,12 @@
 // ltpl_hip.hip -- MI355X (gfx950 / CDNA4) backend of the graph_ltpl online hot path. C ABI: include/ltpl_hip.h.
 //
-// One workgroup (256 threads = 4 wave64) plans one scenario (= one call of the reference's main_online_path_gen):
-//   phase 1  obstacle -> closest reference-line layer (wave-level lexicographic min-reduction)        [M1]
-//   phase 2  obstacle x edge-sample collision mask, lanes over the coalesced sample arrays of a layer
-//            transition, result = bit per horizon edge in LDS                                          [M2]
-//   phase 3  closest object / node, action-template choice                                            [M3, T1]
-//   phase 4  four layered min-plus sweeps in parallel, one wave per filter (planning_range, default,
-//            overtake_left, overtake_right); lane = destination node, private min over its in-edges
-//            (CSC, no atomics), frontier distances double-buffered in LDS, parents in LDS              [F1, S1]
-//   phase 5  horizon back-off / reduced-horizon logic on the per-layer goal table                      [S2]
-//   phase 6  one wave per offered primitive: backtrack, gather, tridiagonal C2 spline solve,
-//            re-sampling, heading / curvature                                                          [G1, P1-P3]
+// Seam (1) lives in paths_team.hpp: a team of NW wave64s plans one scenario (NW = 1 for batches, NW = 4 for single
+// ticks). Seam (2) (velocity profiles) and the fused tick live in this file.
 // The lattice (< 15 MB for Monteblanco) is uploaded once and is L2 / Infinity-Cache resident afterwards.
 // Everything is IEEE fp64 and compiled with -ffp-contract=off so that masks, arg-mins and path costs are
 // bit-identical to the NumPy arithmetic of the reference.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -26,6 +18,7 @@
 #include "../../include/ltpl_hip.h"
 
 #define WG_THREADS 256
+#define PIPELINE_MIN_SCEN 64   // batches from this size on use the one-wave-per-scenario pipeline
 #define NUM_WAVES 4
 #define MAX_POS 192      // obstacle positions (own + predicted) per scenario
 #define MAX_VEH 96       // vehicles per scenario
@@ -49,6 +42,15 @@ struct DevLat {
     const int* in_ptr; const int* edge_src; const double* edge_cost; const double* edge_len; const int* samp_ptr;
     const double* sx; const double* sy; const double* spsi; const double* slen;
     const double* glob_rl;
+    // derived at ltpl_create
+    const int* rng_end;               // [L]     end layer of the planning range that starts in layer l
+    const int* layer_ebase;           // [L + 1] first edge INTO layer l (= in_ptr[layer_off[l]]); [L] = E
+    const unsigned char* edge_src8;   // [E]     edge_src as bytes (<= 255 nodes per layer)
+    const unsigned char* edge_dst8;   // [E]     destination node index inside its layer
+    const unsigned char* edge_rank8;  // [E]     rank of the edge among the in-edges of its destination
+    const int* layer_degmax;          // [L]     largest in-degree of a node of layer l
+    const unsigned* edge_meta;        // [E]     source node | destination node << 8 | in-edge rank << 16
+    const double* edge_cx; const double* edge_cy; const double* edge_cr;   // [E] bounding circle of the edge's samples
 };
 
 struct DevPathsIn {
@@ -68,21 +70,6 @@ struct DevPathsOut {
     int* nodes; int* node_idx; double* coeff; double* path_param;
 };
 
-// dynamic-LDS plan (byte offsets), computed once per lattice on the host
-struct LdsPlan {
-    int kpad;          // padded max nodes per layer
-    int hmax;          // max layers in a planning range (H + 1)
-    int off_blocked;   // u32[(ehmax + 31) / 32]
-    int off_zone;      // u32[(nhmax + 31) / 32]
-    int off_dist;      // double[NFILT][2][kpad]
-    int off_par;       // uchar2 [NFILT][hmax][kpad]  (.x = source node, .y = in-edge rank | tie bit 0x80)
-    int off_best;      // int[NFILT][hmax]           goal node of layer j (-1 none), bit 30 = goal tie
-    int off_path;      // per wave: path scratch (see PATH_* below)
-    int path_stride;   // bytes per wave
-    int words_blocked, words_zone;
-    int total;
-    long long* dbg;    // optional cycle stamps (LTPL_DEBUG_TIMING=1): [block][32], nullptr in production
-};
 
 #define DBG_SLOTS 64
 __device__ __forceinline__ void dbg_stamp(long long* dbg, int k)
@@ -116,6 +103,13 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total)
     return x - v;
 }
 
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __device__ __forceinline__ double normalize_psi_dev(double psi)
 {
     double sgn = (psi > 0.0) ? 1.0 : ((psi < 0.0) ? -1.0 : 0.0);
@@ -125,492 +119,22 @@ __device__ __forceinline__ double normalize_psi_dev(double psi)
     return out;
 }
 
-// per-scenario scalars shared by the workgroup
-struct TickShared {
-    int start_layer, start_node, flags, end_layer, H;
-    int e_base, EH, n_base, NH;
-    int n_pos, n_veh, pos0, veh0;
-    int closest_idx, cl, cn, have_cn;
-    int n_act, filt[LTPL_MAX_ACTIONS], name[LTPL_MAX_ACTIONS];
-    int need[NFILT];
-    int start_ok[NFILT];
-    int slot_valid[LTPL_MAX_ACTIONS], slot_j[LTPL_MAX_ACTIONS], slot_name[LTPL_MAX_ACTIONS], slot_reduced[LTPL_MAX_ACTIONS];
-    int n_last; int last_layer[LTPL_MAX_LAST_NODES]; int last_node[LTPL_MAX_LAST_NODES];
-};
-
-__device__ __forceinline__ bool node_removed(const TickShared& ts, const unsigned* zone_bits, const DevLat& lat,
-                                             int f, int layer, int n, int gid)
-{
-    int nl = gid - ts.n_base; if (nl < 0) nl += lat.V;
-    if (zone_bits[nl >> 5] & (1u << (nl & 31))) return true;
-    if (f == F_LEFT && layer == ts.cl && n >= ts.cn) return true;     // main_online_path_gen.py:148-152
-    if (f == F_RIGHT && layer == ts.cl && n < ts.cn) return true;     // main_online_path_gen.py:155-159
-    return false;
-}
-
-// per-wave path scratch layout (doubles first for alignment)
-#define PATH_NARR 9   // kx ky el mx my cpx cpy (7 double arrays of hmax) + pedge, pidx (2 int arrays of hmax + 1)
-
 // ---------------------------------------------------------------------------------------------------------------------
 // the path kernel (seam 1)
 // ---------------------------------------------------------------------------------------------------------------------
 // Result of the path stage for the calling wave (waves 0..2 own one action slot each).
 struct WavePath { int valid; int n_pts; int n_nodes; int name; int reduced; int goal_layer; int end_node; };
 
-__device__ __forceinline__ WavePath plan_paths_body(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out,
-                                                    const LdsPlan& lp, unsigned char* smem, TickShared& ts,
-                                                    int* sh_pos_layer, double* vel_kappa, double* vel_len,
-                                                    double* vel_x = nullptr, double* vel_y = nullptr)
-{
+#include "paths_team.hpp"
 
-    const int s = blockIdx.x;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int L = lat.L;
-
-    unsigned* blocked_bits = reinterpret_cast<unsigned*>(smem + lp.off_blocked);
-    unsigned* zone_bits = reinterpret_cast<unsigned*>(smem + lp.off_zone);
-    double* dist = reinterpret_cast<double*>(smem + lp.off_dist);
-    uchar2* par = reinterpret_cast<uchar2*>(smem + lp.off_par);
-    int* best = reinterpret_cast<int*>(smem + lp.off_best);
-
-    dbg_stamp(lp.dbg, 0);
-    // ---- phase 0: scenario scalars, planning range (gen_local_node_template.py:101-147) ----------------------------
-    if (wave == 0) {
-        const int sl = in.start_layer[s];
-        int cnt = 0;
-        if (lat.mode == 0) {
-            double des = lat.s_rl[sl] + lat.min_plan_horizon;
-            if (des > lat.s_rl[L - 1]) des -= lat.s_rl[L - 1];
-            // bisect_left on a sorted array = number of entries < des
-            for (int l0 = 0; l0 < L; l0 += 64) {
-                int l = l0 + lane;
-                bool lt = (l < L) && (lat.s_rl[l] < des);
-                cnt += __popcll(__ballot(lt));
-            }
-        } else {
-            cnt = (sl + (int)lat.min_plan_horizon) % L;
-        }
-        if (lane == 0) {
-            ts.start_layer = sl; ts.start_node = in.start_node[s]; ts.flags = in.flags[s];
-            int el = cnt >= L ? L - 1 : cnt;      // host rejects lattices where this could clamp
-            ts.end_layer = el;
-            int H = el - sl; if (H < 0) H = L - sl + el;
-            ts.H = H;
-            int first = sl + 1; if (first >= L) first -= L;
-            ts.e_base = lat.in_ptr[lat.layer_off[first]];
-            int e_end = lat.in_ptr[lat.layer_off[el + 1]];
-            int EH = e_end - ts.e_base; if (EH < 0) EH += lat.E;
-            ts.EH = EH;
-            ts.n_base = lat.layer_off[sl];
-            int NH = lat.layer_off[el + 1] - ts.n_base; if (NH <= 0) NH += lat.V;
-            ts.NH = NH;
-            ts.veh0 = in.veh_off[s]; ts.n_veh = in.veh_off[s + 1] - ts.veh0;
-            ts.pos0 = in.pos_off[ts.veh0]; ts.n_pos = in.pos_off[ts.veh0 + ts.n_veh] - ts.pos0;
-            int nl = in.n_last[s]; ts.n_last = nl;
-            for (int i = 0; i < LTPL_MAX_LAST_NODES; ++i) {
-                ts.last_layer[i] = in.last_layer[s * LTPL_MAX_LAST_NODES + i];
-                ts.last_node[i] = in.last_node[s * LTPL_MAX_LAST_NODES + i];
-            }
-        }
-    }
-    for (int i = tid; i < lp.words_blocked; i += WG_THREADS) blocked_bits[i] = 0u;
-    for (int i = tid; i < lp.words_zone; i += WG_THREADS) zone_bits[i] = 0u;
-    __syncthreads();
-
-    // zone-removed nodes of the "overtaking_zones" filter (gen_local_node_template.py:96; GraphBase.py:713-745)
-    for (int i = in.zone_off[s] + tid; i < in.zone_off[s + 1]; i += WG_THREADS) {
-        int nl = in.zone_gid[i] - ts.n_base; if (nl < 0) nl += lat.V;
-        if (nl < ts.NH) atomicOr(&zone_bits[nl >> 5], 1u << (nl & 31));
-    }
-
-    dbg_stamp(lp.dbg, 1);
-    // ---- phase 1: closest reference-line layer per obstacle position (get_intersec_edges.py:40-51) -----------------
-    for (int p = wave; p < ts.n_pos; p += NUM_WAVES) {
-        const double px = in.pos_x[ts.pos0 + p], py = in.pos_y[ts.pos0 + p];
-        double bd = INFINITY, dummy = 0.0; int bl = 0x7fffffff;
-        for (int l = lane; l < L; l += 64) {
-            double dx = lat.ref_x[l] - px, dy = lat.ref_y[l] - py;
-            double d2 = dx * dx + dy * dy;
-            if (d2 < bd) { bd = d2; bl = l; }
-        }
-        wave_min3(bd, dummy, bl);
-        if (lane == 0) {
-            const int ol = bl, sl = ts.start_layer, el = ts.end_layer;
-            bool gate = (sl - 1 <= ol && ol <= el + 1) || (sl > el && (sl - 1 <= ol || ol <= el + 1));
-            sh_pos_layer[p] = gate ? ol : -1;
-        }
-    }
-    __syncthreads();
-
-    dbg_stamp(lp.dbg, 2);
-    // ---- phase 2: obstacle x edge-sample mask (GraphBase.get_intersec_edges_in_range, GraphBase.py:567-646) --------
-    // Work item = (position, window transition); each wave takes items round-robin, lanes stride the contiguous
-    // sample arrays of that transition. Window = layers [ol-1, ol+1] with the reference's wrap quirks (:597-600):
-    // the transition ol -> ol+1 is only part of it for ol <= L-2.
-    for (int item = wave; item < 2 * ts.n_pos; item += NUM_WAVES) {
-        const int p = item >> 1, second = item & 1;
-        const int ol = sh_pos_layer[p];
-        if (ol < 0) continue;
-        if (second && ol > L - 2) continue;
-        int b = ol + second; if (b >= L) b -= L;               // destination layer of the transition
-        int jb = b - ts.start_layer; if (jb < 0) jb += L;
-        if (jb < 1 || jb > ts.H) continue;                    // both end points must lie in the planning range
-        // vehicle of this position -> radius
-        int vlo = 0, vhi = ts.n_veh;                           // last vehicle with pos_off <= pos0 + p
-        while (vhi - vlo > 1) { int mid = (vlo + vhi) >> 1; if (in.pos_off[ts.veh0 + mid] <= ts.pos0 + p) vlo = mid; else vhi = mid; }
-        const double rr = in.veh_radius[ts.veh0 + vlo] + lat.veh_width / 2;
-        double ref = rr * rr;
-        ref += (lat.sampled_resolution * lat.sampled_resolution) / 4;
-        const double px = in.pos_x[ts.pos0 + p], py = in.pos_y[ts.pos0 + p];
-        const int e0 = lat.in_ptr[lat.layer_off[b]], e1 = lat.in_ptr[lat.layer_off[b + 1]];
-        const int s0 = lat.samp_ptr[e0], s1 = lat.samp_ptr[e1];
-        for (int k = s0 + lane; k < s1; k += 64) {
-            double x = lat.sx[k] - px, y = lat.sy[k] - py;
-            if (x * x + y * y <= ref) {
-                int lo = e0, hi = e1;                          // edge owning sample k
-                while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (lat.samp_ptr[mid] <= k) lo = mid; else hi = mid; }
-                int el_ = lo - ts.e_base; if (el_ < 0) el_ += lat.E;
-                atomicOr(&blocked_bits[el_ >> 5], 1u << (el_ & 31));
-            }
-        }
-    }
-
-    dbg_stamp(lp.dbg, 3);
-    // ---- phase 3: closest object (gen_local_node_template.py:191-213) and action template (mopg.py:124-174) --------
-    if (tid == 0) {
-        int ci = -1, cd = -1, cl = -1;
-        for (int k = 0; k < ts.n_veh; ++k) {
-            int plast = in.pos_off[ts.veh0 + k + 1] - 1 - ts.pos0;
-            int ol = (plast >= 0 && plast < ts.n_pos && in.pos_off[ts.veh0 + k + 1] > in.pos_off[ts.veh0 + k])
-                         ? sh_pos_layer[plast] : -1;
-            if (ol >= 0) {
-                int ld = ol - ts.start_layer; if (ld < 0) ld = L - ts.start_layer + ol;
-                if (ld <= ts.H && (cd < 0 || ld < cd)) { cd = ld; ci = k; cl = ol; }
-            }
-        }
-        ts.closest_idx = ci; ts.cl = cl; ts.have_cn = cd >= 0; ts.cn = -1;
-    }
-    __syncthreads();
-    if (wave == 0 && ts.have_cn) {
-        const int p = in.pos_off[ts.veh0 + ts.closest_idx];
-        const double px = in.pos_x[p], py = in.pos_y[p];
-        const int v0 = lat.layer_off[ts.cl], K = lat.layer_off[ts.cl + 1] - v0;
-        double bd = INFINITY, dummy = 0.0; int bn = 0x7fffffff;
-        for (int n = lane; n < K; n += 64) {
-            double dx = lat.node_x[v0 + n] - px, dy = lat.node_y[v0 + n] - py;
-            double d2 = dx * dx + dy * dy;
-            if (d2 < bd) { bd = d2; bn = n; }
-        }
-        wave_min3(bd, dummy, bn);
-        if (lane == 0) ts.cn = bn;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const int flags = ts.flags;
-        const bool action_sets = flags & LTPL_FLAG_ACTION_SETS, in_const = flags & LTPL_FLAG_OBJ_IN_CONST,
-                   besides = flags & LTPL_FLAG_OBJ_BESIDES;
-        int closest_idx = ts.closest_idx;
-        if (in.const_closest[s] >= 0) closest_idx = in.const_closest[s];
-        int n_act = 0;
-        for (int f = 0; f < NFILT; ++f) ts.need[f] = 0;
-        if (action_sets && (in_const || besides)) {
-            ts.filt[n_act] = F_PR; ts.name[n_act++] = LTPL_ACT_FOLLOW;
-            const int la = in.last_action[s];
-            if (!in_const && (la == LTPL_ACT_LEFT || la == LTPL_ACT_RIGHT)) { ts.filt[n_act] = F_DEF; ts.name[n_act++] = la; }
-            else if (!in_const) {
-                ts.filt[n_act] = F_DEF; ts.name[n_act++] = LTPL_ACT_LEFT;
-                ts.filt[n_act] = F_DEF; ts.name[n_act++] = LTPL_ACT_RIGHT;
-            }
-        } else if (action_sets && closest_idx >= 0 && ts.have_cn) {
-            ts.filt[0] = F_PR; ts.name[0] = LTPL_ACT_FOLLOW;
-            ts.filt[1] = F_LEFT; ts.name[1] = LTPL_ACT_LEFT;
-            ts.filt[2] = F_RIGHT; ts.name[2] = LTPL_ACT_RIGHT;
-            n_act = 3;
-        } else {
-            ts.filt[0] = F_DEF; ts.name[0] = LTPL_ACT_STRAIGHT; n_act = 1;
-        }
-        ts.n_act = n_act;
-        for (int a = 0; a < n_act; ++a) ts.need[ts.filt[a]] = 1;
-        out.end_layer[s] = ts.end_layer;
-        out.closest_obj_index[s] = closest_idx;
-        out.closest_obj_node[2 * s] = ts.have_cn ? ts.cl : -1;
-        out.closest_obj_node[2 * s + 1] = ts.have_cn ? ts.cn : -1;
-        out.n_actions[s] = n_act;
-    }
-    __syncthreads();
-
-    dbg_stamp(lp.dbg, 4);
-    // ---- phase 4: layered min-plus sweeps, wave = filter (GraphBase.search_graph_layer, GraphBase.py:854-894) ------
-    // dist[v in layer j] = min over in-edges (u, v) of dist[u] + cost(u, v); strict '<' updates; among exact ties the
-    // predecessor with the smaller dist[u], then the smaller node id wins (= order in which Dijkstra settles them).
-    {
-        const int f = wave;
-        const bool active = ts.need[f] != 0;
-        const int H = ts.H, kpad = lp.kpad;
-        const int n_fac = min(ts.n_last - 1, in.n_w_last);
-        double* d0 = dist + (size_t)(f * 2) * kpad;
-        if (active) {
-            const int sl = ts.start_layer, sn = ts.start_node;
-            const int K0 = lat.layer_off[sl + 1] - lat.layer_off[sl];
-            bool ok = sn >= 0 && sn < K0 && !node_removed(ts, zone_bits, lat, f, sl, sn, lat.layer_off[sl] + sn);
-            for (int n = lane; n < kpad; n += 64) d0[n] = (ok && n == sn) ? 0.0 : INFINITY;
-            if (lane == 0) { ts.start_ok[f] = ok; best[f * lp.hmax] = -1; }
-        }
-        __syncthreads();
-        for (int j = 1; j <= H; ++j) {
-            if (active) {
-                int b = ts.start_layer + j; if (b >= L) b -= L;
-                const int v0 = lat.layer_off[b], Kb = lat.layer_off[b + 1] - v0;
-                const double* dprev = dist + (size_t)(f * 2 + ((j - 1) & 1)) * kpad;
-                double* dcur = dist + (size_t)(f * 2 + (j & 1)) * kpad;
-                uchar2* pj = par + ((size_t)f * lp.hmax + j) * kpad;
-                // cost discount along the previous solution (gen_local_node_template.py:154-162): edge j-1 -> j
-                int fac_src = -1, fac_dst = -1; double fac = 1.0;
-                if (j - 1 < n_fac) {
-                    int pl = ts.last_layer[j - 1], nl_ = ts.last_layer[j];
-                    int pb = b - 1; if (pb < 0) pb += L;
-                    if (pl == pb && nl_ == b) { fac_src = ts.last_node[j - 1]; fac_dst = ts.last_node[j]; fac = in.w_last[j - 1]; }
-                }
-                double g1 = INFINITY, g2 = INFINITY; int gn = 0x7fffffff;
-                for (int n = lane; n < Kb; n += 64) {
-                    const int v = v0 + n;
-                    double bestc = INFINITY, bestdu = INFINITY; int bk = 0, bsrc = 0, tie = 0;
-                    if (!node_removed(ts, zone_bits, lat, f, b, n, v)) {
-                        const int e0 = lat.in_ptr[v], e1 = lat.in_ptr[v + 1];
-                        for (int e = e0; e < e1; ++e) {
-                            const int src = lat.edge_src[e];
-                            const double du = dprev[src];
-                            double c = lat.edge_cost[e];
-                            if (f != F_PR) {
-                                int el_ = e - ts.e_base; if (el_ < 0) el_ += lat.E;
-                                if (blocked_bits[el_ >> 5] & (1u << (el_ & 31))) continue;
-                            }
-                            if (!(du < INFINITY)) continue;
-                            if (src == fac_src && n == fac_dst) c *= fac;
-                            const double cand = du + c;
-                            if (cand < bestc) { bestc = cand; bestdu = du; bk = e - e0; bsrc = src; tie = 0; }
-                            else if (cand == bestc) {
-                                tie = 1;
-                                if (du < bestdu) { bestdu = du; bk = e - e0; bsrc = src; }
-                            }
-                        }
-                    }
-                    dcur[n] = bestc;
-                    pj[n] = make_uchar2((unsigned char)bsrc, (unsigned char)(bk | (tie ? 0x80 : 0)));
-                    if (bestc < INFINITY) {
-                        // virtual goal edge (GraphBase.py:188-194)
-                        double tot = bestc + lat.vgoal[v];
-                        if (tot < g1 || (tot == g1 && (bestc < g2 || (bestc == g2 && n < gn)))) { g1 = tot; g2 = bestc; gn = n; }
-                    }
-                }
-                for (int n = Kb + lane; n < kpad; n += 64) dcur[n] = INFINITY;
-                double m1 = g1, m2 = g2; int mn = gn;
-                wave_min3(m1, m2, mn);
-                int ntie = __popcll(__ballot(g1 == m1 && g1 < INFINITY));   // NOTE: per-lane best only (Kb <= 64 exact)
-                if (lane == 0) best[f * lp.hmax + j] = (m1 < INFINITY) ? (mn | (ntie > 1 ? (1 << 30) : 0)) : -1;
-            }
-            __syncthreads();
-        }
-    }
-
-    dbg_stamp(lp.dbg, 5);
-    // ---- phase 5: search loop with horizon back-off (main_online_path_gen.py:187-248) -------------------------------
-    if (tid == 0) {
-        const bool in_const = ts.flags & LTPL_FLAG_OBJ_IN_CONST;
-        int mod_j = ts.H;
-        for (int a = 0; a < LTPL_MAX_ACTIONS; ++a) {
-            const int slot = s * LTPL_MAX_ACTIONS + a;
-            ts.slot_valid[a] = 0; ts.slot_j[a] = 0;
-            if (a >= ts.n_act) {
-                out.action_id[slot] = LTPL_ACT_NONE; out.valid[slot] = 0; out.reduced[slot] = 0; out.goal_layer[slot] = -1;
-                out.n_nodes[slot] = 0; out.n_pts[slot] = 0; out.n_ties[slot] = 0;
-                continue;
-            }
-            const int f = ts.filt[a]; int nm = ts.name[a];
-            bool found = false;
-            for (;;) {
-                if (mod_j == 0) break;
-                found = ts.start_ok[f] && best[f * lp.hmax + mod_j] >= 0;
-                if (found || !(nm == LTPL_ACT_FOLLOW || nm == LTPL_ACT_STRAIGHT)) break;
-                mod_j -= 1;
-            }
-            const bool reduced = mod_j != ts.H;
-            int goal = ts.start_layer + mod_j; if (goal >= L) goal -= L;
-            if (reduced) {
-                const int cl = ts.cl, sl = ts.start_layer;
-                bool in_mod = ts.have_cn && ((sl <= cl && cl <= goal) || (sl > goal && (cl >= sl || cl <= goal)));
-                if (!in_const && ts.have_cn && !in_mod) {
-                    if (nm == LTPL_ACT_FOLLOW || nm == LTPL_ACT_STRAIGHT) nm = LTPL_ACT_STRAIGHT;
-                    else found = false;
-                }
-            }
-            out.action_id[slot] = nm; out.reduced[slot] = reduced ? 1 : 0; out.goal_layer[slot] = goal;
-            out.valid[slot] = found ? 1 : 0;
-            if (!found) { out.n_nodes[slot] = 0; out.n_pts[slot] = 0; out.n_ties[slot] = 0; }
-            ts.slot_valid[a] = found ? 1 : 0; ts.slot_j[a] = mod_j; ts.slot_name[a] = nm; ts.slot_reduced[a] = reduced ? 1 : 0;
-        }
-    }
-    __syncthreads();
-
-    dbg_stamp(lp.dbg, 6);
-    // ---- phase 6: wave a assembles primitive a (main_online_path_gen.py:250-328) ------------------------------------
-    WavePath wp; wp.valid = 0; wp.n_pts = 0; wp.n_nodes = 0; wp.name = LTPL_ACT_NONE; wp.reduced = 0; wp.goal_layer = -1;
-    wp.end_node = -1;
-    if (wave < LTPL_MAX_ACTIONS && wave < ts.n_act) {
-        wp.name = ts.slot_name[wave]; wp.reduced = ts.slot_reduced[wave];
-    }
-    if (wave < LTPL_MAX_ACTIONS && wave < ts.n_act && ts.slot_valid[wave]) {
-        const int a = wave, slot = s * LTPL_MAX_ACTIONS + a, f = ts.filt[a], J = ts.slot_j[a], N = J;   // N segments
-        unsigned char* pw = smem + lp.off_path + (size_t)a * lp.path_stride;
-        const int hm = lp.hmax;
-        double* kx = reinterpret_cast<double*>(pw);
-        double* ky = kx + hm; double* el = ky + hm; double* mx = el + hm; double* my = mx + hm;
-        double* cpx = my + hm; double* cpy = cpx + hm;
-        int* pedge = reinterpret_cast<int*>(cpy + hm); int* pidx = pedge + hm + 1;
-        int* o_nodes = out.nodes + (size_t)slot * out.cap_nodes;
-        int* o_idx = out.node_idx + (size_t)slot * out.cap_nodes;
-        double* o_coeff = out.coeff + (size_t)slot * out.cap_nodes * 8;
-        double* o_pp = out.path_param + (size_t)slot * out.cap_pts * 5;
-
-        // backtrack along the LDS parent table (lane 0), count exact ties on the way
-        if (lane == 0) {
-            int bj = best[f * hm + J];
-            int ties = (bj >> 30) & 1;
-            int n = bj & 0xffff;
-            for (int j = J; j >= 1; --j) {
-                int b = ts.start_layer + j; if (b >= L) b -= L;
-                o_nodes[j] = n;
-                uchar2 pr = par[((size_t)f * hm + j) * lp.kpad + n];
-                pedge[j - 1] = lat.in_ptr[lat.layer_off[b] + n] + (pr.y & 0x7f);
-                ties += (pr.y >> 7) & 1;
-                n = pr.x;
-            }
-            o_nodes[0] = n;
-            out.n_nodes[slot] = J + 1;
-            out.n_ties[slot] = ties;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-        // gather: rows per edge, node row indices, knots, element lengths (:260-297)
-        int run = 0;
-        for (int i0 = 0; i0 < N; i0 += 64) {
-            const int i = i0 + lane;
-            int take = 0, e = 0, k0 = 0, k1 = 0;
-            if (i < N) {
-                e = pedge[i]; k0 = lat.samp_ptr[e]; k1 = lat.samp_ptr[e + 1];
-                take = (i == N - 1) ? (k1 - k0) : (k1 - k0 - 1);
-            }
-            int tot; int off = wave_excl_scan(take, lane, tot);
-            if (i < N) {
-                pidx[i] = run + off;
-                kx[i] = lat.sx[k0]; ky[i] = lat.sy[k0]; el[i] = lat.edge_len[e];
-                if (i == N - 1) { kx[N] = lat.sx[k1 - 1]; ky[N] = lat.sy[k1 - 1]; pidx[N] = run + off + take - 1; }
-            }
-            run += tot;
-        }
-        const int n_pts = run;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        for (int i = lane; i <= N; i += 64) o_idx[i] = pidx[i];
-        if (lane == 0) out.n_pts[slot] = n_pts;
-
-        // tph.calc_splines (main_online_path_gen.py:299-309) as the equivalent clamped C2 spline in the cumulated
-        // el_lengths parameter: tridiagonal system in the knot slopes m_i, Thomas algorithm; lane 0 -> x, lane 1 -> y
-        if (lane < 2) {
-            const int e_first = pedge[0], e_last = pedge[N - 1];
-            const double psi_s = (ts.flags & LTPL_FLAG_HAS_PSI_S) ? in.psi_s[s] : lat.spsi[lat.samp_ptr[e_first]];
-            const double psi_e = lat.spsi[lat.samp_ptr[e_last + 1] - 1];
-            const double* kk = lane == 0 ? kx : ky;
-            double* m = lane == 0 ? mx : my;
-            double* cp = lane == 0 ? cpx : cpy;
-            const double m0 = lane == 0 ? cos(psi_s + D_PI / 2) : sin(psi_s + D_PI / 2);
-            const double mN = lane == 0 ? cos(psi_e + D_PI / 2) : sin(psi_e + D_PI / 2);
-            m[0] = m0; m[N] = mN;
-            if (N >= 2) {
-                double cprev = 0.0, dprev_ = 0.0;
-                for (int i = 1; i <= N - 1; ++i) {
-                    const double h0 = el[i - 1], h1 = el[i];
-                    const double ai = 1.0 / h0, ci = 1.0 / h1, bi = 2.0 * (ai + ci);
-                    double di = 3.0 * ((kk[i] - kk[i - 1]) / (h0 * h0) + (kk[i + 1] - kk[i]) / (h1 * h1));
-                    if (i == 1) di -= ai * m0;
-                    if (i == N - 1) di -= ci * mN;
-                    const double cc = (i == N - 1) ? 0.0 : ci;
-                    const double denom = (i == 1) ? bi : (bi - ai * cprev);
-                    const double cpi = cc / denom;
-                    const double dpi = (i == 1) ? di / denom : (di - ai * dprev_) / denom;
-                    cp[i] = cpi; m[i] = dpi; cprev = cpi; dprev_ = dpi;
-                }
-                for (int i = N - 2; i >= 1; --i) m[i] = m[i] - cp[i] * m[i + 1];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-        // coefficients per segment, t in [0, 1]: a0 = k_i, a1 = m_i h, a2 = 3 d - 2 T0 - T1, a3 = -2 d + T0 + T1
-        for (int i = lane; i < N; i += 64) {
-            const double h = el[i];
-            {
-                const double T0 = mx[i] * h, T1 = mx[i + 1] * h, dlt = kx[i + 1] - kx[i];
-                o_coeff[i * 8 + 0] = kx[i]; o_coeff[i * 8 + 1] = T0;
-                o_coeff[i * 8 + 2] = 3.0 * dlt - 2.0 * T0 - T1; o_coeff[i * 8 + 3] = -2.0 * dlt + T0 + T1;
-            }
-            {
-                const double T0 = my[i] * h, T1 = my[i + 1] * h, dlt = ky[i + 1] - ky[i];
-                o_coeff[i * 8 + 4] = ky[i]; o_coeff[i * 8 + 5] = T0;
-                o_coeff[i * 8 + 6] = 3.0 * dlt - 2.0 * T0 - T1; o_coeff[i * 8 + 7] = -2.0 * dlt + T0 + T1;
-            }
-        }
-
-        // tph.interp_splines(stepnum_fixed) + tph.calc_head_curv_an (:311-322); column 4 keeps the offline spacing
-        for (int r = lane; r < n_pts; r += 64) {
-            int lo = 0, hi = N;                                // segment i with pidx[i] <= r < pidx[i+1] (last: <=)
-            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (pidx[mid] <= r) lo = mid; else hi = mid; }
-            const int i = lo, k = r - pidx[i];
-            const int n_i = pidx[i + 1] - pidx[i] + 1;
-            const double t = (k == n_i - 1) ? 1.0 : (double)k * (1.0 / (double)(n_i - 1));
-            const double h = el[i];
-            const double Tx0 = mx[i] * h, Tx1 = mx[i + 1] * h, dx_ = kx[i + 1] - kx[i];
-            const double Ty0 = my[i] * h, Ty1 = my[i + 1] * h, dy_ = ky[i + 1] - ky[i];
-            const double ax0 = kx[i], ax1 = Tx0, ax2 = 3.0 * dx_ - 2.0 * Tx0 - Tx1, ax3 = -2.0 * dx_ + Tx0 + Tx1;
-            const double ay0 = ky[i], ay1 = Ty0, ay2 = 3.0 * dy_ - 2.0 * Ty0 - Ty1, ay3 = -2.0 * dy_ + Ty0 + Ty1;
-            const double t2 = t * t, t3 = t2 * t;
-            double x = ((ax0 + ax1 * t) + ax2 * t2) + ax3 * t3;
-            double y = ((ay0 + ay1 * t) + ay2 * t2) + ay3 * t3;
-            if (r == n_pts - 1) { x = ((ax0 + ax1) + ax2) + ax3; y = ((ay0 + ay1) + ay2) + ay3; }
-            const double xd = ax1 + 2.0 * ax2 * t + 3.0 * ax3 * t2, yd = ay1 + 2.0 * ay2 * t + 3.0 * ay3 * t2;
-            const double xdd = 2.0 * ax2 + 6.0 * ax3 * t, ydd = 2.0 * ay2 + 6.0 * ay3 * t;
-            const double q = xd * xd + yd * yd;
-            double* row = o_pp + (size_t)r * 5;
-            row[0] = x; row[1] = y;
-            row[2] = normalize_psi_dev(atan2(yd, xd) - D_PI / 2);
-            row[3] = (xd * ydd - yd * xdd) / (q * sqrt(q));
-            const double len_r = lat.slen[lat.samp_ptr[pedge[i]] + k];
-            row[4] = len_r;
-            if (vel_kappa) { vel_kappa[r] = row[3]; vel_len[r] = len_r; }
-            if (vel_x) { vel_x[r] = x; vel_y[r] = y; }
-        }
-        wp.valid = 1; wp.n_pts = n_pts; wp.n_nodes = J + 1;
-        { int gl = ts.start_layer + J; if (gl >= L) gl -= L; wp.goal_layer = gl; }
-        wp.end_node = best[f * hm + J] & 0xffff;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    dbg_stamp(lp.dbg, 7);
-    return wp;
-}
-
-__global__ __launch_bounds__(WG_THREADS) void k_plan_paths(DevLat lat, DevPathsIn in, DevPathsOut out, LdsPlan lp)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 1 ? 3 : 1)) void k_paths(DevLat lat, DevPathsIn in, DevPathsOut out, TeamLds lp)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ TickShared ts;
-    __shared__ int sh_pos_layer[MAX_POS];
-    (void)plan_paths_body(lat, in, out, lp, smem, ts, sh_pos_layer, nullptr, nullptr);
+    __shared__ TeamShared ts;
+    (void)team_paths_body<NW>(lat, in, out, lp, smem, ts, nullptr, nullptr, nullptr, nullptr);
 }
+
 
 // ---------------------------------------------------------------------------------------------------------------------
 // velocity stage (seam 2): tph.calc_vel_profile / calc_vel_profile_brake / calc_vel_profile_follow on the device
@@ -644,13 +168,6 @@ struct VelScratch {
     double* chunk;    // 128 doubles: staging of the global race line for the opponent brake scan
     int cap;
 };
-
-__device__ __forceinline__ void wave_sync_lds()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 
 // np.interp(v, axm[:, 0], axm[:, 1]) on the LDS copy of the table
 __device__ __forceinline__ double interp_axm(double v, const double* t, int n)
@@ -1193,18 +710,17 @@ __device__ void tick_vel_stage(const DevLat& lat, const DevPathsIn& in, const De
 }
 
 template <int EM, bool AXM1>
-__global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, DevPathsOut out, LdsPlan lp,
+__global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, DevPathsOut out, TeamLds lp,
                                                      DevVelParams p, DevTickVelIn vin, DevTickVelOut vout,
                                                      int vel_off, int vel_stride, int vel_cap)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ TickShared ts;
-    __shared__ int sh_pos_layer[MAX_POS];
+    __shared__ TeamShared ts;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     VelScratch vs; double* px = nullptr; double* py = nullptr;
     if (wave < LTPL_MAX_ACTIONS) vs = carve_vel_scratch(smem + vel_off + (size_t)wave * vel_stride, vel_cap, false, true, &px, &py);
-    WavePath wp = plan_paths_body(lat, in, out, lp, smem, ts, sh_pos_layer, wave < LTPL_MAX_ACTIONS ? vs.kabs : nullptr,
-                                  wave < LTPL_MAX_ACTIONS ? vs.el : nullptr, px, py);
+    WavePath wp = team_paths_body<NUM_WAVES>(lat, in, out, lp, smem, ts, wave < LTPL_MAX_ACTIONS ? vs.kabs : nullptr,
+                                             wave < LTPL_MAX_ACTIONS ? vs.el : nullptr, px, py);
     const int s = blockIdx.x;
     if (wave < LTPL_MAX_ACTIONS) {
         const int slot = s * LTPL_MAX_ACTIONS + wave;
@@ -1594,22 +1110,21 @@ __device__ void follow_prep(const DevLat& lat, const DevPathsIn& in, const DevPa
     if (lane == 0) { prep.obj_dist[slot] = odist; prep.v_obj[slot] = vobj; prep.obj_x[slot] = ox; prep.obj_y[slot] = oy; prep.idx_s_opp[slot] = idx; }
 }
 
-// path kernel + follow preparation (first kernel of the two-kernel batch pipeline)
-__global__ __launch_bounds__(WG_THREADS) void k_plan_paths_prep(DevLat lat, DevPathsIn in, DevPathsOut out, LdsPlan lp,
-                                                                DevTickVelIn vin, DevVelPrep prep, int prep_off, int prep_stride)
+// follow preparation as its own small kernel between the path kernel and the lane kernel: one wave per action slot,
+// slots without a valid 'follow' path exit at once. The path rows are re-read from the path kernel's output.
+__global__ __launch_bounds__(64) void k_follow_prep(DevLat lat, DevPathsIn in, DevPathsOut out, DevTickVelIn vin,
+                                                    DevVelPrep prep, int n_slots)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ TickShared ts;
-    __shared__ int sh_pos_layer[MAX_POS];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double* base = reinterpret_cast<double*>(smem + prep_off + (size_t)(wave < LTPL_MAX_ACTIONS ? wave : 0) * prep_stride);
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    if (slot >= n_slots || !out.valid[slot] || out.action_id[slot] != LTPL_ACT_FOLLOW) return;
+    const int n = out.n_pts[slot];
     const int c1 = out.cap_pts + 2;
-    double* sk = base; double* sel = base + c1; double* sx = base + 2 * c1; double* sy = base + 3 * c1; double* ss = base + 4 * c1;
-    const bool w3 = wave < LTPL_MAX_ACTIONS;
-    WavePath wp = plan_paths_body(lat, in, out, lp, smem, ts, sh_pos_layer, w3 ? sk : nullptr, w3 ? sel : nullptr,
-                                  w3 ? sx : nullptr, w3 ? sy : nullptr);
-    if (w3 && wp.valid && wp.name == LTPL_ACT_FOLLOW)
-        follow_prep(lat, in, out, vin, prep, wp.n_pts, ss, sel, sx, sy, blockIdx.x, blockIdx.x * LTPL_MAX_ACTIONS + wave, lane);
+    double* sel = reinterpret_cast<double*>(smem); double* sx = sel + c1; double* sy = sx + c1; double* ss = sy + c1;
+    const double* pp = out.path_param + (size_t)slot * out.cap_pts * 5;
+    for (int i = lane; i < n; i += 64) { sx[i] = pp[(size_t)i * 5]; sy[i] = pp[(size_t)i * 5 + 1]; sel[i] = pp[(size_t)i * 5 + 4]; }
+    wave_sync_lds();
+    follow_prep(lat, in, out, vin, prep, n, ss, sel, sx, sy, slot / LTPL_MAX_ACTIONS, slot, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1624,7 +1139,8 @@ struct ltpl_handle {
     hipStream_t stream = nullptr;
     std::string err;
     DevLat lat{};
-    LdsPlan lp{};
+    TeamLds lp1{}, lp4{};            // LDS plans of the path kernel: one wave / four waves per scenario
+    int batch_nw = 1;                // waves per scenario used for batches (LTPL_BATCH_NW)
     ltpl_caps caps{};
     std::vector<void*> dev_allocs;
     // staging
@@ -1684,7 +1200,7 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // planning-range statistics over all start layers (sizes the LDS plan and the output capacities)
 static int horizon_stats(const ltpl_lattice_desc* d, int* hmax, int* ehmax, int* nhmax, int* ptsmax, int* kmax,
-                         int* degmax, std::string* why)
+                         int* degmax, int* etmax, std::vector<int>* rng_end, std::string* why)
 {
     const int L = d->num_layers;
     std::vector<int> edges_into(L, 0), maxsamp_into(L, 0);
@@ -1697,6 +1213,7 @@ static int horizon_stats(const ltpl_lattice_desc* d, int* hmax, int* ehmax, int*
             if (deg > *degmax) *degmax = deg;
             edges_into[l] += deg;
             for (int e = d->in_ptr[v]; e < d->in_ptr[v + 1]; ++e) {
+                if (!(d->edge_cost[e] >= 0.0)) { *why = "negative or NaN edge cost"; return LTPL_ERR_INVALID_ARG; }
                 int ns = d->samp_ptr[e + 1] - d->samp_ptr[e];
                 if (ns < 2) { *why = "edge with fewer than 2 samples"; return LTPL_ERR_INVALID_ARG; }
                 if (ns > maxsamp_into[l]) maxsamp_into[l] = ns;
@@ -1707,7 +1224,9 @@ static int horizon_stats(const ltpl_lattice_desc* d, int* hmax, int* ehmax, int*
             }
         }
     }
-    *hmax = *ehmax = *nhmax = *ptsmax = 0;
+    *hmax = *ehmax = *nhmax = *ptsmax = 0; *etmax = 0;
+    for (int l = 0; l < L; ++l) if (edges_into[l] > *etmax) *etmax = edges_into[l];
+    rng_end->assign((size_t)L, 0);
     for (int sl = 0; sl < L; ++sl) {
         int el;
         if (d->plan_horizon_mode == 0) {
@@ -1718,6 +1237,7 @@ static int horizon_stats(const ltpl_lattice_desc* d, int* hmax, int* ehmax, int*
             el = lo;
         } else el = (sl + (int)d->min_plan_horizon) % L;
         if (el >= L) { *why = "planning horizon runs past the last layer (track shorter than the horizon?)"; return LTPL_ERR_UNSUPPORTED; }
+        (*rng_end)[(size_t)sl] = el;
         int H = el - sl; if (H < 0) H = L - sl + el;
         if (H <= 0 || H >= L - 1) { *why = "planning range covers the whole track; not supported"; return LTPL_ERR_UNSUPPORTED; }
         int eh = 0, nh = d->layer_node_off[sl + 1] - d->layer_node_off[sl], pts = 1;
@@ -1766,9 +1286,11 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
     if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
     if (device >= ndev) { g_create_error = "device index out of range"; return LTPL_ERR_NO_DEVICE; }
 
-    int hmax, ehmax, nhmax, ptsmax, kmax, degmax;
-    int rc = horizon_stats(d, &hmax, &ehmax, &nhmax, &ptsmax, &kmax, &degmax, &g_create_error);
+    int hmax, ehmax, nhmax, ptsmax, kmax, degmax, etmax;
+    std::vector<int> rng_end;
+    int rc = horizon_stats(d, &hmax, &ehmax, &nhmax, &ptsmax, &kmax, &degmax, &etmax, &rng_end, &g_create_error);
     if (rc) return rc;
+    if (etmax > 65535) { g_create_error = "more than 65535 edges in one layer transition"; return LTPL_ERR_CAPACITY; }
     if (kmax > 255 || degmax > 127) { g_create_error = "more than 255 nodes per layer or 127 in-edges per node"; return LTPL_ERR_CAPACITY; }
 
     ltpl_handle* h = new ltpl_handle();
@@ -1791,41 +1313,97 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
     UP(edge_len, d->edge_len, L.E); UP(samp_ptr, d->samp_ptr, L.E + 1);
     UP(sx, d->samp_x, L.S); UP(sy, d->samp_y, L.S); UP(spsi, d->samp_psi, L.S); UP(slen, d->samp_len, L.S);
     UP(glob_rl, d->glob_rl, (size_t)L.G * 5);
+    {
+        // derived tables: planning range per start layer, first edge into every layer, byte-wide edge sources
+        std::vector<int> ebase((size_t)L.L + 1);
+        for (int l = 0; l <= L.L; ++l) ebase[(size_t)l] = d->in_ptr[d->layer_node_off[l]];
+        std::vector<unsigned char> src8((size_t)L.E);
+        for (int e = 0; e < L.E; ++e) src8[(size_t)e] = (unsigned char)d->edge_src[e];
+        std::vector<unsigned char> dst8((size_t)L.E);
+        for (int l = 0; l < L.L; ++l)
+            for (int v = d->layer_node_off[l]; v < d->layer_node_off[l + 1]; ++v)
+                for (int e = d->in_ptr[v]; e < d->in_ptr[v + 1]; ++e) dst8[(size_t)e] = (unsigned char)(v - d->layer_node_off[l]);
+        UP(rng_end, rng_end.data(), L.L); UP(layer_ebase, ebase.data(), L.L + 1); UP(edge_src8, src8.data(), L.E);
+        UP(edge_dst8, dst8.data(), L.E);
+        std::vector<unsigned char> rank8((size_t)L.E);
+        for (int v = 0; v < L.V; ++v)
+            for (int e = d->in_ptr[v]; e < d->in_ptr[v + 1]; ++e) rank8[(size_t)e] = (unsigned char)(e - d->in_ptr[v]);
+        UP(edge_rank8, rank8.data(), L.E);
+        std::vector<int> ldeg((size_t)L.L, 0);
+        for (int l = 0; l < L.L; ++l)
+            for (int v = d->layer_node_off[l]; v < d->layer_node_off[l + 1]; ++v)
+                ldeg[(size_t)l] = std::max(ldeg[(size_t)l], d->in_ptr[v + 1] - d->in_ptr[v]);
+        UP(layer_degmax, ldeg.data(), L.L);
+        std::vector<unsigned> meta((size_t)L.E);
+        for (int e = 0; e < L.E; ++e) meta[(size_t)e] = (unsigned)src8[(size_t)e] | ((unsigned)dst8[(size_t)e] << 8) | ((unsigned)rank8[(size_t)e] << 16);
+        UP(edge_meta, meta.data(), L.E);
+        // bounding circle per edge: centre of the samples' bounding box, radius = largest centre distance (inflated)
+        std::vector<double> cx((size_t)L.E), cy((size_t)L.E), cr((size_t)L.E);
+        for (int e = 0; e < L.E; ++e) {
+            double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+            for (int k = d->samp_ptr[e]; k < d->samp_ptr[e + 1]; ++k) {
+                x0 = std::fmin(x0, d->samp_x[k]); x1 = std::fmax(x1, d->samp_x[k]);
+                y0 = std::fmin(y0, d->samp_y[k]); y1 = std::fmax(y1, d->samp_y[k]);
+            }
+            const double mx = 0.5 * (x0 + x1), my = 0.5 * (y0 + y1);
+            double r2 = 0.0;
+            for (int k = d->samp_ptr[e]; k < d->samp_ptr[e + 1]; ++k) {
+                const double dx = d->samp_x[k] - mx, dy = d->samp_y[k] - my;
+                r2 = std::fmax(r2, dx * dx + dy * dy);
+            }
+            cx[(size_t)e] = mx; cy[(size_t)e] = my; cr[(size_t)e] = std::sqrt(r2) * (1.0 + 1.0e-9) + 1.0e-9;
+        }
+        UP(edge_cx, cx.data(), L.E); UP(edge_cy, cy.data(), L.E); UP(edge_cr, cr.data(), L.E);
+    }
 #undef UP
 
-    LdsPlan& lp = h->lp;
-    lp.kpad = (int)align_up((size_t)kmax, 4);
-    lp.hmax = hmax + 1;
-    lp.words_blocked = (ehmax + 31) / 32 + 1;
-    lp.words_zone = (nhmax + 31) / 32 + 1;
-    size_t off = 0;
-    lp.off_dist = (int)off; off += sizeof(double) * NFILT * 2 * lp.kpad;
-    lp.path_stride = (int)align_up(sizeof(double) * 7 * lp.hmax + sizeof(int) * 2 * (lp.hmax + 1), 16);
-    lp.off_path = (int)off; off += (size_t)lp.path_stride * LTPL_MAX_ACTIONS;
-    lp.off_best = (int)off; off += sizeof(int) * NFILT * lp.hmax; off = align_up(off, 16);
-    lp.off_blocked = (int)off; off += sizeof(unsigned) * lp.words_blocked; off = align_up(off, 16);
-    lp.off_zone = (int)off; off += sizeof(unsigned) * lp.words_zone; off = align_up(off, 16);
-    lp.off_par = (int)off; off += sizeof(uchar2) * NFILT * (size_t)lp.hmax * lp.kpad; off = align_up(off, 16);
-    lp.total = (int)off;
-    lp.dbg = nullptr;
+    auto make_plan = [&](int nw, TeamLds* lp) {
+        lp->kpad = (int)align_up((size_t)kmax, 4);
+        lp->hmax = hmax + 1;
+        lp->etmax = etmax;
+        lp->words_blocked = (ehmax + 31) / 32 + 1;
+        lp->words_zone = (nhmax + 31) / 32 + 1;
+        lp->n_path_bufs = nw < LTPL_MAX_ACTIONS ? nw : LTPL_MAX_ACTIONS;
+        size_t off = 0;
+        lp->off_dist = (int)off; off += sizeof(double) * NFILT * 2 * lp->kpad;
+        lp->off_cnt = (int)off; off += sizeof(unsigned) * NFILT * lp->kpad;
+        lp->off_widx = (int)off; off += sizeof(unsigned) * NFILT * lp->kpad; off = align_up(off, 16);
+        lp->path_stride = (int)align_up(sizeof(double) * 7 * lp->hmax + sizeof(int) * 2 * (lp->hmax + 1), 16);
+        lp->off_path = (int)off; off += (size_t)lp->path_stride * lp->n_path_bufs;
+        lp->off_best = (int)off; off += sizeof(int) * NFILT * lp->hmax; off = align_up(off, 16);
+        lp->off_blocked = (int)off; off += sizeof(unsigned) * lp->words_blocked; off = align_up(off, 16);
+        lp->off_zone = (int)off; off += sizeof(unsigned) * lp->words_zone; off = align_up(off, 16);
+        lp->off_par = (int)off; off += sizeof(uchar2) * NFILT * (size_t)lp->hmax * lp->kpad; off = align_up(off, 16);
+        lp->ref_lds = (sizeof(double) * 2 * (size_t)d->num_layers <= sizeof(uchar2) * NFILT * (size_t)lp->hmax * lp->kpad) ? 1 : 0;
+        lp->off_lay = (int)off; off += sizeof(int) * 4 * (size_t)lp->hmax;
+        lp->off_pos_layer = (int)off; off += sizeof(short) * MAX_POS; off = align_up(off, 16);
+        lp->off_pos_veh = (int)off; off += MAX_POS; off = align_up(off, 16);
+        lp->total = (int)off;
+        lp->ablate = getenv("LTPL_ABLATE") ? atoi(getenv("LTPL_ABLATE")) : 0;
+        lp->dbg = nullptr;
+    };
+    make_plan(1, &h->lp1); make_plan(NUM_WAVES, &h->lp4);
+    if (const char* e = getenv("LTPL_BATCH_NW")) h->batch_nw = atoi(e) == 4 ? 4 : 1;
     if (getenv("LTPL_DEBUG_TIMING")) {
         if (hipMalloc(reinterpret_cast<void**>(&h->d_dbg), sizeof(long long) * 256 * DBG_SLOTS) == hipSuccess) {
             (void)hipMemset(h->d_dbg, 0, sizeof(long long) * 256 * DBG_SLOTS);
-            lp.dbg = h->d_dbg;
+            h->lp1.dbg = h->d_dbg; h->lp4.dbg = h->d_dbg;
         }
     }
-    if (off > 150 * 1024) {
-        h->err = "planning horizon too large for the LDS-resident sweep (" + std::to_string(off) + " B > 150 KiB)";
+    if (h->lp4.total > 150 * 1024) {
+        h->err = "planning horizon too large for the LDS-resident sweep (" + std::to_string(h->lp4.total) + " B > 150 KiB)";
         return fail(LTPL_ERR_CAPACITY);
     }
-    if (lp.total > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan_paths), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lp.total) != hipSuccess) { h->err = "cannot raise dynamic LDS limit"; return fail(LTPL_ERR_HIP); }
+    if (h->lp4.total > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_paths<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                h->lp1.total) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_paths<NUM_WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                h->lp4.total) != hipSuccess) { h->err = "cannot raise dynamic LDS limit"; return fail(LTPL_ERR_HIP); }
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { h->err = "hipGetDeviceProperties failed"; return fail(LTPL_ERR_HIP); }
     h->caps.max_path_nodes = hmax; h->caps.max_path_pts = ptsmax; h->caps.max_horizon_edges = ehmax;
-    h->caps.device = device; h->caps.num_cus = prop.multiProcessorCount; h->caps.lds_bytes_paths = lp.total;
+    h->caps.device = device; h->caps.num_cus = prop.multiProcessorCount; h->caps.lds_bytes_paths = h->lp1.total;
     *out_handle = h;
     return LTPL_OK;
 }
@@ -2013,11 +1591,14 @@ extern "C" int ltpl_plan_paths(ltpl_handle* h, const ltpl_paths_in* in, ltpl_pat
     pack_in(in, li, static_cast<unsigned char*>(h->h_in), static_cast<const unsigned char*>(h->d_in), &di);
     bind_out(static_cast<unsigned char*>(h->d_out), lo, out->cap_nodes, out->cap_pts, &dout);
     HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, li.total, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_plan_paths, dim3(in->n_scen), dim3(WG_THREADS), h->lp.total, h->stream, h->lat, di, dout, h->lp);
+    if (in->n_scen >= PIPELINE_MIN_SCEN && h->batch_nw == 1)
+        hipLaunchKernelGGL(k_paths<1>, dim3(in->n_scen), dim3(64), h->lp1.total, h->stream, h->lat, di, dout, h->lp1);
+    else
+        hipLaunchKernelGGL(k_paths<NUM_WAVES>, dim3(in->n_scen), dim3(WG_THREADS), h->lp4.total, h->stream, h->lat, di, dout, h->lp4);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, lo.total, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    dbg_report(h, "k_plan_paths", in->n_scen);
+    dbg_report(h, "k_paths", in->n_scen);
     scatter_out(static_cast<const unsigned char*>(h->h_out), lo, in->n_scen, out);
     return LTPL_OK;
 }
@@ -2030,7 +1611,7 @@ static int vel_variant(const ltpl_vel_params* vp)
     return em * 2 + (vp->n_ax_max_machines == 1 ? 1 : 0);
 }
 typedef void (*vel_kernel_t)(DevLat, DevVelParams, const DevVelJob*, const double*, double*, int*, int, long long*);
-typedef void (*tick_kernel_t)(DevLat, DevPathsIn, DevPathsOut, LdsPlan, DevVelParams, DevTickVelIn, DevTickVelOut, int, int, int);
+typedef void (*tick_kernel_t)(DevLat, DevPathsIn, DevPathsOut, TeamLds, DevVelParams, DevTickVelIn, DevTickVelOut, int, int, int);
 typedef void (*lanes_kernel_t)(DevLat, DevPathsIn, DevPathsOut, DevVelParams, DevTickVelIn, DevTickVelOut, DevVelPrep, double*, int, long long*);
 static lanes_kernel_t lanes_kernel_of(int v)
 {
@@ -2127,7 +1708,7 @@ extern "C" int ltpl_vel_profile(ltpl_handle* h, const ltpl_vel_params* vp, int n
     unsigned char* dob = static_cast<unsigned char*>(h->d_out);
     hipLaunchKernelGGL(kern, dim3(n_jobs), dim3(64), lds, h->stream, h->lat, p,
                        reinterpret_cast<const DevVelJob*>(db + o_jobs), reinterpret_cast<const double*>(db + o_pool),
-                       reinterpret_cast<double*>(dob + o_vx), reinterpret_cast<int*>(dob + o_flags), cap, h->lp.dbg);
+                       reinterpret_cast<double*>(dob + o_vx), reinterpret_cast<int*>(dob + o_flags), cap, h->lp4.dbg);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, aout.size, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -2154,7 +1735,6 @@ struct TickLayout {
     bool pipeline; size_t prep_odist, prep_vobj, prep_ox, prep_oy, prep_idx; size_t planes_bytes;
     DevVelPrep dprep; int prep_off, prep_stride; size_t lds_prep;
 };
-#define PIPELINE_MIN_SCEN 64
 
 static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin, int cap_nodes, int cap_pts,
                         TickLayout* t)
@@ -2191,13 +1771,12 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
     t->prep_idx = b.add(sizeof(int) * (size_t)n * LTPL_MAX_ACTIONS);
     t->out_total = b.size;
     t->planes_bytes = t->pipeline ? sizeof(double) * 3 * (size_t)cap_pts * (size_t)n * LTPL_MAX_ACTIONS : 0;
-    t->prep_off = h->lp.total;
-    t->prep_stride = (int)align_up(sizeof(double) * 5 * (size_t)(cap_pts + 2), 16);
-    t->lds_prep = (size_t)h->lp.total + (size_t)t->prep_stride * LTPL_MAX_ACTIONS;
+    t->prep_off = 0; t->prep_stride = 0;
+    t->lds_prep = align_up(sizeof(double) * 4 * (size_t)(cap_pts + 2), 16);      // k_follow_prep: el, x, y, s
     t->vel_cap = h->caps.max_path_pts;
     t->vel_stride = (int)vel_scratch_bytes(t->vel_cap, false, true);
-    t->vel_off = h->lp.total;
-    t->lds = (size_t)h->lp.total + (size_t)t->vel_stride * LTPL_MAX_ACTIONS;
+    t->vel_off = h->lp4.total;
+    t->lds = (size_t)h->lp4.total + (size_t)t->vel_stride * LTPL_MAX_ACTIONS;
     if (t->lds > 150 * 1024) { h->err = "fused tick exceeds the LDS budget"; return LTPL_ERR_CAPACITY; }
     return LTPL_OK;
 }
@@ -2243,16 +1822,21 @@ static int tick_pack(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_ve
 static int tick_launch(ltpl_handle* h, const TickLayout& t)
 {
     if (t.pipeline) {
-        hipLaunchKernelGGL(k_plan_paths_prep, dim3(t.n_scen), dim3(WG_THREADS), t.lds_prep, h->stream, h->lat, t.di, t.dout,
-                           h->lp, t.dvin, t.dprep, t.prep_off, t.prep_stride);
+        if (h->batch_nw == 1)
+            hipLaunchKernelGGL(k_paths<1>, dim3(t.n_scen), dim3(64), h->lp1.total, h->stream, h->lat, t.di, t.dout, h->lp1);
+        else
+            hipLaunchKernelGGL(k_paths<NUM_WAVES>, dim3(t.n_scen), dim3(WG_THREADS), h->lp4.total, h->stream, h->lat, t.di, t.dout, h->lp4);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL(k_follow_prep, dim3(t.n_scen * LTPL_MAX_ACTIONS), dim3(64), t.lds_prep, h->stream, h->lat, t.di, t.dout,
+                           t.dvin, t.dprep, t.n_scen * LTPL_MAX_ACTIONS);
         HIP_TRY(h, hipGetLastError());
         const int n_slots = t.n_scen * LTPL_MAX_ACTIONS;
         hipLaunchKernelGGL(lanes_kernel_of(t.variant), dim3((n_slots + 63) / 64), dim3(64), 0, h->stream, h->lat, t.di, t.dout,
-                           t.p, t.dvin, t.dvout, t.dprep, static_cast<double*>(h->d_planes), n_slots, h->lp.dbg);
+                           t.p, t.dvin, t.dvout, t.dprep, static_cast<double*>(h->d_planes), n_slots, h->lp4.dbg);
         HIP_TRY(h, hipGetLastError());
         return LTPL_OK;
     }
-    hipLaunchKernelGGL(tick_kernel_of(t.variant), dim3(t.n_scen), dim3(WG_THREADS), t.lds, h->stream, h->lat, t.di, t.dout, h->lp, t.p,
+    hipLaunchKernelGGL(tick_kernel_of(t.variant), dim3(t.n_scen), dim3(WG_THREADS), t.lds, h->stream, h->lat, t.di, t.dout, h->lp4, t.p,
                        t.dvin, t.dvout, t.vel_off, t.vel_stride, t.vel_cap);
     HIP_TRY(h, hipGetLastError());
     return LTPL_OK;
@@ -2272,9 +1856,6 @@ static void tick_scatter(const unsigned char* hb, const TickLayout& t, ltpl_path
 
 static int tick_set_lds_limit(ltpl_handle* h, size_t lds, int variant)
 {
-    if (h->lp.total + 5 * 8 * (h->caps.max_path_pts + 4) * LTPL_MAX_ACTIONS > 48 * 1024)
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan_paths_prep), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       h->lp.total + 5 * 8 * (h->caps.max_path_pts + 4) * LTPL_MAX_ACTIONS));
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(tick_kernel_of(variant)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return LTPL_OK;

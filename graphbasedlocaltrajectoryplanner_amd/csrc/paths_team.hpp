@@ -1,0 +1,917 @@
+// paths_team.hpp -- seam (1) on the device: a TEAM of NW wave64s plans one scenario (= one call of the reference's
+// main_online_path_gen, graph_ltpl/online_graph/src/main_online_path_gen.py:11-334). Included by ltpl_hip.hip.
+//
+//   NW = 1  throughput form: one wave per scenario, ~10 KB of LDS, up to 16 scenarios resident per CU; every latency
+//           chain of one scenario is covered by the other resident scenarios.
+//   NW = 4  latency form: four waves per scenario (single-tick path, fused with the velocity stage in k_tick).
+//
+// Phases (reference rows of SURVEY.md section 8a in brackets):
+//   1  closest reference-line layer per obstacle position, lexicographic wave min-reduction              [M1]
+//   2  obstacle x edge-sample collision mask. Transition-major: the sample arrays of a layer transition are
+//      streamed ONCE (coalesced, unrolled for memory-level parallelism) and tested against every obstacle position
+//      whose 3-layer window contains the transition; result = one bit per horizon edge in LDS              [M2]
+//   3  closest object / node and action-template choice (uniform, computed redundantly per wave)        [M3, T1]
+//   4  layered min-plus sweeps. Per layer transition the edges (cost, source) are staged ONCE into LDS by
+//      coalesced loads and shared by all filters; blocked edges are marked in the sign bit of the staged cost.
+//      Lane = destination node, private min over its in-edges (CSC => no atomics); filters are node / edge
+//      predicates (planning_range, default, overtake_left, overtake_right), not graph copies. overtake_left /
+//      overtake_right equal `default` in front of the object layer, so they branch off the `default` sweep there.
+//      Goal nodes are evaluated lazily: only for the layer a path actually ends in                        [F1, S1]
+//   5  horizon back-off / reduced-horizon logic on the per-layer reachability table                         [S2]
+//   6  backtrack, gather, tridiagonal C2 spline solve, re-sampling, heading / curvature                 [G1, P1-P3]
+#pragma once
+
+struct TeamLds {                 // dynamic-LDS plan (byte offsets), computed once per lattice on the host
+    int kpad, hmax, etmax;
+    int words_blocked, words_zone;
+    int off_pos_layer;           // short[MAX_POS]   closest reference-line layer per position, -1 = gated out
+    int off_pos_veh;             // uchar[MAX_POS]   vehicle of a position
+    int off_blocked;             // u32[words_blocked]
+    int off_zone;                // u32[words_zone]
+    int off_dist;                // double[NFILT][2][kpad]
+    int off_par;                 // uchar2[NFILT][hmax][kpad]  (.x = source node, .y = in-edge rank | tie bit 0x80)
+    int off_best;                // int[NFILT][hmax]  -1 unreachable, -2 reachable (goal not evaluated), >= 0 goal node | tie << 30
+    int off_cnt;                 // u32[NFILT][kpad]  number of in-edges that attain the minimum
+    int off_widx;                // u32[NFILT][kpad]  (edge index in the transition << 16 | in-edge rank << 8 | source node) of the first
+    int off_lay;                 // int4[hmax]  per horizon layer j: first node id, #nodes, first / past-last edge INTO it
+    int ref_lds;                 // 1: the reference line (x, y interleaved) is staged in the `par` region during phase 1
+    int off_path;                // path scratch, `n_path_bufs` buffers of `path_stride` bytes
+    int path_stride, n_path_bufs;
+    int total;
+    int ablate;                  // profiling only (LTPL_ABLATE): 1 = skip the mask, 2 = skip the sweeps, 4 = skip path assembly
+    long long* dbg;
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+struct TeamShared {
+    int closest_idx, cl, cn, have_cn;          // written by wave 0 in phase 3
+    int start_ok[NFILT];
+    // previous-solution cost discount per layer transition j (gen_local_node_template.py:154-162), filled in phase 0
+    int fac_src[LTPL_MAX_LAST_NODES], fac_dst[LTPL_MAX_LAST_NODES];
+    double fac[LTPL_MAX_LAST_NODES];
+};
+
+// uniform per-scenario state, computed redundantly by every wave (scalar registers)
+struct Scen {
+    int s, sl, sn, flags, el, H;
+    int e_base, n_base, NH;
+    int veh0, n_veh, pos0, n_pos;
+    int n_fac;
+};
+
+__device__ __forceinline__ bool team_node_removed(const unsigned* zone_bits, const DevLat& lat, const Scen& sc, int cl, int cn,
+                                                  int f, int layer, int n, int gid)
+{
+    int nl = gid - sc.n_base; if (nl < 0) nl += lat.V;
+    if (zone_bits[nl >> 5] & (1u << (nl & 31))) return true;
+    if (f == F_LEFT && layer == cl && n >= cn) return true;      // main_online_path_gen.py:148-152
+    if (f == F_RIGHT && layer == cl && n < cn) return true;      // main_online_path_gen.py:155-159
+    return false;
+}
+
+template <int NW>
+__device__ __forceinline__ void team_sync()
+{
+    if constexpr (NW == 1) {
+        // one wave: DS operations of a wave execute in order, so only the compiler has to be kept from reordering
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+// register image of one edge of the NEXT layer transition (raw prefetched values, consumed one layer later)
+struct EdgeRegs { double c; unsigned meta; };     // meta = source node | destination node << 8 | in-edge rank << 16
+
+// goal node of layer j for filter f from the frontier distances in `dcur` (virtual goal edges, GraphBase.py:188-194):
+// lexicographic min over (dist + vgoal, dist, node); returns node | (tie << 30) or -1
+__device__ __noinline__ int team_goal(const DevLat& lat, const double* dcur, int v0, int Kb, int lane)
+{
+    double g1 = INFINITY, g2 = INFINITY; int gn = 0x7fffffff;
+    for (int n = lane; n < Kb; n += 64) {
+        const double bestc = dcur[n];
+        if (bestc < INFINITY) {
+            const double tot = bestc + lat.vgoal[v0 + n];
+            if (tot < g1 || (tot == g1 && (bestc < g2 || (bestc == g2 && n < gn)))) { g1 = tot; g2 = bestc; gn = n; }
+        }
+    }
+    double m1 = g1, m2 = g2; int mn = gn;
+    wave_min3(m1, m2, mn);
+    const int ntie = __popcll(__ballot(g1 == m1 && g1 < INFINITY));
+    return (m1 < INFINITY) ? (mn | (ntie > 1 ? (1 << 30) : 0)) : -1;
+}
+
+// Serial form of one sweep layer for filter f (lane = destination node, private loop over its in-edges in CSC order):
+// dcur[n] = min over in-edges (u, n) of dprev[u] + cost(u, n); strict '<' updates; among exact ties the predecessor with
+// the smaller dprev[u], then the smaller node id wins (= the order in which Dijkstra settles them). Used by the rare
+// re-sweep of reduced-horizon paths; the hot sweep is the edge-parallel form in team_paths_body.
+__device__ __forceinline__ void team_serial_node(const DevLat& lat, const Scen& sc, const unsigned* blocked_bits, int f, int n,
+                                                 int v, const double* dprev, int fac_src, int fac_dst, double fac,
+                                                 double& bestc, int& bsrc, int& bk, int& tie)
+{
+    double bestdu = INFINITY;
+    bestc = INFINITY; bk = 0; bsrc = 0; tie = 0;
+    const int e0 = lat.in_ptr[v], e1 = lat.in_ptr[v + 1];
+    for (int e = e0; e < e1; ++e) {
+        const int src = lat.edge_src8[e];
+        double c = lat.edge_cost[e];
+        if (f != F_PR) {
+            int el_ = e - sc.e_base; if (el_ < 0) el_ += lat.E;
+            if ((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u) continue;
+        }
+        const double du = dprev[src];
+        if (!(du < INFINITY)) continue;
+        if (src == fac_src && n == fac_dst) c *= fac;
+        const double cand = du + c;
+        if (cand < bestc) { bestc = cand; bestdu = du; bk = e - e0; bsrc = src; tie = 0; }
+        else if (cand == bestc) {
+            tie = 1;
+            if (du < bestdu) { bestdu = du; bk = e - e0; bsrc = src; }
+        }
+    }
+}
+
+// out-of-line, value-returning form for the rare exact tie-break inside the hot sweep (no address-taken locals there):
+// returns source node | in-edge rank << 8 | tie << 16
+__device__ __noinline__ int team_serial_node_packed(const DevLat& lat, int e_base, const unsigned* blocked_bits, int f, int n, int v,
+                                                    const double* dprev, int fac_src, int fac_dst, double fac)
+{
+    Scen sc; sc.e_base = e_base;
+    double bc; int bsrc, bk, tie;
+    team_serial_node(lat, sc, blocked_bits, f, n, v, dprev, fac_src, fac_dst, fac, bc, bsrc, bk, tie);
+    return bsrc | (bk << 8) | (tie << 16);
+}
+
+__device__ __forceinline__ bool team_relax_layer(const DevLat& lat, const DevPathsIn& in, const Scen& sc, const TeamLds& lp,
+                                                 unsigned char* smem, int cl, int cn, int f, int j, int b, int v0, int Kb,
+                                                 const double* dprev, double* dcur, uchar2* pj, int lane,
+                                                 int fac_src, int fac_dst, double fac)
+{
+    const unsigned* blocked_bits = reinterpret_cast<const unsigned*>(smem + lp.off_blocked);
+    const unsigned* zone_bits = reinterpret_cast<const unsigned*>(smem + lp.off_zone);
+    bool any = false;
+    for (int n = lane; n < Kb; n += 64) {
+        const int v = v0 + n;
+        double bestc = INFINITY; int bk = 0, bsrc = 0, tie = 0;
+        if (!team_node_removed(zone_bits, lat, sc, cl, cn, f, b, n, v))
+            team_serial_node(lat, sc, blocked_bits, f, n, v, dprev, fac_src, fac_dst, fac, bestc, bsrc, bk, tie);
+        dcur[n] = bestc;
+        pj[n] = make_uchar2((unsigned char)bsrc, (unsigned char)(bk | (tie ? 0x80 : 0)));
+        any = any || (bestc < INFINITY);
+    }
+    for (int n = Kb + lane; n < lp.kpad; n += 64) dcur[n] = INFINITY;
+    return __ballot(any) != 0ull;
+}
+
+// cost discount along the previous solution (gen_local_node_template.py:154-162) for the transition j-1 -> j
+__device__ __forceinline__ void team_factor(const DevLat& lat, const DevPathsIn& in, const Scen& sc, int j, int b,
+                                            int& fac_src, int& fac_dst, double& fac)
+{
+    fac_src = -1; fac_dst = -1; fac = 1.0;
+    if (j - 1 < sc.n_fac) {
+        const int* ll = in.last_layer + (size_t)sc.s * LTPL_MAX_LAST_NODES;
+        const int* ln = in.last_node + (size_t)sc.s * LTPL_MAX_LAST_NODES;
+        int pb = b - 1; if (pb < 0) pb += lat.L;
+        if (ll[j - 1] == pb && ll[j] == b) { fac_src = ln[j - 1]; fac_dst = ln[j]; fac = in.w_last[j - 1]; }
+    }
+}
+
+// Re-sweep of one filter up to layer J straight from global memory (reduced-horizon paths only: the goal node of a
+// layer in front of the planning horizon is needed). Parents are rewritten with identical values.
+__device__ void team_resweep(const DevLat& lat, const DevPathsIn& in, const Scen& sc, const TeamLds& lp, unsigned char* smem,
+                             const TeamShared& ts, int f, int J, int lane)
+{
+    double* dist = reinterpret_cast<double*>(smem + lp.off_dist);
+    uchar2* par = reinterpret_cast<uchar2*>(smem + lp.off_par);
+    int* best = reinterpret_cast<int*>(smem + lp.off_best);
+    const unsigned* zone_bits = reinterpret_cast<const unsigned*>(smem + lp.off_zone);
+    const int L = lat.L, kpad = lp.kpad;
+    double* d0 = dist + (size_t)(f * 2) * kpad;
+    const int K0 = lat.layer_off[sc.sl + 1] - lat.layer_off[sc.sl];
+    const bool ok = sc.sn >= 0 && sc.sn < K0 &&
+                    !team_node_removed(zone_bits, lat, sc, ts.cl, ts.cn, f, sc.sl, sc.sn, lat.layer_off[sc.sl] + sc.sn);
+    for (int n = lane; n < kpad; n += 64) d0[n] = (ok && n == sc.sn) ? 0.0 : INFINITY;
+    wave_sync_lds();
+    for (int j = 1; j <= J; ++j) {
+        int b = sc.sl + j; if (b >= L) b -= L;
+        const int v0 = lat.layer_off[b], Kb = lat.layer_off[b + 1] - v0;
+        int fs, fd; double fac;
+        team_factor(lat, in, sc, j, b, fs, fd, fac);
+        const double* dprev = dist + (size_t)(f * 2 + ((j - 1) & 1)) * kpad;
+        double* dcur = dist + (size_t)(f * 2 + (j & 1)) * kpad;
+        (void)team_relax_layer(lat, in, sc, lp, smem, ts.cl, ts.cn, f, j, b, v0, Kb, dprev, dcur,
+                                par + ((size_t)f * lp.hmax + j) * kpad, lane, fs, fd, fac);
+        wave_sync_lds();
+    }
+    int b = sc.sl + J; if (b >= L) b -= L;
+    const int v0 = lat.layer_off[b], Kb = lat.layer_off[b + 1] - v0;
+    const int g = team_goal(lat, dist + (size_t)(f * 2 + (J & 1)) * kpad, v0, Kb, lane);
+    if (lane == 0) best[f * lp.hmax + J] = g;
+    wave_sync_lds();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// phase 6: assemble primitive `a` (one wave): backtrack, gather, spline, re-sampling (main_online_path_gen.py:250-328)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const Scen& sc,
+                                  const TeamLds& lp, unsigned char* smem, int a, int f, int J, int name, int reduced,
+                                  int jcl, bool share_prefix, int lane, unsigned char* pw,
+                                  double* vel_kappa, double* vel_len, double* vel_x, double* vel_y)
+{
+    const int L = lat.L, hm = lp.hmax, N = J, s = sc.s;
+    const int slot = s * LTPL_MAX_ACTIONS + a;
+    const uchar2* par = reinterpret_cast<const uchar2*>(smem + lp.off_par);
+    const int* best = reinterpret_cast<const int*>(smem + lp.off_best);
+    double* kx = reinterpret_cast<double*>(pw);
+    double* ky = kx + hm; double* el = ky + hm; double* mx = el + hm; double* my = mx + hm;
+    double* cpx = my + hm; double* cpy = cpx + hm;
+    int* pedge = reinterpret_cast<int*>(cpy + hm); int* pidx = pedge + hm + 1;
+    int* o_nodes = out.nodes + (size_t)slot * out.cap_nodes;
+    int* o_idx = out.node_idx + (size_t)slot * out.cap_nodes;
+    double* o_coeff = out.coeff + (size_t)slot * out.cap_nodes * 8;
+    double* o_pp = out.path_param + (size_t)slot * out.cap_pts * 5;
+    WavePath wp; wp.valid = 1; wp.name = name; wp.reduced = reduced;
+
+    // backtrack along the LDS parent table (lane 0), count exact ties on the way; rank of the in-edge -> pedge (as rank
+    // first, resolved to edge ids by all lanes afterwards: the global in_ptr loads are then independent)
+    if (lane == 0) {
+        const int bj = best[f * hm + J];
+        int ties = (bj >> 30) & 1;
+        int n = bj & 0xffff;
+        for (int j = J; j >= 1; --j) {
+            const int pf = (share_prefix && j < jcl) ? F_DEF : f;
+            const uchar2 pr = par[((size_t)pf * hm + j) * lp.kpad + n];
+            pidx[j] = n;                                   // node of layer j (temporarily)
+            pedge[j - 1] = pr.y & 0x7f;
+            ties += (pr.y >> 7) & 1;
+            n = pr.x;
+        }
+        pidx[0] = n;
+        out.n_nodes[slot] = J + 1;
+        out.n_ties[slot] = ties;
+    }
+    wave_sync_lds();
+    for (int i0 = 0; i0 <= N; i0 += 64) {
+        const int i = i0 + lane;
+        int node = 0, e = 0;
+        if (i <= N) node = pidx[i];
+        if (i >= 1 && i <= N) {
+            int b = sc.sl + i; if (b >= L) b -= L;
+            e = lat.in_ptr[lat.layer_off[b] + node] + pedge[i - 1];
+        }
+        wave_sync_lds();
+        if (i <= N) o_nodes[i] = node;
+        if (i >= 1 && i <= N) pedge[i - 1] = e;
+    }
+    wave_sync_lds();
+
+    // gather: rows per edge, node row indices, knots, element lengths (:260-297)
+    int run = 0;
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        const int i = i0 + lane;
+        int take = 0, e = 0, k0 = 0, k1 = 0;
+        if (i < N) {
+            e = pedge[i]; k0 = lat.samp_ptr[e]; k1 = lat.samp_ptr[e + 1];
+            take = (i == N - 1) ? (k1 - k0) : (k1 - k0 - 1);
+        }
+        int tot; const int off = wave_excl_scan(take, lane, tot);
+        if (i < N) {
+            pidx[i] = run + off;
+            kx[i] = lat.sx[k0]; ky[i] = lat.sy[k0]; el[i] = lat.edge_len[e];
+            if (i == N - 1) { kx[N] = lat.sx[k1 - 1]; ky[N] = lat.sy[k1 - 1]; pidx[N] = run + off + take - 1; }
+        }
+        run += tot;
+    }
+    const int n_pts = run;
+    wave_sync_lds();
+    for (int i = lane; i <= N; i += 64) o_idx[i] = pidx[i];
+    if (lane == 0) out.n_pts[slot] = n_pts;
+
+    // tph.calc_splines (main_online_path_gen.py:299-309) as the equivalent clamped C2 spline in the cumulated
+    // el_lengths parameter: tridiagonal system in the knot slopes m_i, Thomas algorithm; lane 0 -> x, lane 1 -> y
+    if (lane < 2) {
+        const int e_first = pedge[0], e_last = pedge[N - 1];
+        const double psi_s = (sc.flags & LTPL_FLAG_HAS_PSI_S) ? in.psi_s[s] : lat.spsi[lat.samp_ptr[e_first]];
+        const double psi_e = lat.spsi[lat.samp_ptr[e_last + 1] - 1];
+        const double* kk = lane == 0 ? kx : ky;
+        double* m = lane == 0 ? mx : my;
+        double* cp = lane == 0 ? cpx : cpy;
+        const double m0 = lane == 0 ? cos(psi_s + D_PI / 2) : sin(psi_s + D_PI / 2);
+        const double mN = lane == 0 ? cos(psi_e + D_PI / 2) : sin(psi_e + D_PI / 2);
+        m[0] = m0; m[N] = mN;
+        if (N >= 2) {
+            double cprev = 0.0, dprev_ = 0.0;
+            for (int i = 1; i <= N - 1; ++i) {
+                const double h0 = el[i - 1], h1 = el[i];
+                const double ai = 1.0 / h0, ci = 1.0 / h1, bi = 2.0 * (ai + ci);
+                double di = 3.0 * ((kk[i] - kk[i - 1]) / (h0 * h0) + (kk[i + 1] - kk[i]) / (h1 * h1));
+                if (i == 1) di -= ai * m0;
+                if (i == N - 1) di -= ci * mN;
+                const double cc = (i == N - 1) ? 0.0 : ci;
+                const double denom = (i == 1) ? bi : (bi - ai * cprev);
+                const double cpi = cc / denom;
+                const double dpi = (i == 1) ? di / denom : (di - ai * dprev_) / denom;
+                cp[i] = cpi; m[i] = dpi; cprev = cpi; dprev_ = dpi;
+            }
+            for (int i = N - 2; i >= 1; --i) m[i] = m[i] - cp[i] * m[i + 1];
+        }
+    }
+    wave_sync_lds();
+
+    // coefficients per segment, t in [0, 1]: a0 = k_i, a1 = m_i h, a2 = 3 d - 2 T0 - T1, a3 = -2 d + T0 + T1
+    for (int i = lane; i < N; i += 64) {
+        const double h = el[i];
+        {
+            const double T0 = mx[i] * h, T1 = mx[i + 1] * h, dlt = kx[i + 1] - kx[i];
+            o_coeff[i * 8 + 0] = kx[i]; o_coeff[i * 8 + 1] = T0;
+            o_coeff[i * 8 + 2] = 3.0 * dlt - 2.0 * T0 - T1; o_coeff[i * 8 + 3] = -2.0 * dlt + T0 + T1;
+        }
+        {
+            const double T0 = my[i] * h, T1 = my[i + 1] * h, dlt = ky[i + 1] - ky[i];
+            o_coeff[i * 8 + 4] = ky[i]; o_coeff[i * 8 + 5] = T0;
+            o_coeff[i * 8 + 6] = 3.0 * dlt - 2.0 * T0 - T1; o_coeff[i * 8 + 7] = -2.0 * dlt + T0 + T1;
+        }
+    }
+
+    // tph.interp_splines(stepnum_fixed) + tph.calc_head_curv_an (:311-322); column 4 keeps the offline spacing
+    for (int r = lane; r < n_pts; r += 64) {
+        int lo = 0, hi = N;                                // segment i with pidx[i] <= r < pidx[i+1] (last: <=)
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pidx[mid] <= r) lo = mid; else hi = mid; }
+        const int i = lo, k = r - pidx[i];
+        const int n_i = pidx[i + 1] - pidx[i] + 1;
+        const double t = (k == n_i - 1) ? 1.0 : (double)k * (1.0 / (double)(n_i - 1));
+        const double h = el[i];
+        const double Tx0 = mx[i] * h, Tx1 = mx[i + 1] * h, dx_ = kx[i + 1] - kx[i];
+        const double Ty0 = my[i] * h, Ty1 = my[i + 1] * h, dy_ = ky[i + 1] - ky[i];
+        const double ax0 = kx[i], ax1 = Tx0, ax2 = 3.0 * dx_ - 2.0 * Tx0 - Tx1, ax3 = -2.0 * dx_ + Tx0 + Tx1;
+        const double ay0 = ky[i], ay1 = Ty0, ay2 = 3.0 * dy_ - 2.0 * Ty0 - Ty1, ay3 = -2.0 * dy_ + Ty0 + Ty1;
+        const double t2 = t * t, t3 = t2 * t;
+        double x = ((ax0 + ax1 * t) + ax2 * t2) + ax3 * t3;
+        double y = ((ay0 + ay1 * t) + ay2 * t2) + ay3 * t3;
+        if (r == n_pts - 1) { x = ((ax0 + ax1) + ax2) + ax3; y = ((ay0 + ay1) + ay2) + ay3; }
+        const double xd = ax1 + 2.0 * ax2 * t + 3.0 * ax3 * t2, yd = ay1 + 2.0 * ay2 * t + 3.0 * ay3 * t2;
+        const double xdd = 2.0 * ax2 + 6.0 * ax3 * t, ydd = 2.0 * ay2 + 6.0 * ay3 * t;
+        const double q = xd * xd + yd * yd;
+        double* row = o_pp + (size_t)r * 5;
+        row[0] = x; row[1] = y;
+        row[2] = normalize_psi_dev(atan2(yd, xd) - D_PI / 2);
+        const double kap = (xd * ydd - yd * xdd) / (q * sqrt(q));
+        row[3] = kap;
+        const double len_r = lat.slen[lat.samp_ptr[pedge[i]] + k];
+        row[4] = len_r;
+        if (vel_kappa) { vel_kappa[r] = kap; vel_len[r] = len_r; }
+        if (vel_x) { vel_x[r] = x; vel_y[r] = y; }
+    }
+    wp.n_pts = n_pts; wp.n_nodes = J + 1;
+    { int gl = sc.sl + J; if (gl >= L) gl -= L; wp.goal_layer = gl; }
+    wp.end_node = best[f * hm + J] & 0xffff;
+    wave_sync_lds();
+    return wp;
+}
+
+// One sweep layer for the (compile-time) filter set ACT, EDGE-PARALLEL: lane = edge of the transition (register image
+// `er`, prefetched one layer ahead with coalesced loads), two rounds of LDS atomics per layer:
+//   round 0  frontier[dst] = min(frontier[dst], dprev[src] + cost)      ds_min_u64 on the fp64 bit pattern (costs >= 0)
+//   round 1  edges that attain the minimum count themselves and elect the first of them in CSC order
+// then lane = destination node: parents, reachability, node filters (zone / overtake side), goal of the last layer. The
+// exact tie-break of the reference order only matters when the minimum is attained more than once: those nodes (rare)
+// re-scan their in-edges serially.
+struct LayerArgs {
+    int j, b, v0, Kb, ne, kpad, hm, cur, prv, H;
+    int fs, fd, cl_hit, cn;                      // cl_hit: this layer is the closest object's layer
+    bool from_def;
+    double fac;
+};
+
+template <int NW, int CH, unsigned ACT>
+__device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, const TeamLds& lp, unsigned char* smem,
+                                           const LayerArgs& A, const EdgeRegs (&er)[CH], const unsigned long long (&blkm)[CH],
+                                           int wave, int lane)
+{
+    const unsigned* blocked_bits = reinterpret_cast<const unsigned*>(smem + lp.off_blocked);
+    const unsigned* zone_bits = reinterpret_cast<const unsigned*>(smem + lp.off_zone);
+    double* dist = reinterpret_cast<double*>(smem + lp.off_dist);
+    uchar2* par = reinterpret_cast<uchar2*>(smem + lp.off_par);
+    int* best = reinterpret_cast<int*>(smem + lp.off_best);
+    unsigned* cnt_all = reinterpret_cast<unsigned*>(smem + lp.off_cnt);
+    unsigned* widx_all = reinterpret_cast<unsigned*>(smem + lp.off_widx);
+    const int kpad = A.kpad, tid = wave * 64 + lane;
+    constexpr int NT = NW * 64;
+    int poff[NFILT], coff[NFILT];
+#pragma unroll
+    for (int f = 0; f < NFILT; ++f) {
+        const int fprev = (A.from_def && (f == F_LEFT || f == F_RIGHT)) ? F_DEF : f;
+        poff[f] = (fprev * 2 + A.prv) * kpad; coff[f] = (f * 2 + A.cur) * kpad;
+    }
+    // reset the targets of this layer
+    for (int n = tid; n < kpad; n += NT) {
+#pragma unroll
+        for (int f = 0; f < NFILT; ++f)
+            if ((ACT >> f) & 1u) { dist[coff[f] + n] = INFINITY; cnt_all[f * kpad + n] = 0u; widx_all[f * kpad + n] = 0xffffffffu; }
+    }
+    team_sync<NW>();
+    double cand[CH][NFILT]; unsigned okm[CH];
+#pragma unroll
+    for (int ci = 0; ci < CH; ++ci) {
+        okm[ci] = 0u;
+        if ((ci * NW) * 64 >= A.ne) continue;                       // uniform: no edges in this chunk
+        const int ei = (ci * NW + wave) * 64 + lane;
+        const int src = er[ci].meta & 255u, dst = (er[ci].meta >> 8) & 255u;
+        const bool valid = ei < A.ne;
+        const bool unbl = !((blkm[ci] >> lane) & 1ull);
+        double c = er[ci].c;
+        if (A.fs >= 0 && src == A.fs && dst == A.fd) c *= A.fac;
+#pragma unroll
+        for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) cand[ci][f] = dist[poff[f] + (valid ? src : 0)];
+#pragma unroll
+        for (int f = 0; f < NFILT; ++f) {
+            if (!((ACT >> f) & 1u)) continue;
+            bool ok = valid && cand[ci][f] < INFINITY;
+            if (f != F_PR) ok = ok && unbl;
+            cand[ci][f] = cand[ci][f] + c;
+            if (ok) {
+                okm[ci] |= 1u << f;
+                atomicMin(reinterpret_cast<unsigned long long*>(&dist[coff[f] + dst]), (unsigned long long)__double_as_longlong(cand[ci][f]));
+            }
+        }
+    }
+    team_sync<NW>();
+#pragma unroll
+    for (int ci = 0; ci < CH; ++ci) {
+        if ((ci * NW) * 64 >= A.ne) continue;
+        const int ei = (ci * NW + wave) * 64 + lane;
+        const int dst = (er[ci].meta >> 8) & 255u;
+        const unsigned key = ((unsigned)ei << 16) | ((er[ci].meta >> 8) & 0xff00u) | (er[ci].meta & 255u);
+        double got[NFILT];
+#pragma unroll
+        for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) got[f] = dist[coff[f] + dst];
+#pragma unroll
+        for (int f = 0; f < NFILT; ++f)
+            if (((ACT >> f) & 1u) && ((okm[ci] >> f) & 1u) && got[f] == cand[ci][f]) {
+                atomicAdd(&cnt_all[f * kpad + dst], 1u);
+                atomicMin(&widx_all[f * kpad + dst], key);
+            }
+    }
+    team_sync<NW>();
+    // lane = destination node
+#pragma unroll
+    for (int f = 0; f < NFILT; ++f) {
+        if (!((ACT >> f) & 1u)) continue;
+        if (NW > 1 && (f % NW) != wave) continue;
+        bool any = false;
+        for (int n = lane; n < A.Kb; n += 64) {
+            const unsigned c = cnt_all[f * kpad + n], w = widx_all[f * kpad + n];
+            int nl = A.v0 + n - sc.n_base; if (nl < 0) nl += lat.V;
+            bool rem = (zone_bits[nl >> 5] >> (nl & 31)) & 1u;
+            if (f == F_LEFT) rem = rem || (A.cl_hit && n >= A.cn);
+            if (f == F_RIGHT) rem = rem || (A.cl_hit && n < A.cn);
+            const bool fin = c >= 1u && !rem;
+            int bsrc = fin ? (int)(w & 255u) : 0, bk = fin ? (int)((w >> 8) & 255u) : 0, tie = 0;
+            if (fin && c >= 2u) {
+                const int r = team_serial_node_packed(lat, sc.e_base, blocked_bits, f, n, A.v0 + n, dist + poff[f], A.fs, A.fd, A.fac);
+                bsrc = r & 255; bk = (r >> 8) & 255; tie = (r >> 16) & 1;
+            }
+            if (rem) dist[coff[f] + n] = INFINITY;
+            par[((size_t)f * A.hm + A.j) * kpad + n] = make_uchar2((unsigned char)bsrc, (unsigned char)(bk | (tie ? 0x80 : 0)));
+            any = any || fin;
+        }
+        any = __ballot(any) != 0ull;
+        int g = any ? -2 : -1;
+        if (A.j == A.H && any) { wave_sync_lds(); g = team_goal(lat, dist + coff[f], A.v0, A.Kb, lane); }
+        if (lane == 0) best[f * A.hm + A.j] = g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the team body. Returns, for every wave, the result of the LAST primitive the wave assembled (NW = 4: wave a <-> slot a)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NW>
+__device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out,
+                                                    const TeamLds& lp, unsigned char* smem, TeamShared& ts,
+                                                    double* vel_kappa, double* vel_len, double* vel_x, double* vel_y)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int L = lat.L;
+    constexpr int NT = NW * 64;
+    constexpr int CH = NW == 1 ? 4 : 1;          // register chunks of 64 * NW edges prefetched per layer transition
+
+    short* pos_layer = reinterpret_cast<short*>(smem + lp.off_pos_layer);
+    unsigned char* pos_veh = smem + lp.off_pos_veh;
+    unsigned* blocked_bits = reinterpret_cast<unsigned*>(smem + lp.off_blocked);
+    unsigned* zone_bits = reinterpret_cast<unsigned*>(smem + lp.off_zone);
+    double* dist = reinterpret_cast<double*>(smem + lp.off_dist);
+    uchar2* par = reinterpret_cast<uchar2*>(smem + lp.off_par);
+    int* best = reinterpret_cast<int*>(smem + lp.off_best);
+    int4* lay = reinterpret_cast<int4*>(smem + lp.off_lay);
+
+    dbg_stamp(lp.dbg, 0);
+    // ---- phase 0: scenario scalars (uniform; the planning range only depends on the start layer and is tabulated at
+    //      ltpl_create: gen_local_node_template.py:101-147) -----------------------------------------------------------
+    Scen sc;
+    sc.s = blockIdx.x;
+    sc.sl = in.start_layer[sc.s]; sc.sn = in.start_node[sc.s]; sc.flags = in.flags[sc.s];
+    sc.veh0 = in.veh_off[sc.s]; sc.n_veh = in.veh_off[sc.s + 1] - sc.veh0;
+    sc.n_fac = min(in.n_last[sc.s] - 1, in.n_w_last);
+    const int zone0 = in.zone_off[sc.s], zone1 = in.zone_off[sc.s + 1];
+    const int const_closest = in.const_closest[sc.s], last_action = in.last_action[sc.s];
+    sc.el = lat.rng_end[sc.sl];
+    sc.pos0 = in.pos_off[sc.veh0]; sc.n_pos = in.pos_off[sc.veh0 + sc.n_veh] - sc.pos0;
+    sc.H = sc.el - sc.sl; if (sc.H < 0) sc.H = L - sc.sl + sc.el;
+    {
+        int first = sc.sl + 1; if (first >= L) first -= L;
+        sc.e_base = lat.layer_ebase[first];
+        sc.n_base = lat.layer_off[sc.sl];
+        int NH = lat.layer_off[sc.el + 1] - sc.n_base; if (NH <= 0) NH += lat.V;
+        sc.NH = NH;
+    }
+    const int H = sc.H, kpad = lp.kpad, hm = lp.hmax;
+
+    for (int i = tid; i < lp.words_blocked; i += NT) blocked_bits[i] = 0u;
+    for (int i = tid; i < lp.words_zone; i += NT) zone_bits[i] = 0u;
+    // per-layer table of the planning range
+    for (int j = tid; j <= H; j += NT) {
+        int b = sc.sl + j; if (b >= L) b -= L;
+        const int v0 = lat.layer_off[b];
+        lay[j] = make_int4(v0, (lat.layer_off[b + 1] - v0) | (lat.layer_degmax[b] << 16), lat.layer_ebase[b], lat.layer_ebase[b + 1]);
+    }
+    if (tid >= 1 && tid < LTPL_MAX_LAST_NODES) {
+        int b = sc.sl + tid; if (b >= L) b -= L;
+        int fs, fd; double fac;
+        team_factor(lat, in, sc, tid, b, fs, fd, fac);
+        ts.fac_src[tid] = fs; ts.fac_dst[tid] = fd; ts.fac[tid] = fac;
+    }
+    // vehicle of every position (radius lookup in phase 2)
+    for (int k = tid; k < sc.n_veh; k += NT) {
+        const int p0 = in.pos_off[sc.veh0 + k] - sc.pos0, p1 = in.pos_off[sc.veh0 + k + 1] - sc.pos0;
+        for (int p = p0; p < p1; ++p) pos_veh[p] = (unsigned char)k;
+    }
+    // reference line -> LDS (aliases the parent table, which is not live before phase 4)
+    double* refl = reinterpret_cast<double*>(smem + lp.off_par);
+    if (lp.ref_lds)
+        for (int l = tid; l < L; l += NT) { refl[2 * l] = lat.ref_x[l]; refl[2 * l + 1] = lat.ref_y[l]; }
+    team_sync<NW>();
+    // zone-removed nodes of the "overtaking_zones" filter (gen_local_node_template.py:96; GraphBase.py:713-745)
+    for (int i = zone0 + tid; i < zone1; i += NT) {
+        int nl = in.zone_gid[i] - sc.n_base; if (nl < 0) nl += lat.V;
+        if (nl < sc.NH) atomicOr(&zone_bits[nl >> 5], 1u << (nl & 31));
+    }
+
+    dbg_stamp(lp.dbg, 1);
+    // ---- phase 1: closest reference-line layer per obstacle position (get_intersec_edges.py:40-51) -----------------
+    // lane = (layer segment, position): every lane scans its segment of the reference line for its position (strict '<'
+    // keeps the first minimum), the segments of a position are then combined by log2(#segments) shuffle steps.
+    for (int pp0 = 0; pp0 < sc.n_pos; pp0 += 64) {
+        const int cnt = min(64, sc.n_pos - pp0);
+        const int cntw = (cnt - wave + NW - 1) / NW;                 // positions of this wave: q = wave + NW * i
+        if (cntw <= 0) continue;
+        int np2 = 1; while (np2 < cntw) np2 <<= 1;
+        const int nseg = 64 / np2, chunk = (L + nseg - 1) / nseg;
+        const int qi = lane & (np2 - 1), seg = lane / np2;
+        const int q = wave + NW * qi;
+        const bool qv = qi < cntw;
+        double px = 0.0, py = 0.0;
+        if (qv) { px = in.pos_x[sc.pos0 + pp0 + q]; py = in.pos_y[sc.pos0 + pp0 + q]; }
+        double bd = INFINITY; int bl = 0x7fffffff;
+        const int l0 = seg * chunk, l1 = min(L, l0 + chunk);
+        if (lp.ref_lds) {
+            for (int l = l0; l < l1; ++l) {
+                const double dx = refl[2 * l] - px, dy = refl[2 * l + 1] - py;
+                const double d2 = dx * dx + dy * dy;
+                if (d2 < bd) { bd = d2; bl = l; }
+            }
+        } else {
+            for (int l = l0; l < l1; ++l) {
+                const double dx = lat.ref_x[l] - px, dy = lat.ref_y[l] - py;
+                const double d2 = dx * dx + dy * dy;
+                if (d2 < bd) { bd = d2; bl = l; }
+            }
+        }
+        for (int m = np2; m < 64; m <<= 1) {
+            const double od = __shfl_xor(bd, m); const int ol = __shfl_xor(bl, m);
+            if (od < bd || (od == bd && ol < bl)) { bd = od; bl = ol; }
+        }
+        if (qv && seg == 0) {
+            const int ol = bl, sl = sc.sl, el = sc.el;
+            const bool gate = (sl - 1 <= ol && ol <= el + 1) || (sl > el && (sl - 1 <= ol || ol <= el + 1));
+            pos_layer[pp0 + q] = (short)(gate ? ol : -1);
+        }
+    }
+    team_sync<NW>();
+
+    dbg_stamp(lp.dbg, 2);
+    // ---- phase 2: obstacle x edge-sample mask (GraphBase.get_intersec_edges_in_range, GraphBase.py:567-646) --------
+    // Window of a position with closest layer ol = layers [ol-1, ol+1] with the reference's wrap quirks (:597-600):
+    // the transitions into layer ol and into layer ol+1 (the latter never across the seam); both end points must lie in
+    // the planning range. Transition-major and edge-parallel: positions live in lanes, a ballot selects the positions
+    // whose window contains transition j; lane = edge of the transition; an edge whose bounding circle (centre + radius
+    // over its samples, tabulated at ltpl_create) cannot reach the obstacle disc is rejected without touching its
+    // samples, the others test their samples exactly like the reference (d^2 <= (r + w/2)^2 + step^2 / 4).
+    for (int pp0 = 0; pp0 < sc.n_pos && !(lp.ablate & 1); pp0 += 64) {
+        const int p = pp0 + lane;
+        int ol = -1; double mpx = 0.0, mpy = 0.0, mref = 0.0, msq = 0.0;
+        if (p < sc.n_pos) {
+            ol = pos_layer[p];
+            mpx = in.pos_x[sc.pos0 + p]; mpy = in.pos_y[sc.pos0 + p];
+            const double rr = in.veh_radius[sc.veh0 + pos_veh[p]] + lat.veh_width / 2;
+            mref = rr * rr;
+            mref += (lat.sampled_resolution * lat.sampled_resolution) / 4;
+            msq = sqrt(mref);
+        }
+        if (__ballot(ol >= 0) == 0ull) continue;
+        for (int j = 1; j <= H; ++j) {
+            int b = sc.sl + j; if (b >= L) b -= L;
+            unsigned long long m = __ballot(ol >= 0 && (ol == b || ol + 1 == b));
+            if (m == 0ull) continue;
+            const int4 ly = lay[j];
+            const int eb = ly.z, ee = ly.w;
+            while (m) {
+                // up to MQ matching positions per round, broadcast into uniform registers
+                constexpr int MQ = 4;
+                double qx[MQ], qy[MQ], qr[MQ], qs[MQ];
+#pragma unroll
+                for (int q = 0; q < MQ; ++q) {
+                    if (m) {
+                        const int src_lane = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        qx[q] = readlane_f64(mpx, src_lane); qy[q] = readlane_f64(mpy, src_lane);
+                        qr[q] = readlane_f64(mref, src_lane); qs[q] = readlane_f64(msq, src_lane);
+                    } else { qx[q] = 0.0; qy[q] = 0.0; qr[q] = -1.0; qs[q] = -1.0e30; }   // never near, never hit
+                }
+                for (int e0 = eb + wave * 64; e0 < ee; e0 += NT) {
+                    const int e = e0 + lane;
+                    if (e >= ee) continue;
+                    int el_ = e - sc.e_base; if (el_ < 0) el_ += lat.E;
+                    if ((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u) continue;       // already blocked by another object
+                    const double cx = lat.edge_cx[e], cy = lat.edge_cy[e], cr = lat.edge_cr[e];
+                    unsigned near = 0;
+#pragma unroll
+                    for (int q = 0; q < MQ; ++q) {
+                        const double dx = cx - qx[q], dy = cy - qy[q], lim = qs[q] + cr;
+                        if (dx * dx + dy * dy <= lim * lim * (1.0 + 1.0e-9)) near |= 1u << q;
+                    }
+                    if (!near) continue;
+                    const int k0 = lat.samp_ptr[e], k1 = lat.samp_ptr[e + 1];
+                    bool hit = false;
+                    for (int k = k0; k < k1 && !hit; k += 4) {
+                        double xs[4], ys[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int kk = min(k + u, k1 - 1); xs[u] = lat.sx[kk]; ys[u] = lat.sy[kk]; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int q = 0; q < MQ; ++q) {
+                                const double dx = xs[u] - qx[q], dy = ys[u] - qy[q];
+                                hit = hit || (dx * dx + dy * dy <= qr[q]);
+                            }
+                    }
+                    if (hit) atomicOr(&blocked_bits[el_ >> 5], 1u << (el_ & 31));
+                }
+            }
+        }
+    }
+
+    dbg_stamp(lp.dbg, 3);
+    // ---- phase 3: closest object (gen_local_node_template.py:191-213) and action template (mopg.py:124-174) --------
+    if (wave == 0) {
+        // closest = smallest layer distance of the vehicle's LAST position; first vehicle wins ties
+        int key = 0x7fffffff;
+        for (int k = lane; k < sc.n_veh; k += 64) {
+            const int plast = in.pos_off[sc.veh0 + k + 1] - 1 - sc.pos0;
+            const int ol = (plast >= 0 && plast < sc.n_pos && in.pos_off[sc.veh0 + k + 1] > in.pos_off[sc.veh0 + k])
+                               ? (int)pos_layer[plast] : -1;
+            if (ol >= 0) {
+                int ld = ol - sc.sl; if (ld < 0) ld = L - sc.sl + ol;
+                if (ld <= H) { const int kk = ld * 256 + k; if (kk < key) key = kk; }
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(key, m); key = o < key ? o : key; }
+        int ci = -1, cl = -1, have = 0, cn = -1;
+        if (key != 0x7fffffff) {
+            ci = key & 255; have = 1;
+            cl = sc.sl + (key >> 8); if (cl >= L) cl -= L;
+            const int p = in.pos_off[sc.veh0 + ci];
+            const double px = in.pos_x[p], py = in.pos_y[p];
+            const int4 ly = lay[key >> 8];
+            const int v0 = ly.x, K = ly.y & 0xffff;
+            double bd = INFINITY, dummy = 0.0; int bn = 0x7fffffff;
+            for (int n = lane; n < K; n += 64) {
+                const double dx = lat.node_x[v0 + n] - px, dy = lat.node_y[v0 + n] - py;
+                const double d2 = dx * dx + dy * dy;
+                if (d2 < bd) { bd = d2; bn = n; }
+            }
+            wave_min3(bd, dummy, bn);
+            cn = bn;
+        }
+        if (lane == 0) { ts.closest_idx = ci; ts.cl = cl; ts.cn = cn; ts.have_cn = have; }
+    }
+    team_sync<NW>();
+    const int t_cl = ts.cl, t_cn = ts.cn, t_have = ts.have_cn;
+    // action template (uniform, every thread)
+    int n_act = 0, filt[LTPL_MAX_ACTIONS], nm0[LTPL_MAX_ACTIONS];
+    int closest_idx = ts.closest_idx;
+    {
+        const bool action_sets = sc.flags & LTPL_FLAG_ACTION_SETS, in_const = sc.flags & LTPL_FLAG_OBJ_IN_CONST,
+                   besides = sc.flags & LTPL_FLAG_OBJ_BESIDES;
+        if (const_closest >= 0) closest_idx = const_closest;
+        for (int a = 0; a < LTPL_MAX_ACTIONS; ++a) { filt[a] = F_DEF; nm0[a] = LTPL_ACT_NONE; }
+        if (action_sets && (in_const || besides)) {
+            filt[n_act] = F_PR; nm0[n_act++] = LTPL_ACT_FOLLOW;
+            const int la = last_action;
+            if (!in_const && (la == LTPL_ACT_LEFT || la == LTPL_ACT_RIGHT)) { filt[n_act] = F_DEF; nm0[n_act++] = la; }
+            else if (!in_const) {
+                filt[n_act] = F_DEF; nm0[n_act++] = LTPL_ACT_LEFT;
+                filt[n_act] = F_DEF; nm0[n_act++] = LTPL_ACT_RIGHT;
+            }
+        } else if (action_sets && closest_idx >= 0 && t_have) {
+            filt[0] = F_PR; nm0[0] = LTPL_ACT_FOLLOW;
+            filt[1] = F_LEFT; nm0[1] = LTPL_ACT_LEFT;
+            filt[2] = F_RIGHT; nm0[2] = LTPL_ACT_RIGHT;
+            n_act = 3;
+        } else {
+            filt[0] = F_DEF; nm0[0] = LTPL_ACT_STRAIGHT; n_act = 1;
+        }
+    }
+    unsigned need = 0;
+    for (int a = 0; a < n_act; ++a) need |= 1u << filt[a];
+    // overtake_left / overtake_right differ from `default` only from the object layer on: branch them off the
+    // `default` sweep there (jcl = distance of the object layer from the start layer)
+    const bool lr = (need & ((1u << F_LEFT) | (1u << F_RIGHT))) != 0;
+    int jcl = 0;
+    if (lr) { jcl = t_cl - sc.sl; if (jcl < 0) jcl += L; }
+    const bool share_prefix = lr && jcl >= 1;
+    if (tid == 0) {
+        out.end_layer[sc.s] = sc.el;
+        out.closest_obj_index[sc.s] = closest_idx;
+        out.closest_obj_node[2 * sc.s] = t_have ? t_cl : -1;
+        out.closest_obj_node[2 * sc.s + 1] = t_have ? t_cn : -1;
+        out.n_actions[sc.s] = n_act;
+    }
+
+    dbg_stamp(lp.dbg, 4);
+    // ---- phase 4: layered min-plus sweeps (GraphBase.search_graph_layer, GraphBase.py:854-894) ---------------------
+    // Edge-parallel (team_layer): the edges of a transition (cost + packed source / destination / rank) are loaded with
+    // coalesced loads one layer AHEAD into registers, so that the global latency hides behind the LDS work of the current
+    // layer; all active filters share the edge registers.
+    {
+        // initial frontier of every filter that starts at layer 0
+        for (int f = wave; f < NFILT; f += NW) {
+            const bool own_start = (need >> f) & 1u || (f == F_DEF && share_prefix);
+            if (!own_start) continue;
+            const int K0 = lay[0].y & 0xffff;
+            const bool ok = sc.sn >= 0 && sc.sn < K0 &&
+                            !team_node_removed(zone_bits, lat, sc, t_cl, t_cn, f, sc.sl, sc.sn, sc.n_base + sc.sn);
+            double* d0 = dist + (size_t)(f * 2) * kpad;
+            for (int n = lane; n < kpad; n += 64) d0[n] = (ok && n == sc.sn) ? 0.0 : INFINITY;
+            if (lane == 0) { ts.start_ok[f] = ok; best[f * hm] = -1; }
+        }
+        EdgeRegs er[CH], en[CH];
+        unsigned long long bm[CH], bn[CH];
+        auto prefetch = [&](int j, EdgeRegs (&dr)[CH], unsigned long long (&db)[CH]) {
+            const int4 ly = lay[j];
+            unsigned bw[CH]; int sh[CH];
+#pragma unroll
+            for (int ci = 0; ci < CH; ++ci) {
+                const int e = ly.z + (ci * NW + wave) * 64 + lane;
+                // always load (clamped address): a fixed number of loads in flight lets the compiler wait precisely
+                const int ec = e < ly.w ? e : ly.w - 1;
+                dr[ci].c = lat.edge_cost[ec]; dr[ci].meta = lat.edge_meta[ec];
+                int el_ = ec - sc.e_base; if (el_ < 0) el_ += lat.E;
+                bw[ci] = blocked_bits[el_ >> 5]; sh[ci] = (e < ly.w) ? (el_ & 31) : 32;
+            }
+#pragma unroll
+            for (int ci = 0; ci < CH; ++ci) db[ci] = __ballot(sh[ci] < 32 && ((bw[ci] >> (sh[ci] & 31)) & 1u));
+        };
+        team_sync<NW>();
+        prefetch(1, er, bm);
+        for (int j = 1; j <= H && !(lp.ablate & 2); ++j) {
+            int b = sc.sl + j; if (b >= L) b -= L;
+            const int4 ly = lay[j];
+            LayerArgs A;
+            A.j = j; A.b = b; A.v0 = ly.x; A.Kb = ly.y & 0xffff; A.ne = ly.w - ly.z; A.kpad = kpad; A.hm = hm; A.cur = j & 1; A.prv = (j - 1) & 1;
+            A.H = H; A.cl_hit = (b == t_cl) ? 1 : 0; A.cn = t_cn;
+            A.fs = -1; A.fd = -1; A.fac = 1.0;
+            if (j - 1 < sc.n_fac) { A.fs = ts.fac_src[j]; A.fd = ts.fac_dst[j]; A.fac = ts.fac[j]; }
+            // filters that advance through this layer; left / right read `default`'s frontier in their first own layer
+            unsigned actm = 0;
+            if ((need >> F_PR) & 1u) actm |= 1u << F_PR;
+            if (((need >> F_DEF) & 1u) || (share_prefix && j < jcl)) actm |= 1u << F_DEF;
+            if (((need >> F_LEFT) & 1u) && (!share_prefix || j >= jcl)) actm |= 1u << F_LEFT;
+            if (((need >> F_RIGHT) & 1u) && (!share_prefix || j >= jcl)) actm |= 1u << F_RIGHT;
+            A.from_def = share_prefix && j == jcl;
+            if (j < H) prefetch(j + 1, en, bn);                    // global loads in flight during this layer's LDS work
+            if (A.Kb <= 64 && A.ne <= CH * NT) {
+                // compile-time specialisations for the filter sets the action templates produce
+                switch (actm) {
+                    case (1u << F_DEF): team_layer<NW, CH, (1u << F_DEF)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
+                    case (1u << F_PR) | (1u << F_DEF): team_layer<NW, CH, (1u << F_PR) | (1u << F_DEF)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
+                    case (1u << F_PR) | (1u << F_LEFT) | (1u << F_RIGHT):
+                        team_layer<NW, CH, (1u << F_PR) | (1u << F_LEFT) | (1u << F_RIGHT)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
+                    default: team_layer<NW, CH, 15u>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
+                }
+            } else {
+                // more than 64 nodes in the layer or more edges than the register image holds: serial form (lane = node)
+                for (int f = wave; f < NFILT; f += NW) {
+                    if (!((actm >> f) & 1u)) continue;
+                    const int fprev = (A.from_def && (f == F_LEFT || f == F_RIGHT)) ? F_DEF : f;
+                    double* dcur = dist + (size_t)(f * 2 + A.cur) * kpad;
+                    const bool any = team_relax_layer(lat, in, sc, lp, smem, t_cl, t_cn, f, j, b, A.v0, A.Kb,
+                                                      dist + (size_t)(fprev * 2 + A.prv) * kpad, dcur,
+                                                      par + ((size_t)f * hm + j) * kpad, lane, A.fs, A.fd, A.fac);
+                    int g = any ? -2 : -1;
+                    if (j == H && any) { wave_sync_lds(); g = team_goal(lat, dcur, A.v0, A.Kb, lane); }
+                    if (lane == 0) best[f * hm + j] = g;
+                }
+            }
+#pragma unroll
+            for (int ci = 0; ci < CH; ++ci) { er[ci] = en[ci]; bm[ci] = bn[ci]; }
+            team_sync<NW>();
+        }
+        if (share_prefix && wave == 0 && lane == 0) { ts.start_ok[F_LEFT] = ts.start_ok[F_DEF]; ts.start_ok[F_RIGHT] = ts.start_ok[F_DEF]; }
+        team_sync<NW>();
+    }
+
+    dbg_stamp(lp.dbg, 5);
+    // ---- phase 5: search loop with horizon back-off (main_online_path_gen.py:187-248); uniform, every thread ---------
+    int slot_valid[LTPL_MAX_ACTIONS], slot_j[LTPL_MAX_ACTIONS], slot_name[LTPL_MAX_ACTIONS], slot_red[LTPL_MAX_ACTIONS];
+    {
+        const bool in_const = sc.flags & LTPL_FLAG_OBJ_IN_CONST;
+        int mod_j = H;
+        for (int a = 0; a < LTPL_MAX_ACTIONS; ++a) {
+            slot_valid[a] = 0; slot_j[a] = 0; slot_name[a] = LTPL_ACT_NONE; slot_red[a] = 0;
+            if (a >= n_act) continue;
+            const int f = filt[a]; int nm = nm0[a];
+            bool found = false;
+            for (;;) {
+                if (mod_j == 0) break;
+                // reachability of layer mod_j under filter f (prefix layers of left / right live in the default table)
+                const int pf = (share_prefix && (f == F_LEFT || f == F_RIGHT) && mod_j < jcl) ? F_DEF : f;
+                found = ts.start_ok[f] && best[pf * hm + mod_j] != -1;
+                if (found || !(nm == LTPL_ACT_FOLLOW || nm == LTPL_ACT_STRAIGHT)) break;
+                mod_j -= 1;
+            }
+            const bool reduced = mod_j != H;
+            int goal = sc.sl + mod_j; if (goal >= L) goal -= L;
+            if (reduced) {
+                const int cl = t_cl, sl = sc.sl;
+                const bool in_mod = t_have && ((sl <= cl && cl <= goal) || (sl > goal && (cl >= sl || cl <= goal)));
+                if (!in_const && t_have && !in_mod) {
+                    if (nm == LTPL_ACT_FOLLOW || nm == LTPL_ACT_STRAIGHT) nm = LTPL_ACT_STRAIGHT;
+                    else found = false;
+                }
+            }
+            slot_valid[a] = found ? 1 : 0; slot_j[a] = mod_j; slot_name[a] = nm; slot_red[a] = reduced ? 1 : 0;
+        }
+        if (tid == 0) {
+            for (int a = 0; a < LTPL_MAX_ACTIONS; ++a) {
+                const int slot = sc.s * LTPL_MAX_ACTIONS + a;
+                if (a >= n_act) {
+                    out.action_id[slot] = LTPL_ACT_NONE; out.valid[slot] = 0; out.reduced[slot] = 0; out.goal_layer[slot] = -1;
+                    out.n_nodes[slot] = 0; out.n_pts[slot] = 0; out.n_ties[slot] = 0;
+                    continue;
+                }
+                int goal = sc.sl + slot_j[a]; if (goal >= L) goal -= L;
+                out.action_id[slot] = slot_name[a]; out.reduced[slot] = slot_red[a]; out.goal_layer[slot] = goal;
+                out.valid[slot] = slot_valid[a];
+                if (!slot_valid[a]) { out.n_nodes[slot] = 0; out.n_pts[slot] = 0; out.n_ties[slot] = 0; }
+            }
+        }
+    }
+    // goal nodes of reduced-horizon paths: re-sweep the filter up to that layer (rare). A left / right path that ends
+    // in front of the object layer is a `default` path.
+    {
+        bool any_resweep = false;
+        for (int f = 0; f < NFILT; ++f) {
+            int Jf = -1;
+            for (int a = 0; a < n_act; ++a) if (slot_valid[a] && filt[a] == f && slot_j[a] != H) Jf = slot_j[a];
+            if (Jf < 0) continue;
+            any_resweep = true;
+            if (wave == f % NW) team_resweep(lat, in, sc, lp, smem, ts, f, Jf, lane);
+        }
+        if (any_resweep) team_sync<NW>();
+    }
+
+    dbg_stamp(lp.dbg, 6);
+    // ---- phase 6: wave (a mod NW) assembles primitive a --------------------------------------------------------------
+    WavePath wp; wp.valid = 0; wp.n_pts = 0; wp.n_nodes = 0; wp.name = LTPL_ACT_NONE; wp.reduced = 0; wp.goal_layer = -1;
+    wp.end_node = -1;
+    for (int a = wave; a < n_act; a += NW) {
+        wp.name = slot_name[a]; wp.reduced = slot_red[a]; wp.valid = 0;
+        if (!slot_valid[a] || (lp.ablate & 4)) continue;
+        unsigned char* pw = smem + lp.off_path + (size_t)(wave < lp.n_path_bufs ? wave : lp.n_path_bufs - 1) * lp.path_stride;
+        // after a re-sweep the parents of every layer belong to filter f itself
+        const bool sp = share_prefix && (filt[a] == F_LEFT || filt[a] == F_RIGHT) && slot_j[a] == H;
+        wp = team_assemble(lat, in, out, sc, lp, smem, a, filt[a], slot_j[a], slot_name[a], slot_red[a], jcl, sp, lane, pw,
+                           vel_kappa, vel_len, vel_x, vel_y);
+    }
+    dbg_stamp(lp.dbg, 7);
+    return wp;
+}

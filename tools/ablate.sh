@@ -1,0 +1,7 @@
+#!/bin/bash
+# per-phase cost attribution of the path kernel by ablation (results are wrong with LTPL_ABLATE != 0; timing only)
+export TMPDIR=/tmp
+for A in 0 1 4 5 6 7; do
+  rm -rf gpurun_out/abl; LTPL_ABLATE=$A rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abl -o q -- python bench.py --steps 30 --warmup 3 --no-cpu --latency-ticks 50 > /dev/null 2>&1
+  echo "ablate=$A $(grep k_paths gpurun_out/abl/q_kernel_stats.csv | python3 -c "import sys,csv; r=list(csv.reader(sys.stdin))[0]; print(r[3])")"
+done
