@@ -13,8 +13,9 @@ the barrier and the max-over-ranks of the timed region.
 
 The JSON line also carries
   roofline      algorithmic bytes per launch (graphbasedlocaltrajectoryplanner_amd/roofline.py) divided by
-                the kernel's average duration measured with HIP events on the library's own stream, against the 8 TB/s
-                HBM peak of MI355X; `traffic` = HBM bytes per launch from the rocprofv3 PMC passes, if profiles/ holds them
+                the DOMINANT kernel's (path kernel: mask + sweeps + spline) average duration measured with HIP events on
+                the library's own stream, against the 8 TB/s HBM peak of MI355X; `traffic` = HBM bytes per launch of that
+                kernel from the rocprofv3 PMC passes, if profiles/ holds them; `pipeline_ms` lists all kernels of a step
   cpu_baseline  the oracle's plain-C restatement (kind "port", 1 core) timed on a bounded sample of the same scenarios
   latency_us    p50 / p99 of single-scenario ticks through ltpl_tick_batch including all host marshalling and PCIe
 """
@@ -130,11 +131,15 @@ def main():
         elapsed = float(t.item())
     res, vres = hip.batch_download()
 
+    # per-kernel durations of the pipeline (HIP events between the launches on the library's stream), outside the timed region
+    prof_ms = hip.batch_run_profile(reps=min(args.steps, 20))
     if rank == 0:
         ab = algorithmic_bytes(lat, batch, res)
         kern_ms = ms_kernel / args.steps
-        achieved = ab["total"] / (kern_ms * 1e-3) / 1e9
         n_paths = int(res.valid.sum())
+        # dominant kernel = the path kernel (mask + sweeps + spline); its algorithmic bytes exclude the velocity stage
+        ab_paths = ab["mask"] + ab["sweep"] + ab["path"]
+        achieved = ab_paths / (prof_ms[0] * 1e-3) / 1e9
         # single-scenario latency through the synchronous C call (host marshalling + H2D + kernel + D2H)
         lat_us = []
         one_res, one_vres = hip.new_paths_result(1), _capi.TickVelResult(1, hip.caps.max_path_pts)
@@ -145,7 +150,7 @@ def main():
                                     np.array([[vel.pos_x[i], vel.pos_y[i]]]),
                                     vel.veh_vel[batch.veh_off[i]:batch.veh_off[i + 1]])
             singles.append((b1, v1))
-        for i in range(100 + args.latency_ticks):
+        for i in range((100 + args.latency_ticks) if args.latency_ticks > 0 else 0):
             b1, v1 = singles[i % 64]
             t1 = time.perf_counter()
             hip.tick_batch(b1, v1, one_res, one_vres)
@@ -167,12 +172,16 @@ def main():
                        "batch_per_gpu": args.batch, "parallelism": "scenario-sharded x%d (no collective)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": read_traffic(),
-                         "kernel": "k_tick", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": ab["total"],
+                         "kernel": "k_paths<1>", "kernel_ms": prof_ms[0],
+                         "algorithmic_bytes_per_launch": ab_paths,
                          "algorithmic_bytes_per_tick": ab["total"] / args.batch,
-                         "split": {k: ab[k] / args.batch for k in ("mask", "sweep", "path", "vel")}},
-            "latency_us": {"p50": float(np.percentile(lat_us, 50)), "p99": float(np.percentile(lat_us, 99)),
-                           "mean": float(lat_us.mean()), "ticks": int(lat_us.size),
+                         "split_per_tick": {k: ab[k] / args.batch for k in ("mask", "sweep", "path", "vel")},
+                         "pipeline_ms": {"k_paths": prof_ms[0], "k_follow_prep": prof_ms[1], "k_vel_lanes": prof_ms[2],
+                                         "all_kernels_back_to_back": kern_ms},
+                         "whole_tick_achieved": ab["total"] / (kern_ms * 1e-3) / 1e9},
+            "latency_us": {"p50": float(np.percentile(lat_us, 50)) if lat_us.size else None,
+                           "p99": float(np.percentile(lat_us, 99)) if lat_us.size else None,
+                           "mean": float(lat_us.mean()) if lat_us.size else None, "ticks": int(lat_us.size),
                            "what": "one scenario per ltpl_tick_batch call, host wall time incl. marshalling + PCIe"},
             "paths_per_tick": n_paths / args.batch,
         }

@@ -396,6 +396,7 @@ class HipBackend(object):
         L.ltpl_batch_upload.argtypes = [C.c_void_p, C.POINTER(PathsIn), C.POINTER(TickVelIn), C.c_int32, C.c_int32]
         L.ltpl_batch_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
         L.ltpl_batch_download.argtypes = [C.c_void_p, C.POINTER(PathsOut), C.POINTER(TickVelOut)]
+        L.ltpl_batch_run_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
 
     def _check(self, rc):
         if rc != 0:
@@ -449,6 +450,12 @@ class HipBackend(object):
         ms = C.c_float(0.0)
         self._check(self.lib.ltpl_batch_run(self.handle, int(reps), C.byref(ms) if timed else None))
         return float(ms.value)
+
+    def batch_run_profile(self, reps=10):
+        """ms per launch of (path kernel, follow preparation, velocity lane kernel), HIP events on the library's stream."""
+        ms = (C.c_float * 3)()
+        self._check(self.lib.ltpl_batch_run_profile(self.handle, int(reps), ms))
+        return [float(v) / reps for v in ms]
 
     def batch_download(self):
         result = self.new_paths_result(self._resident_n)

@@ -103,11 +103,13 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total)
     return x - v;
 }
 
+// LDS hand-over between the lanes of ONE wave: DS operations of a wave execute in order, so only the compiler has to be
+// kept from reordering (wavefront-scope fences emit no s_waitcnt vmcnt and do not serialise outstanding global loads)
 __device__ __forceinline__ void wave_sync_lds()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ double normalize_psi_dev(double psi)
@@ -221,12 +223,17 @@ __device__ __forceinline__ double ax_poss_w(double w, double kq, double ax_max, 
     }
 }
 
-// one sweep of tph __solver_fb_acc_profile on w[0..n) (lane 0). Backward sweeps address the profile, curvature and
-// element lengths mirrored but -- restated quirk of the reference solver -- the gg limits unmirrored.
+// one sweep of tph __solver_fb_acc_profile on w[0..n). Backward sweeps address the profile, curvature and element
+// lengths mirrored but -- restated quirk of the reference solver -- the gg limits unmirrored.
+// The recurrence is sequential, but everything except the state is known up front: the wave handles 64 steps at a
+// time, lane l prepares the operands (for exponent 1 and a constant machine limit: the affine coefficients) of step
+// base + l in registers, then the steps are executed in order on wave-uniform values fetched with v_readlane -- no
+// LDS access and no divergent branch inside the dependent chain.
 template <int EM, bool AXM1, bool GGARR, bool BACK>
 __device__ void fb_sweep(int n, const VelScratch& vs, double cax, double cay, const DevVelParams& p, double vmax2, int lane)
 {
-    // run starts: first index of every run of positive differences of the (mirrored) profile
+    if (n < 2) return;
+    // run starts: first index of every run of positive differences of the (mirrored) profile BEFORE the sweep
     for (int i = lane; i < n - 1; i += 64) {
         const int a = BACK ? n - 1 - i : i, b = BACK ? n - 2 - i : i + 1;
         const bool acc = vs.w[b] - vs.w[a] > 0.0;
@@ -235,76 +242,66 @@ __device__ void fb_sweep(int n, const VelScratch& vs, double cax, double cay, co
         vs.start[i] = (acc && !prev) ? 1 : 0;
     }
     wave_sync_lds();
-    if (lane == 0 && n >= 2) {
-        bool active = false;
-        constexpr int MODE = BACK ? VMODE_DECEL_BACKW : VMODE_ACCEL_FORW;
-        const double icay = 1.0 / cay;
-        const double axm1 = vs.axm[1];
-        const double dm = p.drag_m;
-        const double* __restrict__ kabs = vs.kabs; const double* __restrict__ el = vs.el;
-        const double* __restrict__ gax = vs.gax; const double* __restrict__ igay = vs.igay;
-        const unsigned char* __restrict__ st = vs.start;
-        double* w = vs.w;
-        // operands of step i are fetched one step ahead: none of them depends on the recurrence state
-        int pn = BACK ? n - 2 : 1;
-        double wi = w[BACK ? n - 1 : 0];
-        double kq_i = kabs[BACK ? n - 1 : 0] * (GGARR ? igay[0] : icay);
-        double kq_n = kabs[pn] * (GGARR ? igay[1] : icay);
-        double e_i = el[BACK ? n - 2 : 0], wold = w[pn];
-        double ax_i = GGARR ? fabs(gax[0]) : fabs(cax), ax_n = GGARR ? fabs(gax[1]) : fabs(cax);
-        int st_i = st[0];
-        for (int i = 0; i < n - 1; ++i) {
-            const int i2 = (i + 2 < n) ? i + 2 : n - 1;
-            const int pn2 = BACK ? n - 1 - i2 : i2;
-            const int ei2 = BACK ? (n - 3 - i >= 0 ? n - 3 - i : 0) : (i + 1 < n - 1 ? i + 1 : i);
-            const double kq_n2 = kabs[pn2] * (GGARR ? igay[i2] : icay);
-            const double e_i2 = el[ei2], wold2 = w[pn2];
-            const double ax_n2 = GGARR ? fabs(gax[i2]) : fabs(cax);
-            const int st_2 = (i + 1 < n - 1) ? st[i + 1] : 0;
-            active = active || (st_i != 0);
-            double wnext_val = wold;
-            if (active) {
-                double wn;
-                if constexpr (EM == 1 && AXM1) {
-                    // Exponent 1 and a constant machine limit make one step piecewise affine in w = v^2:
-                    //   forward : w' = min(max(T, Z), M),  T = w (1 - 2e (ax kq + dm)) + 2e ax, Z = w (1 - 2e dm),
-                    //             M = Z + 2e axm
-                    //   backward: w' = max(T, Z),          T = w (1 - 2e (ax kq - dm)) + 2e ax, Z = w (1 + 2e dm), then
-                    //             the look-ahead with the limits of the next point (same form, state w').
-                    // All coefficients are independent of the state and leave the dependent fp64 chain.
-                    const double te = 2.0 * e_i;
-                    if constexpr (!BACK) {
-                        const double A0 = 1.0 - te * dm, A1 = A0 - te * (ax_i * kq_i), B1 = te * ax_i, B2 = te * axm1;
-                        const double Z = A0 * wi, T = fma(A1, wi, B1), M = fma(A0, wi, B2);
-                        wn = fmax(fmin(fmax(T, Z), M), 0.0);
-                    } else {
-                        const double A0 = 1.0 + te * dm, A1 = A0 - te * (ax_i * kq_i), B1 = te * ax_i;
-                        const double C0 = te * dm, C1 = C0 - te * (ax_n * kq_n), D1 = te * ax_n;
-                        const double Z = A0 * wi, T = fma(A1, wi, B1);
-                        wn = fmax(fmax(T, Z), 0.0);
-                        const double t0 = fma(C0, wn, wi), t1 = fma(C1, wn, wi + D1);
-                        wn = fmin(fmax(fmax(t1, t0), 0.0), wn);
-                    }
+    constexpr int MODE = BACK ? VMODE_DECEL_BACKW : VMODE_ACCEL_FORW;
+    constexpr bool AFFINE = EM == 1 && AXM1;
+    const double icay = 1.0 / cay, axm1 = vs.axm[1], dm = p.drag_m;
+    double wi = vs.w[BACK ? n - 1 : 0];
+    bool active = false;
+    for (int base = 0; base < n - 1; base += 64) {
+        const int cnt = (n - 1 - base) < 64 ? (n - 1 - base) : 64;
+        const int ic = (lane < cnt) ? base + lane : base + cnt - 1;
+        const int Pa = BACK ? n - 1 - ic : ic, Pb = BACK ? n - 2 - ic : ic + 1, Ei = BACK ? n - 2 - ic : ic;
+        // operands of step ic (the gg limits are indexed by the step, the rest by the mirrored point)
+        const double kq_i = vs.kabs[Pa] * (GGARR ? vs.igay[ic] : icay), kq_n = vs.kabs[Pb] * (GGARR ? vs.igay[ic + 1] : icay);
+        const double ax_i = GGARR ? fabs(vs.gax[ic]) : fabs(cax), ax_n = GGARR ? fabs(vs.gax[ic + 1]) : fabs(cax);
+        const double e_i = vs.el[Ei], wold = vs.w[Pb];
+        const int st = vs.start[ic];
+        // affine coefficients (state independent):
+        //   forward : w' = min(max(T, Z), M),  T = w A1 + B1, Z = w A0, M = w A0 + B2
+        //   backward: w' = max(T, Z), then the look-ahead with the limits of the next point (t0 = wn C0 + w, t1 = wn C1 + w + D1)
+        const double te = 2.0 * e_i;
+        const double A0 = BACK ? 1.0 + te * dm : 1.0 - te * dm, A1 = A0 - te * (ax_i * kq_i), B1 = te * ax_i, B2 = te * axm1;
+        const double C0 = te * dm, C1 = C0 - te * (ax_n * kq_n), D1 = te * ax_n;
+        double wout = wold;
+        for (int sidx = 0; sidx < cnt; ++sidx) {
+            const double wold_s = readlane_f64(wold, sidx);
+            active = active || (__builtin_amdgcn_readlane(st, sidx) != 0);
+            double wn;
+            if constexpr (AFFINE) {
+                const double a0 = readlane_f64(A0, sidx), a1 = readlane_f64(A1, sidx), b1 = readlane_f64(B1, sidx);
+                if constexpr (!BACK) {
+                    const double b2 = readlane_f64(B2, sidx);
+                    const double Z = a0 * wi, T = fma(a1, wi, b1), M = fma(a0, wi, b2);
+                    wn = fmax(fmin(fmax(T, Z), M), 0.0);
                 } else {
-                    const double acur = ax_poss_w<EM, AXM1, MODE>(wi, kq_i, ax_i, p, vs.axm, axm1);
-                    wn = wi + 2.0 * acur * e_i;
-                    wn = wn < 0.0 ? 0.0 : wn;
-                    if constexpr (BACK) {
-                        const double anext = ax_poss_w<EM, AXM1, MODE>(wn, kq_n, ax_n, p, vs.axm, axm1);
-                        double wt = wi + 2.0 * anext * e_i;
-                        wt = wt < 0.0 ? 0.0 : wt;
-                        wn = wt < wn ? wt : wn;
-                    }
+                    const double c0 = readlane_f64(C0, sidx), c1 = readlane_f64(C1, sidx), d1 = readlane_f64(D1, sidx);
+                    const double Z = a0 * wi, T = fma(a1, wi, b1);
+                    wn = fmax(fmax(T, Z), 0.0);
+                    const double t0 = fma(c0, wn, wi), t1 = fma(c1, wn, wi + d1);
+                    wn = fmin(fmax(fmax(t1, t0), 0.0), wn);
                 }
-                if (wn < wold) { wnext_val = wn; w[pn] = wn; }
-                active = !(wn > vmax2);
+            } else {
+                const double kqi = readlane_f64(kq_i, sidx), axi = readlane_f64(ax_i, sidx), ei = readlane_f64(e_i, sidx);
+                const double acur = ax_poss_w<EM, AXM1, MODE>(wi, kqi, axi, p, vs.axm, axm1);
+                wn = wi + 2.0 * acur * ei;
+                wn = wn < 0.0 ? 0.0 : wn;
+                if constexpr (BACK) {
+                    const double kqn = readlane_f64(kq_n, sidx), axn = readlane_f64(ax_n, sidx);
+                    const double anext = ax_poss_w<EM, AXM1, MODE>(wn, kqn, axn, p, vs.axm, axm1);
+                    double wt = wi + 2.0 * anext * ei;
+                    wt = wt < 0.0 ? 0.0 : wt;
+                    wn = wt < wn ? wt : wn;
+                }
             }
-            wi = wnext_val; pn = pn2;
-            kq_i = kq_n; kq_n = kq_n2; e_i = e_i2; wold = wold2;
-            ax_i = ax_n; ax_n = ax_n2; st_i = st_2;
+            const bool upd = active && (wn < wold_s);
+            const double wnext = upd ? wn : wold_s;
+            active = active && !(wn > vmax2);
+            if (lane == sidx) wout = wnext;
+            wi = wnext;
         }
+        if (lane < cnt) vs.w[Pb] = wout;
+        wave_sync_lds();
     }
-    wave_sync_lds();
 }
 
 // tph.calc_vel_profile(closed=False): vs.kabs / el / (gax, gay) hold the inputs, result in vs.w (as v^2)
@@ -332,37 +329,38 @@ __device__ void fb_profile(int n, const VelScratch& vs, double cax, double cay, 
     dbg_stamp(vs.dbg, 10);
 }
 
-// tph.calc_vel_profile_brake on LDS arrays (lane 0): out[0..n) as v^2, zeros after standstill
+// tph.calc_vel_profile_brake on LDS arrays: out[0..n) as v^2, zeros after standstill. Same register scheme as fb_sweep:
+// lane l prepares the operands of step base + l, the steps run in order on wave-uniform values.
 template <int EM, bool GGARR>
 __device__ void brake_profile(int n, double* out, const VelScratch& vs, double cax, double cay, double v_start,
                               const DevVelParams& p, int lane)
 {
-    for (int i = lane; i < n; i += 64) out[i] = 0.0;
-    wave_sync_lds();
-    if (lane == 0) {
-        const double icay = 1.0 / cay;
-        const double* __restrict__ kabs = vs.kabs; const double* __restrict__ el = vs.el;
-        const double* __restrict__ gax = vs.gax; const double* __restrict__ igay = vs.igay;
-        double w = v_start * v_start;
-        out[0] = w;
-        double kq_i = kabs[0] * (GGARR ? igay[0] : icay), e_i = el[0], ax_i = GGARR ? gax[0] : cax;
-        for (int i = 0; i + 1 < n; ++i) {
-            const int i1 = i + 1 < n - 1 ? i + 1 : i;
-            const double kq_2 = kabs[i1] * (GGARR ? igay[i1] : icay), e_2 = el[i1], ax_2 = GGARR ? gax[i1] : cax;
+    const double icay = 1.0 / cay;
+    double w = v_start * v_start;
+    bool stopped = false;
+    if (lane == 0) out[0] = w;
+    for (int base = 0; base < n - 1; base += 64) {
+        const int cnt = (n - 1 - base) < 64 ? (n - 1 - base) : 64;
+        const int ic = (lane < cnt) ? base + lane : base + cnt - 1;
+        const double kq_i = vs.kabs[ic] * (GGARR ? vs.igay[ic] : icay), e_i = vs.el[ic], ax_i = GGARR ? vs.gax[ic] : cax;
+        const double te = 2.0 * e_i, axa = fabs(ax_i);
+        const double A0 = 1.0 - te * p.drag_m, A1 = A0 + te * (axa * kq_i), B1 = te * axa;
+        double wout = 0.0;
+        for (int sidx = 0; sidx < cnt; ++sidx) {
             double r;
             if constexpr (EM == 1) {
-                const double te = 2.0 * e_i, axa = fabs(ax_i);
-                const double A0 = 1.0 - te * p.drag_m, A1 = A0 + te * (axa * kq_i), B1 = te * axa;
-                const double Z = A0 * w, T = fma(A1, w, -B1);
-                r = fmin(T, Z);
+                const double a0 = readlane_f64(A0, sidx), a1 = readlane_f64(A1, sidx), b1 = readlane_f64(B1, sidx);
+                r = fmin(fma(a1, w, -b1), a0 * w);
             } else {
-                const double a = ax_poss_w<EM, true, VMODE_DECEL_FORW>(w, kq_i, ax_i, p, vs.axm, 0.0);
-                r = w + 2.0 * a * e_i;
+                const double kqi = readlane_f64(kq_i, sidx), axi = readlane_f64(ax_i, sidx), ei = readlane_f64(e_i, sidx);
+                const double a = ax_poss_w<EM, true, VMODE_DECEL_FORW>(w, kqi, axi, p, vs.axm, 0.0);
+                r = w + 2.0 * a * ei;
             }
-            if (r < 0.0) break;
-            w = r; out[i + 1] = w;
-            kq_i = kq_2; e_i = e_2; ax_i = ax_2;
+            stopped = stopped || (r < 0.0);
+            w = stopped ? w : r;
+            if (lane == sidx) wout = stopped ? 0.0 : r;
         }
+        if (lane < cnt) out[base + lane + 1] = wout;
     }
     wave_sync_lds();
 }
@@ -1819,26 +1817,32 @@ static int tick_pack(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_ve
     return LTPL_OK;
 }
 
-static int tick_launch(ltpl_handle* h, const TickLayout& t)
+static int tick_launch(ltpl_handle* h, const TickLayout& t, hipEvent_t* ev = nullptr)
 {
+    // ev (optional, 4 events): recorded before the path kernel, after it, after the follow preparation, after the lane kernel
+    if (ev) HIP_TRY(h, hipEventRecord(ev[0], h->stream));
     if (t.pipeline) {
         if (h->batch_nw == 1)
             hipLaunchKernelGGL(k_paths<1>, dim3(t.n_scen), dim3(64), h->lp1.total, h->stream, h->lat, t.di, t.dout, h->lp1);
         else
             hipLaunchKernelGGL(k_paths<NUM_WAVES>, dim3(t.n_scen), dim3(WG_THREADS), h->lp4.total, h->stream, h->lat, t.di, t.dout, h->lp4);
         HIP_TRY(h, hipGetLastError());
+        if (ev) HIP_TRY(h, hipEventRecord(ev[1], h->stream));
         hipLaunchKernelGGL(k_follow_prep, dim3(t.n_scen * LTPL_MAX_ACTIONS), dim3(64), t.lds_prep, h->stream, h->lat, t.di, t.dout,
                            t.dvin, t.dprep, t.n_scen * LTPL_MAX_ACTIONS);
         HIP_TRY(h, hipGetLastError());
+        if (ev) HIP_TRY(h, hipEventRecord(ev[2], h->stream));
         const int n_slots = t.n_scen * LTPL_MAX_ACTIONS;
         hipLaunchKernelGGL(lanes_kernel_of(t.variant), dim3((n_slots + 63) / 64), dim3(64), 0, h->stream, h->lat, t.di, t.dout,
                            t.p, t.dvin, t.dvout, t.dprep, static_cast<double*>(h->d_planes), n_slots, h->lp4.dbg);
         HIP_TRY(h, hipGetLastError());
+        if (ev) HIP_TRY(h, hipEventRecord(ev[3], h->stream));
         return LTPL_OK;
     }
     hipLaunchKernelGGL(tick_kernel_of(t.variant), dim3(t.n_scen), dim3(WG_THREADS), t.lds, h->stream, h->lat, t.di, t.dout, h->lp4, t.p,
                        t.dvin, t.dvout, t.vel_off, t.vel_stride, t.vel_cap);
     HIP_TRY(h, hipGetLastError());
+    if (ev) { HIP_TRY(h, hipEventRecord(ev[1], h->stream)); HIP_TRY(h, hipEventRecord(ev[2], h->stream)); HIP_TRY(h, hipEventRecord(ev[3], h->stream)); }
     return LTPL_OK;
 }
 
@@ -1923,6 +1927,25 @@ extern "C" int ltpl_batch_run(ltpl_handle* h, int reps, float* ms_total)
         HIP_TRY(h, hipEventElapsedTime(ms_total, e0, e1));
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
+    return LTPL_OK;
+}
+
+extern "C" int ltpl_batch_run_profile(ltpl_handle* h, int reps, float* ms_kernels)
+{
+    if (!h) return LTPL_ERR_INVALID_ARG;
+    if (!h->resident) { h->err = "no resident batch: call ltpl_batch_upload first"; return LTPL_ERR_INVALID_ARG; }
+    if (reps < 1 || !ms_kernels) { h->err = "reps < 1 or null output"; return LTPL_ERR_INVALID_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipEvent_t ev[4];
+    for (int i = 0; i < 4; ++i) HIP_TRY(h, hipEventCreate(&ev[i]));
+    ms_kernels[0] = ms_kernels[1] = ms_kernels[2] = 0.0f;
+    for (int r = 0; r < reps; ++r) {
+        int rc = tick_launch(h, *h->resident, ev);
+        if (rc) return rc;
+        HIP_TRY(h, hipEventSynchronize(ev[3]));
+        for (int k = 0; k < 3; ++k) { float ms = 0.0f; HIP_TRY(h, hipEventElapsedTime(&ms, ev[k], ev[k + 1])); ms_kernels[k] += ms; }
+    }
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
     return LTPL_OK;
 }
 

@@ -253,6 +253,9 @@ int ltpl_batch_upload(ltpl_handle* handle, const ltpl_paths_in* in, const ltpl_t
                       int32_t cap_nodes, int32_t cap_pts);
 int ltpl_batch_run(ltpl_handle* handle, int reps, float* ms_total);
 int ltpl_batch_download(ltpl_handle* handle, ltpl_paths_out* out, ltpl_tick_vel_out* vout);
+/* Profiling variant of ltpl_batch_run: HIP events between the kernels of the pipeline on the handle's stream.
+ * ms_kernels[3] = summed durations over `reps` of {path kernel, follow preparation, velocity lane kernel}. */
+int ltpl_batch_run_profile(ltpl_handle* handle, int reps, float* ms_kernels);
 
 #ifdef __cplusplus
 }

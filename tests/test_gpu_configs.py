@@ -1,0 +1,134 @@
+"""GPU: the BASELINE configurations that are parity-test cases rather than bench lines.
+
+  C3  synthetic 10 000-node / 98 000-edge oval, 32 static obstacles (64 obstacle positions) per scenario
+  C4  1 024 independent C2 scenarios, block-sharded into 8 parts (the per-GPU shards of an 8 x MI355X node are run one
+      after the other on the single GPU of the test box): identical bits to the unsharded batch
+  C5  high-resolution oval (0.5 m layer spacing, 21 lateral nodes) with a slow opponent ahead: the single-tick latency
+      kernel incl. the follow-mode velocity profile on every tick
+All through the C ABI (libltpl_hip.so) against the oracle on identical packed inputs."""
+import numpy as np
+import pytest
+
+from test_gpu_paths import compare_results
+from test_gpu_vel import compare_tick
+from graphbasedlocaltrajectoryplanner_amd import _capi
+from graphbasedlocaltrajectoryplanner_amd.scenario_gen import c2_scenarios, raceline_state
+from graphbasedlocaltrajectoryplanner_amd.sharding import shard_bounds, RESULT_FIELDS, VEL_FIELDS
+from graphbasedlocaltrajectoryplanner_amd.synthetic_lattice import c3_lattice, c5_lattice, scattered_obstacle_scenarios
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c3():
+    from oracle.oracle_lib import OracleBackend
+    lat = c3_lattice()
+    return lat, _capi.HipBackend(lat), OracleBackend(lat)
+
+
+def vel_inputs(lat, scen, vels, seed):
+    n = len(scen)
+    rng = np.random.default_rng(seed)
+    vplan = rng.uniform(3.0, 50.0, n)
+    pos = np.array([lat.node_pos[lat.layer_off[s['start_node'][0]] + s['start_node'][1]] for s in scen])
+    params = _capi.VelParamSet(len_veh=lat.veh_length)
+    return _capi.TickVelBatch(params, n, vplan, vplan, pos, np.concatenate(vels) if len(vels) else np.zeros(0))
+
+
+def test_c3_synthetic_lattice_matches_oracle(c3):
+    lat, hip, orc = c3
+    assert lat.num_nodes == 10000 and 90000 < lat.num_edges < 110000
+    scen, vels = scattered_obstacle_scenarios(lat, 256, n_obj=32, seed=0)
+    batch = _capi.PathsBatch(scen, w_last_edges=[0.0, 0.5, 0.8])
+    assert int(batch.pos_off[-1]) == 256 * 64                      # O = 64 obstacle positions per scenario
+    res, ref = hip.plan_paths(batch), orc.plan_paths(batch)
+    compare_results(res, ref, lat)
+    assert int(res.n_ties.sum()) > 0                               # the symmetric oval produces exact cost ties
+    names = set(int(x) for x in res.action_id[res.valid == 1])
+    assert {_capi.ACT_FOLLOW, _capi.ACT_LEFT, _capi.ACT_RIGHT} <= names
+    vel = vel_inputs(lat, scen, vels, 3)
+    r2, v2 = hip.tick_batch(batch, vel)
+    o2, ov2 = orc.tick_batch(batch, vel)
+    compare_tick(r2, v2, o2, ov2)
+    # single-scenario (latency kernel) launches give the same bits as the batch kernel
+    for i in (0, 17, 101):
+        b1 = _capi.PathsBatch([scen[i]], w_last_edges=[0.0, 0.5, 0.8])
+        r1 = hip.plan_paths(b1)
+        for name in ("valid", "action_id", "n_pts", "n_nodes", "reduced", "n_ties"):
+            assert np.array_equal(getattr(r1, name)[0], getattr(res, name)[i]), name
+        for a in range(3):
+            if res.valid[i, a]:
+                nn, npts = int(res.n_nodes[i, a]), int(res.n_pts[i, a])
+                assert np.array_equal(r1.nodes[0, a, :nn], res.nodes[i, a, :nn])
+                assert np.array_equal(r1.path_param[0, a, :npts], res.path_param[i, a, :npts])
+
+
+def test_c4_sharded_batch_is_bit_identical(monteblanco, hip_backend):
+    lat = monteblanco
+    n, world = 1024, 8
+    scen, vels = c2_scenarios(lat, n, seed=1)
+    vel_all = vel_inputs(lat, scen, vels, 5)
+    batch = _capi.PathsBatch(scen, w_last_edges=[0.0, 0.5, 0.8])
+    full, vfull = hip_backend.tick_batch(batch, vel_all)
+    for rank in range(world):
+        lo, hi = shard_bounds(n, rank, world)
+        assert hi - lo == 128
+        b = _capi.PathsBatch(scen[lo:hi], w_last_edges=[0.0, 0.5, 0.8])
+        v = _capi.TickVelBatch(vel_all.params, hi - lo, vel_all.vel_plan[lo:hi], vel_all.vel_est[lo:hi],
+                               np.column_stack((vel_all.pos_x[lo:hi], vel_all.pos_y[lo:hi])), np.concatenate(vels[lo:hi]))
+        part, vpart = hip_backend.tick_batch(b, v)
+        # per-scenario / per-slot scalars: identical; slabs: identical on the rows the call defines (capacity padding and
+        # slots without a path are not written by the library)
+        for k in ("end_layer", "closest_obj_index", "closest_obj_node", "n_actions", "action_id", "valid", "reduced",
+                  "goal_layer", "n_nodes", "n_pts", "n_ties"):
+            assert np.array_equal(getattr(part, k), getattr(full, k)[lo:hi]), k
+        assert np.array_equal(vpart.vel_bound, vfull.vel_bound[lo:hi]) and np.array_equal(vpart.too_close, vfull.too_close[lo:hi])
+        for s_ in range(hi - lo):
+            for a in range(3):
+                if not part.valid[s_, a]:
+                    continue
+                nn, npts = int(part.n_nodes[s_, a]), int(part.n_pts[s_, a])
+                assert np.array_equal(part.nodes[s_, a, :nn], full.nodes[lo + s_, a, :nn])
+                assert np.array_equal(part.node_idx[s_, a, :nn], full.node_idx[lo + s_, a, :nn])
+                assert np.array_equal(part.coeff[s_, a, :nn - 1], full.coeff[lo + s_, a, :nn - 1])
+                assert np.array_equal(part.path_param[s_, a, :npts], full.path_param[lo + s_, a, :npts])
+                assert np.array_equal(vpart.vx[s_, a, :npts], vfull.vx[lo + s_, a, :npts])
+                assert np.array_equal(vpart.ax[s_, a, :npts], vfull.ax[lo + s_, a, :npts])
+    assert int(full.valid.sum()) >= n
+
+
+def test_c5_highres_follow_ticks_match_oracle():
+    from oracle.oracle_lib import OracleBackend
+    lat = c5_lattice()
+    assert lat.num_layers == 1600 and int(lat.nodes_in_layer.max()) == 21
+    hip, orc = _capi.HipBackend(lat), OracleBackend(lat)
+    rng = np.random.default_rng(2)
+    scen, vels = [], []
+    for _ in range(48):
+        sl = int(rng.integers(0, lat.num_layers))
+        sn = int(lat.raceline_index[sl])
+        s_ego = float(lat.s_raceline[sl])
+        x, y, psi, v = raceline_state(lat, s_ego + rng.uniform(20.0, 80.0))          # slow opponent ahead on the race line
+        v = float(v) * rng.uniform(0.2, 0.5)
+        pred = np.array([[x - np.sin(psi) * v * 0.2, y + np.cos(psi) * v * 0.2]])
+        scen.append({"start_node": (sl, sn), "action_sets": True, "vehicles": [(2.5, np.vstack((np.array([[x, y]]), pred)))],
+                     "zone_gids": [], "last_nodes": None, "obj_in_const": False, "obj_besides": False, "last_action": None,
+                     "const_closest": None, "psi_s": float(lat.node_psi[lat.layer_off[sl] + sn])})
+        vels.append(np.array([v]))
+    vel = vel_inputs(lat, scen, vels, 9)
+    # one call per tick = the latency kernel (one workgroup per scenario, path + velocity fused)
+    n_follow = 0
+    for i in range(len(scen)):
+        b1 = _capi.PathsBatch([scen[i]], w_last_edges=[0.0, 0.5, 0.8])
+        v1 = _capi.TickVelBatch(vel.params, 1, vel.vel_plan[i:i + 1], vel.vel_est[i:i + 1],
+                                np.array([[vel.pos_x[i], vel.pos_y[i]]]), vels[i])
+        r, vr = hip.tick_batch(b1, v1)
+        o, ov = orc.tick_batch(b1, v1)
+        compare_tick(r, vr, o, ov)
+        n_follow += int(((r.action_id == _capi.ACT_FOLLOW) & (r.valid == 1)).sum())
+    assert n_follow >= 24                                        # the follow-mode profile really ran
+    # and the same scenarios as one batch through the throughput pipeline
+    batch = _capi.PathsBatch(scen, w_last_edges=[0.0, 0.5, 0.8])
+    r, vr = hip.tick_batch(batch, vel)
+    o, ov = orc.tick_batch(batch, vel)
+    compare_tick(r, vr, o, ov)
