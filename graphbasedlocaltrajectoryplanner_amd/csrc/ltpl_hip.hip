@@ -68,6 +68,7 @@ struct DevPathsOut {
     int* end_layer; int* closest_obj_index; int* closest_obj_node; int* n_actions;
     int* action_id; int* valid; int* reduced; int* goal_layer; int* n_nodes; int* n_pts; int* n_ties;
     int* nodes; int* node_idx; double* coeff; double* path_param;
+    double* vkap; double* vlen;      // optional tiled planes (|kappa|, element length) for the batch velocity stage
 };
 
 
@@ -735,22 +736,37 @@ __global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, 
 // throughput form of the velocity stage: ONE LANE PER PROFILE
 // ---------------------------------------------------------------------------------------------------------------------
 // The recurrences are sequential per profile, so a wave that owns a single profile runs them with 1/64 of its lanes.
-// For batches the velocity stage therefore runs as a second kernel in which every lane of a wave64 integrates its own
-// profile (slot = scenario * 3 + action): 64 independent dependent-chains per instruction stream. Curvature / element
-// length come straight from the path kernel's path_param rows (L1 / L2 resident: 40 B row stride), the profile state
-// lives in three transposed scratch planes [row][slot] so that a wave's accesses to row i are one coalesced line.
-struct DevVelPrep {             // per-slot scalars produced by the path kernel (follow action only)
+// For batches the velocity stage therefore runs as its own kernel in which every lane of a wave64 integrates its own
+// profile: 64 independent dependent-chains per instruction stream. All per-row data a lane touches lives in TILED
+// planes: element (slot, row) at ((slot / 64) * cap_pts + row) * 64 + slot % 64, so that the 64 lanes of a wave
+// (64 consecutive slots) read / write row i as ONE coalesced 512-byte line. The path kernel writes |kappa| and the
+// element lengths of every path into two such planes.
+//   job type 0 (one lane per action slot):  'follow' -> the controlled profile (ego brake, opponent stop distance, segment
+//            forward-backward profile; calc_vel_profile_follow.py:151-294); other primitives -> the generic
+//            forward-backward profile with the race-line end velocity (OTH.py:834-903)
+//   job type 1 (one lane per scenario):     the unconstrained profile of a 'follow' slot (calc_vel_profile_follow.py:297-307)
+//            -- independent of type 0, so the two halves of the follow mode run on different lanes
+// k_vel_final (lane per slot, no recurrence) intersects / selects the profiles, derives ax and writes the outputs.
+struct DevVelPrep {             // per-slot scalars produced by k_follow_prep (follow action only)
     double* obj_dist; double* v_obj; double* obj_x; double* obj_y; int* idx_s_opp;
 };
 
-struct LaneProf {
-    const double* pp;           // path_param rows of this slot [n][5]
-    double* W; double* WB; double* WC;     // transposed planes, element i at [i * P]
-    size_t P;
+struct VelPlanes {              // tiled planes (doubles); per-slot planes have n_slots_pad slots, P1 n_scen_pad
+    double* K; double* E;       // |kappa|, element length          (written by the path kernel)
+    double* P0;                 // type 0 result: follow -> "vx_profile" (:289/:294), else the generic profile
+    double* P1;                 // type 1 result: unconstrained profile of the follow slot, indexed by SCENARIO
+    double* P2;                 // ego brake profile (follow)
+    double* P3;                 // segment profile (follow), afterwards the generic profile of a reduced-horizon follow slot
+    int* flags;                 // per slot: bit 0 vel_bound of the follow part, bit 1 too_close, bit 2 generic profile in P3,
+                                //           bit 3 vel_bound of the generic profile, bits 8.. = n_decel / stop_idx packing unused
+    int cap_pts;
 };
 
-__device__ __forceinline__ double lp_kabs(const LaneProf& L, int i) { return fabs(L.pp[(size_t)i * 5 + 3]); }
-__device__ __forceinline__ double lp_el(const LaneProf& L, int i) { return L.pp[(size_t)i * 5 + 4]; }
+__device__ __forceinline__ size_t tile_base(int idx, int cap_pts) { return ((size_t)(idx >> 6) * cap_pts) * 64 + (idx & 63); }
+
+struct LaneProf {
+    const double* K; const double* E;     // tile-strided: element i at [i * 64]
+};
 
 #define LCH 8      // rows per register chunk: all loads of a chunk are issued before the chunk's recurrence steps
 
@@ -764,11 +780,10 @@ __device__ void lane_fb_profile(const LaneProf& L, double* D, int off, int n, do
     if (v_start < 0.0) v_start = 0.0;
     if (has_v_end && v_end < 0.0) v_end = 0.0;
     const double vmax2 = v_max * v_max, icay = 1.0 / cay, axm1 = axm_tab[1], dm = p.drag_m, axa = fabs(cax);
-    const size_t P = L.P;
-    const double* pp = L.pp + (size_t)off * 5;
-    double* Dp = D + (size_t)off * P;
+    const double* Kp = L.K + (size_t)off * 64; const double* Ep = L.E + (size_t)off * 64;
+    double* Dp = D + (size_t)off * 64;
     // ---- lateral-limit speed + forward sweep (accel_forw) in one pass -------------------------------------------------
-    double kabs_i = fabs(pp[3]), e_i = pp[4];
+    double kabs_i = Kp[0], e_i = Ep[0];
     double wi = cay / kabs_i;
     if (!(wi < vmax2)) wi = vmax2;
     if (wi > v_start * v_start) wi = v_start * v_start;
@@ -782,7 +797,7 @@ __device__ void lane_fb_profile(const LaneProf& L, double* D, int off, int n, do
 #pragma unroll
             for (int c = 0; c < LCH; ++c) {
                 const int r = base + 1 + c < n ? base + 1 + c : n - 1;
-                kr[c] = fabs(pp[(size_t)r * 5 + 3]); er[c] = pp[(size_t)r * 5 + 4];
+                kr[c] = Kp[(size_t)r * 64]; er[c] = Ep[(size_t)r * 64];
             }
 #pragma unroll
             for (int c = 0; c < LCH; ++c) {
@@ -809,7 +824,7 @@ __device__ void lane_fb_profile(const LaneProf& L, double* D, int off, int n, do
                         active = !(wn > vmax2);
                     }
                     if (has_v_end && i + 1 == n - 1 && wnext > v_end * v_end) wnext = v_end * v_end;
-                    Dp[(size_t)(i + 1) * P] = wnext;
+                    Dp[(size_t)(i + 1) * 64] = wnext;
                     orig_i = w0n; wi = wnext; kabs_i = kr[c]; e_i = er[c];
                 }
             }
@@ -817,7 +832,6 @@ __device__ void lane_fb_profile(const LaneProf& L, double* D, int off, int n, do
     }
     // ---- backward sweep (decel_backw), mirrored indices; with a constant gg the unmirrored-gg quirk is void --------------
     {
-        // wi = value at row n-1 (still in the register), kabs_i = |kappa| at row n-1
         double orig_i = wi;
         bool active = false, prev_acc = false;
         for (int base = 0; base < n - 1; base += LCH) {
@@ -825,7 +839,7 @@ __device__ void lane_fb_profile(const LaneProf& L, double* D, int off, int n, do
 #pragma unroll
             for (int c = 0; c < LCH; ++c) {
                 const int r = n - 2 - base - c >= 0 ? n - 2 - base - c : 0;
-                kr[c] = fabs(pp[(size_t)r * 5 + 3]); er[c] = pp[(size_t)r * 5 + 4]; wr[c] = Dp[(size_t)r * P];
+                kr[c] = Kp[(size_t)r * 64]; er[c] = Ep[(size_t)r * 64]; wr[c] = Dp[(size_t)r * 64];
             }
 #pragma unroll
             for (int c = 0; c < LCH; ++c) {
@@ -852,7 +866,7 @@ __device__ void lane_fb_profile(const LaneProf& L, double* D, int off, int n, do
                             const double a2 = ax_poss_w<EM, AXM1, VMODE_DECEL_BACKW>(wn, kq_n, cax, p, axm_tab, axm1);
                             wn = fmin(fmax(wi + 2.0 * a2 * e_b, 0.0), wn);
                         }
-                        if (wn < wold) { wnext = wn; Dp[(size_t)(n - 2 - i) * P] = wn; }
+                        if (wn < wold) { wnext = wn; Dp[(size_t)(n - 2 - i) * 64] = wn; }
                         active = !(wn > vmax2);
                     }
                     orig_i = wold; wi = wnext; kabs_i = kr[c];
@@ -862,38 +876,84 @@ __device__ void lane_fb_profile(const LaneProf& L, double* D, int off, int n, do
     }
 }
 
+#define VF_BOUND_FOLLOW 1
+#define VF_TOO_CLOSE    2
+#define VF_HAS_GENERIC  4
+#define VF_BOUND_GENERIC 8
+
+// the generic forward-backward profile of a slot (OTH.py:834-903) into plane D; returns its vel_bound flag
+template <int EM, bool AXM1>
+__device__ int lane_generic_profile(const DevLat& lat, const DevPathsOut& out, const LaneProf& L, double* D, int slot, int n,
+                                    int reduced, double cax, double cay, const DevVelParams& p, const double* axm_tab,
+                                    double vel_plan, double v_max_offset)
+{
+    const int goal = out.goal_layer[slot];
+    const int end_node = out.nodes[(size_t)slot * out.cap_nodes + out.n_nodes[slot] - 1];
+    int dn = end_node - lat.rl_idx[goal]; if (dn < 0) dn = -dn;
+    const double raceline_offset = (double)dn * lat.lat_offset;
+    double v_end; int v_idx;
+    if (reduced) {
+        v_end = 0.0;
+        double spl_len = 0.0;
+        for (int i = 0; i < n - 1; ++i) spl_len += L.E[(size_t)i * 64];
+        int first = -1; double c = 0.0;
+        for (int i = 0; i < n - 1; ++i) { c += L.E[(size_t)i * 64]; if (first < 0 && !(c < (spl_len - 5.0))) first = i; }
+        v_idx = (first < 0 ? 0 : first) + 1;
+        if (v_idx == 1 && n > 1) v_idx = n;
+    } else {
+        v_end = lat.vel_rl[goal];
+        const double red = v_end * lat.vel_decrease_lat * raceline_offset;
+        v_end -= (red < v_end ? red : v_end);
+        v_idx = n;
+    }
+    if (v_idx > 1) lane_fb_profile<EM, AXM1>(L, D, 0, v_idx, cax, cay, p, axm_tab, p.v_max, vel_plan, true, v_end);
+    else D[0] = 0.0;
+    for (int i = (v_idx > 1 ? v_idx : 1); i < n; ++i) D[(size_t)i * 64] = 0.0;
+    return fabs(sqrt(D[0]) - vel_plan) < v_max_offset ? 1 : 0;
+}
+
 template <int EM, bool AXM1>
 __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, DevPathsOut out, DevVelParams p,
-                                                  DevTickVelIn vin, DevTickVelOut vout, DevVelPrep prep,
-                                                  double* planes, int n_slots, long long* dbg)
+                                                  DevTickVelIn vin, DevVelPrep prep, VelPlanes vp, int n_slots, int n_scen,
+                                                  int n_blocks0, long long* dbg)
 {
     __shared__ double axm_tab[128];
     const int lane = threadIdx.x;
     for (int i = lane; i < 2 * p.n_axm; i += 64) axm_tab[i] = p.axm[i];
     __syncthreads();
     dbg_stamp(dbg, 0);
+    const double cax = vin.gg_ax, cay = vin.gg_ay, icay = 1.0 / cay;
+    if ((int)blockIdx.x >= n_blocks0) {
+        // ---- job type 1: unconstrained profile of the follow slot of scenario s --------------------------------------
+        const int s = ((int)blockIdx.x - n_blocks0) * 64 + lane;
+        if (s >= n_scen) return;
+        const int slot = s * LTPL_MAX_ACTIONS;
+        if (!out.valid[slot] || out.action_id[slot] != LTPL_ACT_FOLLOW) return;
+        LaneProf L; L.K = vp.K + tile_base(slot, vp.cap_pts); L.E = vp.E + tile_base(slot, vp.cap_pts);
+        lane_fb_profile<EM, AXM1>(L, vp.P1 + tile_base(s, vp.cap_pts), 0, out.n_pts[slot], cax, cay, p, axm_tab, p.v_max,
+                                  vin.vel_plan[s], false, 0.0);
+        return;
+    }
+    // ---- job type 0 ----------------------------------------------------------------------------------------------------
     const int slot = blockIdx.x * 64 + lane;
     if (slot >= n_slots) return;
     const int s = slot / LTPL_MAX_ACTIONS;
-    if (!out.valid[slot]) { vout.vel_bound[slot] = 0; vout.too_close[slot] = 0; return; }
+    if (!out.valid[slot]) { vp.flags[slot] = 0; return; }
     const int n = out.n_pts[slot];
-    const size_t P = (size_t)n_slots;
-    LaneProf L;
-    L.pp = out.path_param + (size_t)slot * out.cap_pts * 5;
-    L.P = P;
-    L.W = planes + slot; L.WB = planes + (size_t)out.cap_pts * P + slot; L.WC = planes + 2 * (size_t)out.cap_pts * P + slot;
-    const double cax = vin.gg_ax, cay = vin.gg_ay, icay = 1.0 / cay;
+    LaneProf L; L.K = vp.K + tile_base(slot, vp.cap_pts); L.E = vp.E + tile_base(slot, vp.cap_pts);
+    double* P0 = vp.P0 + tile_base(slot, vp.cap_pts);
+    double* P2 = vp.P2 + tile_base(slot, vp.cap_pts);
+    double* P3 = vp.P3 + tile_base(slot, vp.cap_pts);
     const double vel_plan = vin.vel_plan[s];
     const int name = out.action_id[slot], reduced = out.reduced[slot];
-    int too_close = 0, vel_bound = 1;
-    bool have_follow = false;
-    const double* pp = L.pp;
+    int flags = VF_BOUND_FOLLOW;
 
     if (name == LTPL_ACT_FOLLOW) {                                                       // OTH.py:763-830
-        // calc_vel_profile_follow.py:78-313 for this lane
+        // calc_vel_profile_follow.py:78-294 for this lane
+        int vel_bound = 1;
         const double v_start = vel_plan, v_ego = vin.vel_est[s], v_obj = prep.v_obj[slot], obj_dist = prep.obj_dist[slot];
         const double control_d = p.c_p * vin.safety_d + p.len_veh, safety_d = vin.safety_d + p.len_veh;
-        too_close = (obj_dist - safety_d) < 0.0;
+        if ((obj_dist - safety_d) < 0.0) flags |= VF_TOO_CLOSE;
         const double v_max = p.v_max;
         double v_control;
         if (p.ctrl == 0) v_control = (v_obj - p.k_p * (control_d - obj_dist) + p.k_d * (v_obj - v_ego));
@@ -935,7 +995,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
                 }
             }
         }
-        // one pass over the path rows: ego brake profile -> WB (:152-159), ego stop distance (:162-166), first index at
+        // one pass over the path rows: ego brake profile -> P2 (:152-159), ego stop distance (:162-166), first index at
         // or below the control speed (:254), arc length and stop index (:203-209)
         const double s_stop = obj_dist - safety_d + opp_stop;                            // :206
         double ego_stop = 0.0, s_run = 0.0, s_last = 0.0; int first_le = -1, stop_idx = 0;
@@ -946,14 +1006,14 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
 #pragma unroll
                 for (int c = 0; c < LCH; ++c) {
                     const int r = base + c < n ? base + c : n - 1;
-                    kr[c] = fabs(pp[(size_t)r * 5 + 3]); er[c] = pp[(size_t)r * 5 + 4];
+                    kr[c] = L.K[(size_t)r * 64]; er[c] = L.E[(size_t)r * 64];
                 }
 #pragma unroll
                 for (int c = 0; c < LCH; ++c) {
                     const int i = base + c;
                     if (i < n) {
                         const double wv = braking ? w : 0.0;
-                        L.WB[(size_t)i * P] = wv;
+                        P2[(size_t)i * 64] = wv;
                         if (first_le < 0 && wv <= wctl) first_le = i;
                         if (counting) { if (wv > 0.01) ego_stop += er[c]; else counting = false; }
                         if (searching) { if (i < n - 1 && s_run < s_stop) stop_idx = i + 1; else searching = false; }
@@ -987,7 +1047,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
             int j = (idx % G) + idx_s_opp; if (j >= G) j -= G;
             v_end = grl[(size_t)j * 5 + 4];
         }
-        int idx_c = 0, n_decel = 0; bool two_seg = ego_stop < s_stop;
+        int idx_c = 0, n_decel = 0; const bool two_seg = ego_stop < s_stop;
         if (two_seg) {                                                                   // :247-292
             double vcs = v_start;
             if (v_start > v_control && stop_idx >= 2) {
@@ -995,71 +1055,79 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
                 if (idx_c > stop_idx) idx_c = stop_idx;
                 if (idx_c == 0) idx_c = stop_idx;
                 n_decel = idx_c + 1 < n ? idx_c + 1 : n;
-                vcs = sqrt(L.WB[(size_t)(n_decel - 1) * P]);
+                vcs = sqrt(P2[(size_t)(n_decel - 1) * 64]);
             } else if (!(stop_idx >= 2)) vel_bound = 0;
             const int m = (stop_idx + 1 < n ? stop_idx + 1 : n) - idx_c;
             if (stop_idx - idx_c > 0) {
-                lane_fb_profile<EM, AXM1>(L, L.WC, idx_c, m, cax, cay, p, axm_tab, v_control, vcs, true, v_end);
-                if (fabs(sqrt(L.WC[(size_t)idx_c * P]) - vcs) > 1.0) vel_bound = 0;
-            } else if (stop_idx - idx_c == 0) L.WC[(size_t)idx_c * P] = vcs * vcs;
-            const double first_v = (n_decel - 1 > 0) ? sqrt(L.WB[0]) : sqrt(L.WC[0]);
+                lane_fb_profile<EM, AXM1>(L, P3, idx_c, m, cax, cay, p, axm_tab, v_control, vcs, true, v_end);
+                if (fabs(sqrt(P3[(size_t)idx_c * 64]) - vcs) > 1.0) vel_bound = 0;
+            } else if (stop_idx - idx_c == 0) P3[(size_t)idx_c * 64] = vcs * vcs;
+            const double first_v = (n_decel - 1 > 0) ? sqrt(P2[0]) : sqrt(P3[0]);
             if (fabs(first_v - v_start) > 1.0) vel_bound = 0;
         }
-        lane_fb_profile<EM, AXM1>(L, L.W, 0, n, cax, cay, p, axm_tab, v_max, v_start, false, 0.0);
-        // vx_profile (:289 / :294) intersected with the complete profile (:310), chunked
+        // "vx_profile" (:289 / :294) -> P0, chunked
         for (int base = 0; base < n; base += LCH) {
-            double a[LCH], b[LCH];
+            double a[LCH];
 #pragma unroll
             for (int c = 0; c < LCH; ++c) {
                 const int i = base + c < n ? base + c : n - 1;
                 const bool from_b = !two_seg || i < n_decel - 1;
-                a[c] = from_b ? L.WB[(size_t)i * P] : ((i > stop_idx) ? 0.0 : L.WC[(size_t)i * P]);
-                b[c] = L.W[(size_t)i * P];
+                a[c] = from_b ? P2[(size_t)i * 64] : ((i > stop_idx) ? 0.0 : P3[(size_t)i * 64]);
             }
 #pragma unroll
-            for (int c = 0; c < LCH; ++c) if (base + c < n) L.W[(size_t)(base + c) * P] = a[c] < b[c] ? a[c] : b[c];
+            for (int c = 0; c < LCH; ++c) if (base + c < n) P0[(size_t)(base + c) * 64] = a[c];
         }
-        have_follow = true;
+        if (!vel_bound) flags &= ~VF_BOUND_FOLLOW;
+        if (reduced) {                                                                   // OTH.py:834-923 on top of follow
+            flags |= VF_HAS_GENERIC;
+            if (lane_generic_profile<EM, AXM1>(lat, out, L, P3, slot, n, reduced, cax, cay, p, axm_tab, vel_plan, vin.v_max_offset))
+                flags |= VF_BOUND_GENERIC;
+        }
+    } else {
+        if (lane_generic_profile<EM, AXM1>(lat, out, L, P0, slot, n, reduced, cax, cay, p, axm_tab, vel_plan, vin.v_max_offset))
+            flags |= VF_BOUND_GENERIC;
     }
-    if (name != LTPL_ACT_FOLLOW || reduced) {                                            // OTH.py:834-923
-        if (have_follow) for (int i = 0; i < n; ++i) L.WB[(size_t)i * P] = L.W[(size_t)i * P];
-        const int goal = out.goal_layer[slot];
-        const int end_node = out.nodes[(size_t)slot * out.cap_nodes + out.n_nodes[slot] - 1];
-        int dn = end_node - lat.rl_idx[goal]; if (dn < 0) dn = -dn;
-        const double raceline_offset = (double)dn * lat.lat_offset;
-        double v_end; int v_idx;
-        if (reduced) {
-            v_end = 0.0;
-            double spl_len = 0.0;
-            for (int i = 0; i < n - 1; ++i) spl_len += lp_el(L, i);
-            int first = -1; double c = 0.0;
-            for (int i = 0; i < n - 1; ++i) { c += lp_el(L, i); if (first < 0 && !(c < (spl_len - 5.0))) first = i; }
-            v_idx = (first < 0 ? 0 : first) + 1;
-            if (v_idx == 1 && n > 1) v_idx = n;
-        } else {
-            v_end = lat.vel_rl[goal];
-            const double red = v_end * lat.vel_decrease_lat * raceline_offset;
-            v_end -= (red < v_end ? red : v_end);
-            v_idx = n;
-        }
-        if (v_idx > 1) lane_fb_profile<EM, AXM1>(L, L.W, 0, v_idx, cax, cay, p, axm_tab, p.v_max, vel_plan, true, v_end);
-        else L.W[0] = 0.0;
-        for (int i = (v_idx > 1 ? v_idx : 1); i < n; ++i) L.W[(size_t)i * P] = 0.0;
-        vel_bound = fabs(sqrt(L.W[0]) - vel_plan) < vin.v_max_offset ? 1 : 0;
-        if (have_follow && n >= 6) {
-            if (sqrt(L.WB[5 * P]) < sqrt(L.W[5 * P])) for (int i = 0; i < n; ++i) L.W[(size_t)i * P] = L.WB[(size_t)i * P];
+    vp.flags[slot] = flags;
+    dbg_stamp(dbg, 1);
+}
+
+// final step of the batch velocity stage, lane per slot, no recurrence: intersection of the two follow profiles
+// (calc_vel_profile_follow.py:310), choice between follow and generic profile for reduced horizons (OTH.py:923, row 5),
+// vx = sqrt(w), ax from neighbouring points with -5 at standstill (OTH.py:925-941)
+__global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn vin, DevTickVelOut vout, VelPlanes vp, int n_slots)
+{
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= n_slots) return;
+    if (!out.valid[slot]) { vout.vel_bound[slot] = 0; vout.too_close[slot] = 0; return; }
+    const int s = slot / LTPL_MAX_ACTIONS, n = out.n_pts[slot], flags = vp.flags[slot];
+    const bool follow = out.action_id[slot] == LTPL_ACT_FOLLOW;
+    const double* P0 = vp.P0 + tile_base(slot, vp.cap_pts);
+    const double* P1 = vp.P1 + tile_base(s, vp.cap_pts);
+    const double* P3 = vp.P3 + tile_base(slot, vp.cap_pts);
+    const double* E = vp.E + tile_base(slot, vp.cap_pts);
+    int vel_bound = follow ? ((flags & VF_BOUND_FOLLOW) ? 1 : 0) : ((flags & VF_BOUND_GENERIC) ? 1 : 0);
+    int sel = follow ? 1 : 0;                     // 0: P0, 1: min(P0, P1), 2: P3
+    if (follow && (flags & VF_HAS_GENERIC)) {
+        vel_bound = (flags & VF_BOUND_GENERIC) ? 1 : 0;
+        sel = 2;
+        if (n >= 6) {
+            const double f5 = fmin(P0[5 * 64], P1[5 * 64]);
+            if (sqrt(f5) < sqrt(P3[5 * 64])) sel = 1;
         }
     }
-    // finalise (OTH.py:925-941), chunked
     double* o_vx = vout.vx + (size_t)slot * out.cap_pts;
     double* o_ax = vout.ax + (size_t)slot * out.cap_pts;
-    double s_i = 0.0, w_i = L.W[0];
+    auto value = [&](int i) {
+        const size_t o = (size_t)i * 64;
+        return sel == 0 ? P0[o] : (sel == 1 ? fmin(P0[o], P1[o]) : P3[o]);
+    };
+    double s_i = 0.0, w_i = value(0);
     for (int base = 0; base < n; base += LCH) {
         double wr[LCH], er[LCH];
 #pragma unroll
         for (int c = 0; c < LCH; ++c) {
             const int r = base + c + 1 < n ? base + c + 1 : n - 1;
-            wr[c] = L.W[(size_t)r * P]; er[c] = pp[(size_t)(base + c < n ? base + c : n - 1) * 5 + 4];
+            wr[c] = value(r); er[c] = E[(size_t)(base + c < n ? base + c : n - 1) * 64];
         }
 #pragma unroll
         for (int c = 0; c < LCH; ++c) {
@@ -1080,8 +1148,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
             }
         }
     }
-    vout.vel_bound[slot] = vel_bound; vout.too_close[slot] = too_close;
-    dbg_stamp(dbg, 1);
+    vout.vel_bound[slot] = vel_bound; vout.too_close[slot] = (flags & VF_TOO_CLOSE) ? 1 : 0;
 }
 
 // follow preparation executed by the path kernel's wave that owns a "follow" action: the wave-parallel reductions
@@ -1148,7 +1215,15 @@ struct ltpl_handle {
     void* d_out = nullptr; size_t d_out_cap = 0;
     struct TickLayout* resident = nullptr;   // device-resident batch of ltpl_batch_upload
     long long* d_dbg = nullptr;              // LTPL_DEBUG_TIMING=1: cycle stamps
-    void* d_planes = nullptr; size_t d_planes_cap = 0;   // transposed profile planes of the lane kernel
+    void* d_planes = nullptr; size_t d_planes_cap = 0;   // tiled profile planes of the lane kernel
+    // second buffer set + stream of the device-resident batch: the velocity kernels of step k overlap the path kernel of
+    // step k + 1 (ltpl_batch_run)
+    struct TickLayout* resident2 = nullptr;
+    void* d_out2 = nullptr; size_t d_out2_cap = 0;
+    void* d_planes2 = nullptr; size_t d_planes2_cap = 0;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_paths[2] = {nullptr, nullptr}, ev_vel[2] = {nullptr, nullptr};
+    int last_set = 0;
 };
 
 static void dbg_report(ltpl_handle* h, const char* what, int n_blocks)
@@ -1265,6 +1340,11 @@ extern "C" int ltpl_destroy(ltpl_handle* h)
     if (h->d_out) (void)hipFree(h->d_out);
     if (h->d_dbg) (void)hipFree(h->d_dbg);
     if (h->d_planes) (void)hipFree(h->d_planes);
+    if (h->d_planes2) (void)hipFree(h->d_planes2);
+    if (h->d_out2) (void)hipFree(h->d_out2);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    for (int i = 0; i < 2; ++i) { if (h->ev_paths[i]) (void)hipEventDestroy(h->ev_paths[i]); if (h->ev_vel[i]) (void)hipEventDestroy(h->ev_vel[i]); }
+    free_resident(h->resident2);
     if (h->h_in) (void)hipHostFree(h->h_in);
     if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1548,6 +1628,7 @@ static void bind_out(unsigned char* db, const OutLayout& lo, int cap_nodes, int 
     d->n_ties = reinterpret_cast<int*>(db + lo.n_ties); d->nodes = reinterpret_cast<int*>(db + lo.nodes);
     d->node_idx = reinterpret_cast<int*>(db + lo.node_idx); d->coeff = reinterpret_cast<double*>(db + lo.coeff);
     d->path_param = reinterpret_cast<double*>(db + lo.path_param);
+    d->vkap = nullptr; d->vlen = nullptr;
 }
 
 static void scatter_out(const unsigned char* hb, const OutLayout& lo, int n, ltpl_paths_out* out)
@@ -1610,7 +1691,7 @@ static int vel_variant(const ltpl_vel_params* vp)
 }
 typedef void (*vel_kernel_t)(DevLat, DevVelParams, const DevVelJob*, const double*, double*, int*, int, long long*);
 typedef void (*tick_kernel_t)(DevLat, DevPathsIn, DevPathsOut, TeamLds, DevVelParams, DevTickVelIn, DevTickVelOut, int, int, int);
-typedef void (*lanes_kernel_t)(DevLat, DevPathsIn, DevPathsOut, DevVelParams, DevTickVelIn, DevTickVelOut, DevVelPrep, double*, int, long long*);
+typedef void (*lanes_kernel_t)(DevLat, DevPathsIn, DevPathsOut, DevVelParams, DevTickVelIn, DevVelPrep, VelPlanes, int, int, int, long long*);
 static lanes_kernel_t lanes_kernel_of(int v)
 {
     switch (v) {
@@ -1732,6 +1813,7 @@ struct TickLayout {
     // two-kernel batch pipeline (n_scen >= PIPELINE_MIN_SCEN)
     bool pipeline; size_t prep_odist, prep_vobj, prep_ox, prep_oy, prep_idx; size_t planes_bytes;
     DevVelPrep dprep; int prep_off, prep_stride; size_t lds_prep;
+    VelPlanes vp{}; int n_slots_pad = 0, n_scen_pad = 0;
 };
 
 static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin, int cap_nodes, int cap_pts,
@@ -1768,7 +1850,10 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
     t->prep_oy = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS);
     t->prep_idx = b.add(sizeof(int) * (size_t)n * LTPL_MAX_ACTIONS);
     t->out_total = b.size;
-    t->planes_bytes = t->pipeline ? sizeof(double) * 3 * (size_t)cap_pts * (size_t)n * LTPL_MAX_ACTIONS : 0;
+    t->n_slots_pad = (int)align_up((size_t)n * LTPL_MAX_ACTIONS, 64); t->n_scen_pad = (int)align_up((size_t)n, 64);
+    // tiled planes: K, E, P0, P2, P3 per slot, P1 per scenario, flags per slot
+    t->planes_bytes = t->pipeline ? sizeof(double) * (size_t)cap_pts * (5 * (size_t)t->n_slots_pad + (size_t)t->n_scen_pad)
+                                        + sizeof(int) * (size_t)t->n_slots_pad : 0;
     t->prep_off = 0; t->prep_stride = 0;
     t->lds_prep = align_up(sizeof(double) * 4 * (size_t)(cap_pts + 2), 16);      // k_follow_prep: el, x, y, s
     t->vel_cap = h->caps.max_path_pts;
@@ -1777,6 +1862,28 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
     t->lds = (size_t)h->lp4.total + (size_t)t->vel_stride * LTPL_MAX_ACTIONS;
     if (t->lds > 150 * 1024) { h->err = "fused tick exceeds the LDS budget"; return LTPL_ERR_CAPACITY; }
     return LTPL_OK;
+}
+
+// device-side output pointers of a tick layout for one buffer set (output slab + tiled planes)
+static void tick_bind_outputs(TickLayout* t, unsigned char* dob, double* planes)
+{
+    bind_out(dob, t->out, t->cap_nodes, t->cap_pts, &t->dout);
+    t->dvout.vx = reinterpret_cast<double*>(dob + t->vx); t->dvout.ax = reinterpret_cast<double*>(dob + t->ax);
+    t->dvout.vel_bound = reinterpret_cast<int*>(dob + t->vel_bound);
+    t->dvout.too_close = reinterpret_cast<int*>(dob + t->too_close);
+    t->dprep.obj_dist = reinterpret_cast<double*>(dob + t->prep_odist);
+    t->dprep.v_obj = reinterpret_cast<double*>(dob + t->prep_vobj);
+    t->dprep.obj_x = reinterpret_cast<double*>(dob + t->prep_ox);
+    t->dprep.obj_y = reinterpret_cast<double*>(dob + t->prep_oy);
+    t->dprep.idx_s_opp = reinterpret_cast<int*>(dob + t->prep_idx);
+    if (t->pipeline && planes) {
+        const size_t per_slot = (size_t)t->cap_pts * (size_t)t->n_slots_pad, per_scen = (size_t)t->cap_pts * (size_t)t->n_scen_pad;
+        t->vp.K = planes; t->vp.E = planes + per_slot; t->vp.P0 = planes + 2 * per_slot; t->vp.P2 = planes + 3 * per_slot;
+        t->vp.P3 = planes + 4 * per_slot; t->vp.P1 = planes + 5 * per_slot;
+        t->vp.flags = reinterpret_cast<int*>(planes + 5 * per_slot + per_scen);
+        t->vp.cap_pts = t->cap_pts;
+        t->dout.vkap = t->vp.K; t->dout.vlen = t->vp.E;
+    }
 }
 
 static int tick_pack(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin, TickLayout* t,
@@ -1799,43 +1906,51 @@ static int tick_pack(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_ve
     t->dvin.pos_est_x = reinterpret_cast<const double*>(db + t->pos_x);
     t->dvin.pos_est_y = reinterpret_cast<const double*>(db + t->pos_y);
     t->dvin.veh_vel = reinterpret_cast<const double*>(db + t->veh_vel);
-    bind_out(dob, t->out, t->cap_nodes, t->cap_pts, &t->dout);
-    t->dvout.vx = reinterpret_cast<double*>(dob + t->vx); t->dvout.ax = reinterpret_cast<double*>(dob + t->ax);
-    t->dvout.vel_bound = reinterpret_cast<int*>(dob + t->vel_bound);
-    t->dvout.too_close = reinterpret_cast<int*>(dob + t->too_close);
-    t->dprep.obj_dist = reinterpret_cast<double*>(dob + t->prep_odist);
-    t->dprep.v_obj = reinterpret_cast<double*>(dob + t->prep_vobj);
-    t->dprep.obj_x = reinterpret_cast<double*>(dob + t->prep_ox);
-    t->dprep.obj_y = reinterpret_cast<double*>(dob + t->prep_oy);
-    t->dprep.idx_s_opp = reinterpret_cast<int*>(dob + t->prep_idx);
     if (t->pipeline && t->planes_bytes > h->d_planes_cap) {
         if (h->d_planes) (void)hipFree(h->d_planes);
         h->d_planes = nullptr; h->d_planes_cap = 0;
         HIP_TRY(h, hipMalloc(&h->d_planes, t->planes_bytes));
         h->d_planes_cap = t->planes_bytes;
     }
+    tick_bind_outputs(t, dob, static_cast<double*>(h->d_planes));
+    return LTPL_OK;
+}
+
+static int tick_launch_paths(ltpl_handle* h, const TickLayout& t, hipStream_t st)
+{
+    if (h->batch_nw == 1)
+        hipLaunchKernelGGL(k_paths<1>, dim3(t.n_scen), dim3(64), h->lp1.total, st, h->lat, t.di, t.dout, h->lp1);
+    else
+        hipLaunchKernelGGL(k_paths<NUM_WAVES>, dim3(t.n_scen), dim3(WG_THREADS), h->lp4.total, st, h->lat, t.di, t.dout, h->lp4);
+    HIP_TRY(h, hipGetLastError());
+    return LTPL_OK;
+}
+
+static int tick_launch_vel(ltpl_handle* h, const TickLayout& t, hipStream_t st, hipEvent_t ev_after_prep = nullptr)
+{
+    hipLaunchKernelGGL(k_follow_prep, dim3(t.n_scen * LTPL_MAX_ACTIONS), dim3(64), t.lds_prep, st, h->lat, t.di, t.dout,
+                       t.dvin, t.dprep, t.n_scen * LTPL_MAX_ACTIONS);
+    HIP_TRY(h, hipGetLastError());
+    if (ev_after_prep) HIP_TRY(h, hipEventRecord(ev_after_prep, st));
+    const int n_slots = t.n_scen * LTPL_MAX_ACTIONS;
+    const int nb0 = (n_slots + 63) / 64, nb1 = (t.n_scen + 63) / 64;
+    hipLaunchKernelGGL(lanes_kernel_of(t.variant), dim3(nb0 + nb1), dim3(64), 0, st, h->lat, t.di, t.dout,
+                       t.p, t.dvin, t.dprep, t.vp, n_slots, t.n_scen, nb0, h->lp4.dbg);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL(k_vel_final, dim3(nb0), dim3(64), 0, st, t.dout, t.dvin, t.dvout, t.vp, n_slots);
+    HIP_TRY(h, hipGetLastError());
     return LTPL_OK;
 }
 
 static int tick_launch(ltpl_handle* h, const TickLayout& t, hipEvent_t* ev = nullptr)
 {
-    // ev (optional, 4 events): recorded before the path kernel, after it, after the follow preparation, after the lane kernel
+    // ev (optional, 4 events): recorded before the path kernel, after it, after the follow preparation, after the lane kernels
     if (ev) HIP_TRY(h, hipEventRecord(ev[0], h->stream));
     if (t.pipeline) {
-        if (h->batch_nw == 1)
-            hipLaunchKernelGGL(k_paths<1>, dim3(t.n_scen), dim3(64), h->lp1.total, h->stream, h->lat, t.di, t.dout, h->lp1);
-        else
-            hipLaunchKernelGGL(k_paths<NUM_WAVES>, dim3(t.n_scen), dim3(WG_THREADS), h->lp4.total, h->stream, h->lat, t.di, t.dout, h->lp4);
-        HIP_TRY(h, hipGetLastError());
+        int rc = tick_launch_paths(h, t, h->stream);
+        if (rc) return rc;
         if (ev) HIP_TRY(h, hipEventRecord(ev[1], h->stream));
-        hipLaunchKernelGGL(k_follow_prep, dim3(t.n_scen * LTPL_MAX_ACTIONS), dim3(64), t.lds_prep, h->stream, h->lat, t.di, t.dout,
-                           t.dvin, t.dprep, t.n_scen * LTPL_MAX_ACTIONS);
-        HIP_TRY(h, hipGetLastError());
-        if (ev) HIP_TRY(h, hipEventRecord(ev[2], h->stream));
-        const int n_slots = t.n_scen * LTPL_MAX_ACTIONS;
-        hipLaunchKernelGGL(lanes_kernel_of(t.variant), dim3((n_slots + 63) / 64), dim3(64), 0, h->stream, h->lat, t.di, t.dout,
-                           t.p, t.dvin, t.dvout, t.dprep, static_cast<double*>(h->d_planes), n_slots, h->lp4.dbg);
-        HIP_TRY(h, hipGetLastError());
+        if ((rc = tick_launch_vel(h, t, h->stream, ev ? ev[2] : nullptr))) return rc;
         if (ev) HIP_TRY(h, hipEventRecord(ev[3], h->stream));
         return LTPL_OK;
     }
@@ -1906,6 +2021,29 @@ extern "C" int ltpl_batch_upload(ltpl_handle* h, const ltpl_paths_in* in, const 
     HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, t->in_total, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->resident = t;
+    h->last_set = 0;
+    delete h->resident2; h->resident2 = nullptr;
+    if (t->pipeline && !getenv("LTPL_NO_OVERLAP")) {
+        // second buffer set for the two-stream software pipeline of ltpl_batch_run
+        if (t->out_total > h->d_out2_cap) {
+            if (h->d_out2) (void)hipFree(h->d_out2);
+            h->d_out2 = nullptr; h->d_out2_cap = 0;
+            HIP_TRY(h, hipMalloc(&h->d_out2, t->out_total)); h->d_out2_cap = t->out_total;
+        }
+        if (t->planes_bytes > h->d_planes2_cap) {
+            if (h->d_planes2) (void)hipFree(h->d_planes2);
+            h->d_planes2 = nullptr; h->d_planes2_cap = 0;
+            HIP_TRY(h, hipMalloc(&h->d_planes2, t->planes_bytes)); h->d_planes2_cap = t->planes_bytes;
+        }
+        if (!h->stream2) HIP_TRY(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            if (!h->ev_paths[i]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_paths[i], hipEventDisableTiming));
+            if (!h->ev_vel[i]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_vel[i], hipEventDisableTiming));
+        }
+        TickLayout* t2 = new TickLayout(*t);
+        tick_bind_outputs(t2, static_cast<unsigned char*>(h->d_out2), static_cast<double*>(h->d_planes2));
+        h->resident2 = t2;
+    }
     return LTPL_OK;
 }
 
@@ -1920,12 +2058,34 @@ extern "C" int ltpl_batch_run(ltpl_handle* h, int reps, float* ms_total)
         HIP_TRY(h, hipEventCreate(&e0)); HIP_TRY(h, hipEventCreate(&e1));
         HIP_TRY(h, hipEventRecord(e0, h->stream));
     }
-    for (int r = 0; r < reps; ++r) { int rc = tick_launch(h, *h->resident); if (rc) return rc; }
+    if (h->resident2) {
+        // software pipeline over steps: path kernel of step r on `stream`, velocity kernels of step r on `stream2`, two
+        // buffer sets; the path kernel of step r + 2 waits until the velocity kernels of step r released its set
+        for (int r = 0; r < reps; ++r) {
+            const int set = r & 1;
+            const TickLayout& T = set ? *h->resident2 : *h->resident;
+            if (r >= 2) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_vel[set], 0));
+            int rc = tick_launch_paths(h, T, h->stream);
+            if (rc) return rc;
+            HIP_TRY(h, hipEventRecord(h->ev_paths[set], h->stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_paths[set], 0));
+            if ((rc = tick_launch_vel(h, T, h->stream2))) return rc;
+            HIP_TRY(h, hipEventRecord(h->ev_vel[set], h->stream2));
+            h->last_set = set;
+        }
+        // everything joins `stream` again (the caller's events / synchronisation are on it)
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_vel[0], 0));
+        if (reps >= 2) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_vel[1], 0));
+    } else {
+        for (int r = 0; r < reps; ++r) { int rc = tick_launch(h, *h->resident); if (rc) return rc; }
+    }
     if (ms_total) {
         HIP_TRY(h, hipEventRecord(e1, h->stream));
         HIP_TRY(h, hipEventSynchronize(e1));
         HIP_TRY(h, hipEventElapsedTime(ms_total, e0, e1));
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    } else {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     return LTPL_OK;
 }
@@ -1957,7 +2117,8 @@ extern "C" int ltpl_batch_download(ltpl_handle* h, ltpl_paths_out* out, ltpl_tic
         h->err = "output capacities differ from ltpl_batch_upload"; return LTPL_ERR_INVALID_ARG;
     }
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, h->resident->out_total, hipMemcpyDeviceToHost, h->stream));
+    const void* src = (h->resident2 && h->last_set == 1) ? h->d_out2 : h->d_out;
+    HIP_TRY(h, hipMemcpyAsync(h->h_out, src, h->resident->out_total, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     tick_scatter(static_cast<const unsigned char*>(h->h_out), *h->resident, out, vout);
     return LTPL_OK;

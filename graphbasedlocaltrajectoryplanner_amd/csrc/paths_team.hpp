@@ -368,6 +368,10 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
         const double len_r = lat.slen[lat.samp_ptr[pedge[i]] + k];
         row[4] = len_r;
         if (vel_kappa) { vel_kappa[r] = kap; vel_len[r] = len_r; }
+        if (out.vkap) {                                    // tiled planes of the batch velocity stage
+            const size_t o = (((size_t)(slot >> 6) * out.cap_pts) + r) * 64 + (slot & 63);
+            out.vkap[o] = fabs(kap); out.vlen[o] = len_r;
+        }
         if (vel_x) { vel_x[r] = x; vel_y[r] = y; }
     }
     wp.n_pts = n_pts; wp.n_nodes = J + 1;
