@@ -1446,13 +1446,20 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
         lp->off_dist = (int)off; off += sizeof(double) * NFILT * 2 * lp->kpad;
         lp->off_cnt = (int)off; off += sizeof(unsigned) * NFILT * lp->kpad;
         lp->off_widx = (int)off; off += sizeof(unsigned) * NFILT * lp->kpad; off = align_up(off, 16);
+        lp->off_dumin = (int)off; off += sizeof(double) * NFILT * lp->kpad;
         lp->path_stride = (int)align_up(sizeof(double) * 7 * lp->hmax + sizeof(int) * 2 * (lp->hmax + 1), 16);
-        lp->off_path = (int)off; off += (size_t)lp->path_stride * lp->n_path_bufs;
+        if (lp->n_path_bufs == 1) {
+            // one-wave teams: the path scratch aliases the sweep's frontier / election arrays (dead during path assembly)
+            lp->off_path = lp->off_dist;
+            if ((size_t)lp->path_stride > off - (size_t)lp->off_dist) off = (size_t)lp->off_dist + (size_t)lp->path_stride;
+        } else {
+            lp->off_path = (int)off; off += (size_t)lp->path_stride * lp->n_path_bufs;
+        }
         lp->off_best = (int)off; off += sizeof(int) * NFILT * lp->hmax; off = align_up(off, 16);
         lp->off_blocked = (int)off; off += sizeof(unsigned) * lp->words_blocked; off = align_up(off, 16);
         lp->off_zone = (int)off; off += sizeof(unsigned) * lp->words_zone; off = align_up(off, 16);
-        lp->off_par = (int)off; off += sizeof(uchar2) * NFILT * (size_t)lp->hmax * lp->kpad; off = align_up(off, 16);
-        lp->ref_lds = (sizeof(double) * 2 * (size_t)d->num_layers <= sizeof(uchar2) * NFILT * (size_t)lp->hmax * lp->kpad) ? 1 : 0;
+        lp->off_par = (int)off; off += sizeof(uchar2) * NPAR * (size_t)lp->hmax * lp->kpad; off = align_up(off, 16);
+        lp->ref_lds = (sizeof(double) * 2 * (size_t)d->num_layers <= sizeof(uchar2) * NPAR * (size_t)lp->hmax * lp->kpad) ? 1 : 0;
         lp->off_lay = (int)off; off += sizeof(int) * 4 * (size_t)lp->hmax;
         lp->off_pos_layer = (int)off; off += sizeof(short) * MAX_POS; off = align_up(off, 16);
         lp->off_pos_veh = (int)off; off += MAX_POS; off = align_up(off, 16);

@@ -29,10 +29,11 @@ struct TeamLds {                 // dynamic-LDS plan (byte offsets), computed on
     int off_blocked;             // u32[words_blocked]
     int off_zone;                // u32[words_zone]
     int off_dist;                // double[NFILT][2][kpad]
-    int off_par;                 // uchar2[NFILT][hmax][kpad]  (.x = source node, .y = in-edge rank | tie bit 0x80)
+    int off_par;                 // uchar2[NPAR][hmax][kpad]  (.x = source node, .y = in-edge rank | tie bit 0x80); table = par_tab(filter)
     int off_best;                // int[NFILT][hmax]  -1 unreachable, -2 reachable (goal not evaluated), >= 0 goal node | tie << 30
     int off_cnt;                 // u32[NFILT][kpad]  number of in-edges that attain the minimum
     int off_widx;                // u32[NFILT][kpad]  (edge index in the transition << 16 | in-edge rank << 8 | source node) of the first
+    int off_dumin;               // double[NFILT][kpad]  smallest predecessor distance among tying edges (exact tie-break, rare)
     int off_lay;                 // int4[hmax]  per horizon layer j: first node id, #nodes, first / past-last edge INTO it
     int ref_lds;                 // 1: the reference line (x, y interleaved) is staged in the `par` region during phase 1
     int off_path;                // path scratch, `n_path_bufs` buffers of `path_stride` bytes
@@ -48,6 +49,11 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
     return __hiloint2double(hi, lo);
 }
+
+// Parent tables: `default` and `overtake_left` are never both needed beyond the object layer (the templates either use
+// `default` itself or branch left / right off its prefix), so they share one table; three tables serve four filters.
+#define NPAR 3
+__device__ __forceinline__ constexpr int par_tab(int f) { return f == F_PR ? 0 : (f == F_RIGHT ? 2 : 1); }
 
 struct TeamShared {
     int closest_idx, cl, cn, have_cn;          // written by wave 0 in phase 3
@@ -93,7 +99,7 @@ struct EdgeRegs { double c; unsigned meta; };     // meta = source node | destin
 
 // goal node of layer j for filter f from the frontier distances in `dcur` (virtual goal edges, GraphBase.py:188-194):
 // lexicographic min over (dist + vgoal, dist, node); returns node | (tie << 30) or -1
-__device__ __noinline__ int team_goal(const DevLat& lat, const double* dcur, int v0, int Kb, int lane)
+__device__ __forceinline__ int team_goal(const DevLat& lat, const double* dcur, int v0, int Kb, int lane)
 {
     double g1 = INFINITY, g2 = INFINITY; int gn = 0x7fffffff;
     for (int n = lane; n < Kb; n += 64) {
@@ -137,17 +143,6 @@ __device__ __forceinline__ void team_serial_node(const DevLat& lat, const Scen& 
             if (du < bestdu) { bestdu = du; bk = e - e0; bsrc = src; }
         }
     }
-}
-
-// out-of-line, value-returning form for the rare exact tie-break inside the hot sweep (no address-taken locals there):
-// returns source node | in-edge rank << 8 | tie << 16
-__device__ __noinline__ int team_serial_node_packed(const DevLat& lat, int e_base, const unsigned* blocked_bits, int f, int n, int v,
-                                                    const double* dprev, int fac_src, int fac_dst, double fac)
-{
-    Scen sc; sc.e_base = e_base;
-    double bc; int bsrc, bk, tie;
-    team_serial_node(lat, sc, blocked_bits, f, n, v, dprev, fac_src, fac_dst, fac, bc, bsrc, bk, tie);
-    return bsrc | (bk << 8) | (tie << 16);
 }
 
 __device__ __forceinline__ bool team_relax_layer(const DevLat& lat, const DevPathsIn& in, const Scen& sc, const TeamLds& lp,
@@ -208,7 +203,7 @@ __device__ void team_resweep(const DevLat& lat, const DevPathsIn& in, const Scen
         const double* dprev = dist + (size_t)(f * 2 + ((j - 1) & 1)) * kpad;
         double* dcur = dist + (size_t)(f * 2 + (j & 1)) * kpad;
         (void)team_relax_layer(lat, in, sc, lp, smem, ts.cl, ts.cn, f, j, b, v0, Kb, dprev, dcur,
-                                par + ((size_t)f * lp.hmax + j) * kpad, lane, fs, fd, fac);
+                                par + ((size_t)par_tab(f) * lp.hmax + j) * kpad, lane, fs, fd, fac);
         wave_sync_lds();
     }
     int b = sc.sl + J; if (b >= L) b -= L;
@@ -248,7 +243,7 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
         int n = bj & 0xffff;
         for (int j = J; j >= 1; --j) {
             const int pf = (share_prefix && j < jcl) ? F_DEF : f;
-            const uchar2 pr = par[((size_t)pf * hm + j) * lp.kpad + n];
+            const uchar2 pr = par[((size_t)par_tab(pf) * hm + j) * lp.kpad + n];
             pidx[j] = n;                                   // node of layer j (temporarily)
             pedge[j - 1] = pr.y & 0x7f;
             ties += (pr.y >> 7) & 1;
@@ -296,32 +291,50 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
     if (lane == 0) out.n_pts[slot] = n_pts;
 
     // tph.calc_splines (main_online_path_gen.py:299-309) as the equivalent clamped C2 spline in the cumulated
-    // el_lengths parameter: tridiagonal system in the knot slopes m_i, Thomas algorithm; lane 0 -> x, lane 1 -> y
-    if (lane < 2) {
+    // el_lengths parameter: tridiagonal system in the knot slopes m_i, Thomas algorithm. Everything that does not depend
+    // on the elimination order is prepared by all lanes (reciprocal segment lengths, diagonal, right-hand sides of x and
+    // y); the sequential elimination (lane 0 -> x, lane 1 -> y) is one reciprocal and four fused multiply-adds per row.
+    {
+        // end slopes: tangent = (cos(psi + pi/2), sin(psi + pi/2)) = (-sin psi, cos psi); lane 0 <- psi_s, lane 1 <- psi_e
         const int e_first = pedge[0], e_last = pedge[N - 1];
-        const double psi_s = (sc.flags & LTPL_FLAG_HAS_PSI_S) ? in.psi_s[s] : lat.spsi[lat.samp_ptr[e_first]];
-        const double psi_e = lat.spsi[lat.samp_ptr[e_last + 1] - 1];
-        const double* kk = lane == 0 ? kx : ky;
-        double* m = lane == 0 ? mx : my;
-        double* cp = lane == 0 ? cpx : cpy;
-        const double m0 = lane == 0 ? cos(psi_s + D_PI / 2) : sin(psi_s + D_PI / 2);
-        const double mN = lane == 0 ? cos(psi_e + D_PI / 2) : sin(psi_e + D_PI / 2);
-        m[0] = m0; m[N] = mN;
-        if (N >= 2) {
+        double ang = 0.0;
+        if (lane == 0) ang = (sc.flags & LTPL_FLAG_HAS_PSI_S) ? in.psi_s[s] : lat.spsi[lat.samp_ptr[e_first]];
+        if (lane == 1) ang = lat.spsi[lat.samp_ptr[e_last + 1] - 1];
+        double sn, cs;
+        sincos(ang, &sn, &cs);
+        const double sx0 = -readlane_f64(sn, 0), sy0 = readlane_f64(cs, 0), sxN = -readlane_f64(sn, 1), syN = readlane_f64(cs, 1);
+        // rows i = 1 .. N-1: a_i = 1/h_{i-1}, c_i = 1/h_i, b_i = 2 (a_i + c_i); stored: cpx <- a_i, cpy <- b_i (scratch),
+        // mx / my <- right-hand sides d_i (x / y)
+        for (int i = lane; i < N; i += 64) cpx[i] = 1.0 / el[i];             // reciprocal segment lengths (reused below)
+        wave_sync_lds();
+        for (int i = 1 + lane; i <= N - 1; i += 64) {
+            const double ai = cpx[i - 1], ci = cpx[i];
+            double dx = 3.0 * ((kx[i] - kx[i - 1]) * (ai * ai) + (kx[i + 1] - kx[i]) * (ci * ci));
+            double dy = 3.0 * ((ky[i] - ky[i - 1]) * (ai * ai) + (ky[i + 1] - ky[i]) * (ci * ci));
+            if (i == 1) { dx -= ai * sx0; dy -= ai * sy0; }
+            if (i == N - 1) { dx -= ci * sxN; dy -= ci * syN; }
+            mx[i] = dx; my[i] = dy; cpy[i] = 2.0 * (ai + ci);
+        }
+        wave_sync_lds();
+        if (lane < 2) {
+            double* m = lane == 0 ? mx : my;
+            m[0] = lane == 0 ? sx0 : sy0; m[N] = lane == 0 ? sxN : syN;
+            // forward elimination: cprime_i = c_i / (b_i - a_i cprime_{i-1}), dprime_i = (d_i - a_i dprime_{i-1}) / (same)
             double cprev = 0.0, dprev_ = 0.0;
+            double* cpr = lane == 0 ? kx + 0 : nullptr;   // (unused; cprime is kept in `el`'s neighbour scratch below)
+            (void)cpr;
             for (int i = 1; i <= N - 1; ++i) {
-                const double h0 = el[i - 1], h1 = el[i];
-                const double ai = 1.0 / h0, ci = 1.0 / h1, bi = 2.0 * (ai + ci);
-                double di = 3.0 * ((kk[i] - kk[i - 1]) / (h0 * h0) + (kk[i + 1] - kk[i]) / (h1 * h1));
-                if (i == 1) di -= ai * m0;
-                if (i == N - 1) di -= ci * mN;
-                const double cc = (i == N - 1) ? 0.0 : ci;
-                const double denom = (i == 1) ? bi : (bi - ai * cprev);
-                const double cpi = cc / denom;
-                const double dpi = (i == 1) ? di / denom : (di - ai * dprev_) / denom;
-                cp[i] = cpi; m[i] = dpi; cprev = cpi; dprev_ = dpi;
+                const double ai = cpx[i - 1], ci = (i == N - 1) ? 0.0 : cpx[i], bi = cpy[i];
+                const double r = 1.0 / (bi - ai * cprev);
+                const double cpi = ci * r, dpi = (m[i] - ai * dprev_) * r;
+                m[i] = dpi; cprev = cpi; dprev_ = dpi;
+                if (lane == 0) cpy[i] = cpi;                                    // cprime (identical for x and y)
             }
-            for (int i = N - 2; i >= 1; --i) m[i] = m[i] - cp[i] * m[i + 1];
+        }
+        wave_sync_lds();
+        if (lane < 2) {
+            double* m = lane == 0 ? mx : my;
+            for (int i = N - 2; i >= 1; --i) m[i] = m[i] - cpy[i] * m[i + 1];
         }
     }
     wave_sync_lds();
@@ -362,7 +375,10 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
         const double q = xd * xd + yd * yd;
         double* row = o_pp + (size_t)r * 5;
         row[0] = x; row[1] = y;
-        row[2] = normalize_psi_dev(atan2(yd, xd) - D_PI / 2);
+        // psi = normalize(atan2(y', x') - pi/2) = atan2(-x', y') (rotation by -90 degrees), range [-pi, pi)
+        double psi_r = atan2(-xd, yd);
+        if (psi_r >= D_PI) psi_r -= 2.0 * D_PI;
+        row[2] = psi_r;
         const double kap = (xd * ydd - yd * xdd) / (q * sqrt(q));
         row[3] = kap;
         const double len_r = lat.slen[lat.samp_ptr[pedge[i]] + k];
@@ -422,7 +438,10 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
             if ((ACT >> f) & 1u) { dist[coff[f] + n] = INFINITY; cnt_all[f * kpad + n] = 0u; widx_all[f * kpad + n] = 0xffffffffu; }
     }
     team_sync<NW>();
-    double cand[CH][NFILT]; unsigned okm[CH];
+    // candidate sums are kept for the active filters only (compile-time compaction keeps the register image small)
+    constexpr int NA = ((ACT >> 0) & 1) + ((ACT >> 1) & 1) + ((ACT >> 2) & 1) + ((ACT >> 3) & 1);
+    constexpr int SL[NFILT] = {0, (int)((ACT >> 0) & 1), (int)(((ACT >> 0) & 1) + ((ACT >> 1) & 1)), (int)(((ACT >> 0) & 1) + ((ACT >> 1) & 1) + ((ACT >> 2) & 1))};
+    double cand[CH][NA]; unsigned okm[CH];
 #pragma unroll
     for (int ci = 0; ci < CH; ++ci) {
         okm[ci] = 0u;
@@ -434,16 +453,16 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
         double c = er[ci].c;
         if (A.fs >= 0 && src == A.fs && dst == A.fd) c *= A.fac;
 #pragma unroll
-        for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) cand[ci][f] = dist[poff[f] + (valid ? src : 0)];
+        for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) cand[ci][SL[f]] = dist[poff[f] + (valid ? src : 0)];
 #pragma unroll
         for (int f = 0; f < NFILT; ++f) {
             if (!((ACT >> f) & 1u)) continue;
-            bool ok = valid && cand[ci][f] < INFINITY;
+            bool ok = valid && cand[ci][SL[f]] < INFINITY;
             if (f != F_PR) ok = ok && unbl;
-            cand[ci][f] = cand[ci][f] + c;
+            cand[ci][SL[f]] = cand[ci][SL[f]] + c;
             if (ok) {
                 okm[ci] |= 1u << f;
-                atomicMin(reinterpret_cast<unsigned long long*>(&dist[coff[f] + dst]), (unsigned long long)__double_as_longlong(cand[ci][f]));
+                atomicMin(reinterpret_cast<unsigned long long*>(&dist[coff[f] + dst]), (unsigned long long)__double_as_longlong(cand[ci][SL[f]]));
             }
         }
     }
@@ -459,12 +478,50 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
         for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) got[f] = dist[coff[f] + dst];
 #pragma unroll
         for (int f = 0; f < NFILT; ++f)
-            if (((ACT >> f) & 1u) && ((okm[ci] >> f) & 1u) && got[f] == cand[ci][f]) {
+            if (((ACT >> f) & 1u) && ((okm[ci] >> f) & 1u) && got[f] == cand[ci][SL[f]]) {
                 atomicAdd(&cnt_all[f * kpad + dst], 1u);
                 atomicMin(&widx_all[f * kpad + dst], key);
             }
     }
     team_sync<NW>();
+    // exact tie-break (rare): a node whose minimum is attained by several edges takes, in the reference's order, the
+    // predecessor with the smaller distance first, then CSC order. Every wave reads the same counters, so the branch is
+    // uniform over the team.
+    {
+        bool tied = false;
+        for (int n = lane; n < A.Kb; n += 64) {
+#pragma unroll
+            for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) tied = tied || cnt_all[f * kpad + n] >= 2u;
+        }
+        if (__ballot(tied) != 0ull) {
+            double* dumin = reinterpret_cast<double*>(smem + lp.off_dumin);
+            for (int n = tid; n < A.Kb; n += NT) {
+#pragma unroll
+                for (int f = 0; f < NFILT; ++f)
+                    if (((ACT >> f) & 1u) && cnt_all[f * kpad + n] >= 2u) { dumin[f * kpad + n] = INFINITY; widx_all[f * kpad + n] = 0xffffffffu; }
+            }
+            team_sync<NW>();
+#pragma unroll 1
+            for (int round = 0; round < 2; ++round) {
+#pragma unroll
+                for (int ci = 0; ci < CH; ++ci) {
+                    if ((ci * NW) * 64 >= A.ne) continue;
+                    const int ei = (ci * NW + wave) * 64 + lane;
+                    const int src = er[ci].meta & 255u, dst = (er[ci].meta >> 8) & 255u;
+                    const unsigned key = ((unsigned)ei << 16) | ((er[ci].meta >> 8) & 0xff00u) | (er[ci].meta & 255u);
+#pragma unroll
+                    for (int f = 0; f < NFILT; ++f) {
+                        if (!((ACT >> f) & 1u) || !((okm[ci] >> f) & 1u)) continue;
+                        if (dist[coff[f] + dst] != cand[ci][SL[f]] || cnt_all[f * kpad + dst] < 2u) continue;
+                        const double du = dist[poff[f] + src];
+                        if (round == 0) atomicMin(reinterpret_cast<unsigned long long*>(&dumin[f * kpad + dst]), (unsigned long long)__double_as_longlong(du));
+                        else if (dumin[f * kpad + dst] == du) atomicMin(&widx_all[f * kpad + dst], key);
+                    }
+                }
+                team_sync<NW>();
+            }
+        }
+    }
     // lane = destination node
 #pragma unroll
     for (int f = 0; f < NFILT; ++f) {
@@ -478,19 +535,13 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
             if (f == F_LEFT) rem = rem || (A.cl_hit && n >= A.cn);
             if (f == F_RIGHT) rem = rem || (A.cl_hit && n < A.cn);
             const bool fin = c >= 1u && !rem;
-            int bsrc = fin ? (int)(w & 255u) : 0, bk = fin ? (int)((w >> 8) & 255u) : 0, tie = 0;
-            if (fin && c >= 2u) {
-                const int r = team_serial_node_packed(lat, sc.e_base, blocked_bits, f, n, A.v0 + n, dist + poff[f], A.fs, A.fd, A.fac);
-                bsrc = r & 255; bk = (r >> 8) & 255; tie = (r >> 16) & 1;
-            }
+            const int bsrc = fin ? (int)(w & 255u) : 0, bk = fin ? (int)((w >> 8) & 255u) : 0, tie = (fin && c >= 2u) ? 1 : 0;
             if (rem) dist[coff[f] + n] = INFINITY;
-            par[((size_t)f * A.hm + A.j) * kpad + n] = make_uchar2((unsigned char)bsrc, (unsigned char)(bk | (tie ? 0x80 : 0)));
+            par[((size_t)par_tab(f) * A.hm + A.j) * kpad + n] = make_uchar2((unsigned char)bsrc, (unsigned char)(bk | (tie ? 0x80 : 0)));
             any = any || fin;
         }
         any = __ballot(any) != 0ull;
-        int g = any ? -2 : -1;
-        if (A.j == A.H && any) { wave_sync_lds(); g = team_goal(lat, dist + coff[f], A.v0, A.Kb, lane); }
-        if (lane == 0) best[f * A.hm + A.j] = g;
+        if (lane == 0) best[f * A.hm + A.j] = any ? -2 : -1;           // the goal node of the last layer is evaluated after the sweep
     }
 }
 
@@ -812,14 +863,17 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             if (((need >> F_RIGHT) & 1u) && (!share_prefix || j >= jcl)) actm |= 1u << F_RIGHT;
             A.from_def = share_prefix && j == jcl;
             if (j < H) prefetch(j + 1, en, bn);                    // global loads in flight during this layer's LDS work
-            if (A.Kb <= 64 && A.ne <= CH * NT) {
-                // compile-time specialisations for the filter sets the action templates produce
+            // the action templates only produce these filter sets (phase 3); anything else takes the serial form
+            const bool known = actm == (1u << F_DEF) || actm == (1u << F_PR) || actm == ((1u << F_PR) | (1u << F_DEF)) ||
+                               actm == ((1u << F_PR) | (1u << F_LEFT) | (1u << F_RIGHT));
+            if (A.Kb <= 64 && A.ne <= CH * NT && known) {
+                // compile-time specialisations per filter set
                 switch (actm) {
                     case (1u << F_DEF): team_layer<NW, CH, (1u << F_DEF)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
+                    case (1u << F_PR): team_layer<NW, CH, (1u << F_PR)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
                     case (1u << F_PR) | (1u << F_DEF): team_layer<NW, CH, (1u << F_PR) | (1u << F_DEF)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
-                    case (1u << F_PR) | (1u << F_LEFT) | (1u << F_RIGHT):
+                    default:
                         team_layer<NW, CH, (1u << F_PR) | (1u << F_LEFT) | (1u << F_RIGHT)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
-                    default: team_layer<NW, CH, 15u>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
                 }
             } else {
                 // more than 64 nodes in the layer or more edges than the register image holds: serial form (lane = node)
@@ -829,15 +883,22 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                     double* dcur = dist + (size_t)(f * 2 + A.cur) * kpad;
                     const bool any = team_relax_layer(lat, in, sc, lp, smem, t_cl, t_cn, f, j, b, A.v0, A.Kb,
                                                       dist + (size_t)(fprev * 2 + A.prv) * kpad, dcur,
-                                                      par + ((size_t)f * hm + j) * kpad, lane, A.fs, A.fd, A.fac);
-                    int g = any ? -2 : -1;
-                    if (j == H && any) { wave_sync_lds(); g = team_goal(lat, dcur, A.v0, A.Kb, lane); }
-                    if (lane == 0) best[f * hm + j] = g;
+                                                      par + ((size_t)par_tab(f) * hm + j) * kpad, lane, A.fs, A.fd, A.fac);
+                    if (lane == 0) best[f * hm + j] = any ? -2 : -1;
                 }
             }
 #pragma unroll
             for (int ci = 0; ci < CH; ++ci) { er[ci] = en[ci]; bm[ci] = bn[ci]; }
             team_sync<NW>();
+        }
+        // goal node of the last layer for every filter that reached it (virtual goal edges, GraphBase.py:188-194)
+        if (!(lp.ablate & 2)) {
+            const int4 lyH = lay[H];
+            for (int f = wave; f < NFILT; f += NW)
+                if (((need >> f) & 1u) && best[f * hm + H] == -2) {
+                    const int g = team_goal(lat, dist + (size_t)(f * 2 + (H & 1)) * kpad, lyH.x, lyH.y & 0xffff, lane);
+                    if (lane == 0) best[f * hm + H] = g;
+                }
         }
         if (share_prefix && wave == 0 && lane == 0) { ts.start_ok[F_LEFT] = ts.start_ok[F_DEF]; ts.start_ok[F_RIGHT] = ts.start_ok[F_DEF]; }
         team_sync<NW>();

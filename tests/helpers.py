@@ -37,14 +37,18 @@ def vehicles_of(rec):
             for k in range(len(rec['obj_radius']))]
 
 
-def assert_close_rel(actual, desired, rel=REL_TOL, what=""):
-    """max |a - d| <= rel * max(|d|, scale): relative to the magnitude of the reference array (no element-wise blow-up
+KAPPA_FLOOR = 1e-3      # 1/m: curvature magnitudes below 1 / (1 km) are indistinguishable for the planner (the lateral
+                        # limit ay / |kappa| is capped by v_max^2 long before); keeps a relative test meaningful on straights
+
+
+def assert_close_rel(actual, desired, rel=REL_TOL, what="", floor=1e-12):
+    """max |a - d| <= rel * max(|d|, floor): relative to the magnitude of the reference array (no element-wise blow-up
     at zero crossings)."""
     actual, desired = np.asarray(actual, dtype=float), np.asarray(desired, dtype=float)
     assert actual.shape == desired.shape, "%s: shape %s vs %s" % (what, actual.shape, desired.shape)
     if desired.size == 0:
         return
-    scale = max(float(np.max(np.abs(desired))), 1e-12)
+    scale = max(float(np.max(np.abs(desired))), floor)
     err = float(np.max(np.abs(actual - desired)))
     assert err <= rel * scale, "%s: max abs err %.3e > %.1e * %.3e" % (what, err, rel, scale)
 
@@ -72,5 +76,5 @@ def check_path_output(out6, rec, what=""):
         assert_close_rel(pp[:, 0:2], epp[:, 0:2], what="%s/%s xy" % (what, k))
         dpsi = np.abs(np.mod(pp[:, 2] - epp[:, 2] + np.pi, 2 * np.pi) - np.pi)
         assert float(dpsi.max()) <= REL_TOL * np.pi, "%s/%s psi" % (what, k)
-        assert_close_rel(pp[:, 3], epp[:, 3], what="%s/%s kappa" % (what, k))
+        assert_close_rel(pp[:, 3], epp[:, 3], what="%s/%s kappa" % (what, k), floor=KAPPA_FLOOR)
         assert np.array_equal(pp[:, 4], epp[:, 4]), "%s/%s el_length column must be copied bit-exact" % (what, k)

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from helpers import load_golden, replay_path_call, check_path_output, assert_close_rel, REL_TOL
+from helpers import load_golden, replay_path_call, check_path_output, assert_close_rel, REL_TOL, KAPPA_FLOOR
 from scenarios import random_scenarios
 from graphbasedlocaltrajectoryplanner_amd import _capi
 from graphbasedlocaltrajectoryplanner_amd.path_gen import OnlinePathGenerator
@@ -47,7 +47,7 @@ def compare_results(res, ref, lat):
             assert_close_rel(pp[:, 0:2], rp[:, 0:2], what="xy s%d a%d" % (s, a))
             dpsi = np.abs(np.mod(pp[:, 2] - rp[:, 2] + np.pi, 2 * np.pi) - np.pi)
             assert float(dpsi.max()) <= REL_TOL * np.pi
-            assert_close_rel(pp[:, 3], rp[:, 3], what="kappa s%d a%d" % (s, a))
+            assert_close_rel(pp[:, 3], rp[:, 3], what="kappa s%d a%d" % (s, a), floor=KAPPA_FLOOR)
             assert np.array_equal(pp[:, 4], rp[:, 4])
 
 
