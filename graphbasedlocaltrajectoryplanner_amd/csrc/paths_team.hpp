@@ -689,7 +689,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             const int eb = ly.z, ee = ly.w;
             while (m) {
                 // up to MQ matching positions per round, broadcast into uniform registers
-                constexpr int MQ = 4;
+                constexpr int MQ = 2;
                 double qx[MQ], qy[MQ], qr[MQ], qs[MQ];
 #pragma unroll
                 for (int q = 0; q < MQ; ++q) {
@@ -835,8 +835,10 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             unsigned bw[CH]; int sh[CH];
 #pragma unroll
             for (int ci = 0; ci < CH; ++ci) {
+                bw[ci] = 0u; sh[ci] = 32;
+                if (ci >= 2 && ly.z + ci * NT >= ly.w) continue;   // uniform: chunks 0 and 1 are always loaded, the rest on demand
                 const int e = ly.z + (ci * NW + wave) * 64 + lane;
-                // always load (clamped address): a fixed number of loads in flight lets the compiler wait precisely
+                // clamped address: a fixed number of loads in flight lets the compiler wait precisely
                 const int ec = e < ly.w ? e : ly.w - 1;
                 dr[ci].c = lat.edge_cost[ec]; dr[ci].meta = lat.edge_meta[ec];
                 int el_ = ec - sc.e_base; if (el_ < 0) el_ += lat.E;
