@@ -224,12 +224,25 @@ __device__ __forceinline__ double ax_poss_w(double w, double kq, double ax_max, 
     }
 }
 
+// lane l <- lane l - 1 across the whole wave64 (DPP wave_shr:1); lane 0 receives `first`
+__device__ __forceinline__ double wave_shr1_f64(double v, double first)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(first), __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(first), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int wave_shr1_i32(int v, int first)
+{
+    return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false);
+}
+
 // one sweep of tph __solver_fb_acc_profile on w[0..n). Backward sweeps address the profile, curvature and element
 // lengths mirrored but -- restated quirk of the reference solver -- the gg limits unmirrored.
-// The recurrence is sequential, but everything except the state is known up front: the wave handles 64 steps at a
-// time, lane l prepares the operands (for exponent 1 and a constant machine limit: the affine coefficients) of step
-// base + l in registers, then the steps are executed in order on wave-uniform values fetched with v_readlane -- no
-// LDS access and no divergent branch inside the dependent chain.
+// The recurrence is sequential, but everything except the state is known up front. SYSTOLIC form: the wave handles 64
+// steps at a time, lane l holds the operands of step base + l (for exponent 1 and a constant machine limit: the affine
+// coefficients); in every iteration ALL lanes evaluate their step on the state handed over by the lane below (DPP
+// wave_shr:1, no LDS, no broadcast), so after iteration l lane l holds the final value of its step. One iteration is the
+// bare dependent chain: ~a dozen VALU instructions.
 template <int EM, bool AXM1, bool GGARR, bool BACK>
 __device__ void fb_sweep(int n, const VelScratch& vs, double cax, double cay, const DevVelParams& p, double vmax2, int lane)
 {
@@ -246,8 +259,8 @@ __device__ void fb_sweep(int n, const VelScratch& vs, double cax, double cay, co
     constexpr int MODE = BACK ? VMODE_DECEL_BACKW : VMODE_ACCEL_FORW;
     constexpr bool AFFINE = EM == 1 && AXM1;
     const double icay = 1.0 / cay, axm1 = vs.axm[1], dm = p.drag_m;
-    double wi = vs.w[BACK ? n - 1 : 0];
-    bool active = false;
+    double wi = vs.w[BACK ? n - 1 : 0];                   // state entering the chunk (uniform)
+    int active = 0;
     for (int base = 0; base < n - 1; base += 64) {
         const int cnt = (n - 1 - base) < 64 ? (n - 1 - base) : 64;
         const int ic = (lane < cnt) ? base + lane : base + cnt - 1;
@@ -263,44 +276,41 @@ __device__ void fb_sweep(int n, const VelScratch& vs, double cax, double cay, co
         const double te = 2.0 * e_i;
         const double A0 = BACK ? 1.0 + te * dm : 1.0 - te * dm, A1 = A0 - te * (ax_i * kq_i), B1 = te * ax_i, B2 = te * axm1;
         const double C0 = te * dm, C1 = C0 - te * (ax_n * kq_n), D1 = te * ax_n;
-        double wout = wold;
-        for (int sidx = 0; sidx < cnt; ++sidx) {
-            const double wold_s = readlane_f64(wold, sidx);
-            active = active || (__builtin_amdgcn_readlane(st, sidx) != 0);
+        double w_in = wi, wnext = wold;
+        int act_in = active, act_out = 0;
+        for (int it = 0; it < cnt; ++it) {
+            const bool act = (act_in | st) != 0;
             double wn;
             if constexpr (AFFINE) {
-                const double a0 = readlane_f64(A0, sidx), a1 = readlane_f64(A1, sidx), b1 = readlane_f64(B1, sidx);
                 if constexpr (!BACK) {
-                    const double b2 = readlane_f64(B2, sidx);
-                    const double Z = a0 * wi, T = fma(a1, wi, b1), M = fma(a0, wi, b2);
+                    const double Z = A0 * w_in, T = fma(A1, w_in, B1), M = fma(A0, w_in, B2);
                     wn = fmax(fmin(fmax(T, Z), M), 0.0);
                 } else {
-                    const double c0 = readlane_f64(C0, sidx), c1 = readlane_f64(C1, sidx), d1 = readlane_f64(D1, sidx);
-                    const double Z = a0 * wi, T = fma(a1, wi, b1);
+                    const double Z = A0 * w_in, T = fma(A1, w_in, B1);
                     wn = fmax(fmax(T, Z), 0.0);
-                    const double t0 = fma(c0, wn, wi), t1 = fma(c1, wn, wi + d1);
+                    const double t0 = fma(C0, wn, w_in), t1 = fma(C1, wn, w_in + D1);
                     wn = fmin(fmax(fmax(t1, t0), 0.0), wn);
                 }
             } else {
-                const double kqi = readlane_f64(kq_i, sidx), axi = readlane_f64(ax_i, sidx), ei = readlane_f64(e_i, sidx);
-                const double acur = ax_poss_w<EM, AXM1, MODE>(wi, kqi, axi, p, vs.axm, axm1);
-                wn = wi + 2.0 * acur * ei;
+                const double acur = ax_poss_w<EM, AXM1, MODE>(w_in, kq_i, ax_i, p, vs.axm, axm1);
+                wn = w_in + 2.0 * acur * e_i;
                 wn = wn < 0.0 ? 0.0 : wn;
                 if constexpr (BACK) {
-                    const double kqn = readlane_f64(kq_n, sidx), axn = readlane_f64(ax_n, sidx);
-                    const double anext = ax_poss_w<EM, AXM1, MODE>(wn, kqn, axn, p, vs.axm, axm1);
-                    double wt = wi + 2.0 * anext * ei;
+                    const double anext = ax_poss_w<EM, AXM1, MODE>(wn, kq_n, ax_n, p, vs.axm, axm1);
+                    double wt = w_in + 2.0 * anext * e_i;
                     wt = wt < 0.0 ? 0.0 : wt;
                     wn = wt < wn ? wt : wn;
                 }
             }
-            const bool upd = active && (wn < wold_s);
-            const double wnext = upd ? wn : wold_s;
-            active = active && !(wn > vmax2);
-            if (lane == sidx) wout = wnext;
-            wi = wnext;
+            wnext = (act && (wn < wold)) ? wn : wold;
+            act_out = (act && !(wn > vmax2)) ? 1 : 0;
+            // hand the state to the next lane; lane 0 keeps the state entering the chunk
+            w_in = wave_shr1_f64(wnext, wi);
+            act_in = wave_shr1_i32(act_out, active);
         }
-        if (lane < cnt) vs.w[Pb] = wout;
+        if (lane < cnt) vs.w[Pb] = wnext;
+        wi = readlane_f64(wnext, cnt - 1);
+        active = __builtin_amdgcn_readlane(act_out, cnt - 1);
         wave_sync_lds();
     }
 }
@@ -330,15 +340,14 @@ __device__ void fb_profile(int n, const VelScratch& vs, double cax, double cay, 
     dbg_stamp(vs.dbg, 10);
 }
 
-// tph.calc_vel_profile_brake on LDS arrays: out[0..n) as v^2, zeros after standstill. Same register scheme as fb_sweep:
-// lane l prepares the operands of step base + l, the steps run in order on wave-uniform values.
+// tph.calc_vel_profile_brake on LDS arrays: out[0..n) as v^2, zeros after standstill. Same systolic scheme as fb_sweep.
 template <int EM, bool GGARR>
 __device__ void brake_profile(int n, double* out, const VelScratch& vs, double cax, double cay, double v_start,
                               const DevVelParams& p, int lane)
 {
     const double icay = 1.0 / cay;
-    double w = v_start * v_start;
-    bool stopped = false;
+    double w = v_start * v_start;                          // state entering the chunk (uniform)
+    int stopped = 0;
     if (lane == 0) out[0] = w;
     for (int base = 0; base < n - 1; base += 64) {
         const int cnt = (n - 1 - base) < 64 ? (n - 1 - base) : 64;
@@ -346,22 +355,19 @@ __device__ void brake_profile(int n, double* out, const VelScratch& vs, double c
         const double kq_i = vs.kabs[ic] * (GGARR ? vs.igay[ic] : icay), e_i = vs.el[ic], ax_i = GGARR ? vs.gax[ic] : cax;
         const double te = 2.0 * e_i, axa = fabs(ax_i);
         const double A0 = 1.0 - te * p.drag_m, A1 = A0 + te * (axa * kq_i), B1 = te * axa;
-        double wout = 0.0;
-        for (int sidx = 0; sidx < cnt; ++sidx) {
-            double r;
-            if constexpr (EM == 1) {
-                const double a0 = readlane_f64(A0, sidx), a1 = readlane_f64(A1, sidx), b1 = readlane_f64(B1, sidx);
-                r = fmin(fma(a1, w, -b1), a0 * w);
-            } else {
-                const double kqi = readlane_f64(kq_i, sidx), axi = readlane_f64(ax_i, sidx), ei = readlane_f64(e_i, sidx);
-                const double a = ax_poss_w<EM, true, VMODE_DECEL_FORW>(w, kqi, axi, p, vs.axm, 0.0);
-                r = w + 2.0 * a * ei;
-            }
-            stopped = stopped || (r < 0.0);
-            w = stopped ? w : r;
-            if (lane == sidx) wout = stopped ? 0.0 : r;
+        double w_in = w, w_out = w; int st_in = stopped, st_out = 0;
+        double r = 0.0;
+        for (int it = 0; it < cnt; ++it) {
+            if constexpr (EM == 1) r = fmin(fma(A1, w_in, -B1), A0 * w_in);
+            else r = w_in + 2.0 * ax_poss_w<EM, true, VMODE_DECEL_FORW>(w_in, kq_i, ax_i, p, vs.axm, 0.0) * e_i;
+            st_out = (st_in || (r < 0.0)) ? 1 : 0;
+            w_out = st_out ? w_in : r;
+            w_in = wave_shr1_f64(w_out, w);
+            st_in = wave_shr1_i32(st_out, stopped);
         }
-        if (lane < cnt) out[base + lane + 1] = wout;
+        if (lane < cnt) out[base + lane + 1] = st_out ? 0.0 : r;
+        w = readlane_f64(w_out, cnt - 1);
+        stopped = __builtin_amdgcn_readlane(st_out, cnt - 1);
     }
     wave_sync_lds();
 }
@@ -1484,6 +1490,12 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
                                 h->lp1.total) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_paths<NUM_WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 h->lp4.total) != hipSuccess) { h->err = "cannot raise dynamic LDS limit"; return fail(LTPL_ERR_HIP); }
+    }
+    if (getenv("LTPL_DEBUG_OCC")) {
+        int nb1 = -1, nb4 = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, reinterpret_cast<const void*>(k_paths<1>), 64, (size_t)h->lp1.total);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb4, reinterpret_cast<const void*>(k_paths<NUM_WAVES>), WG_THREADS, (size_t)h->lp4.total);
+        fprintf(stderr, "[ltpl occ] k_paths<1>: %d blocks/CU at %d B LDS; k_paths<4>: %d blocks/CU at %d B LDS\n", nb1, h->lp1.total, nb4, h->lp4.total);
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { h->err = "hipGetDeviceProperties failed"; return fail(LTPL_ERR_HIP); }

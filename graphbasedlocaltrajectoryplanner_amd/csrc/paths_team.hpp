@@ -281,7 +281,9 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
         if (i < N) {
             pidx[i] = run + off;
             kx[i] = lat.sx[k0]; ky[i] = lat.sy[k0]; el[i] = lat.edge_len[e];
-            if (i == N - 1) { kx[N] = lat.sx[k1 - 1]; ky[N] = lat.sy[k1 - 1]; pidx[N] = run + off + take - 1; }
+            pedge[i] = k0;                                   // from here on: first sample of the segment's edge
+            if (i == 0) el[N] = lat.spsi[k0];               // heading of the first / last gathered sample (spline end slopes)
+            if (i == N - 1) { kx[N] = lat.sx[k1 - 1]; ky[N] = lat.sy[k1 - 1]; pidx[N] = run + off + take - 1; cpy[0] = lat.spsi[k1 - 1]; }
         }
         run += tot;
     }
@@ -296,10 +298,9 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
     // y); the sequential elimination (lane 0 -> x, lane 1 -> y) is one reciprocal and four fused multiply-adds per row.
     {
         // end slopes: tangent = (cos(psi + pi/2), sin(psi + pi/2)) = (-sin psi, cos psi); lane 0 <- psi_s, lane 1 <- psi_e
-        const int e_first = pedge[0], e_last = pedge[N - 1];
         double ang = 0.0;
-        if (lane == 0) ang = (sc.flags & LTPL_FLAG_HAS_PSI_S) ? in.psi_s[s] : lat.spsi[lat.samp_ptr[e_first]];
-        if (lane == 1) ang = lat.spsi[lat.samp_ptr[e_last + 1] - 1];
+        if (lane == 0) ang = (sc.flags & LTPL_FLAG_HAS_PSI_S) ? in.psi_s[s] : el[N];
+        if (lane == 1) ang = cpy[0];
         double sn, cs;
         sincos(ang, &sn, &cs);
         const double sx0 = -readlane_f64(sn, 0), sy0 = readlane_f64(cs, 0), sxN = -readlane_f64(sn, 1), syN = readlane_f64(cs, 1);
@@ -381,7 +382,7 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
         row[2] = psi_r;
         const double kap = (xd * ydd - yd * xdd) / (q * sqrt(q));
         row[3] = kap;
-        const double len_r = lat.slen[lat.samp_ptr[pedge[i]] + k];
+        const double len_r = lat.slen[pedge[i] + k];
         row[4] = len_r;
         if (vel_kappa) { vel_kappa[r] = kap; vel_len[r] = len_r; }
         if (out.vkap) {                                    // tiled planes of the batch velocity stage
@@ -580,19 +581,13 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     sc.el = lat.rng_end[sc.sl];
     sc.pos0 = in.pos_off[sc.veh0]; sc.n_pos = in.pos_off[sc.veh0 + sc.n_veh] - sc.pos0;
     sc.H = sc.el - sc.sl; if (sc.H < 0) sc.H = L - sc.sl + sc.el;
-    {
-        int first = sc.sl + 1; if (first >= L) first -= L;
-        sc.e_base = lat.layer_ebase[first];
-        sc.n_base = lat.layer_off[sc.sl];
-        int NH = lat.layer_off[sc.el + 1] - sc.n_base; if (NH <= 0) NH += lat.V;
-        sc.NH = NH;
-    }
     const int H = sc.H, kpad = lp.kpad, hm = lp.hmax;
 
     for (int i = tid; i < lp.words_blocked; i += NT) blocked_bits[i] = 0u;
     for (int i = tid; i < lp.words_zone; i += NT) zone_bits[i] = 0u;
     // per-layer table of the planning range
-    for (int j = tid; j <= H; j += NT) {
+    // (rows beyond the planning range are harmless: the bound only depends on the lattice, so the loads do not wait for H)
+    for (int j = tid; j < hm; j += NT) {
         int b = sc.sl + j; if (b >= L) b -= L;
         const int v0 = lat.layer_off[b];
         lay[j] = make_int4(v0, (lat.layer_off[b + 1] - v0) | (lat.layer_degmax[b] << 16), lat.layer_ebase[b], lat.layer_ebase[b + 1]);
@@ -613,6 +608,13 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     if (lp.ref_lds)
         for (int l = tid; l < L; l += NT) { refl[2 * l] = lat.ref_x[l]; refl[2 * l + 1] = lat.ref_y[l]; }
     team_sync<NW>();
+    {
+        // offsets of the planning range from the layer table (no further dependent scalar loads)
+        const int4 l0 = lay[0], l1 = lay[1], lH = lay[H];
+        sc.e_base = l1.z; sc.n_base = l0.x;
+        int NH = lH.x + (lH.y & 0xffff) - sc.n_base; if (NH <= 0) NH += lat.V;
+        sc.NH = NH;
+    }
     // zone-removed nodes of the "overtaking_zones" filter (gen_local_node_template.py:96; GraphBase.py:713-745)
     for (int i = zone0 + tid; i < zone1; i += NT) {
         int nl = in.zone_gid[i] - sc.n_base; if (nl < 0) nl += lat.V;
@@ -738,10 +740,12 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     if (wave == 0) {
         // closest = smallest layer distance of the vehicle's LAST position; first vehicle wins ties
         int key = 0x7fffffff;
+        double vpx = 0.0, vpy = 0.0;                       // first position of vehicle `lane` (vehicles 0 .. 63)
         for (int k = lane; k < sc.n_veh; k += 64) {
-            const int plast = in.pos_off[sc.veh0 + k + 1] - 1 - sc.pos0;
-            const int ol = (plast >= 0 && plast < sc.n_pos && in.pos_off[sc.veh0 + k + 1] > in.pos_off[sc.veh0 + k])
-                               ? (int)pos_layer[plast] : -1;
+            const int pfirst = in.pos_off[sc.veh0 + k], pnext = in.pos_off[sc.veh0 + k + 1];
+            if (k < 64) { vpx = in.pos_x[pfirst]; vpy = in.pos_y[pfirst]; }
+            const int plast = pnext - 1 - sc.pos0;
+            const int ol = (plast >= 0 && plast < sc.n_pos && pnext > pfirst) ? (int)pos_layer[plast] : -1;
             if (ol >= 0) {
                 int ld = ol - sc.sl; if (ld < 0) ld = L - sc.sl + ol;
                 if (ld <= H) { const int kk = ld * 256 + k; if (kk < key) key = kk; }
@@ -753,8 +757,9 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
         if (key != 0x7fffffff) {
             ci = key & 255; have = 1;
             cl = sc.sl + (key >> 8); if (cl >= L) cl -= L;
-            const int p = in.pos_off[sc.veh0 + ci];
-            const double px = in.pos_x[p], py = in.pos_y[p];
+            double px, py;
+            if (ci < 64) { px = readlane_f64(vpx, ci); py = readlane_f64(vpy, ci); }
+            else { const int p = in.pos_off[sc.veh0 + ci]; px = in.pos_x[p]; py = in.pos_y[p]; }
             const int4 ly = lay[key >> 8];
             const int v0 = ly.x, K = ly.y & 0xffff;
             double bd = INFINITY, dummy = 0.0; int bn = 0x7fffffff;
