@@ -372,6 +372,35 @@ __device__ void brake_profile(int n, double* out, const VelScratch& vs, double c
     wave_sync_lds();
 }
 
+// out[0] = 0, out[i] = out[i - 1] + src[i - 1] for i < m, in the SEQUENTIAL summation order of np.cumsum (bit-identical),
+// executed systolically: lane l adds its element to the partial sum handed over by lane l - 1 (DPP wave_shr:1)
+__device__ void wave_cumsum_seq(const double* src, double* out, int m, int lane)
+{
+    double carry = 0.0;
+    if (lane == 0 && m > 0) out[0] = 0.0;
+    for (int base = 0; base < m - 1; base += 64) {
+        const int cnt = (m - 1 - base) < 64 ? (m - 1 - base) : 64;
+        const double e = src[(lane < cnt) ? base + lane : base + cnt - 1];
+        double s_in = carry, s_out = 0.0;
+        for (int it = 0; it < cnt; ++it) { s_out = s_in + e; s_in = wave_shr1_f64(s_out, carry); }
+        if (lane < cnt) out[base + lane + 1] = s_out;
+        carry = readlane_f64(s_out, cnt - 1);
+    }
+    wave_sync_lds();
+}
+
+// first index i in [0, m) with pred(i), or m (wave-parallel search; pred is evaluated per lane)
+template <typename Pred>
+__device__ __forceinline__ int wave_find_first(int m, int lane, Pred pred)
+{
+    for (int base = 0; base < m; base += 64) {
+        const int i = base + lane;
+        const unsigned long long b = __ballot(i < m && pred(i));
+        if (b) return base + __ffsll((long long)b) - 1;
+    }
+    return m;
+}
+
 __device__ __forceinline__ double angle3pt_dev(double ax, double ay, double bx, double by, double cx, double cy)
 {
     double ang = atan2(cy - by, cx - bx) - atan2(ay - by, ax - bx);
@@ -412,9 +441,12 @@ __device__ double get_s_coord_dev(int n, const double* x, const double* y, int s
 struct FollowIn { double v_start, v_ego, v_obj, safety_d, obj_dist, obj_x, obj_y; };
 
 // calc_vel_profile_follow.py:78-313. Inputs: vs.kabs[n], vs.el[n_el >= n] (tailing zero), gg; result vs.w (v^2).
+// `ext_sync`: when set, the unconstrained profile (:297-307) has been computed by ANOTHER wave of the workgroup into vs.w; the
+// function then joins that wave at a workgroup barrier instead of computing it itself (k_tick: wave 3 works for wave 0).
 template <int EM, bool AXM1, bool GGARR>
 __device__ void follow_profile(const DevLat& lat, int n, int n_el, const VelScratch& vs, double cax, double cay,
-                               const DevVelParams& p, const FollowIn& fi, int lane, int* too_close, int* vel_bound)
+                               const DevVelParams& p, const FollowIn& fi, int lane, int* too_close, int* vel_bound,
+                               bool ext_sync = false)
 {
     int vb = 1;
     const double control_d = p.c_p * fi.safety_d + p.len_veh;                            // :141
@@ -424,17 +456,12 @@ __device__ void follow_profile(const DevLat& lat, int n, int n_el, const VelScra
 
     brake_profile<EM, GGARR>(n, vs.wb, vs, cax, cay, fi.v_start, p, lane);   // :152-159
     // arc length s = [0, cumsum(el[:-1])] (:203) next to the ego stop distance (:162-166)
+    wave_cumsum_seq(vs.el, vs.s, n_el, lane);                  // s[i] = sum of el[0 .. i-1], sequential order
+    // first point at or below 0.1 m/s on the brake profile; the ego stop distance is the arc length up to it (:162-166)
+    int idb = wave_find_first(n, lane, [&](int i) { return !(vs.wb[i] > 0.01); });
+    if (idb > n_el) idb = n_el;
     double ego_stop = 0.0;
-    if (lane == 0) {
-        int idb = 0;
-        while (idb < n && vs.wb[idb] > 0.01) ++idb;                                      // v > 0.1
-        double acc = 0.0;
-        for (int i = 0; i < idb && i < n_el; ++i) acc += vs.el[i];
-        ego_stop = acc;
-        vs.s[0] = 0.0;
-        for (int i = 1; i < n_el; ++i) vs.s[i] = vs.s[i - 1] + vs.el[i - 1];
-    }
-    ego_stop = __shfl(ego_stop, 0);
+    if (idb > 0) ego_stop = (idb < n_el) ? vs.s[idb] : vs.s[n_el - 1] + vs.el[n_el - 1];
 
     // opponent: closest point of the global race line (:172-179), brake scan with ggv [100, 14, 14] (:134,185-199)
     const int G = lat.G - 1;
@@ -472,9 +499,9 @@ __device__ void follow_profile(const DevLat& lat, int n, int n_el, const VelScra
 
     // characteristic indices (:201-221)
     const double s_stop = fi.obj_dist - safety_d + opp_stop;                             // :206
-    int stop_idx = 0; double v_end = 0.0;
+    int stop_idx = wave_find_first(n_el - 1, lane, [&](int i) { return !(vs.s[i] < s_stop); });   // :208-209
+    double v_end = 0.0;
     if (lane == 0) {
-        while (stop_idx < n_el - 1 && vs.s[stop_idx] < s_stop) ++stop_idx;               // :208-209
         if (s_stop > vs.s[n_el - 1]) {                                                   // :212-221
             const double s_ends = opp_stop - (s_stop - vs.s[n_el - 1]);
             int idx = 0; double summed = 0.0;
@@ -487,7 +514,7 @@ __device__ void follow_profile(const DevLat& lat, int n, int n_el, const VelScra
             v_end = grl[(size_t)j * 5 + 4];
         }
     }
-    stop_idx = __shfl(stop_idx, 0); v_end = __shfl(v_end, 0);
+    v_end = __shfl(v_end, 0);
 
     // control velocity (:232-239, get_control_vel :28-75)
     double v_control;
@@ -542,7 +569,8 @@ __device__ void follow_profile(const DevLat& lat, int n, int n_el, const VelScra
         wave_sync_lds();
     }
     // complete profile (:297-307) and intersection (:310)
-    fb_profile<EM, AXM1, GGARR>(n, vs, cax, cay, p, v_max, fi.v_start, false, 0.0, lane);
+    if (ext_sync) __syncthreads();                             // the helper wave has written vs.w
+    else fb_profile<EM, AXM1, GGARR>(n, vs, cax, cay, p, v_max, fi.v_start, false, 0.0, lane);
     for (int i = lane; i < n; i += 64) { const double a = vs.wc[i], b = vs.w[i]; vs.w[i] = a < b ? a : b; }
     wave_sync_lds();
     *too_close = tc; *vel_bound = vb;
@@ -634,18 +662,15 @@ struct DevTickVelOut { double* vx; double* ax; int* vel_bound; int* too_close; }
 template <int EM, bool AXM1>
 __device__ void tick_vel_stage(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const WavePath& wp,
                                const VelScratch& vs, const double* px, const double* py, const DevVelParams& p,
-                               const DevTickVelIn& vin, const DevTickVelOut& vout, int s, int slot, int lane)
+                               const DevTickVelIn& vin, const DevTickVelOut& vout, int s, int slot, int lane,
+                               bool helper_wave)
 {
+    // vs.kabs already holds |kappa| (k_tick). helper_wave: another wave computes the unconstrained follow profile into vs.w
     const int n = wp.n_pts;
     const double vel_plan = vin.vel_plan[s];
     const double cax = vin.gg_ax, cay = vin.gg_ay;
-    for (int i = lane; i < n; i += 64) vs.kabs[i] = fabs(vs.kabs[i]);
-    if (lane == 0) {
-        // s = [0, cumsum(el[:-1])] (OTH.py:743), one extra entry for get_s_coord's zero-prefixed cumsum (:777)
-        vs.s[0] = 0.0;
-        for (int i = 1; i <= n; ++i) vs.s[i] = vs.s[i - 1] + vs.el[i - 1];
-    }
-    wave_sync_lds();
+    // s = [0, cumsum(el[:-1])] (OTH.py:743), one extra entry for get_s_coord's zero-prefixed cumsum (:777)
+    wave_cumsum_seq(vs.el, vs.s, n + 1, lane);
     int too_close = 0, vel_bound = 1;
     bool have_follow = false;
     if (wp.name == LTPL_ACT_FOLLOW) {                                                    // OTH.py:763-830
@@ -662,7 +687,7 @@ __device__ void tick_vel_stage(const DevLat& lat, const DevPathsIn& in, const De
             fi.obj_dist = s_obj - s_sta;
         }
         // follow_profile rebuilds vs.s as [0, cumsum(el[:-1])] for n_el = n: identical values
-        follow_profile<EM, AXM1, false>(lat, n, n, vs, cax, cay, p, fi, lane, &too_close, &vel_bound);
+        follow_profile<EM, AXM1, false>(lat, n, n, vs, cax, cay, p, fi, lane, &too_close, &vel_bound, helper_wave);
         have_follow = true;
     }
     if (wp.name != LTPL_ACT_FOLLOW || wp.reduced) {                                      // OTH.py:834-923
@@ -727,14 +752,32 @@ __global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, 
     WavePath wp = team_paths_body<NUM_WAVES>(lat, in, out, lp, smem, ts, wave < LTPL_MAX_ACTIONS ? vs.kabs : nullptr,
                                              wave < LTPL_MAX_ACTIONS ? vs.el : nullptr, px, py);
     const int s = blockIdx.x;
+    // The fourth wave has no primitive of its own: it computes the unconstrained profile of the 'follow' slot
+    // (calc_vel_profile_follow.py:297-307, independent of the controlled part) while wave 0 runs the brake / segment part.
+    __shared__ int sh_follow_n;
+    if (wave < LTPL_MAX_ACTIONS) {
+        for (int i = lane; i < 2 * p.n_axm; i += 64) vs.axm[i] = p.axm[i];
+        if (wp.valid) for (int i = lane; i < wp.n_pts; i += 64) vs.kabs[i] = fabs(vs.kabs[i]);
+        if (wave == 0 && lane == 0) sh_follow_n = (wp.valid && wp.name == LTPL_ACT_FOLLOW) ? wp.n_pts : 0;
+    }
+    __syncthreads();
+    const int follow_n = sh_follow_n;
     if (wave < LTPL_MAX_ACTIONS) {
         const int slot = s * LTPL_MAX_ACTIONS + wave;
-        for (int i = lane; i < 2 * p.n_axm; i += 64) vs.axm[i] = p.axm[i];
-        wave_sync_lds();
         vs.dbg = lp.dbg;
-        if (wp.valid) tick_vel_stage<EM, AXM1>(lat, in, out, wp, vs, px, py, p, vin, vout, s, slot, lane);
+        if (wp.valid) tick_vel_stage<EM, AXM1>(lat, in, out, wp, vs, px, py, p, vin, vout, s, slot, lane, wave == 0 && follow_n > 0);
         else if (lane == 0) { vout.vel_bound[slot] = 0; vout.too_close[slot] = 0; }
         dbg_stamp(lp.dbg, 11);
+        if (!(wave == 0 && follow_n > 0)) __syncthreads();     // wave 0 with a follow slot joins inside follow_profile
+    } else {
+        if (follow_n > 0) {
+            double* dpx; double* dpy;
+            VelScratch v0 = carve_vel_scratch(smem + vel_off, vel_cap, false, true, &dpx, &dpy);   // wave 0's arrays
+            v0.start = smem + vel_off + (size_t)LTPL_MAX_ACTIONS * vel_stride;                     // own run-start flags
+            v0.dbg = nullptr;
+            fb_profile<EM, AXM1, false>(follow_n, v0, vin.gg_ax, vin.gg_ay, p, p.v_max, vin.vel_plan[s], false, 0.0, lane);
+        }
+        __syncthreads();
     }
 }
 
@@ -1878,7 +1921,7 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
     t->vel_cap = h->caps.max_path_pts;
     t->vel_stride = (int)vel_scratch_bytes(t->vel_cap, false, true);
     t->vel_off = h->lp4.total;
-    t->lds = (size_t)h->lp4.total + (size_t)t->vel_stride * LTPL_MAX_ACTIONS;
+    t->lds = (size_t)h->lp4.total + (size_t)t->vel_stride * LTPL_MAX_ACTIONS + align_up((size_t)t->vel_cap + 16, 16);
     if (t->lds > 150 * 1024) { h->err = "fused tick exceeds the LDS budget"; return LTPL_ERR_CAPACITY; }
     return LTPL_OK;
 }

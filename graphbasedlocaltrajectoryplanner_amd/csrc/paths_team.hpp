@@ -90,7 +90,9 @@ __device__ __forceinline__ void team_sync()
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     } else {
-        __syncthreads();
+        // LDS-only workgroup barrier: the team only exchanges data through LDS, so outstanding GLOBAL loads (the edge
+        // prefetch of the next layer) must not be drained here -- __syncthreads() would wait for vmcnt(0) as well
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
 
