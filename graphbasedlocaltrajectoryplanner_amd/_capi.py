@@ -397,6 +397,7 @@ class HipBackend(object):
         L.ltpl_batch_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
         L.ltpl_batch_download.argtypes = [C.c_void_p, C.POINTER(PathsOut), C.POINTER(TickVelOut)]
         L.ltpl_batch_run_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+        L.ltpl_batch_last_paths_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
 
     def _check(self, rc):
         if rc != 0:
@@ -449,6 +450,12 @@ class HipBackend(object):
     def batch_run(self, reps=1, timed=True):
         ms = C.c_float(0.0)
         self._check(self.lib.ltpl_batch_run(self.handle, int(reps), C.byref(ms) if timed else None))
+        return float(ms.value)
+
+    def batch_last_paths_ms(self):
+        """Average path-kernel duration inside the last timed batch_run (HIP events around each launch, overlapped run)."""
+        ms = C.c_float(0.0)
+        self._check(self.lib.ltpl_batch_last_paths_ms(self.handle, C.byref(ms)))
         return float(ms.value)
 
     def batch_run_profile(self, reps=10):

@@ -1273,6 +1273,8 @@ struct ltpl_handle {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_paths[2] = {nullptr, nullptr}, ev_vel[2] = {nullptr, nullptr};
     int last_set = 0;
+    std::vector<hipEvent_t> ev_step;          // timing events around the path kernel of every step of the last timed run
+    float last_paths_ms = 0.0f; int last_paths_n = 0;
 };
 
 static void dbg_report(ltpl_handle* h, const char* what, int n_blocks)
@@ -1394,6 +1396,7 @@ extern "C" int ltpl_destroy(ltpl_handle* h)
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     for (int i = 0; i < 2; ++i) { if (h->ev_paths[i]) (void)hipEventDestroy(h->ev_paths[i]); if (h->ev_vel[i]) (void)hipEventDestroy(h->ev_vel[i]); }
     free_resident(h->resident2);
+    for (hipEvent_t e : h->ev_step) (void)hipEventDestroy(e);
     if (h->h_in) (void)hipHostFree(h->h_in);
     if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -2120,6 +2123,10 @@ extern "C" int ltpl_batch_run(ltpl_handle* h, int reps, float* ms_total)
         HIP_TRY(h, hipEventCreate(&e0)); HIP_TRY(h, hipEventCreate(&e1));
         HIP_TRY(h, hipEventRecord(e0, h->stream));
     }
+    if (h->resident2 && ms_total) {
+        while (h->ev_step.size() < 2 * (size_t)reps) { hipEvent_t e; HIP_TRY(h, hipEventCreate(&e)); h->ev_step.push_back(e); }
+    }
+    h->last_paths_ms = 0.0f; h->last_paths_n = 0;
     if (h->resident2) {
         // software pipeline over steps: path kernel of step r on `stream`, velocity kernels of step r on `stream2`, two
         // buffer sets; the path kernel of step r + 2 waits until the velocity kernels of step r released its set
@@ -2127,8 +2134,10 @@ extern "C" int ltpl_batch_run(ltpl_handle* h, int reps, float* ms_total)
             const int set = r & 1;
             const TickLayout& T = set ? *h->resident2 : *h->resident;
             if (r >= 2) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_vel[set], 0));
+            if (ms_total) HIP_TRY(h, hipEventRecord(h->ev_step[2 * (size_t)r], h->stream));
             int rc = tick_launch_paths(h, T, h->stream);
             if (rc) return rc;
+            if (ms_total) HIP_TRY(h, hipEventRecord(h->ev_step[2 * (size_t)r + 1], h->stream));
             HIP_TRY(h, hipEventRecord(h->ev_paths[set], h->stream));
             HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_paths[set], 0));
             if ((rc = tick_launch_vel(h, T, h->stream2))) return rc;
@@ -2146,9 +2155,24 @@ extern "C" int ltpl_batch_run(ltpl_handle* h, int reps, float* ms_total)
         HIP_TRY(h, hipEventSynchronize(e1));
         HIP_TRY(h, hipEventElapsedTime(ms_total, e0, e1));
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (h->resident2) {
+            for (int r = 0; r < reps; ++r) {
+                float ms = 0.0f;
+                HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_step[2 * (size_t)r], h->ev_step[2 * (size_t)r + 1]));
+                h->last_paths_ms += ms;
+            }
+            h->last_paths_n = reps;
+        }
     } else {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
+    return LTPL_OK;
+}
+
+extern "C" int ltpl_batch_last_paths_ms(ltpl_handle* h, float* ms_avg)
+{
+    if (!h || !ms_avg) return LTPL_ERR_INVALID_ARG;
+    *ms_avg = h->last_paths_n > 0 ? h->last_paths_ms / (float)h->last_paths_n : 0.0f;
     return LTPL_OK;
 }
 

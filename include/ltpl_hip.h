@@ -256,6 +256,9 @@ int ltpl_batch_download(ltpl_handle* handle, ltpl_paths_out* out, ltpl_tick_vel_
 /* Profiling variant of ltpl_batch_run: HIP events between the kernels of the pipeline on the handle's stream.
  * ms_kernels[3] = summed durations over `reps` of {path kernel, follow preparation, velocity lane kernel}. */
 int ltpl_batch_run_profile(ltpl_handle* handle, int reps, float* ms_kernels);
+/* Average duration (ms) of the path kernel inside the last timed ltpl_batch_run, measured with HIP events recorded around
+ * every launch of it on the handle's stream, i.e. under the same overlap with the velocity kernels as the timed region. */
+int ltpl_batch_last_paths_ms(ltpl_handle* handle, float* ms_avg);
 
 #ifdef __cplusplus
 }
