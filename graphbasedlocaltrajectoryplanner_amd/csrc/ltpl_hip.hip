@@ -817,6 +817,16 @@ struct LaneProf {
     const double* K; const double* E;     // tile-strided: element i at [i * 64]
 };
 
+// a / b with the hardware reciprocal and two Newton steps (~1 ulp; the velocity stage is checked to 1e-5 relative). b = 0
+// yields NaN, which the callers' `!(w < vmax2)` clamp treats like +inf.
+__device__ __forceinline__ double fast_div(double a, double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return a * r;
+}
+
 #define LCH 8      // rows per register chunk: all loads of a chunk are issued before the chunk's recurrence steps
 
 // tph.calc_vel_profile(closed=False) for one lane: rows [off, off + n) of the path, result into plane D (as v^2).
@@ -833,7 +843,7 @@ __device__ void lane_fb_profile(const LaneProf& L, double* D, int off, int n, do
     double* Dp = D + (size_t)off * 64;
     // ---- lateral-limit speed + forward sweep (accel_forw) in one pass -------------------------------------------------
     double kabs_i = Kp[0], e_i = Ep[0];
-    double wi = cay / kabs_i;
+    double wi = fast_div(cay, kabs_i);
     if (!(wi < vmax2)) wi = vmax2;
     if (wi > v_start * v_start) wi = v_start * v_start;
     Dp[0] = wi;
@@ -852,7 +862,7 @@ __device__ void lane_fb_profile(const LaneProf& L, double* D, int off, int n, do
             for (int c = 0; c < LCH; ++c) {
                 const int i = base + c;
                 if (i < n - 1) {
-                    double w0n = cay / kr[c];
+                    double w0n = fast_div(cay, kr[c]);
                     if (!(w0n < vmax2)) w0n = vmax2;
                     const bool acc = w0n - orig_i > 0.0;
                     if (acc && !prev_acc) active = true;
@@ -1200,15 +1210,14 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
     vout.vel_bound[slot] = vel_bound; vout.too_close[slot] = (flags & VF_TOO_CLOSE) ? 1 : 0;
 }
 
-// follow preparation executed by the path kernel's wave that owns a "follow" action: the wave-parallel reductions
-// (projection of the object and of the ego position on the path, OTH.py:774-784; projection of the object on the
-// global race line, calc_vel_profile_follow.py:172-176) so that the lane kernel only runs recurrences
+// follow preparation: the wave-parallel reductions of the follow mode (projection of the object and of the ego position on
+// the path, OTH.py:774-784; projection of the object on the global race line, calc_vel_profile_follow.py:172-176) so that
+// the lane kernel only runs recurrences
 __device__ void follow_prep(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const DevTickVelIn& vin,
                             const DevVelPrep& prep, int n, double* s_arr, const double* el, const double* px,
                             const double* py, int s, int slot, int lane)
 {
-    if (lane == 0) { s_arr[0] = 0.0; for (int i = 1; i <= n; ++i) s_arr[i] = s_arr[i - 1] + el[i - 1]; }
-    wave_sync_lds();
+    wave_cumsum_seq(el, s_arr, n + 1, lane);
     const int ci = out.closest_obj_index[s], v0 = in.veh_off[s];
     double ox, oy, vobj, odist;
     if (ci < 0 || ci >= in.veh_off[s + 1] - v0) { odist = 0.0; vobj = 0.0; ox = vin.pos_est_x[s]; oy = vin.pos_est_y[s]; }
