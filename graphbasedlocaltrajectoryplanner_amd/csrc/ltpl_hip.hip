@@ -69,6 +69,12 @@ struct DevPathsOut {
     int* action_id; int* valid; int* reduced; int* goal_layer; int* n_nodes; int* n_pts; int* n_ties;
     int* nodes; int* node_idx; double* coeff; double* path_param;
     double* vkap; double* vlen;      // optional tiled planes (|kappa|, element length) for the batch velocity stage
+    // job compaction of the batch velocity stage (all nullptr outside the pipeline): every valid path takes a job index
+    // from a counter of its class (0 = generic forward-backward profile, 1 = follow); its planes are tiled by JOB, so
+    // the lanes of a velocity wave (64 consecutive jobs of one class) are all busy and equally long
+    int* job_cnt;                    // [2]
+    int* job_slot;                   // [n_slots_pad] generic jobs -> slot, then [n_scen_pad] follow jobs -> slot
+    int n_slots_pad;                 // tile index of follow job j = n_slots_pad + j
 };
 
 
@@ -800,14 +806,13 @@ struct DevVelPrep {             // per-slot scalars produced by k_follow_prep (f
     double* obj_dist; double* v_obj; double* obj_x; double* obj_y; int* idx_s_opp;
 };
 
-struct VelPlanes {              // tiled planes (doubles); per-slot planes have n_slots_pad slots, P1 n_scen_pad
-    double* K; double* E;       // |kappa|, element length          (written by the path kernel)
-    double* P0;                 // type 0 result: follow -> "vx_profile" (:289/:294), else the generic profile
-    double* P1;                 // type 1 result: unconstrained profile of the follow slot, indexed by SCENARIO
-    double* P2;                 // ego brake profile (follow)
-    double* P3;                 // segment profile (follow), afterwards the generic profile of a reduced-horizon follow slot
-    int* flags;                 // per slot: bit 0 vel_bound of the follow part, bit 1 too_close, bit 2 generic profile in P3,
-                                //           bit 3 vel_bound of the generic profile, bits 8.. = n_decel / stop_idx packing unused
+struct VelPlanes {              // tiled planes (doubles), tile index = job index: generic jobs [0, n_slots_pad), follow jobs behind
+    double* K; double* E;       // |kappa|, element length          (written by the path kernel)   n_slots_pad + n_scen_pad tiles
+    double* P0;                 // type 0 result: follow -> "vx_profile" (:289/:294), else the generic profile     (same size)
+    double* P1;                 // type 1 result: unconstrained profile of a follow job                n_scen_pad tiles
+    double* P2;                 // ego brake profile (follow)                                           n_scen_pad tiles
+    double* P3;                 // segment profile (follow), afterwards the generic profile of a reduced-horizon follow job
+    int* flags;                 // per tile: VF_* bits
     int cap_pts;
 };
 
@@ -976,33 +981,40 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
                                                   DevTickVelIn vin, DevVelPrep prep, VelPlanes vp, int n_slots, int n_scen,
                                                   int n_blocks0, long long* dbg)
 {
+    // blocks [0, nbG): generic jobs; [nbG, nbG + nbF): follow jobs, controlled part; [nbG + nbF, nbG + 2 nbF): follow jobs,
+    // unconstrained profile. Waves beyond the job counters (known only on the device) exit at once.
     __shared__ double axm_tab[128];
     const int lane = threadIdx.x;
+    const int nbG = n_blocks0, nbF = (n_scen + 63) / 64;
+    const int cntG = out.job_cnt[0], cntF = out.job_cnt[1];
+    const int b = blockIdx.x;
+    if ((b < nbG && b * 64 >= cntG) || (b >= nbG && ((b - nbG) % nbF) * 64 >= cntF)) return;
     for (int i = lane; i < 2 * p.n_axm; i += 64) axm_tab[i] = p.axm[i];
     __syncthreads();
     dbg_stamp(dbg, 0);
     const double cax = vin.gg_ax, cay = vin.gg_ay, icay = 1.0 / cay;
-    if ((int)blockIdx.x >= n_blocks0) {
-        // ---- job type 1: unconstrained profile of the follow slot of scenario s --------------------------------------
-        const int s = ((int)blockIdx.x - n_blocks0) * 64 + lane;
-        if (s >= n_scen) return;
-        const int slot = s * LTPL_MAX_ACTIONS;
-        if (!out.valid[slot] || out.action_id[slot] != LTPL_ACT_FOLLOW) return;
-        LaneProf L; L.K = vp.K + tile_base(slot, vp.cap_pts); L.E = vp.E + tile_base(slot, vp.cap_pts);
-        lane_fb_profile<EM, AXM1>(L, vp.P1 + tile_base(s, vp.cap_pts), 0, out.n_pts[slot], cax, cay, p, axm_tab, p.v_max,
-                                  vin.vel_plan[s], false, 0.0);
+    const int fbase = out.n_slots_pad;
+    if (b >= nbG + nbF) {
+        // ---- follow jobs, unconstrained profile (calc_vel_profile_follow.py:297-307) -------------------------------------
+        const int j = (b - nbG - nbF) * 64 + lane;
+        if (j >= cntF) return;
+        const int slot = out.job_slot[fbase + j];
+        LaneProf L; L.K = vp.K + tile_base(fbase + j, vp.cap_pts); L.E = vp.E + tile_base(fbase + j, vp.cap_pts);
+        lane_fb_profile<EM, AXM1>(L, vp.P1 + tile_base(j, vp.cap_pts), 0, out.n_pts[slot], cax, cay, p, axm_tab, p.v_max,
+                                  vin.vel_plan[slot / LTPL_MAX_ACTIONS], false, 0.0);
         return;
     }
-    // ---- job type 0 ----------------------------------------------------------------------------------------------------
-    const int slot = blockIdx.x * 64 + lane;
-    if (slot >= n_slots) return;
+    const bool fjob = b >= nbG;
+    const int j = (fjob ? b - nbG : b) * 64 + lane;
+    if (j >= (fjob ? cntF : cntG)) return;
+    const int tile = fjob ? fbase + j : j;
+    const int slot = out.job_slot[tile];
     const int s = slot / LTPL_MAX_ACTIONS;
-    if (!out.valid[slot]) { vp.flags[slot] = 0; return; }
     const int n = out.n_pts[slot];
-    LaneProf L; L.K = vp.K + tile_base(slot, vp.cap_pts); L.E = vp.E + tile_base(slot, vp.cap_pts);
-    double* P0 = vp.P0 + tile_base(slot, vp.cap_pts);
-    double* P2 = vp.P2 + tile_base(slot, vp.cap_pts);
-    double* P3 = vp.P3 + tile_base(slot, vp.cap_pts);
+    LaneProf L; L.K = vp.K + tile_base(tile, vp.cap_pts); L.E = vp.E + tile_base(tile, vp.cap_pts);
+    double* P0 = vp.P0 + tile_base(tile, vp.cap_pts);
+    double* P2 = vp.P2 + tile_base(fjob ? j : 0, vp.cap_pts);
+    double* P3 = vp.P3 + tile_base(fjob ? j : 0, vp.cap_pts);
     const double vel_plan = vin.vel_plan[s];
     const int name = out.action_id[slot], reduced = out.reduced[slot];
     int flags = VF_BOUND_FOLLOW;
@@ -1146,24 +1158,29 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
         if (lane_generic_profile<EM, AXM1>(lat, out, L, P0, slot, n, reduced, cax, cay, p, axm_tab, vel_plan, vin.v_max_offset))
             flags |= VF_BOUND_GENERIC;
     }
-    vp.flags[slot] = flags;
+    vp.flags[tile] = flags;
     dbg_stamp(dbg, 1);
 }
 
 // final step of the batch velocity stage, lane per slot, no recurrence: intersection of the two follow profiles
 // (calc_vel_profile_follow.py:310), choice between follow and generic profile for reduced horizons (OTH.py:923, row 5),
 // vx = sqrt(w), ax from neighbouring points with -5 at standstill (OTH.py:925-941)
-__global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn vin, DevTickVelOut vout, VelPlanes vp, int n_slots)
+__global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn vin, DevTickVelOut vout, VelPlanes vp, int n_slots,
+                                                  int n_scen)
 {
-    const int slot = blockIdx.x * 64 + threadIdx.x;
-    if (slot >= n_slots) return;
-    if (!out.valid[slot]) { vout.vel_bound[slot] = 0; vout.too_close[slot] = 0; return; }
-    const int s = slot / LTPL_MAX_ACTIONS, n = out.n_pts[slot], flags = vp.flags[slot];
-    const bool follow = out.action_id[slot] == LTPL_ACT_FOLLOW;
-    const double* P0 = vp.P0 + tile_base(slot, vp.cap_pts);
-    const double* P1 = vp.P1 + tile_base(s, vp.cap_pts);
-    const double* P3 = vp.P3 + tile_base(slot, vp.cap_pts);
-    const double* E = vp.E + tile_base(slot, vp.cap_pts);
+    // blocks [0, nbG): generic jobs, [nbG, nbG + nbF): follow jobs; slots without a path were initialised by the path kernel
+    const int nbG = (n_slots + 63) / 64;
+    const bool fjob = (int)blockIdx.x >= nbG;
+    const int j = (fjob ? blockIdx.x - nbG : blockIdx.x) * 64 + threadIdx.x;
+    if (j >= out.job_cnt[fjob ? 1 : 0]) return;
+    const int tile = fjob ? out.n_slots_pad + j : j;
+    const int slot = out.job_slot[tile];
+    const int n = out.n_pts[slot], flags = vp.flags[tile];
+    const bool follow = fjob;
+    const double* P0 = vp.P0 + tile_base(tile, vp.cap_pts);
+    const double* P1 = vp.P1 + tile_base(fjob ? j : 0, vp.cap_pts);
+    const double* P3 = vp.P3 + tile_base(fjob ? j : 0, vp.cap_pts);
+    const double* E = vp.E + tile_base(tile, vp.cap_pts);
     int vel_bound = follow ? ((flags & VF_BOUND_FOLLOW) ? 1 : 0) : ((flags & VF_BOUND_GENERIC) ? 1 : 0);
     int sel = follow ? 1 : 0;                     // 0: P0, 1: min(P0, P1), 2: P3
     if (follow && (flags & VF_HAS_GENERIC)) {
@@ -1702,7 +1719,7 @@ static void bind_out(unsigned char* db, const OutLayout& lo, int cap_nodes, int 
     d->n_ties = reinterpret_cast<int*>(db + lo.n_ties); d->nodes = reinterpret_cast<int*>(db + lo.nodes);
     d->node_idx = reinterpret_cast<int*>(db + lo.node_idx); d->coeff = reinterpret_cast<double*>(db + lo.coeff);
     d->path_param = reinterpret_cast<double*>(db + lo.path_param);
-    d->vkap = nullptr; d->vlen = nullptr;
+    d->vkap = nullptr; d->vlen = nullptr; d->job_cnt = nullptr; d->job_slot = nullptr; d->n_slots_pad = 0;
 }
 
 static void scatter_out(const unsigned char* hb, const OutLayout& lo, int n, ltpl_paths_out* out)
@@ -1925,9 +1942,12 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
     t->prep_idx = b.add(sizeof(int) * (size_t)n * LTPL_MAX_ACTIONS);
     t->out_total = b.size;
     t->n_slots_pad = (int)align_up((size_t)n * LTPL_MAX_ACTIONS, 64); t->n_scen_pad = (int)align_up((size_t)n, 64);
-    // tiled planes: K, E, P0, P2, P3 per slot, P1 per scenario, flags per slot
-    t->planes_bytes = t->pipeline ? sizeof(double) * (size_t)cap_pts * (5 * (size_t)t->n_slots_pad + (size_t)t->n_scen_pad)
-                                        + sizeof(int) * (size_t)t->n_slots_pad : 0;
+    // tiled planes by job: K, E, P0 for generic + follow jobs, P1, P2, P3 for follow jobs; flags, job table and counters behind
+    {
+        const size_t tiles = (size_t)t->n_slots_pad + (size_t)t->n_scen_pad;
+        t->planes_bytes = t->pipeline ? sizeof(double) * (size_t)cap_pts * (3 * tiles + 3 * (size_t)t->n_scen_pad)
+                                            + sizeof(int) * (2 * tiles + 16) : 0;
+    }
     t->prep_off = 0; t->prep_stride = 0;
     t->lds_prep = align_up(sizeof(double) * 4 * (size_t)(cap_pts + 2), 16);      // k_follow_prep: el, x, y, s
     t->vel_cap = h->caps.max_path_pts;
@@ -1951,10 +1971,13 @@ static void tick_bind_outputs(TickLayout* t, unsigned char* dob, double* planes)
     t->dprep.obj_y = reinterpret_cast<double*>(dob + t->prep_oy);
     t->dprep.idx_s_opp = reinterpret_cast<int*>(dob + t->prep_idx);
     if (t->pipeline && planes) {
-        const size_t per_slot = (size_t)t->cap_pts * (size_t)t->n_slots_pad, per_scen = (size_t)t->cap_pts * (size_t)t->n_scen_pad;
-        t->vp.K = planes; t->vp.E = planes + per_slot; t->vp.P0 = planes + 2 * per_slot; t->vp.P2 = planes + 3 * per_slot;
-        t->vp.P3 = planes + 4 * per_slot; t->vp.P1 = planes + 5 * per_slot;
-        t->vp.flags = reinterpret_cast<int*>(planes + 5 * per_slot + per_scen);
+        const size_t tiles = (size_t)t->n_slots_pad + (size_t)t->n_scen_pad;
+        const size_t per_all = (size_t)t->cap_pts * tiles, per_scen = (size_t)t->cap_pts * (size_t)t->n_scen_pad;
+        t->vp.K = planes; t->vp.E = planes + per_all; t->vp.P0 = planes + 2 * per_all;
+        t->vp.P1 = planes + 3 * per_all; t->vp.P2 = t->vp.P1 + per_scen; t->vp.P3 = t->vp.P2 + per_scen;
+        int* ints = reinterpret_cast<int*>(t->vp.P3 + per_scen);
+        t->vp.flags = ints; t->dout.job_slot = ints + tiles; t->dout.job_cnt = ints + 2 * tiles;
+        t->dout.n_slots_pad = t->n_slots_pad;
         t->vp.cap_pts = t->cap_pts;
         t->dout.vkap = t->vp.K; t->dout.vlen = t->vp.E;
     }
@@ -1992,6 +2015,7 @@ static int tick_pack(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_ve
 
 static int tick_launch_paths(ltpl_handle* h, const TickLayout& t, hipStream_t st)
 {
+    if (t.dout.job_cnt) HIP_TRY(h, hipMemsetAsync(t.dout.job_cnt, 0, 2 * sizeof(int), st));
     if (h->batch_nw == 1)
         hipLaunchKernelGGL(k_paths<1>, dim3(t.n_scen), dim3(64), h->lp1.total, st, h->lat, t.di, t.dout, h->lp1);
     else
@@ -2002,16 +2026,19 @@ static int tick_launch_paths(ltpl_handle* h, const TickLayout& t, hipStream_t st
 
 static int tick_launch_vel(ltpl_handle* h, const TickLayout& t, hipStream_t st, hipEvent_t ev_after_prep = nullptr)
 {
+    // slots without a path: vel_bound = too_close = 0 (the job kernels only touch slots that own a job)
+    HIP_TRY(h, hipMemsetAsync(t.dvout.vel_bound, 0, sizeof(int) * (size_t)t.n_scen * LTPL_MAX_ACTIONS, st));
+    HIP_TRY(h, hipMemsetAsync(t.dvout.too_close, 0, sizeof(int) * (size_t)t.n_scen * LTPL_MAX_ACTIONS, st));
     hipLaunchKernelGGL(k_follow_prep, dim3(t.n_scen * LTPL_MAX_ACTIONS), dim3(64), t.lds_prep, st, h->lat, t.di, t.dout,
                        t.dvin, t.dprep, t.n_scen * LTPL_MAX_ACTIONS);
     HIP_TRY(h, hipGetLastError());
     if (ev_after_prep) HIP_TRY(h, hipEventRecord(ev_after_prep, st));
     const int n_slots = t.n_scen * LTPL_MAX_ACTIONS;
     const int nb0 = (n_slots + 63) / 64, nb1 = (t.n_scen + 63) / 64;
-    hipLaunchKernelGGL(lanes_kernel_of(t.variant), dim3(nb0 + nb1), dim3(64), 0, st, h->lat, t.di, t.dout,
+    hipLaunchKernelGGL(lanes_kernel_of(t.variant), dim3(nb0 + 2 * nb1), dim3(64), 0, st, h->lat, t.di, t.dout,
                        t.p, t.dvin, t.dprep, t.vp, n_slots, t.n_scen, nb0, h->lp4.dbg);
     HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL(k_vel_final, dim3(nb0), dim3(64), 0, st, t.dout, t.dvin, t.dvout, t.vp, n_slots);
+    hipLaunchKernelGGL(k_vel_final, dim3(nb0 + nb1), dim3(64), 0, st, t.dout, t.dvin, t.dvout, t.vp, n_slots, t.n_scen);
     HIP_TRY(h, hipGetLastError());
     return LTPL_OK;
 }

@@ -236,6 +236,17 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
     double* o_coeff = out.coeff + (size_t)slot * out.cap_nodes * 8;
     double* o_pp = out.path_param + (size_t)slot * out.cap_pts * 5;
     WavePath wp; wp.valid = 1; wp.name = name; wp.reduced = reduced;
+    // batch pipeline: take a job of the velocity stage (class 0 = generic profile, 1 = follow); the planes are tiled by job
+    int vtile = -1;
+    if (out.job_cnt) {
+        if (lane == 0) {
+            const int cls = name == LTPL_ACT_FOLLOW ? 1 : 0;
+            const int jb = atomicAdd(&out.job_cnt[cls], 1);
+            vtile = cls ? out.n_slots_pad + jb : jb;
+            out.job_slot[vtile] = slot;
+        }
+        vtile = __builtin_amdgcn_readfirstlane(vtile);
+    }
 
     // backtrack along the LDS parent table (lane 0), count exact ties on the way; rank of the in-edge -> pedge (as rank
     // first, resolved to edge ids by all lanes afterwards: the global in_ptr loads are then independent)
@@ -388,7 +399,7 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
         row[4] = len_r;
         if (vel_kappa) { vel_kappa[r] = kap; vel_len[r] = len_r; }
         if (out.vkap) {                                    // tiled planes of the batch velocity stage
-            const size_t o = (((size_t)(slot >> 6) * out.cap_pts) + r) * 64 + (slot & 63);
+            const size_t o = (((size_t)(vtile >> 6) * out.cap_pts) + r) * 64 + (vtile & 63);
             out.vkap[o] = fabs(kap); out.vlen[o] = len_r;
         }
         if (vel_x) { vel_x[r] = x; vel_y[r] = y; }
