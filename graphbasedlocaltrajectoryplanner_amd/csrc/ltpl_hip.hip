@@ -1256,8 +1256,10 @@ __global__ __launch_bounds__(64) void k_follow_prep(DevLat lat, DevPathsIn in, D
                                                     DevVelPrep prep, int n_slots)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int slot = blockIdx.x, lane = threadIdx.x;
-    if (slot >= n_slots || !out.valid[slot] || out.action_id[slot] != LTPL_ACT_FOLLOW) return;
+    const int lane = threadIdx.x;
+    // one wave per FOLLOW JOB (job table of the path kernel); n_slots = upper bound of the grid
+    if ((int)blockIdx.x >= out.job_cnt[1]) return;
+    const int slot = out.job_slot[out.n_slots_pad + blockIdx.x];
     const int n = out.n_pts[slot];
     const int c1 = out.cap_pts + 2;
     double* sel = reinterpret_cast<double*>(smem); double* sx = sel + c1; double* sy = sx + c1; double* ss = sy + c1;
@@ -2029,8 +2031,8 @@ static int tick_launch_vel(ltpl_handle* h, const TickLayout& t, hipStream_t st, 
     // slots without a path: vel_bound = too_close = 0 (the job kernels only touch slots that own a job)
     HIP_TRY(h, hipMemsetAsync(t.dvout.vel_bound, 0, sizeof(int) * (size_t)t.n_scen * LTPL_MAX_ACTIONS, st));
     HIP_TRY(h, hipMemsetAsync(t.dvout.too_close, 0, sizeof(int) * (size_t)t.n_scen * LTPL_MAX_ACTIONS, st));
-    hipLaunchKernelGGL(k_follow_prep, dim3(t.n_scen * LTPL_MAX_ACTIONS), dim3(64), t.lds_prep, st, h->lat, t.di, t.dout,
-                       t.dvin, t.dprep, t.n_scen * LTPL_MAX_ACTIONS);
+    hipLaunchKernelGGL(k_follow_prep, dim3(t.n_scen), dim3(64), t.lds_prep, st, h->lat, t.di, t.dout,
+                       t.dvin, t.dprep, t.n_scen);
     HIP_TRY(h, hipGetLastError());
     if (ev_after_prep) HIP_TRY(h, hipEventRecord(ev_after_prep, st));
     const int n_slots = t.n_scen * LTPL_MAX_ACTIONS;
