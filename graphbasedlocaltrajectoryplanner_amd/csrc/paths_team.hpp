@@ -419,7 +419,7 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
 // exact tie-break of the reference order only matters when the minimum is attained more than once: those nodes (rare)
 // re-scan their in-edges serially.
 struct LayerArgs {
-    int j, b, v0, Kb, ne, kpad, hm, cur, prv, H;
+    int j, b, v0, Kb, ne, eb, kpad, hm, cur, prv, H;
     int fs, fd, cl_hit, cn;                      // cl_hit: this layer is the closest object's layer
     bool from_def;
     double fac;
@@ -480,6 +480,38 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
             }
         }
     }
+    // transitions with more edges than the register image: the rest straight from global memory (rare, not prefetched);
+    // ROUND = 0: atomic min of the candidate sums, 1: election among the edges that attain it, 2 / 3: exact tie-break
+    auto tail_edges = [&](int ROUND) {
+        double* dumin = reinterpret_cast<double*>(smem + lp.off_dumin);
+        for (int ei = CH * NT + tid; ei < A.ne; ei += NT) {
+            const int e = A.eb + ei;
+            double c = lat.edge_cost[e];
+            const unsigned meta = lat.edge_meta[e];
+            const int src = meta & 255u, dst = (meta >> 8) & 255u;
+            int el_ = e - sc.e_base; if (el_ < 0) el_ += lat.E;
+            const bool unbl = !((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u);
+            if (A.fs >= 0 && src == A.fs && dst == A.fd) c *= A.fac;
+            const unsigned key = ((unsigned)ei << 16) | ((meta >> 8) & 0xff00u) | (meta & 255u);
+#pragma unroll
+            for (int f = 0; f < NFILT; ++f) {
+                if (!((ACT >> f) & 1u)) continue;
+                const double du = dist[poff[f] + src];
+                bool ok = du < INFINITY;
+                if (f != F_PR) ok = ok && unbl;
+                if (!ok) continue;
+                const double cd = du + c;
+                if (ROUND == 0) { atomicMin(reinterpret_cast<unsigned long long*>(&dist[coff[f] + dst]), (unsigned long long)__double_as_longlong(cd)); continue; }
+                if (dist[coff[f] + dst] != cd) continue;
+                if (ROUND == 1) { atomicAdd(&cnt_all[f * kpad + dst], 1u); atomicMin(&widx_all[f * kpad + dst], key); continue; }
+                if (cnt_all[f * kpad + dst] < 2u) continue;
+                if (ROUND == 2) atomicMin(reinterpret_cast<unsigned long long*>(&dumin[f * kpad + dst]), (unsigned long long)__double_as_longlong(du));
+                else if (dumin[f * kpad + dst] == du) atomicMin(&widx_all[f * kpad + dst], key);
+            }
+        }
+    };
+    const bool has_tail = A.ne > CH * NT;
+    if (has_tail) tail_edges(0);
     team_sync<NW>();
 #pragma unroll
     for (int ci = 0; ci < CH; ++ci) {
@@ -497,6 +529,7 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
                 atomicMin(&widx_all[f * kpad + dst], key);
             }
     }
+    if (has_tail) tail_edges(1);
     team_sync<NW>();
     // exact tie-break (rare): a node whose minimum is attained by several edges takes, in the reference's order, the
     // predecessor with the smaller distance first, then CSC order. Every wave reads the same counters, so the branch is
@@ -532,6 +565,7 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
                         else if (dumin[f * kpad + dst] == du) atomicMin(&widx_all[f * kpad + dst], key);
                     }
                 }
+                if (has_tail) tail_edges(2 + round);
                 team_sync<NW>();
             }
         }
@@ -871,7 +905,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             int b = sc.sl + j; if (b >= L) b -= L;
             const int4 ly = lay[j];
             LayerArgs A;
-            A.j = j; A.b = b; A.v0 = ly.x; A.Kb = ly.y & 0xffff; A.ne = ly.w - ly.z; A.kpad = kpad; A.hm = hm; A.cur = j & 1; A.prv = (j - 1) & 1;
+            A.j = j; A.b = b; A.v0 = ly.x; A.Kb = ly.y & 0xffff; A.ne = ly.w - ly.z; A.eb = ly.z; A.kpad = kpad; A.hm = hm; A.cur = j & 1; A.prv = (j - 1) & 1;
             A.H = H; A.cl_hit = (b == t_cl) ? 1 : 0; A.cn = t_cn;
             A.fs = -1; A.fd = -1; A.fac = 1.0;
             if (j - 1 < sc.n_fac) { A.fs = ts.fac_src[j]; A.fd = ts.fac_dst[j]; A.fac = ts.fac[j]; }
@@ -886,7 +920,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             // the action templates only produce these filter sets (phase 3); anything else takes the serial form
             const bool known = actm == (1u << F_DEF) || actm == (1u << F_PR) || actm == ((1u << F_PR) | (1u << F_DEF)) ||
                                actm == ((1u << F_PR) | (1u << F_LEFT) | (1u << F_RIGHT));
-            if (A.Kb <= 64 && A.ne <= CH * NT && known) {
+            if (A.Kb <= 64 && known) {
                 // compile-time specialisations per filter set
                 switch (actm) {
                     case (1u << F_DEF): team_layer<NW, CH, (1u << F_DEF)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
@@ -896,7 +930,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                         team_layer<NW, CH, (1u << F_PR) | (1u << F_LEFT) | (1u << F_RIGHT)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
                 }
             } else {
-                // more than 64 nodes in the layer or more edges than the register image holds: serial form (lane = node)
+                // more than 64 nodes in the layer (or an unknown filter set): serial form (lane = node)
                 for (int f = wave; f < NFILT; f += NW) {
                     if (!((actm >> f) & 1u)) continue;
                     const int fprev = (A.from_def && (f == F_LEFT || f == F_RIGHT)) ? F_DEF : f;
