@@ -137,7 +137,7 @@ struct WavePath { int valid; int n_pts; int n_nodes; int name; int reduced; int 
 #include "paths_team.hpp"
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 1 ? 3 : 1)) void k_paths(DevLat lat, DevPathsIn in, DevPathsOut out, TeamLds lp)
+__global__ __launch_bounds__(64 * NW, (NW == 1 ? 4 : 1)) void k_paths(DevLat lat, DevPathsIn in, DevPathsOut out, TeamLds lp)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ TeamShared ts;

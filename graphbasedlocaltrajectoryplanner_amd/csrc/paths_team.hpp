@@ -455,29 +455,25 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
     // candidate sums are kept for the active filters only (compile-time compaction keeps the register image small)
     constexpr int NA = ((ACT >> 0) & 1) + ((ACT >> 1) & 1) + ((ACT >> 2) & 1) + ((ACT >> 3) & 1);
     constexpr int SL[NFILT] = {0, (int)((ACT >> 0) & 1), (int)(((ACT >> 0) & 1) + ((ACT >> 1) & 1)), (int)(((ACT >> 0) & 1) + ((ACT >> 1) & 1) + ((ACT >> 2) & 1))};
-    double cand[CH][NA]; unsigned okm[CH];
+    // An edge that must not be used (beyond the transition, blocked, unreachable source) simply carries the candidate
+    // +inf: inf + cost = inf never wins the atomic min and never matches a finite minimum, so the rounds need no
+    // per-lane bookkeeping and no divergent control flow.
+    double cand[CH][NA];
 #pragma unroll
     for (int ci = 0; ci < CH; ++ci) {
-        okm[ci] = 0u;
         if ((ci * NW) * 64 >= A.ne) continue;                       // uniform: no edges in this chunk
         const int ei = (ci * NW + wave) * 64 + lane;
         const int src = er[ci].meta & 255u, dst = (er[ci].meta >> 8) & 255u;
-        const bool valid = ei < A.ne;
-        const bool unbl = !((blkm[ci] >> lane) & 1ull);
-        double c = er[ci].c;
-        if (A.fs >= 0 && src == A.fs && dst == A.fd) c *= A.fac;
+        const double c_pr = (ei < A.ne) ? er[ci].c : INFINITY;                        // planning_range: every edge
+        const double c_np = ((blkm[ci] >> lane) & 1ull) ? INFINITY : c_pr;            // other filters: unblocked edges
 #pragma unroll
-        for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) cand[ci][SL[f]] = dist[poff[f] + (valid ? src : 0)];
+        for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) cand[ci][SL[f]] = dist[poff[f] + src];
 #pragma unroll
         for (int f = 0; f < NFILT; ++f) {
             if (!((ACT >> f) & 1u)) continue;
-            bool ok = valid && cand[ci][SL[f]] < INFINITY;
-            if (f != F_PR) ok = ok && unbl;
-            cand[ci][SL[f]] = cand[ci][SL[f]] + c;
-            if (ok) {
-                okm[ci] |= 1u << f;
+            cand[ci][SL[f]] = cand[ci][SL[f]] + (f == F_PR ? c_pr : c_np);
+            if (cand[ci][SL[f]] < INFINITY)
                 atomicMin(reinterpret_cast<unsigned long long*>(&dist[coff[f] + dst]), (unsigned long long)__double_as_longlong(cand[ci][SL[f]]));
-            }
         }
     }
     // transitions with more edges than the register image: the rest straight from global memory (rare, not prefetched);
@@ -524,7 +520,7 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
         for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) got[f] = dist[coff[f] + dst];
 #pragma unroll
         for (int f = 0; f < NFILT; ++f)
-            if (((ACT >> f) & 1u) && ((okm[ci] >> f) & 1u) && got[f] == cand[ci][SL[f]]) {
+            if (((ACT >> f) & 1u) && got[f] == cand[ci][SL[f]] && cand[ci][SL[f]] < INFINITY) {
                 atomicAdd(&cnt_all[f * kpad + dst], 1u);
                 atomicMin(&widx_all[f * kpad + dst], key);
             }
@@ -558,7 +554,7 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
                     const unsigned key = ((unsigned)ei << 16) | ((er[ci].meta >> 8) & 0xff00u) | (er[ci].meta & 255u);
 #pragma unroll
                     for (int f = 0; f < NFILT; ++f) {
-                        if (!((ACT >> f) & 1u) || !((okm[ci] >> f) & 1u)) continue;
+                        if (!((ACT >> f) & 1u) || !(cand[ci][SL[f]] < INFINITY)) continue;
                         if (dist[coff[f] + dst] != cand[ci][SL[f]] || cnt_all[f * kpad + dst] < 2u) continue;
                         const double du = dist[poff[f] + src];
                         if (round == 0) atomicMin(reinterpret_cast<unsigned long long*>(&dumin[f * kpad + dst]), (unsigned long long)__double_as_longlong(du));
@@ -920,6 +916,12 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             // the action templates only produce these filter sets (phase 3); anything else takes the serial form
             const bool known = actm == (1u << F_DEF) || actm == (1u << F_PR) || actm == ((1u << F_PR) | (1u << F_DEF)) ||
                                actm == ((1u << F_PR) | (1u << F_LEFT) | (1u << F_RIGHT));
+            if (A.fs >= 0) {
+                // previous-solution discount (first layers only): patch the one edge in the register image
+#pragma unroll
+                for (int ci = 0; ci < CH; ++ci)
+                    if ((int)(er[ci].meta & 255u) == A.fs && (int)((er[ci].meta >> 8) & 255u) == A.fd) er[ci].c *= A.fac;
+            }
             if (A.Kb <= 64 && known) {
                 // compile-time specialisations per filter set
                 switch (actm) {
