@@ -38,8 +38,12 @@ from graphbasedlocaltrajectoryplanner_amd.scenario_gen import c2_scenarios   # n
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 
-def make_batch(lat, n, seed):
-    scen, vels = c2_scenarios(lat, n, seed=seed)
+def make_batch(lat, n, seed, workload="c2"):
+    if workload == "c3":
+        from graphbasedlocaltrajectoryplanner_amd.synthetic_lattice import scattered_obstacle_scenarios
+        scen, vels = scattered_obstacle_scenarios(lat, n, n_obj=32, seed=seed)
+    else:
+        scen, vels = c2_scenarios(lat, n, seed=seed)
     rng = np.random.default_rng(seed + 77)
     params = _capi.VelParamSet(len_veh=lat.veh_length)      # Graph_LTPL.calc_vel_profile defaults (Graph_LTPL.py:347-351)
     vplan = rng.uniform(5.0, 60.0, n)
@@ -68,17 +72,20 @@ def cpu_baseline(lat, scen_batch, vel, n_sample):
         if el > 10.0 or reps >= 200:
             break
     return {"value": len(scen) * reps / el, "unit": "ticks/s", "cores": 1, "kind": "port",
-            "sample": "%d C2 scenarios x %d passes through oracle_tick_batch (plain C, -O2, single thread)"
+            "sample": "%d scenarios of the same workload x %d passes through oracle_tick_batch (plain C, -O2, single thread)"
                       % (len(scen), reps)}
 
 
-def read_traffic():
-    """HBM bytes per launch from a committed rocprofv3 PMC summary, if present (profiles/pmc_traffic.json)."""
+def read_traffic(batch, workload):
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC summary (profiles/pmc_traffic.json), if it
+    was collected for this workload and batch size (grid = 64 threads x batch); otherwise null."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.isfile(p):
         try:
             with open(p) as fh:
-                return json.load(fh).get("hbm_bytes_per_launch")
+                d = json.load(fh)
+            if d.get("workload", "c2") == workload and int(d.get("grid_size", 0)) == 64 * batch:
+                return d.get("hbm_bytes_per_launch")
         except Exception:
             return None
     return None
@@ -93,6 +100,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--latency-ticks", type=int, default=2000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", choices=("c2", "c3"), default="c2",
+                    help="c2 = BASELINE config the metric is quoted on (default); c3 = synthetic 10k-node / 98k-edge lattice "
+                         "with 32 obstacles per scenario (HBM-roofline run, reported separately under profiles/)")
     args = ap.parse_args()
 
     import torch
@@ -114,9 +124,13 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
 
-    lat = Lattice.load(os.path.join(ROOT, "tests", "golden", "monteblanco_lattice.npz"))
+    if args.workload == "c3":
+        from graphbasedlocaltrajectoryplanner_amd.synthetic_lattice import c3_lattice
+        lat = c3_lattice()
+    else:
+        lat = Lattice.load(os.path.join(ROOT, "tests", "golden", "monteblanco_lattice.npz"))
     hip = _capi.HipBackend(lat, device=dev_index)
-    scen, batch, vel = make_batch(lat, args.batch, seed=1 + rank)
+    scen, batch, vel = make_batch(lat, args.batch, seed=1 + rank, workload=args.workload)
     hip.batch_upload(batch, vel)
 
     def barrier():
@@ -167,20 +181,21 @@ def main():
                 lat_us.append((time.perf_counter() - t1) * 1e6)
         lat_us = np.array(lat_us)
         out = {
-            "metric": "planning ticks/s (all action primitives), Monteblanco lattice",
+            "metric": "planning ticks/s (all action primitives), " + ("Monteblanco lattice" if args.workload == "c2" else "synthetic C3 lattice"),
             "value": world * args.batch * args.steps / elapsed,
             "unit": "ticks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2: Monteblanco lattice (128 layers / 2691 nodes / 14264 edges), 4 action "
-                                   "primitives, 8 dynamic opponents (16 obstacle positions), sample zone; "
-                                   "%d independent scenarios per GPU per step, fused tick (paths + velocity)"
-                                   % args.batch,
+            "config": {"workload": (("C2: Monteblanco lattice (%d layers / %d nodes / %d edges), 4 action primitives, 8 dynamic "
+                                     "opponents (16 obstacle positions), sample zone" if args.workload == "c2" else
+                                     "C3: synthetic oval lattice (%d layers / %d nodes / %d edges), 4 action primitives, 32 static "
+                                     "obstacles (64 obstacle positions)") % (lat.num_layers, lat.num_nodes, lat.num_edges))
+                                   + "; %d independent scenarios per GPU per step, tick pipeline (paths + velocity)" % args.batch,
                        "batch_per_gpu": args.batch, "parallelism": "scenario-sharded x%d (no collective)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": read_traffic(),
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": read_traffic(args.batch, args.workload),
                          "kernel": "k_paths<1>", "kernel_ms": dom_ms,
                          "kernel_ms_not_overlapped": prof_ms[0],
                          "algorithmic_bytes_per_launch": ab_paths,
