@@ -1199,7 +1199,7 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
     };
     double s_i = 0.0, w_i = value(0);
     for (int base = 0; base < n; base += LCH) {
-        double wr[LCH], er[LCH];
+        double wr[LCH], er[LCH], vv[LCH], aa[LCH];
 #pragma unroll
         for (int c = 0; c < LCH; ++c) {
             const int r = base + c + 1 < n ? base + c + 1 : n - 1;
@@ -1208,20 +1208,24 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
 #pragma unroll
         for (int c = 0; c < LCH; ++c) {
             const int i = base + c;
-            if (i < n) {
-                const double v = sqrt(w_i);
-                o_vx[i] = v;
-                double a = 0.0, w_n = 0.0;
-                if (i < n - 1) {
-                    const double s_n = s_i + er[c];
-                    w_n = wr[c];
-                    a = (w_n - w_i) / (2.0 * (s_n - s_i));
-                    if (fabs(v) <= 1e-8 && fabs(a) <= 1e-8) a = -5.0;
-                    s_i = s_n;
-                }
-                o_ax[i] = a;
-                w_i = w_n;
+            const double v = sqrt(w_i);
+            double a = 0.0, w_n = 0.0;
+            if (i < n - 1) {
+                const double s_n = s_i + er[c];
+                w_n = wr[c];
+                a = (w_n - w_i) / (2.0 * (s_n - s_i));
+                if (fabs(v) <= 1e-8 && fabs(a) <= 1e-8) a = -5.0;
+                s_i = s_n;
             }
+            vv[c] = v; aa[c] = a;
+            w_i = w_n;
+        }
+        // rows of a slot are contiguous: 16-byte stores (8-byte aligned)
+#pragma unroll
+        for (int c = 0; c < LCH; c += 2) {
+            const int i = base + c;
+            if (i + 1 < n) { store2_u(o_vx + i, vv[c], vv[c + 1]); store2_u(o_ax + i, aa[c], aa[c + 1]); }
+            else if (i < n) { o_vx[i] = vv[c]; o_ax[i] = aa[c]; }
         }
     }
     vout.vel_bound[slot] = vel_bound; vout.too_close[slot] = (flags & VF_TOO_CLOSE) ? 1 : 0;

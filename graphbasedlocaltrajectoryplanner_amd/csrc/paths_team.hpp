@@ -21,6 +21,12 @@
 //   6  backtrack, gather, tridiagonal C2 spline solve, re-sampling, heading / curvature                 [G1, P1-P3]
 #pragma once
 
+// 16-byte stores of two doubles; the _u form only promises 8-byte alignment (rows of 5 doubles)
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+typedef double dbl2_u __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void store2(double* p, double a, double b) { dbl2 v; v.x = a; v.y = b; *reinterpret_cast<dbl2*>(p) = v; }
+__device__ __forceinline__ void store2_u(double* p, double a, double b) { dbl2_u v; v.x = a; v.y = b; *reinterpret_cast<dbl2_u*>(p) = v; }
+
 struct TeamLds {                 // dynamic-LDS plan (byte offsets), computed once per lattice on the host
     int kpad, hmax, etmax;
     int words_blocked, words_zone;
@@ -358,13 +364,13 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
         const double h = el[i];
         {
             const double T0 = mx[i] * h, T1 = mx[i + 1] * h, dlt = kx[i + 1] - kx[i];
-            o_coeff[i * 8 + 0] = kx[i]; o_coeff[i * 8 + 1] = T0;
-            o_coeff[i * 8 + 2] = 3.0 * dlt - 2.0 * T0 - T1; o_coeff[i * 8 + 3] = -2.0 * dlt + T0 + T1;
+            store2(o_coeff + i * 8 + 0, kx[i], T0);
+            store2(o_coeff + i * 8 + 2, 3.0 * dlt - 2.0 * T0 - T1, -2.0 * dlt + T0 + T1);
         }
         {
             const double T0 = my[i] * h, T1 = my[i + 1] * h, dlt = ky[i + 1] - ky[i];
-            o_coeff[i * 8 + 4] = ky[i]; o_coeff[i * 8 + 5] = T0;
-            o_coeff[i * 8 + 6] = 3.0 * dlt - 2.0 * T0 - T1; o_coeff[i * 8 + 7] = -2.0 * dlt + T0 + T1;
+            store2(o_coeff + i * 8 + 4, ky[i], T0);
+            store2(o_coeff + i * 8 + 6, 3.0 * dlt - 2.0 * T0 - T1, -2.0 * dlt + T0 + T1);
         }
     }
 
@@ -388,15 +394,12 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
         const double xdd = 2.0 * ax2 + 6.0 * ax3 * t, ydd = 2.0 * ay2 + 6.0 * ay3 * t;
         const double q = xd * xd + yd * yd;
         double* row = o_pp + (size_t)r * 5;
-        row[0] = x; row[1] = y;
         // psi = normalize(atan2(y', x') - pi/2) = atan2(-x', y') (rotation by -90 degrees), range [-pi, pi)
         double psi_r = atan2(-xd, yd);
         if (psi_r >= D_PI) psi_r -= 2.0 * D_PI;
-        row[2] = psi_r;
         const double kap = (xd * ydd - yd * xdd) / (q * sqrt(q));
-        row[3] = kap;
         const double len_r = lat.slen[pedge[i] + k];
-        row[4] = len_r;
+        store2_u(row, x, y); store2_u(row + 2, psi_r, kap); row[4] = len_r;
         if (vel_kappa) { vel_kappa[r] = kap; vel_len[r] = len_r; }
         if (out.vkap) {                                    // tiled planes of the batch velocity stage
             const size_t o = (((size_t)(vtile >> 6) * out.cap_pts) + r) * 64 + (vtile & 63);
