@@ -39,7 +39,8 @@ class LatticeDesc(C.Structure):
                 ("in_ptr", _pi32), ("edge_src", _pi32), ("edge_cost", _pf64), ("edge_len", _pf64),
                 ("samp_ptr", _pi32),
                 ("samp_x", _pf64), ("samp_y", _pf64), ("samp_psi", _pf64), ("samp_len", _pf64),
-                ("glob_rl", _pf64)]
+                ("glob_rl", _pf64),
+                ("normvec_x", _pf64), ("normvec_y", _pf64), ("width_right", _pf64), ("width_left", _pf64)]
 
 
 class Caps(C.Structure):
@@ -92,6 +93,31 @@ class TickVelIn(C.Structure):
                 ("veh_vel", _pf64)]
 
 
+class ObjectsIn(C.Structure):
+    _fields_ = [("n_obj", C.c_int32), ("reserved0", C.c_int32), ("dt", C.c_double),
+                ("x", _pf64), ("y", _pf64), ("theta", _pf64), ("v", _pf64), ("length", _pf64)]
+
+
+class ObjectsOut(C.Structure):
+    _fields_ = [("on_track", _pi32), ("pred_x", _pf64), ("pred_y", _pf64), ("radius", _pf64)]
+
+
+def make_objects(x, y, theta, v, length, dt=0.2):
+    """(ObjectsIn, ObjectsOut, output arrays dict, keep-alive list) for n flat objects."""
+    arrs = [_f64(a).reshape(-1) for a in (x, y, theta, v, length)]
+    n = arrs[0].size
+    if n == 0:
+        arrs = [np.zeros(1) for _ in arrs]
+    o = {"on_track": np.zeros(max(n, 1), np.int32), "pred_x": np.zeros(max(n, 1)), "pred_y": np.zeros(max(n, 1)),
+         "radius": np.zeros(max(n, 1))}
+    i, out = ObjectsIn(), ObjectsOut()
+    i.n_obj, i.dt = n, float(dt)
+    i.x, i.y, i.theta, i.v, i.length = (_p(a, _pf64) for a in arrs)
+    out.on_track = _p(o["on_track"], _pi32)
+    out.pred_x, out.pred_y, out.radius = _p(o["pred_x"], _pf64), _p(o["pred_y"], _pf64), _p(o["radius"], _pf64)
+    return i, out, {k: a[:n] for k, a in o.items()}, arrs
+
+
 class TickVelOut(C.Structure):
     _fields_ = [("vx", _pf64), ("ax", _pf64), ("vel_bound", _pi32), ("too_close", _pi32)]
 
@@ -135,6 +161,10 @@ class LatticeBinding(object):
         k["samp_psi"] = _f64(lat.samples[:, 2])
         k["samp_len"] = _f64(lat.samples[:, 4])
         k["glob_rl"] = _f64(lat.glob_rl)
+        k["normvec_x"] = _f64(lat.normvec[:, 0])
+        k["normvec_y"] = _f64(lat.normvec[:, 1])
+        k["width_right"] = _f64(lat.track_width_right)
+        k["width_left"] = _f64(lat.track_width_left)
         d = self.desc = LatticeDesc()
         d.num_layers, d.num_nodes, d.num_edges = lat.num_layers, lat.num_nodes, lat.num_edges
         d.num_samples, d.num_glob_rl = lat.num_samples, lat.glob_rl.shape[0]
@@ -398,6 +428,7 @@ class HipBackend(object):
         L.ltpl_batch_download.argtypes = [C.c_void_p, C.POINTER(PathsOut), C.POINTER(TickVelOut)]
         L.ltpl_batch_run_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
         L.ltpl_batch_last_paths_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.ltpl_process_objects.argtypes = [C.c_void_p, C.POINTER(ObjectsIn), C.POINTER(ObjectsOut)]
 
     def _check(self, rc):
         if rc != 0:
@@ -424,6 +455,14 @@ class HipBackend(object):
             result = self.new_paths_result(batch.n_scen)
         self._check(self.lib.ltpl_plan_paths(self.handle, C.byref(batch.struct), C.byref(result.struct)))
         return result
+
+    # ---- object ingestion ----
+    def process_objects(self, x, y, theta, v, length, dt=0.2):
+        """on_track flags, constant-velocity prediction points and radii for a flat list of objects."""
+        i, o, arrays, keep = make_objects(x, y, theta, v, length, dt)
+        if i.n_obj > 0:
+            self._check(self.lib.ltpl_process_objects(self.handle, C.byref(i), C.byref(o)))
+        return arrays
 
     # ---- seam (2) ----
     def vel_profile(self, params: VelParamSet, jobs):

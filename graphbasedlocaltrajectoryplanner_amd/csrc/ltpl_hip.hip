@@ -50,6 +50,8 @@ struct DevLat {
     const unsigned char* edge_rank8;  // [E]     rank of the edge among the in-edges of its destination
     const int* layer_degmax;          // [L]     largest in-degree of a node of layer l
     const unsigned* edge_meta;        // [E]     source node | destination node << 8 | in-edge rank << 16
+    // track bounds per layer: bound1 = refline + normvec w_right, bound2 = refline - normvec w_left, centre = (b1 + b2) / 2
+    const double* b1x; const double* b1y; const double* b2x; const double* b2y; const double* ctx; const double* cty;
     const double* edge_cx; const double* edge_cy; const double* edge_cr;   // [E] bounding circle of the edge's samples
 };
 
@@ -1274,6 +1276,54 @@ __global__ __launch_bounds__(64) void k_follow_prep(DevLat lat, DevPathsIn in, D
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// object ingestion: ObjectListInterface.process_object_list (ObjectListInterface.py:75-153)
+// ---------------------------------------------------------------------------------------------------------------------
+// One lane per object: closest centre-line point (first minimum), the neighbour with the larger opening angle
+// (get_s_coord.py:34-47,93-96 with closed = True), closest of the 50 np.linspace points between the two bracketing
+// points, comparison of the squared distances to the interpolated bounds with the squared track width
+// (check_inside_bounds.py:26-56); constant-velocity prediction and radius (ObjectListInterface.py:117-133).
+__global__ __launch_bounds__(64) void k_process_objects(DevLat lat, int n_obj, double dt, const double* ox, const double* oy,
+                                                        const double* oth, const double* ov, const double* olen,
+                                                        int* on_track, double* pred_x, double* pred_y, double* radius)
+{
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= n_obj) return;
+    const double px = ox[k], py = oy[k];
+    const int L = lat.L;
+    int nb = 0; double best = INFINITY;
+    for (int l = 0; l < L; ++l) {
+        const double dx = lat.ctx[l] - px, dy = lat.cty[l] - py;
+        const double d2 = dx * dx + dy * dy;
+        if (d2 < best) { best = d2; nb = l; }
+    }
+    int i1 = nb - 1; if (i1 < 0) i1 += L;
+    int i2 = nb + 1; if (i2 > L - 1) i2 = 0;
+    const double ang1 = fabs(angle3pt_dev(lat.ctx[nb], lat.cty[nb], px, py, lat.ctx[i1], lat.cty[i1]));
+    const double ang2 = fabs(angle3pt_dev(lat.ctx[nb], lat.cty[nb], px, py, lat.ctx[i2], lat.cty[i2]));
+    const int a = ang1 >= ang2 ? i1 : nb, b = ang1 >= ang2 ? nb : i2;
+    const double cax = lat.ctx[a], cay = lat.cty[a], cbx = lat.ctx[b], cby = lat.cty[b];
+    // np.linspace(start, stop, 50): y_i = i * ((stop - start) / 49) + start, y_49 = stop
+    const double sx = (cbx - cax) / 49.0, sy = (cby - cay) / 49.0;
+    int bi = 0; double bd = INFINITY;
+    for (int i = 0; i < 50; ++i) {
+        const double qx = i == 49 ? cbx : (double)i * sx + cax, qy = i == 49 ? cby : (double)i * sy + cay;
+        const double dx = qx - px, dy = qy - py;
+        const double d2 = dx * dx + dy * dy;
+        if (d2 < bd) { bd = d2; bi = i; }
+    }
+    auto lin = [&](double A, double B) { return bi == 49 ? B : (double)bi * ((B - A) / 49.0) + A; };
+    const double l1x = lin(lat.b1x[a], lat.b1x[b]), l1y = lin(lat.b1y[a], lat.b1y[b]);
+    const double l2x = lin(lat.b2x[a], lat.b2x[b]), l2y = lin(lat.b2y[a], lat.b2y[b]);
+    const double d_track_2 = (l1x - l2x) * (l1x - l2x) + (l1y - l2y) * (l1y - l2y);
+    const double d_b1_2 = (l1x - px) * (l1x - px) + (l1y - py) * (l1y - py);
+    const double d_b2_2 = (l2x - px) * (l2x - px) + (l2y - py) * (l2y - py);
+    on_track[k] = !(d_b1_2 > d_track_2 || d_b2_2 > d_track_2) ? 1 : 0;
+    pred_x[k] = px - sin(oth[k]) * ov[k] * dt;
+    pred_y[k] = py + cos(oth[k]) * ov[k] * dt;
+    radius[k] = olen[k] / 2.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 static thread_local std::string g_create_error;
@@ -1499,6 +1549,17 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
         std::vector<unsigned> meta((size_t)L.E);
         for (int e = 0; e < L.E; ++e) meta[(size_t)e] = (unsigned)src8[(size_t)e] | ((unsigned)dst8[(size_t)e] << 8) | ((unsigned)rank8[(size_t)e] << 16);
         UP(edge_meta, meta.data(), L.E);
+        if (d->normvec_x && d->normvec_y && d->width_right && d->width_left) {
+            // ObjectListInterface.py:71-72 and check_inside_bounds.py:27 (same operations, no contraction)
+            std::vector<double> b1x((size_t)L.L), b1y((size_t)L.L), b2x((size_t)L.L), b2y((size_t)L.L), cx((size_t)L.L), cy((size_t)L.L);
+            for (int l = 0; l < L.L; ++l) {
+                b1x[(size_t)l] = d->refline_x[l] + d->normvec_x[l] * d->width_right[l]; b1y[(size_t)l] = d->refline_y[l] + d->normvec_y[l] * d->width_right[l];
+                b2x[(size_t)l] = d->refline_x[l] - d->normvec_x[l] * d->width_left[l]; b2y[(size_t)l] = d->refline_y[l] - d->normvec_y[l] * d->width_left[l];
+                cx[(size_t)l] = (b1x[(size_t)l] + b2x[(size_t)l]) / 2; cy[(size_t)l] = (b1y[(size_t)l] + b2y[(size_t)l]) / 2;
+            }
+            UP(b1x, b1x.data(), L.L); UP(b1y, b1y.data(), L.L); UP(b2x, b2x.data(), L.L); UP(b2y, b2y.data(), L.L);
+            UP(ctx, cx.data(), L.L); UP(cty, cy.data(), L.L);
+        }
         // bounding circle per edge: centre of the samples' bounding box, radius = largest centre distance (inflated)
         std::vector<double> cx((size_t)L.E), cy((size_t)L.E), cr((size_t)L.E);
         for (int e = 0; e < L.E; ++e) {
@@ -1776,6 +1837,39 @@ extern "C" int ltpl_plan_paths(ltpl_handle* h, const ltpl_paths_in* in, ltpl_pat
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     dbg_report(h, "k_paths", in->n_scen);
     scatter_out(static_cast<const unsigned char*>(h->h_out), lo, in->n_scen, out);
+    return LTPL_OK;
+}
+
+extern "C" int ltpl_process_objects(ltpl_handle* h, const ltpl_objects_in* in, ltpl_objects_out* out)
+{
+    if (!h) return LTPL_ERR_INVALID_ARG;
+    if (!in || !out || in->n_obj < 1 || !in->x || !in->y || !in->theta || !in->v || !in->length ||
+        !out->on_track || !out->pred_x || !out->pred_y || !out->radius) { h->err = "null argument or n_obj < 1"; return LTPL_ERR_INVALID_ARG; }
+    if (!h->lat.ctx) { h->err = "the lattice was created without track bounds (normvec / width_right / width_left)"; return LTPL_ERR_UNSUPPORTED; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t n = (size_t)in->n_obj;
+    Arena ain, aout;
+    const size_t o_x = ain.add(8 * n), o_y = ain.add(8 * n), o_t = ain.add(8 * n), o_v = ain.add(8 * n), o_l = ain.add(8 * n);
+    const size_t o_px = aout.add(8 * n), o_py = aout.add(8 * n), o_r = aout.add(8 * n), o_on = aout.add(4 * n);
+    int rc;
+    if ((rc = ensure(h, &h->h_in, &h->h_in_cap, &h->d_in, &h->d_in_cap, ain.size))) return rc;
+    if ((rc = ensure(h, &h->h_out, &h->h_out_cap, &h->d_out, &h->d_out_cap, aout.size))) return rc;
+    unsigned char* hb = static_cast<unsigned char*>(h->h_in); unsigned char* db = static_cast<unsigned char*>(h->d_in);
+    unsigned char* dob = static_cast<unsigned char*>(h->d_out);
+    memcpy(hb + o_x, in->x, 8 * n); memcpy(hb + o_y, in->y, 8 * n); memcpy(hb + o_t, in->theta, 8 * n);
+    memcpy(hb + o_v, in->v, 8 * n); memcpy(hb + o_l, in->length, 8 * n);
+    HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, ain.size, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_process_objects, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, h->lat, in->n_obj, in->dt,
+                       reinterpret_cast<const double*>(db + o_x), reinterpret_cast<const double*>(db + o_y),
+                       reinterpret_cast<const double*>(db + o_t), reinterpret_cast<const double*>(db + o_v),
+                       reinterpret_cast<const double*>(db + o_l), reinterpret_cast<int*>(dob + o_on),
+                       reinterpret_cast<double*>(dob + o_px), reinterpret_cast<double*>(dob + o_py), reinterpret_cast<double*>(dob + o_r));
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, aout.size, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const unsigned char* ho = static_cast<const unsigned char*>(h->h_out);
+    memcpy(out->pred_x, ho + o_px, 8 * n); memcpy(out->pred_y, ho + o_py, 8 * n); memcpy(out->radius, ho + o_r, 8 * n);
+    memcpy(out->on_track, ho + o_on, 4 * n);
     return LTPL_OK;
 }
 

@@ -6,6 +6,7 @@ time:
 
   seam (1)  graph_ltpl.online_graph.src.main_online_path_gen.main_online_path_gen     (caller OTH.py:416-427)
   seam (2)  graph_ltpl.online_graph.src.VpForwardBackward.VpForwardBackward           (caller OTH.py:137-144)
+  next row  graph_ltpl.data_objects.ObjectListInterface.ObjectListInterface.process_object_list  (caller Graph_LTPL.py:322)
 
 ``install()`` assigns this package's mirrors to those two attributes and wraps ``OnlineTrajectoryHandler.__init__`` so
 that the lattice held by the reference's ``GraphBase`` is exported (``Lattice.from_graph_base``) and uploaded to HBM
@@ -21,6 +22,7 @@ import logging
 from . import _capi
 from .lattice import Lattice
 from .path_gen import OnlinePathGenerator
+from .object_ingest import make_process_object_list
 from .vp_forward_backward import VpForwardBackward
 
 
@@ -98,6 +100,12 @@ def install(graph_ltpl, backend_factory=None, device=-1) -> Session:
         return orig_init(self, graph_base, *args, **kwargs)
 
     oth_cls.__init__ = oth_init
+
+    # next row in front of seam (1): object ingestion (ObjectListInterface.process_object_list)
+    oli_mod = graph_ltpl.data_objects.ObjectListInterface
+    oli_cls = oli_mod.ObjectListInterface
+    session.originals["oli_process"] = (oli_cls, "process_object_list", oli_cls.process_object_list)
+    oli_cls.process_object_list = make_process_object_list(oli_mod, session)
     return session
 
 

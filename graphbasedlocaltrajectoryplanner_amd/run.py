@@ -47,9 +47,9 @@ def main(argv=None):
     from .install import install
     session = install(graph_ltpl, device=args.device)
 
+    cls = graph_ltpl.Graph_LTPL.Graph_LTPL
+    orig = cls.calc_vel_profile
     if args.ticks > 0:
-        cls = graph_ltpl.Graph_LTPL.Graph_LTPL
-        orig = cls.calc_vel_profile
         state = {"n": 0}
 
         def counted(self, *a, **kw):
@@ -62,7 +62,10 @@ def main(argv=None):
         cls.calc_vel_profile = counted
 
     sys.argv = [script] + list(args.script_args)
-    runpy.run_path(script, run_name="__main__")
+    try:
+        runpy.run_path(script, run_name="__main__")
+    finally:
+        cls.calc_vel_profile = orig          # the tick counter must not outlive the script (in-process callers, tests)
     return session
 
 

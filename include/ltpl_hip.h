@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LTPL_ABI_VERSION 1
+#define LTPL_ABI_VERSION 2
 
 /* status codes */
 #define LTPL_OK               0
@@ -98,6 +98,12 @@ typedef struct {
     const double*  samp_len;
     /* fine global race line, row-major [num_glob_rl][5] = s, x, y, kappa, vel    (GraphBase.glob_rl)             */
     const double*  glob_rl;
+    /* track bounds per layer (ObjectListInterface.set_track_data, ObjectListInterface.py:49-73; fed from GraphBase at
+     * Graph_LTPL.py:232-235): bound1 = refline + normvec * width_right, bound2 = refline - normvec * width_left       */
+    const double*  normvec_x;       /* [num_layers]                                                               */
+    const double*  normvec_y;
+    const double*  width_right;
+    const double*  width_left;
 } ltpl_lattice_desc;
 
 typedef struct {
@@ -226,6 +232,30 @@ typedef struct {
     int32_t* too_close;             /* [n_scen * LTPL_MAX_ACTIONS]                                                */
 } ltpl_tick_vel_out;
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * object ingestion: the arithmetic of ObjectListInterface.process_object_list
+ * (ObjectListInterface.py:75-153) for objects of type "physical": on-track test check_inside_bounds
+ * (check_inside_bounds.py:7-59), constant-velocity prediction over dt (:117-127, dt = 0.2 s) and radius = length / 2 (:133).
+ * One flat list of objects (the caller concatenates the objects of all scenarios).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t n_obj;
+    int32_t reserved0;
+    double  dt;                     /* prediction horizon, 0.2 in the reference                                  */
+    const double* x;                /* [n_obj] object_el['X']                                                     */
+    const double* y;                /* [n_obj] object_el['Y']                                                     */
+    const double* theta;            /* [n_obj] heading, 0 = north                                                 */
+    const double* v;                /* [n_obj]                                                                    */
+    const double* length;           /* [n_obj]                                                                    */
+} ltpl_objects_in;
+
+typedef struct {
+    int32_t* on_track;              /* [n_obj] 1 = inside the track bounds                                        */
+    double*  pred_x;                /* [n_obj] X - sin(theta) v dt                                                */
+    double*  pred_y;                /* [n_obj] Y + cos(theta) v dt                                                */
+    double*  radius;                /* [n_obj] length / 2                                                         */
+} ltpl_objects_out;
+
 /* --- lifecycle ---------------------------------------------------------------------------------------------------- */
 /* Uploads the lattice to HBM once (replaces the pickled GraphBase handed to OnlineTrajectoryHandler,
  * Graph_LTPL.py:202-229). device < 0 selects the current device. */
@@ -237,6 +267,9 @@ int ltpl_version(void);
 
 /* --- seam (1): main_online_path_gen.py:11 ------------------------------------------------------------------------- */
 int ltpl_plan_paths(ltpl_handle* handle, const ltpl_paths_in* in, ltpl_paths_out* out);
+
+/* --- object ingestion: ObjectListInterface.py:75-153, check_inside_bounds.py:7-59 --------------------------------- */
+int ltpl_process_objects(ltpl_handle* handle, const ltpl_objects_in* in, ltpl_objects_out* out);
 
 /* --- seam (2): VpForwardBackward.py:86,141,194,229 ---------------------------------------------------------------- */
 int ltpl_vel_profile(ltpl_handle* handle, const ltpl_vel_params* params, int n_jobs, const ltpl_vel_job* jobs,

@@ -35,6 +35,8 @@ class OracleBackend(object):
                                                C.POINTER(_capi.PathsOut)]
         self.lib.oracle_vel_profile.argtypes = [C.POINTER(_capi.LatticeDesc), C.POINTER(_capi.VelParams), C.c_int,
                                                 C.POINTER(_capi.VelJob), C.POINTER(_capi.VelResult)]
+        self.lib.oracle_process_objects.argtypes = [C.POINTER(_capi.LatticeDesc), C.POINTER(_capi.ObjectsIn),
+                                                    C.POINTER(_capi.ObjectsOut)]
         self.has_tick = hasattr(self.lib, "oracle_tick_batch")
         if self.has_tick:
             self.lib.oracle_tick_batch.argtypes = [C.POINTER(_capi.LatticeDesc), C.POINTER(_capi.PathsIn),
@@ -66,6 +68,12 @@ class OracleBackend(object):
         self._check(self.lib.oracle_vel_profile(C.byref(self.binding.desc), C.byref(params.struct), len(jobs), jarr,
                                                 rarr))
         return [(outs[i], bool(rarr[i].too_close), bool(rarr[i].vel_bound)) for i in range(len(jobs))]
+
+    def process_objects(self, x, y, theta, v, length, dt=0.2):
+        i, o, arrays, keep = _capi.make_objects(x, y, theta, v, length, dt)
+        if i.n_obj > 0:
+            self._check(self.lib.oracle_process_objects(C.byref(self.binding.desc), C.byref(i), C.byref(o)))
+        return arrays
 
     def tick_batch(self, batch, vel, result=None, vresult=None):
         if not self.has_tick:

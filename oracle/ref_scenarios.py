@@ -162,8 +162,9 @@ def get_objects(dummies):
 
 
 def run_loop(graph_ltpl, clock, ltpl_obj, path_dict, n_ticks, dt=0.05, dummies=None, zones=None,
-             action_pref=("right", "left", "straight", "follow"), on_tick=None):
-    """The example drivers' online loop with a fixed time step. Returns per-tick exported trajectory sets."""
+             action_pref=("right", "left", "straight", "follow"), on_tick=None, extra_objects=None):
+    """The example drivers' online loop with a fixed time step. Returns per-tick exported trajectory sets.
+    ``extra_objects(tick)`` may return further object-list dicts (objectlist_dummy.py:171-181 format) for that tick."""
     pos_est, vel_est = set_start(graph_ltpl, ltpl_obj, path_dict)
     traj_set = {'straight': None}
     exported = []
@@ -174,6 +175,8 @@ def run_loop(graph_ltpl, clock, ltpl_obj, path_dict, n_ticks, dt=0.05, dummies=N
             if sel_action in traj_set.keys():
                 break
         obj_list = get_objects(dummies) if dummies is not None else []
+        if extra_objects is not None:
+            obj_list = obj_list + list(extra_objects(tick))
         ltpl_obj.calc_paths(prev_action_id=sel_action, object_list=obj_list, blocked_zones=zones)
         if traj_set[sel_action] is not None:
             pos_est, vel_est = graph_ltpl.testing_tools.src.vdc_dummy.vdc_dummy(

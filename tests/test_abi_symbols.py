@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(lib_path)
     for sym in declared_symbols():
         assert hasattr(lib, sym), "libltpl_hip.so does not export %s" % sym
-    assert lib.ltpl_version() == 1
+    assert lib.ltpl_version() == 2
 
 
 def test_product_fails_loudly_without_library(monteblanco, tmp_path):

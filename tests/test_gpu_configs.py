@@ -178,3 +178,23 @@ def test_capacity_and_argument_errors(monteblanco, hip_backend):
     # the backend keeps working after errors
     ok = hip_backend.plan_paths(_capi.PathsBatch(scen, w_last_edges=[0.0, 0.5, 0.8]))
     assert int(ok.valid.sum()) >= 2
+
+
+def test_object_ingestion_matches_reference_and_oracle(monteblanco, hip_backend, oracle_backend):
+    """ltpl_process_objects: reference golden vectors (bit-exact on-track verdicts) and a large random set vs the oracle."""
+    from test_objects_golden import check_backend_against_golden
+    check_backend_against_golden(hip_backend)
+    lat = monteblanco
+    rng = np.random.default_rng(11)
+    n = 200000
+    l = rng.integers(0, lat.num_layers, n)
+    f = rng.uniform(0.0, 1.0, n)[:, None]
+    base = lat.refline[l] * (1 - f) + lat.refline[(l + 1) % lat.num_layers] * f
+    off = rng.uniform(-2.0, 2.0, n) * np.where(rng.random(n) < 0.5, lat.track_width_right[l], lat.track_width_left[l])
+    p = base + lat.normvec[l] * off[:, None]
+    th, v, ln = rng.uniform(-np.pi, np.pi, n), rng.uniform(0, 80, n), rng.uniform(3, 6, n)
+    a = hip_backend.process_objects(p[:, 0], p[:, 1], th, v, ln)
+    b = oracle_backend.process_objects(p[:, 0], p[:, 1], th, v, ln)
+    assert np.array_equal(a["on_track"], b["on_track"]) and 0.2 < a["on_track"].mean() < 0.8
+    assert np.allclose(a["pred_x"], b["pred_x"], rtol=0, atol=1e-11) and np.allclose(a["pred_y"], b["pred_y"], rtol=0, atol=1e-11)
+    assert np.array_equal(a["radius"], b["radius"])
