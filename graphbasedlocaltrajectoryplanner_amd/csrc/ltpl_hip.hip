@@ -138,13 +138,18 @@ struct WavePath { int valid; int n_pts; int n_nodes; int name; int reduced; int 
 
 #include "paths_team.hpp"
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 1 ? 4 : 1)) void k_paths(DevLat lat, DevPathsIn in, DevPathsOut out, TeamLds lp)
+// Waves per SIMD of the one-wave batch kernel: the register budget must hold the kernel WITHOUT register spills (builds of
+// this kernel that spilled VGPRs to scratch produced wrong parents on gfx950; __graft_entry__.build() rejects such builds).
+// Runtime plan (any lattice): 2 waves per SIMD = 256 VGPRs. Compile-time plan: 3 waves per SIMD = 168 VGPRs.
+template <int NW, class P>
+__global__ __launch_bounds__(64 * NW, (NW == 1 ? (P::fixed ? 3 : 2) : 1)) void k_paths(DevLat lat, DevPathsIn in, DevPathsOut out, TeamLds lp)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ TeamShared ts;
-    (void)team_paths_body<NW>(lat, in, out, lp, smem, ts, nullptr, nullptr, nullptr, nullptr);
+    (void)team_paths_body<NW, P>(lat, in, out, lp, smem, ts, nullptr, nullptr, nullptr, nullptr);
 }
+typedef PlanFx<32, 32, 1> PlanA;      // <= 32 nodes per layer, <= 31 layers of planning range (Monteblanco, stock parameters)
+typedef PlanFx<32, 40, 1> PlanB;      // <= 32 nodes per layer, <= 39 layers (synthetic C3 oval)
 
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -757,7 +762,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     VelScratch vs; double* px = nullptr; double* py = nullptr;
     if (wave < LTPL_MAX_ACTIONS) vs = carve_vel_scratch(smem + vel_off + (size_t)wave * vel_stride, vel_cap, false, true, &px, &py);
-    WavePath wp = team_paths_body<NUM_WAVES>(lat, in, out, lp, smem, ts, wave < LTPL_MAX_ACTIONS ? vs.kabs : nullptr,
+    WavePath wp = team_paths_body<NUM_WAVES, PlanRt>(lat, in, out, lp, smem, ts, wave < LTPL_MAX_ACTIONS ? vs.kabs : nullptr,
                                              wave < LTPL_MAX_ACTIONS ? vs.el : nullptr, px, py);
     const int s = blockIdx.x;
     // The fourth wave has no primitive of its own: it computes the unconstrained profile of the 'follow' slot
@@ -1337,6 +1342,7 @@ struct ltpl_handle {
     DevLat lat{};
     TeamLds lp1{}, lp4{};            // LDS plans of the path kernel: one wave / four waves per scenario
     int batch_nw = 1;                // waves per scenario used for batches (LTPL_BATCH_NW)
+    int plan_class = 0;              // LDS plan of the one-wave batch kernel: 0 = runtime (PlanRt), 1 = PlanA, 2 = PlanB
     ltpl_caps caps{};
     std::vector<void*> dev_allocs;
     // staging
@@ -1358,6 +1364,25 @@ struct ltpl_handle {
     std::vector<hipEvent_t> ev_step;          // timing events around the path kernel of every step of the last timed run
     float last_paths_ms = 0.0f; int last_paths_n = 0;
 };
+
+static const void* paths1_kernel_of(int plan_class)
+{
+    switch (plan_class) {
+        case 1: return reinterpret_cast<const void*>(k_paths<1, PlanA>);
+        case 2: return reinterpret_cast<const void*>(k_paths<1, PlanB>);
+        default: return reinterpret_cast<const void*>(k_paths<1, PlanRt>);
+    }
+}
+
+// the one-wave batch kernel in the LDS plan class chosen for the lattice at ltpl_create
+static void launch_paths1(ltpl_handle* h, int n_scen, hipStream_t st, const DevPathsIn& di, const DevPathsOut& dout)
+{
+    switch (h->plan_class) {
+        case 1: hipLaunchKernelGGL((k_paths<1, PlanA>), dim3(n_scen), dim3(64), h->lp1.total, st, h->lat, di, dout, h->lp1); break;
+        case 2: hipLaunchKernelGGL((k_paths<1, PlanB>), dim3(n_scen), dim3(64), h->lp1.total, st, h->lat, di, dout, h->lp1); break;
+        default: hipLaunchKernelGGL((k_paths<1, PlanRt>), dim3(n_scen), dim3(64), h->lp1.total, st, h->lat, di, dout, h->lp1); break;
+    }
+}
 
 static void dbg_report(ltpl_handle* h, const char* what, int n_blocks)
 {
@@ -1610,9 +1635,40 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
         lp->off_pos_veh = (int)off; off += MAX_POS; off = align_up(off, 16);
         lp->total = (int)off;
         lp->ablate = getenv("LTPL_ABLATE") ? atoi(getenv("LTPL_ABLATE")) : 0;
+        lp->poison_on = getenv("LTPL_LDS_POISON") ? 1 : 0;
+        lp->poison = lp->poison_on ? (unsigned)strtoul(getenv("LTPL_LDS_POISON"), nullptr, 0) : 0u;
         lp->dbg = nullptr;
     };
     make_plan(1, &h->lp1); make_plan(NUM_WAVES, &h->lp4);
+    // compile-time plan classes of the one-wave batch kernel: same arrays, hot offsets taken from the policy (PlanFx)
+    auto make_fixed_plan = [&](auto plan_tag, TeamLds* lp) {
+        typedef decltype(plan_tag) PL;
+        *lp = h->lp1;
+        lp->kpad = PL::c_kpad; lp->hmax = PL::c_hmax; lp->n_path_bufs = PL::c_n_path_bufs;
+        lp->off_dist = PL::c_off_dist; lp->off_cnt = PL::c_off_cnt; lp->off_widx = PL::c_off_widx; lp->off_dumin = PL::c_off_dumin;
+        lp->path_stride = PL::c_path_stride; lp->off_path = PL::c_off_path; lp->off_best = PL::c_off_best;
+        lp->off_par = PL::c_off_par; lp->off_lay = PL::c_off_lay;
+        size_t off = (size_t)PL::c_fixed_end;
+        lp->off_blocked = (int)off; off += sizeof(unsigned) * lp->words_blocked; off = align_up(off, 16);
+        lp->off_zone = (int)off; off += sizeof(unsigned) * lp->words_zone; off = align_up(off, 16);
+        lp->ref_lds = (sizeof(double) * 2 * (size_t)d->num_layers <= (size_t)PL::c_par_bytes) ? 1 : 0;
+        // the per-position tables are dead once phase 3 is over, the parent table is not written before phase 4: they
+        // share its storage (behind the staged reference line) when they fit
+        const size_t ref_bytes = lp->ref_lds ? align_up(sizeof(double) * 2 * (size_t)d->num_layers, 16) : 0;
+        const size_t pos_bytes = align_up(sizeof(short) * MAX_POS, 16) + align_up((size_t)MAX_POS, 16);
+        if (ref_bytes + pos_bytes <= (size_t)PL::c_par_bytes) {
+            lp->off_pos_layer = lp->off_par + (int)ref_bytes;
+            lp->off_pos_veh = lp->off_pos_layer + (int)align_up(sizeof(short) * MAX_POS, 16);
+        } else {
+            lp->off_pos_layer = (int)off; off += sizeof(short) * MAX_POS; off = align_up(off, 16);
+            lp->off_pos_veh = (int)off; off += MAX_POS; off = align_up(off, 16);
+        }
+        lp->total = (int)off;
+    };
+    if (!getenv("LTPL_NO_FIXED_PLAN")) {
+        if (kmax <= PlanA::c_kpad && hmax + 1 <= PlanA::c_hmax && d->num_layers >= PlanA::c_hmax) { h->plan_class = 1; make_fixed_plan(PlanA(), &h->lp1); }
+        else if (kmax <= PlanB::c_kpad && hmax + 1 <= PlanB::c_hmax && d->num_layers >= PlanB::c_hmax) { h->plan_class = 2; make_fixed_plan(PlanB(), &h->lp1); }
+    }
     if (const char* e = getenv("LTPL_BATCH_NW")) h->batch_nw = atoi(e) == 4 ? 4 : 1;
     if (getenv("LTPL_DEBUG_TIMING")) {
         if (hipMalloc(reinterpret_cast<void**>(&h->d_dbg), sizeof(long long) * 256 * DBG_SLOTS) == hipSuccess) {
@@ -1625,16 +1681,16 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
         return fail(LTPL_ERR_CAPACITY);
     }
     if (h->lp4.total > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_paths<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(paths1_kernel_of(h->plan_class), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 h->lp1.total) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_paths<NUM_WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_paths<NUM_WAVES, PlanRt>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 h->lp4.total) != hipSuccess) { h->err = "cannot raise dynamic LDS limit"; return fail(LTPL_ERR_HIP); }
     }
     if (getenv("LTPL_DEBUG_OCC")) {
         int nb1 = -1, nb4 = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, reinterpret_cast<const void*>(k_paths<1>), 64, (size_t)h->lp1.total);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb4, reinterpret_cast<const void*>(k_paths<NUM_WAVES>), WG_THREADS, (size_t)h->lp4.total);
-        fprintf(stderr, "[ltpl occ] k_paths<1>: %d blocks/CU at %d B LDS; k_paths<4>: %d blocks/CU at %d B LDS\n", nb1, h->lp1.total, nb4, h->lp4.total);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, paths1_kernel_of(h->plan_class), 64, (size_t)h->lp1.total);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb4, reinterpret_cast<const void*>(k_paths<NUM_WAVES, PlanRt>), WG_THREADS, (size_t)h->lp4.total);
+        fprintf(stderr, "[ltpl occ] k_paths<1> (plan class %d): %d blocks/CU at %d B LDS; k_paths<4>: %d blocks/CU at %d B LDS\n", h->plan_class, nb1, h->lp1.total, nb4, h->lp4.total);
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { h->err = "hipGetDeviceProperties failed"; return fail(LTPL_ERR_HIP); }
@@ -1809,6 +1865,23 @@ static void scatter_out(const unsigned char* hb, const OutLayout& lo, int n, ltp
     memcpy(out->path_param, hb + lo.path_param, sizeof(double) * n * A * cp * 5);
 }
 
+// testing only (LTPL_SCRATCH_POISON=<hex word>): fills the private-segment arena of the stream with a pattern before the
+// path kernel runs, so that a reload of a register spill slot the lane never stored shows up as a parity failure
+__global__ __launch_bounds__(64) void k_scratch_poison(unsigned pattern, unsigned* sink)
+{
+    volatile unsigned a[256];
+    for (int i = 0; i < 256; ++i) a[i] = pattern;
+    unsigned acc = 0;
+    for (int i = 0; i < 256; i += 37) acc += a[i];
+    if (acc == 0x12345u && sink) *sink = acc;
+}
+
+static void scratch_poison(ltpl_handle* h)
+{
+    if (const char* e = getenv("LTPL_SCRATCH_POISON"))
+        hipLaunchKernelGGL(k_scratch_poison, dim3(256 * 64), dim3(64), 0, h->stream, (unsigned)strtoul(e, nullptr, 0), (unsigned*)nullptr);
+}
+
 extern "C" int ltpl_plan_paths(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_out* out)
 {
     if (!h) return LTPL_ERR_INVALID_ARG;
@@ -1828,10 +1901,11 @@ extern "C" int ltpl_plan_paths(ltpl_handle* h, const ltpl_paths_in* in, ltpl_pat
     pack_in(in, li, static_cast<unsigned char*>(h->h_in), static_cast<const unsigned char*>(h->d_in), &di);
     bind_out(static_cast<unsigned char*>(h->d_out), lo, out->cap_nodes, out->cap_pts, &dout);
     HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, li.total, hipMemcpyHostToDevice, h->stream));
+    scratch_poison(h);
     if (in->n_scen >= PIPELINE_MIN_SCEN && h->batch_nw == 1)
-        hipLaunchKernelGGL(k_paths<1>, dim3(in->n_scen), dim3(64), h->lp1.total, h->stream, h->lat, di, dout, h->lp1);
+        launch_paths1(h, in->n_scen, h->stream, di, dout);
     else
-        hipLaunchKernelGGL(k_paths<NUM_WAVES>, dim3(in->n_scen), dim3(WG_THREADS), h->lp4.total, h->stream, h->lat, di, dout, h->lp4);
+        hipLaunchKernelGGL((k_paths<NUM_WAVES, PlanRt>), dim3(in->n_scen), dim3(WG_THREADS), h->lp4.total, h->stream, h->lat, di, dout, h->lp4);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, lo.total, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -2117,9 +2191,9 @@ static int tick_launch_paths(ltpl_handle* h, const TickLayout& t, hipStream_t st
 {
     if (t.dout.job_cnt) HIP_TRY(h, hipMemsetAsync(t.dout.job_cnt, 0, 2 * sizeof(int), st));
     if (h->batch_nw == 1)
-        hipLaunchKernelGGL(k_paths<1>, dim3(t.n_scen), dim3(64), h->lp1.total, st, h->lat, t.di, t.dout, h->lp1);
+        launch_paths1(h, t.n_scen, st, t.di, t.dout);
     else
-        hipLaunchKernelGGL(k_paths<NUM_WAVES>, dim3(t.n_scen), dim3(WG_THREADS), h->lp4.total, st, h->lat, t.di, t.dout, h->lp4);
+        hipLaunchKernelGGL((k_paths<NUM_WAVES, PlanRt>), dim3(t.n_scen), dim3(WG_THREADS), h->lp4.total, st, h->lat, t.di, t.dout, h->lp4);
     HIP_TRY(h, hipGetLastError());
     return LTPL_OK;
 }

@@ -46,6 +46,8 @@ struct TeamLds {                 // dynamic-LDS plan (byte offsets), computed on
     int path_stride, n_path_bufs;
     int total;
     int ablate;                  // profiling only (LTPL_ABLATE): 1 = skip the mask, 2 = skip the sweeps, 4 = skip path assembly
+    int poison_on; unsigned poison;   // testing only (LTPL_LDS_POISON=<hex word>): fill the team's LDS before phase 0, so that a read of
+                                 // LDS the scenario has not written itself shows up as a parity failure instead of depending on stale data
     long long* dbg;
 };
 
@@ -60,6 +62,48 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)
 // `default` itself or branch left / right off its prefix), so they share one table; three tables serve four filters.
 #define NPAR 3
 __device__ __forceinline__ constexpr int par_tab(int f) { return f == F_PR ? 0 : (f == F_RIGHT ? 2 : 1); }
+
+// LDS plan policies. The sweep's hot arrays (frontiers, election words, reachability, parents, layer table) are addressed
+// through a policy: PlanRt reads every offset from the host-computed TeamLds (any lattice); PlanFx<KPAD, HM, NW> fixes the
+// row pitch, the table height and therewith all hot offsets at compile time, so the address arithmetic folds into
+// instruction offsets (fewer live registers: the one-wave batch kernel then needs no register spills). The variable-size
+// arrays (edge mask, zone mask, per-position tables) keep runtime offsets in both policies.
+constexpr int plan_align16(int x) { return (x + 15) / 16 * 16; }
+struct PlanRt {
+    static constexpr bool fixed = false;
+#define LTPL_PLAN_FIELD(name) static __device__ __forceinline__ int name(const TeamLds& lp) { return lp.name; }
+    LTPL_PLAN_FIELD(kpad) LTPL_PLAN_FIELD(hmax) LTPL_PLAN_FIELD(off_dist) LTPL_PLAN_FIELD(off_cnt) LTPL_PLAN_FIELD(off_widx)
+    LTPL_PLAN_FIELD(off_dumin) LTPL_PLAN_FIELD(off_best) LTPL_PLAN_FIELD(off_par) LTPL_PLAN_FIELD(off_lay)
+    LTPL_PLAN_FIELD(off_path) LTPL_PLAN_FIELD(path_stride) LTPL_PLAN_FIELD(n_path_bufs)
+#undef LTPL_PLAN_FIELD
+};
+template <int KPAD, int HM, int NW>
+struct PlanFx {
+    static constexpr bool fixed = true;
+    static constexpr int c_kpad = KPAD, c_hmax = HM;
+    static constexpr int c_n_path_bufs = NW < LTPL_MAX_ACTIONS ? NW : LTPL_MAX_ACTIONS;
+    static constexpr int c_off_dist = 0;
+    static constexpr int c_off_cnt = c_off_dist + 8 * NFILT * 2 * KPAD;
+    static constexpr int c_off_widx = c_off_cnt + 4 * NFILT * KPAD;
+    static constexpr int c_off_dumin = plan_align16(c_off_widx + 4 * NFILT * KPAD);
+    static constexpr int c_end_elect = c_off_dumin + 8 * NFILT * KPAD;
+    static constexpr int c_path_stride = plan_align16(8 * 7 * HM + 4 * 2 * (HM + 1));
+    // one-wave teams: the path scratch aliases the frontier / election arrays (dead during path assembly)
+    static constexpr int c_off_path = c_n_path_bufs == 1 ? c_off_dist : c_end_elect;
+    static constexpr int c_after_path = c_n_path_bufs == 1
+        ? (c_end_elect > c_off_dist + c_path_stride ? c_end_elect : c_off_dist + c_path_stride)
+        : c_end_elect + c_path_stride * c_n_path_bufs;
+    static constexpr int c_off_best = c_after_path;
+    static constexpr int c_off_par = plan_align16(c_off_best + 4 * NFILT * HM);
+    static constexpr int c_par_bytes = 2 * NPAR * HM * KPAD;
+    static constexpr int c_off_lay = plan_align16(c_off_par + c_par_bytes);
+    static constexpr int c_fixed_end = c_off_lay + 16 * HM;
+#define LTPL_PLAN_FIELD(name) static __host__ __device__ __forceinline__ constexpr int name(const TeamLds&) { return c_##name; }
+    LTPL_PLAN_FIELD(kpad) LTPL_PLAN_FIELD(hmax) LTPL_PLAN_FIELD(off_dist) LTPL_PLAN_FIELD(off_cnt) LTPL_PLAN_FIELD(off_widx)
+    LTPL_PLAN_FIELD(off_dumin) LTPL_PLAN_FIELD(off_best) LTPL_PLAN_FIELD(off_par) LTPL_PLAN_FIELD(off_lay)
+    LTPL_PLAN_FIELD(off_path) LTPL_PLAN_FIELD(path_stride) LTPL_PLAN_FIELD(n_path_bufs)
+#undef LTPL_PLAN_FIELD
+};
 
 struct TeamShared {
     int closest_idx, cl, cn, have_cn;          // written by wave 0 in phase 3
@@ -153,6 +197,7 @@ __device__ __forceinline__ void team_serial_node(const DevLat& lat, const Scen& 
     }
 }
 
+template <class P>
 __device__ __forceinline__ bool team_relax_layer(const DevLat& lat, const DevPathsIn& in, const Scen& sc, const TeamLds& lp,
                                                  unsigned char* smem, int cl, int cn, int f, int j, int b, int v0, int Kb,
                                                  const double* dprev, double* dcur, uchar2* pj, int lane,
@@ -170,7 +215,7 @@ __device__ __forceinline__ bool team_relax_layer(const DevLat& lat, const DevPat
         pj[n] = make_uchar2((unsigned char)bsrc, (unsigned char)(bk | (tie ? 0x80 : 0)));
         any = any || (bestc < INFINITY);
     }
-    for (int n = Kb + lane; n < lp.kpad; n += 64) dcur[n] = INFINITY;
+    for (int n = Kb + lane; n < P::kpad(lp); n += 64) dcur[n] = INFINITY;
     return __ballot(any) != 0ull;
 }
 
@@ -189,14 +234,15 @@ __device__ __forceinline__ void team_factor(const DevLat& lat, const DevPathsIn&
 
 // Re-sweep of one filter up to layer J straight from global memory (reduced-horizon paths only: the goal node of a
 // layer in front of the planning horizon is needed). Parents are rewritten with identical values.
+template <class P>
 __device__ void team_resweep(const DevLat& lat, const DevPathsIn& in, const Scen& sc, const TeamLds& lp, unsigned char* smem,
                              const TeamShared& ts, int f, int J, int lane)
 {
-    double* dist = reinterpret_cast<double*>(smem + lp.off_dist);
-    uchar2* par = reinterpret_cast<uchar2*>(smem + lp.off_par);
-    int* best = reinterpret_cast<int*>(smem + lp.off_best);
+    double* dist = reinterpret_cast<double*>(smem + P::off_dist(lp));
+    uchar2* par = reinterpret_cast<uchar2*>(smem + P::off_par(lp));
+    int* best = reinterpret_cast<int*>(smem + P::off_best(lp));
     const unsigned* zone_bits = reinterpret_cast<const unsigned*>(smem + lp.off_zone);
-    const int L = lat.L, kpad = lp.kpad;
+    const int L = lat.L, kpad = P::kpad(lp);
     double* d0 = dist + (size_t)(f * 2) * kpad;
     const int K0 = lat.layer_off[sc.sl + 1] - lat.layer_off[sc.sl];
     const bool ok = sc.sn >= 0 && sc.sn < K0 &&
@@ -210,29 +256,30 @@ __device__ void team_resweep(const DevLat& lat, const DevPathsIn& in, const Scen
         team_factor(lat, in, sc, j, b, fs, fd, fac);
         const double* dprev = dist + (size_t)(f * 2 + ((j - 1) & 1)) * kpad;
         double* dcur = dist + (size_t)(f * 2 + (j & 1)) * kpad;
-        (void)team_relax_layer(lat, in, sc, lp, smem, ts.cl, ts.cn, f, j, b, v0, Kb, dprev, dcur,
-                                par + ((size_t)par_tab(f) * lp.hmax + j) * kpad, lane, fs, fd, fac);
+        (void)team_relax_layer<P>(lat, in, sc, lp, smem, ts.cl, ts.cn, f, j, b, v0, Kb, dprev, dcur,
+                                par + ((size_t)par_tab(f) * P::hmax(lp) + j) * kpad, lane, fs, fd, fac);
         wave_sync_lds();
     }
     int b = sc.sl + J; if (b >= L) b -= L;
     const int v0 = lat.layer_off[b], Kb = lat.layer_off[b + 1] - v0;
     const int g = team_goal(lat, dist + (size_t)(f * 2 + (J & 1)) * kpad, v0, Kb, lane);
-    if (lane == 0) best[f * lp.hmax + J] = g;
+    if (lane == 0) best[f * P::hmax(lp) + J] = g;
     wave_sync_lds();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // phase 6: assemble primitive `a` (one wave): backtrack, gather, spline, re-sampling (main_online_path_gen.py:250-328)
 // ---------------------------------------------------------------------------------------------------------------------
+template <class P>
 __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const Scen& sc,
                                   const TeamLds& lp, unsigned char* smem, int a, int f, int J, int name, int reduced,
                                   int jcl, bool share_prefix, int lane, unsigned char* pw,
                                   double* vel_kappa, double* vel_len, double* vel_x, double* vel_y)
 {
-    const int L = lat.L, hm = lp.hmax, N = J, s = sc.s;
+    const int L = lat.L, hm = P::hmax(lp), N = J, s = sc.s;
     const int slot = s * LTPL_MAX_ACTIONS + a;
-    const uchar2* par = reinterpret_cast<const uchar2*>(smem + lp.off_par);
-    const int* best = reinterpret_cast<const int*>(smem + lp.off_best);
+    const uchar2* par = reinterpret_cast<const uchar2*>(smem + P::off_par(lp));
+    const int* best = reinterpret_cast<const int*>(smem + P::off_best(lp));
     double* kx = reinterpret_cast<double*>(pw);
     double* ky = kx + hm; double* el = ky + hm; double* mx = el + hm; double* my = mx + hm;
     double* cpx = my + hm; double* cpy = cpx + hm;
@@ -262,7 +309,7 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
         int n = bj & 0xffff;
         for (int j = J; j >= 1; --j) {
             const int pf = (share_prefix && j < jcl) ? F_DEF : f;
-            const uchar2 pr = par[((size_t)par_tab(pf) * hm + j) * lp.kpad + n];
+            const uchar2 pr = par[((size_t)par_tab(pf) * hm + j) * P::kpad(lp) + n];
             pidx[j] = n;                                   // node of layer j (temporarily)
             pedge[j - 1] = pr.y & 0x7f;
             ties += (pr.y >> 7) & 1;
@@ -428,18 +475,18 @@ struct LayerArgs {
     double fac;
 };
 
-template <int NW, int CH, unsigned ACT>
+template <class P, int NW, int CH, unsigned ACT>
 __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, const TeamLds& lp, unsigned char* smem,
                                            const LayerArgs& A, const EdgeRegs (&er)[CH], const unsigned long long (&blkm)[CH],
                                            int wave, int lane)
 {
     const unsigned* blocked_bits = reinterpret_cast<const unsigned*>(smem + lp.off_blocked);
     const unsigned* zone_bits = reinterpret_cast<const unsigned*>(smem + lp.off_zone);
-    double* dist = reinterpret_cast<double*>(smem + lp.off_dist);
-    uchar2* par = reinterpret_cast<uchar2*>(smem + lp.off_par);
-    int* best = reinterpret_cast<int*>(smem + lp.off_best);
-    unsigned* cnt_all = reinterpret_cast<unsigned*>(smem + lp.off_cnt);
-    unsigned* widx_all = reinterpret_cast<unsigned*>(smem + lp.off_widx);
+    double* dist = reinterpret_cast<double*>(smem + P::off_dist(lp));
+    uchar2* par = reinterpret_cast<uchar2*>(smem + P::off_par(lp));
+    int* best = reinterpret_cast<int*>(smem + P::off_best(lp));
+    unsigned* cnt_all = reinterpret_cast<unsigned*>(smem + P::off_cnt(lp));
+    unsigned* widx_all = reinterpret_cast<unsigned*>(smem + P::off_widx(lp));
     const int kpad = A.kpad, tid = wave * 64 + lane;
     constexpr int NT = NW * 64;
     int poff[NFILT], coff[NFILT];
@@ -482,7 +529,7 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
     // transitions with more edges than the register image: the rest straight from global memory (rare, not prefetched);
     // ROUND = 0: atomic min of the candidate sums, 1: election among the edges that attain it, 2 / 3: exact tie-break
     auto tail_edges = [&](int ROUND) {
-        double* dumin = reinterpret_cast<double*>(smem + lp.off_dumin);
+        double* dumin = reinterpret_cast<double*>(smem + P::off_dumin(lp));
         for (int ei = CH * NT + tid; ei < A.ne; ei += NT) {
             const int e = A.eb + ei;
             double c = lat.edge_cost[e];
@@ -540,7 +587,7 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
             for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) tied = tied || cnt_all[f * kpad + n] >= 2u;
         }
         if (__ballot(tied) != 0ull) {
-            double* dumin = reinterpret_cast<double*>(smem + lp.off_dumin);
+            double* dumin = reinterpret_cast<double*>(smem + P::off_dumin(lp));
             for (int n = tid; n < A.Kb; n += NT) {
 #pragma unroll
                 for (int f = 0; f < NFILT; ++f)
@@ -595,7 +642,7 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
 // ---------------------------------------------------------------------------------------------------------------------
 // the team body. Returns, for every wave, the result of the LAST primitive the wave assembled (NW = 4: wave a <-> slot a)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NW>
+template <int NW, class P>
 __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out,
                                                     const TeamLds& lp, unsigned char* smem, TeamShared& ts,
                                                     double* vel_kappa, double* vel_len, double* vel_x, double* vel_y)
@@ -609,14 +656,21 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     unsigned char* pos_veh = smem + lp.off_pos_veh;
     unsigned* blocked_bits = reinterpret_cast<unsigned*>(smem + lp.off_blocked);
     unsigned* zone_bits = reinterpret_cast<unsigned*>(smem + lp.off_zone);
-    double* dist = reinterpret_cast<double*>(smem + lp.off_dist);
-    uchar2* par = reinterpret_cast<uchar2*>(smem + lp.off_par);
-    int* best = reinterpret_cast<int*>(smem + lp.off_best);
-    int4* lay = reinterpret_cast<int4*>(smem + lp.off_lay);
+    double* dist = reinterpret_cast<double*>(smem + P::off_dist(lp));
+    uchar2* par = reinterpret_cast<uchar2*>(smem + P::off_par(lp));
+    int* best = reinterpret_cast<int*>(smem + P::off_best(lp));
+    int4* lay = reinterpret_cast<int4*>(smem + P::off_lay(lp));
 
     dbg_stamp(lp.dbg, 0);
     // ---- phase 0: scenario scalars (uniform; the planning range only depends on the start layer and is tabulated at
     //      ltpl_create: gen_local_node_template.py:101-147) -----------------------------------------------------------
+    if (lp.poison_on) {
+        unsigned* w = reinterpret_cast<unsigned*>(smem);
+        for (int i = tid; i < lp.total / 4; i += NT) w[i] = lp.poison;
+        unsigned* tw = reinterpret_cast<unsigned*>(&ts);
+        for (int i = tid; i < (int)(sizeof(TeamShared) / 4); i += NT) tw[i] = lp.poison;
+        team_sync<NW>();
+    }
     Scen sc;
     sc.s = blockIdx.x;
     sc.sl = in.start_layer[sc.s]; sc.sn = in.start_node[sc.s]; sc.flags = in.flags[sc.s];
@@ -627,7 +681,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     sc.el = lat.rng_end[sc.sl];
     sc.pos0 = in.pos_off[sc.veh0]; sc.n_pos = in.pos_off[sc.veh0 + sc.n_veh] - sc.pos0;
     sc.H = sc.el - sc.sl; if (sc.H < 0) sc.H = L - sc.sl + sc.el;
-    const int H = sc.H, kpad = lp.kpad, hm = lp.hmax;
+    const int H = sc.H, kpad = P::kpad(lp), hm = P::hmax(lp);
 
     for (int i = tid; i < lp.words_blocked; i += NT) blocked_bits[i] = 0u;
     for (int i = tid; i < lp.words_zone; i += NT) zone_bits[i] = 0u;
@@ -650,7 +704,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
         for (int p = p0; p < p1; ++p) pos_veh[p] = (unsigned char)k;
     }
     // reference line -> LDS (aliases the parent table, which is not live before phase 4)
-    double* refl = reinterpret_cast<double*>(smem + lp.off_par);
+    double* refl = reinterpret_cast<double*>(smem + P::off_par(lp));
     if (lp.ref_lds)
         for (int l = tid; l < L; l += NT) { refl[2 * l] = lat.ref_x[l]; refl[2 * l + 1] = lat.ref_y[l]; }
     team_sync<NW>();
@@ -928,11 +982,11 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             if (A.Kb <= 64 && known) {
                 // compile-time specialisations per filter set
                 switch (actm) {
-                    case (1u << F_DEF): team_layer<NW, CH, (1u << F_DEF)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
-                    case (1u << F_PR): team_layer<NW, CH, (1u << F_PR)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
-                    case (1u << F_PR) | (1u << F_DEF): team_layer<NW, CH, (1u << F_PR) | (1u << F_DEF)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
+                    case (1u << F_DEF): team_layer<P, NW, CH, (1u << F_DEF)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
+                    case (1u << F_PR): team_layer<P, NW, CH, (1u << F_PR)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
+                    case (1u << F_PR) | (1u << F_DEF): team_layer<P, NW, CH, (1u << F_PR) | (1u << F_DEF)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
                     default:
-                        team_layer<NW, CH, (1u << F_PR) | (1u << F_LEFT) | (1u << F_RIGHT)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
+                        team_layer<P, NW, CH, (1u << F_PR) | (1u << F_LEFT) | (1u << F_RIGHT)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
                 }
             } else {
                 // more than 64 nodes in the layer (or an unknown filter set): serial form (lane = node)
@@ -940,7 +994,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                     if (!((actm >> f) & 1u)) continue;
                     const int fprev = (A.from_def && (f == F_LEFT || f == F_RIGHT)) ? F_DEF : f;
                     double* dcur = dist + (size_t)(f * 2 + A.cur) * kpad;
-                    const bool any = team_relax_layer(lat, in, sc, lp, smem, t_cl, t_cn, f, j, b, A.v0, A.Kb,
+                    const bool any = team_relax_layer<P>(lat, in, sc, lp, smem, t_cl, t_cn, f, j, b, A.v0, A.Kb,
                                                       dist + (size_t)(fprev * 2 + A.prv) * kpad, dcur,
                                                       par + ((size_t)par_tab(f) * hm + j) * kpad, lane, A.fs, A.fd, A.fac);
                     if (lane == 0) best[f * hm + j] = any ? -2 : -1;
@@ -1018,7 +1072,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             for (int a = 0; a < n_act; ++a) if (slot_valid[a] && filt[a] == f && slot_j[a] != H) Jf = slot_j[a];
             if (Jf < 0) continue;
             any_resweep = true;
-            if (wave == f % NW) team_resweep(lat, in, sc, lp, smem, ts, f, Jf, lane);
+            if (wave == f % NW) team_resweep<P>(lat, in, sc, lp, smem, ts, f, Jf, lane);
         }
         if (any_resweep) team_sync<NW>();
     }
@@ -1030,10 +1084,10 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     for (int a = wave; a < n_act; a += NW) {
         wp.name = slot_name[a]; wp.reduced = slot_red[a]; wp.valid = 0;
         if (!slot_valid[a] || (lp.ablate & 4)) continue;
-        unsigned char* pw = smem + lp.off_path + (size_t)(wave < lp.n_path_bufs ? wave : lp.n_path_bufs - 1) * lp.path_stride;
+        unsigned char* pw = smem + P::off_path(lp) + (size_t)(wave < P::n_path_bufs(lp) ? wave : P::n_path_bufs(lp) - 1) * P::path_stride(lp);
         // after a re-sweep the parents of every layer belong to filter f itself
         const bool sp = share_prefix && (filt[a] == F_LEFT || filt[a] == F_RIGHT) && slot_j[a] == H;
-        wp = team_assemble(lat, in, out, sc, lp, smem, a, filt[a], slot_j[a], slot_name[a], slot_red[a], jcl, sp, lane, pw,
+        wp = team_assemble<P>(lat, in, out, sc, lp, smem, a, filt[a], slot_j[a], slot_name[a], slot_red[a], jcl, sp, lane, pw,
                            vel_kappa, vel_len, vel_x, vel_y);
     }
     dbg_stamp(lp.dbg, 7);

@@ -45,3 +45,15 @@ def test_product_package_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("oracle/", "").replace("the oracle", "") or f == "__init__.py", \
                     "%s mentions the oracle" % f
+
+
+def test_path_kernels_have_no_register_spills():
+    """__graft_entry__.build() rejects a library whose path kernels spill VGPRs (see check_no_register_spills)."""
+    import __graft_entry__ as g
+    g.build_hip()
+    res = g.kernel_resources(g.HIP_LIB)
+    paths = {k: v for k, v in res.items() if "k_paths" in k}
+    assert len(paths) >= 3                                  # runtime plan (1 and 4 waves) + compile-time plan classes
+    for name, r in paths.items():
+        assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, name
+    g.check_no_register_spills(g.HIP_LIB)

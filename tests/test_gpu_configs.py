@@ -63,6 +63,25 @@ def test_c3_synthetic_lattice_matches_oracle(c3):
                 assert np.array_equal(r1.path_param[0, a, :npts], res.path_param[i, a, :npts])
 
 
+@pytest.mark.parametrize("env", [{"LTPL_NO_FIXED_PLAN": "1"},
+                                 {"LTPL_LDS_POISON": "0xfff80000"},
+                                 {"LTPL_LDS_POISON": "0x00000001", "LTPL_NO_FIXED_PLAN": "1"}])
+def test_batch_kernel_plan_classes_and_stale_lds(env, monteblanco, oracle_backend, monkeypatch):
+    """The one-wave batch kernel exists in compile-time LDS plan classes and with a runtime plan (any lattice): both must
+    give the same bits. LTPL_LDS_POISON fills the team's LDS with a word before phase 0 -- a scenario must not depend on
+    what an earlier workgroup left behind."""
+    from oracle.oracle_lib import OracleBackend
+    from scenarios import random_scenarios
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    lat3 = c3_lattice()
+    for lat, orc, scen in ((monteblanco, oracle_backend, random_scenarios(monteblanco, 192, seed=7, n_veh=8)[0]),
+                           (lat3, OracleBackend(lat3), scattered_obstacle_scenarios(lat3, 128, n_obj=32, seed=3)[0])):
+        hip = _capi.HipBackend(lat)                       # environment is read at ltpl_create
+        batch = _capi.PathsBatch(scen, w_last_edges=[0.0, 0.5, 0.8])
+        compare_results(hip.plan_paths(batch), orc.plan_paths(batch), lat)
+
+
 def test_c4_sharded_batch_is_bit_identical(monteblanco, hip_backend):
     lat = monteblanco
     n, world = 1024, 8

@@ -38,7 +38,7 @@ def short(name):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    dominant = sys.argv[2] if len(sys.argv) > 2 else "k_plan_paths_prep"
+    dominant = sys.argv[2] if len(sys.argv) > 2 else "k_paths<1"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
