@@ -140,9 +140,10 @@ struct WavePath { int valid; int n_pts; int n_nodes; int name; int reduced; int 
 
 // Waves per SIMD of the one-wave batch kernel: the register budget must hold the kernel WITHOUT register spills (builds of
 // this kernel that spilled VGPRs to scratch produced wrong parents on gfx950; __graft_entry__.build() rejects such builds).
-// Runtime plan (any lattice): 2 waves per SIMD = 256 VGPRs. Compile-time plan: 3 waves per SIMD = 168 VGPRs.
+// Runtime plan (any lattice): 2 waves per SIMD = 256 VGPRs. Compile-time plan (three register chunks of edges): 4 waves per
+// SIMD = 128 VGPRs.
 template <int NW, class P>
-__global__ __launch_bounds__(64 * NW, (NW == 1 ? (P::fixed ? 3 : 2) : 1)) void k_paths(DevLat lat, DevPathsIn in, DevPathsOut out, TeamLds lp)
+__global__ __launch_bounds__(64 * NW, (NW == 1 ? (P::fixed ? 4 : 2) : 1)) void k_paths(DevLat lat, DevPathsIn in, DevPathsOut out, TeamLds lp)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ TeamShared ts;
@@ -1554,13 +1555,13 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
         // derived tables: planning range per start layer, first edge into every layer, byte-wide edge sources
         std::vector<int> ebase((size_t)L.L + 1);
         for (int l = 0; l <= L.L; ++l) ebase[(size_t)l] = d->in_ptr[d->layer_node_off[l]];
-        std::vector<unsigned char> src8((size_t)L.E);
+        std::vector<unsigned char> src8((size_t)L.E + 16, (unsigned char)0xff);   // padded: path assembly reads 16 bytes at a time
         for (int e = 0; e < L.E; ++e) src8[(size_t)e] = (unsigned char)d->edge_src[e];
         std::vector<unsigned char> dst8((size_t)L.E);
         for (int l = 0; l < L.L; ++l)
             for (int v = d->layer_node_off[l]; v < d->layer_node_off[l + 1]; ++v)
                 for (int e = d->in_ptr[v]; e < d->in_ptr[v + 1]; ++e) dst8[(size_t)e] = (unsigned char)(v - d->layer_node_off[l]);
-        UP(rng_end, rng_end.data(), L.L); UP(layer_ebase, ebase.data(), L.L + 1); UP(edge_src8, src8.data(), L.E);
+        UP(rng_end, rng_end.data(), L.L); UP(layer_ebase, ebase.data(), L.L + 1); UP(edge_src8, src8.data(), L.E + 16);
         UP(edge_dst8, dst8.data(), L.E);
         std::vector<unsigned char> rank8((size_t)L.E);
         for (int v = 0; v < L.V; ++v)

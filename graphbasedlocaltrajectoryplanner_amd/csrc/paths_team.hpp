@@ -35,7 +35,8 @@ struct TeamLds {                 // dynamic-LDS plan (byte offsets), computed on
     int off_blocked;             // u32[words_blocked]
     int off_zone;                // u32[words_zone]
     int off_dist;                // double[NFILT][2][kpad]
-    int off_par;                 // uchar2[NPAR][hmax][kpad]  (.x = source node, .y = in-edge rank | tie bit 0x80); table = par_tab(filter)
+    int off_par;                 // parent entries [NPAR][hmax][kpad], table = par_tab(filter); PlanRt: 2 bytes (source node, in-edge rank |
+                                 // tie bit 0x80), PlanFx: 1 byte (source node | tie bit 0x80; the in-edge is looked up at path assembly)
     int off_best;                // int[NFILT][hmax]  -1 unreachable, -2 reachable (goal not evaluated), >= 0 goal node | tie << 30
     int off_cnt;                 // u32[NFILT][kpad]  number of in-edges that attain the minimum
     int off_widx;                // u32[NFILT][kpad]  (edge index in the transition << 16 | in-edge rank << 8 | source node) of the first
@@ -71,6 +72,8 @@ __device__ __forceinline__ constexpr int par_tab(int f) { return f == F_PR ? 0 :
 constexpr int plan_align16(int x) { return (x + 15) / 16 * 16; }
 struct PlanRt {
     static constexpr bool fixed = false;
+    static constexpr int par_entry = 2;           // bytes per parent entry
+    static constexpr int ch1 = 4;                 // register chunks of 64 edges per layer transition (one-wave team)
 #define LTPL_PLAN_FIELD(name) static __device__ __forceinline__ int name(const TeamLds& lp) { return lp.name; }
     LTPL_PLAN_FIELD(kpad) LTPL_PLAN_FIELD(hmax) LTPL_PLAN_FIELD(off_dist) LTPL_PLAN_FIELD(off_cnt) LTPL_PLAN_FIELD(off_widx)
     LTPL_PLAN_FIELD(off_dumin) LTPL_PLAN_FIELD(off_best) LTPL_PLAN_FIELD(off_par) LTPL_PLAN_FIELD(off_lay)
@@ -80,6 +83,8 @@ struct PlanRt {
 template <int KPAD, int HM, int NW>
 struct PlanFx {
     static constexpr bool fixed = true;
+    static constexpr int par_entry = 1;           // KPAD <= 127: the source node and the tie bit share one byte
+    static constexpr int ch1 = 3;                 // 192 edges in registers: fits 128 VGPRs without spills (4 waves per SIMD)
     static constexpr int c_kpad = KPAD, c_hmax = HM;
     static constexpr int c_n_path_bufs = NW < LTPL_MAX_ACTIONS ? NW : LTPL_MAX_ACTIONS;
     static constexpr int c_off_dist = 0;
@@ -95,7 +100,7 @@ struct PlanFx {
         : c_end_elect + c_path_stride * c_n_path_bufs;
     static constexpr int c_off_best = c_after_path;
     static constexpr int c_off_par = plan_align16(c_off_best + 4 * NFILT * HM);
-    static constexpr int c_par_bytes = 2 * NPAR * HM * KPAD;
+    static constexpr int c_par_bytes = par_entry * NPAR * HM * KPAD;
     static constexpr int c_off_lay = plan_align16(c_off_par + c_par_bytes);
     static constexpr int c_fixed_end = c_off_lay + 16 * HM;
 #define LTPL_PLAN_FIELD(name) static __host__ __device__ __forceinline__ constexpr int name(const TeamLds&) { return c_##name; }
@@ -104,6 +109,13 @@ struct PlanFx {
     LTPL_PLAN_FIELD(off_path) LTPL_PLAN_FIELD(path_stride) LTPL_PLAN_FIELD(n_path_bufs)
 #undef LTPL_PLAN_FIELD
 };
+
+template <class P>
+__device__ __forceinline__ void par_store(unsigned char* par, size_t idx, int src, int rank, int tie)
+{
+    if constexpr (P::par_entry == 2) reinterpret_cast<uchar2*>(par)[idx] = make_uchar2((unsigned char)src, (unsigned char)(rank | (tie ? 0x80 : 0)));
+    else par[idx] = (unsigned char)(src | (tie ? 0x80 : 0));
+}
 
 struct TeamShared {
     int closest_idx, cl, cn, have_cn;          // written by wave 0 in phase 3
@@ -200,7 +212,7 @@ __device__ __forceinline__ void team_serial_node(const DevLat& lat, const Scen& 
 template <class P>
 __device__ __forceinline__ bool team_relax_layer(const DevLat& lat, const DevPathsIn& in, const Scen& sc, const TeamLds& lp,
                                                  unsigned char* smem, int cl, int cn, int f, int j, int b, int v0, int Kb,
-                                                 const double* dprev, double* dcur, uchar2* pj, int lane,
+                                                 const double* dprev, double* dcur, unsigned char* par, size_t row, int lane,
                                                  int fac_src, int fac_dst, double fac)
 {
     const unsigned* blocked_bits = reinterpret_cast<const unsigned*>(smem + lp.off_blocked);
@@ -212,7 +224,7 @@ __device__ __forceinline__ bool team_relax_layer(const DevLat& lat, const DevPat
         if (!team_node_removed(zone_bits, lat, sc, cl, cn, f, b, n, v))
             team_serial_node(lat, sc, blocked_bits, f, n, v, dprev, fac_src, fac_dst, fac, bestc, bsrc, bk, tie);
         dcur[n] = bestc;
-        pj[n] = make_uchar2((unsigned char)bsrc, (unsigned char)(bk | (tie ? 0x80 : 0)));
+        par_store<P>(par, row + n, bsrc, bk, tie);
         any = any || (bestc < INFINITY);
     }
     for (int n = Kb + lane; n < P::kpad(lp); n += 64) dcur[n] = INFINITY;
@@ -239,7 +251,7 @@ __device__ void team_resweep(const DevLat& lat, const DevPathsIn& in, const Scen
                              const TeamShared& ts, int f, int J, int lane)
 {
     double* dist = reinterpret_cast<double*>(smem + P::off_dist(lp));
-    uchar2* par = reinterpret_cast<uchar2*>(smem + P::off_par(lp));
+    unsigned char* par = smem + P::off_par(lp);
     int* best = reinterpret_cast<int*>(smem + P::off_best(lp));
     const unsigned* zone_bits = reinterpret_cast<const unsigned*>(smem + lp.off_zone);
     const int L = lat.L, kpad = P::kpad(lp);
@@ -257,7 +269,7 @@ __device__ void team_resweep(const DevLat& lat, const DevPathsIn& in, const Scen
         const double* dprev = dist + (size_t)(f * 2 + ((j - 1) & 1)) * kpad;
         double* dcur = dist + (size_t)(f * 2 + (j & 1)) * kpad;
         (void)team_relax_layer<P>(lat, in, sc, lp, smem, ts.cl, ts.cn, f, j, b, v0, Kb, dprev, dcur,
-                                par + ((size_t)par_tab(f) * P::hmax(lp) + j) * kpad, lane, fs, fd, fac);
+                                par, ((size_t)par_tab(f) * P::hmax(lp) + j) * kpad, lane, fs, fd, fac);
         wave_sync_lds();
     }
     int b = sc.sl + J; if (b >= L) b -= L;
@@ -278,7 +290,7 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
 {
     const int L = lat.L, hm = P::hmax(lp), N = J, s = sc.s;
     const int slot = s * LTPL_MAX_ACTIONS + a;
-    const uchar2* par = reinterpret_cast<const uchar2*>(smem + P::off_par(lp));
+    const unsigned char* par = smem + P::off_par(lp);
     const int* best = reinterpret_cast<const int*>(smem + P::off_best(lp));
     double* kx = reinterpret_cast<double*>(pw);
     double* ky = kx + hm; double* el = ky + hm; double* mx = el + hm; double* my = mx + hm;
@@ -309,11 +321,18 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
         int n = bj & 0xffff;
         for (int j = J; j >= 1; --j) {
             const int pf = (share_prefix && j < jcl) ? F_DEF : f;
-            const uchar2 pr = par[((size_t)par_tab(pf) * hm + j) * P::kpad(lp) + n];
+            const size_t pi = ((size_t)par_tab(pf) * hm + j) * P::kpad(lp) + n;
             pidx[j] = n;                                   // node of layer j (temporarily)
-            pedge[j - 1] = pr.y & 0x7f;
-            ties += (pr.y >> 7) & 1;
-            n = pr.x;
+            if constexpr (P::par_entry == 2) {
+                const uchar2 pr = reinterpret_cast<const uchar2*>(par)[pi];
+                pedge[j - 1] = pr.y & 0x7f;
+                ties += (pr.y >> 7) & 1;
+                n = pr.x;
+            } else {
+                const unsigned pr = par[pi];
+                ties += pr >> 7;
+                n = (int)(pr & 0x7fu);
+            }
         }
         pidx[0] = n;
         out.n_nodes[slot] = J + 1;
@@ -326,7 +345,24 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
         if (i <= N) node = pidx[i];
         if (i >= 1 && i <= N) {
             int b = sc.sl + i; if (b >= L) b -= L;
-            e = lat.in_ptr[lat.layer_off[b] + node] + pedge[i - 1];
+            if constexpr (P::par_entry == 2) e = lat.in_ptr[lat.layer_off[b] + node] + pedge[i - 1];
+            else {
+                // the table only holds the source NODE: look the in-edge (source -> node) up in the node's CSC segment
+                // (sorted by source): its first 16 sources in two (unaligned) 8-byte loads, longer segments serially
+                const int src = pidx[i - 1], gid = lat.layer_off[b] + node;
+                const int e1 = lat.in_ptr[gid + 1];
+                e = lat.in_ptr[gid];
+                unsigned long long w0, w1;
+                __builtin_memcpy(&w0, lat.edge_src8 + e, 8); __builtin_memcpy(&w1, lat.edge_src8 + e + 8, 8);
+                const unsigned long long pat = 0x0101010101010101ull * (unsigned long long)src;
+                const unsigned long long x0 = w0 ^ pat, x1 = w1 ^ pat;
+                // exact zero-byte detector (no false positives from borrows): bytes are < 0x80 or the 0xff padding
+                const unsigned long long z0 = ~(((x0 & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x0 | 0x7f7f7f7f7f7f7f7full);
+                const unsigned long long z1 = ~(((x1 & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x1 | 0x7f7f7f7f7f7f7f7full);
+                int k = z0 ? (__ffsll((long long)z0) - 1) >> 3 : (z1 ? 8 + ((__ffsll((long long)z1) - 1) >> 3) : 16);
+                if (k >= 16) { k = 16; while (e + k < e1 - 1 && (int)lat.edge_src8[e + k] != src) ++k; }
+                e += k;
+            }
         }
         wave_sync_lds();
         if (i <= N) o_nodes[i] = node;
@@ -483,7 +519,7 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
     const unsigned* blocked_bits = reinterpret_cast<const unsigned*>(smem + lp.off_blocked);
     const unsigned* zone_bits = reinterpret_cast<const unsigned*>(smem + lp.off_zone);
     double* dist = reinterpret_cast<double*>(smem + P::off_dist(lp));
-    uchar2* par = reinterpret_cast<uchar2*>(smem + P::off_par(lp));
+    unsigned char* par = smem + P::off_par(lp);
     int* best = reinterpret_cast<int*>(smem + P::off_best(lp));
     unsigned* cnt_all = reinterpret_cast<unsigned*>(smem + P::off_cnt(lp));
     unsigned* widx_all = reinterpret_cast<unsigned*>(smem + P::off_widx(lp));
@@ -631,7 +667,7 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
             const bool fin = c >= 1u && !rem;
             const int bsrc = fin ? (int)(w & 255u) : 0, bk = fin ? (int)((w >> 8) & 255u) : 0, tie = (fin && c >= 2u) ? 1 : 0;
             if (rem) dist[coff[f] + n] = INFINITY;
-            par[((size_t)par_tab(f) * A.hm + A.j) * kpad + n] = make_uchar2((unsigned char)bsrc, (unsigned char)(bk | (tie ? 0x80 : 0)));
+            par_store<P>(par, ((size_t)par_tab(f) * A.hm + A.j) * kpad + n, bsrc, bk, tie);
             any = any || fin;
         }
         any = __ballot(any) != 0ull;
@@ -650,14 +686,14 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int L = lat.L;
     constexpr int NT = NW * 64;
-    constexpr int CH = NW == 1 ? 4 : 1;          // register chunks of 64 * NW edges prefetched per layer transition
+    constexpr int CH = NW == 1 ? P::ch1 : 1;          // register chunks of 64 * NW edges prefetched per layer transition
 
     short* pos_layer = reinterpret_cast<short*>(smem + lp.off_pos_layer);
     unsigned char* pos_veh = smem + lp.off_pos_veh;
     unsigned* blocked_bits = reinterpret_cast<unsigned*>(smem + lp.off_blocked);
     unsigned* zone_bits = reinterpret_cast<unsigned*>(smem + lp.off_zone);
     double* dist = reinterpret_cast<double*>(smem + P::off_dist(lp));
-    uchar2* par = reinterpret_cast<uchar2*>(smem + P::off_par(lp));
+    unsigned char* par = smem + P::off_par(lp);
     int* best = reinterpret_cast<int*>(smem + P::off_best(lp));
     int4* lay = reinterpret_cast<int4*>(smem + P::off_lay(lp));
 
@@ -996,7 +1032,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                     double* dcur = dist + (size_t)(f * 2 + A.cur) * kpad;
                     const bool any = team_relax_layer<P>(lat, in, sc, lp, smem, t_cl, t_cn, f, j, b, A.v0, A.Kb,
                                                       dist + (size_t)(fprev * 2 + A.prv) * kpad, dcur,
-                                                      par + ((size_t)par_tab(f) * hm + j) * kpad, lane, A.fs, A.fd, A.fac);
+                                                      par, ((size_t)par_tab(f) * hm + j) * kpad, lane, A.fs, A.fd, A.fac);
                     if (lane == 0) best[f * hm + j] = any ? -2 : -1;
                 }
             }
