@@ -1344,6 +1344,8 @@ struct ltpl_handle {
     TeamLds lp1{}, lp4{};            // LDS plans of the path kernel: one wave / four waves per scenario
     int batch_nw = 1;                // waves per scenario used for batches (LTPL_BATCH_NW)
     int plan_class = 0;              // LDS plan of the one-wave batch kernel: 0 = runtime (PlanRt), 1 = PlanA, 2 = PlanB
+    int long_horizon = 0;            // 1: parent tables in global memory (PlanRtG), velocity stage always through the lane kernels
+    void* d_par = nullptr; size_t d_par_cap = 0;         // parent-table slabs of the long-horizon mode
     ltpl_caps caps{};
     std::vector<void*> dev_allocs;
     // staging
@@ -1366,23 +1368,56 @@ struct ltpl_handle {
     float last_paths_ms = 0.0f; int last_paths_n = 0;
 };
 
-static const void* paths1_kernel_of(int plan_class)
+#define HIP_TRY(h, call)                                                                                              \
+    do {                                                                                                              \
+        hipError_t e_ = (call);                                                                                       \
+        if (e_ != hipSuccess) {                                                                                       \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                             \
+            return LTPL_ERR_HIP;                                                                                      \
+        }                                                                                                             \
+    } while (0)
+
+static const void* paths_kernel_of(const ltpl_handle* h, int nw)
 {
-    switch (plan_class) {
-        case 1: return reinterpret_cast<const void*>(k_paths<1, PlanA>);
-        case 2: return reinterpret_cast<const void*>(k_paths<1, PlanB>);
-        default: return reinterpret_cast<const void*>(k_paths<1, PlanRt>);
+    if (nw == 1) {
+        if (h->long_horizon) return reinterpret_cast<const void*>(k_paths<1, PlanRtG>);
+        switch (h->plan_class) {
+            case 1: return reinterpret_cast<const void*>(k_paths<1, PlanA>);
+            case 2: return reinterpret_cast<const void*>(k_paths<1, PlanB>);
+            default: return reinterpret_cast<const void*>(k_paths<1, PlanRt>);
+        }
     }
+    return h->long_horizon ? reinterpret_cast<const void*>(k_paths<NUM_WAVES, PlanRtG>)
+                           : reinterpret_cast<const void*>(k_paths<NUM_WAVES, PlanRt>);
 }
 
-// the one-wave batch kernel in the LDS plan class chosen for the lattice at ltpl_create
-static void launch_paths1(ltpl_handle* h, int n_scen, hipStream_t st, const DevPathsIn& di, const DevPathsOut& dout)
+// the path kernel with `nw` waves per scenario in the LDS plan class chosen for the lattice at ltpl_create
+static int launch_paths(ltpl_handle* h, int nw, int n_scen, hipStream_t st, const DevPathsIn& di, const DevPathsOut& dout)
 {
-    switch (h->plan_class) {
-        case 1: hipLaunchKernelGGL((k_paths<1, PlanA>), dim3(n_scen), dim3(64), h->lp1.total, st, h->lat, di, dout, h->lp1); break;
-        case 2: hipLaunchKernelGGL((k_paths<1, PlanB>), dim3(n_scen), dim3(64), h->lp1.total, st, h->lat, di, dout, h->lp1); break;
-        default: hipLaunchKernelGGL((k_paths<1, PlanRt>), dim3(n_scen), dim3(64), h->lp1.total, st, h->lat, di, dout, h->lp1); break;
+    TeamLds lp = nw == 1 ? h->lp1 : h->lp4;
+    if (h->long_horizon) {
+        const size_t need = (size_t)lp.par_glob_stride * (size_t)n_scen;
+        if (need > h->d_par_cap) {
+            HIP_TRY(h, hipDeviceSynchronize());          // an earlier launch may still use the old slabs
+            if (h->d_par) (void)hipFree(h->d_par);
+            h->d_par = nullptr; h->d_par_cap = 0;
+            HIP_TRY(h, hipMalloc(&h->d_par, need));
+            h->d_par_cap = need;
+        }
+        lp.par_glob = static_cast<unsigned char*>(h->d_par);
     }
+    const dim3 grid(n_scen), block(nw == 1 ? 64 : WG_THREADS);
+    if (nw == 1) {
+        if (h->long_horizon) hipLaunchKernelGGL((k_paths<1, PlanRtG>), grid, block, lp.total, st, h->lat, di, dout, lp);
+        else switch (h->plan_class) {
+            case 1: hipLaunchKernelGGL((k_paths<1, PlanA>), grid, block, lp.total, st, h->lat, di, dout, lp); break;
+            case 2: hipLaunchKernelGGL((k_paths<1, PlanB>), grid, block, lp.total, st, h->lat, di, dout, lp); break;
+            default: hipLaunchKernelGGL((k_paths<1, PlanRt>), grid, block, lp.total, st, h->lat, di, dout, lp); break;
+        }
+    } else if (h->long_horizon) hipLaunchKernelGGL((k_paths<NUM_WAVES, PlanRtG>), grid, block, lp.total, st, h->lat, di, dout, lp);
+    else hipLaunchKernelGGL((k_paths<NUM_WAVES, PlanRt>), grid, block, lp.total, st, h->lat, di, dout, lp);
+    HIP_TRY(h, hipGetLastError());
+    return LTPL_OK;
 }
 
 static void dbg_report(ltpl_handle* h, const char* what, int n_blocks)
@@ -1407,14 +1442,7 @@ static void dbg_report(ltpl_handle* h, const char* what, int n_blocks)
     (void)hipMemset(h->d_dbg, 0, v.size() * sizeof(long long));
 }
 
-#define HIP_TRY(h, call)                                                                                              \
-    do {                                                                                                              \
-        hipError_t e_ = (call);                                                                                       \
-        if (e_ != hipSuccess) {                                                                                       \
-            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                             \
-            return LTPL_ERR_HIP;                                                                                      \
-        }                                                                                                             \
-    } while (0)
+
 
 template <typename T>
 static int upload(ltpl_handle* h, const T* src, size_t n, const T** dst)
@@ -1500,6 +1528,7 @@ extern "C" int ltpl_destroy(ltpl_handle* h)
     if (h->d_dbg) (void)hipFree(h->d_dbg);
     if (h->d_planes) (void)hipFree(h->d_planes);
     if (h->d_planes2) (void)hipFree(h->d_planes2);
+    if (h->d_par) (void)hipFree(h->d_par);
     if (h->d_out2) (void)hipFree(h->d_out2);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     for (int i = 0; i < 2; ++i) { if (h->ev_paths[i]) (void)hipEventDestroy(h->ev_paths[i]); if (h->ev_vel[i]) (void)hipEventDestroy(h->ev_vel[i]); }
@@ -1606,7 +1635,7 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
     }
 #undef UP
 
-    auto make_plan = [&](int nw, TeamLds* lp) {
+    auto make_plan = [&](int nw, TeamLds* lp, bool par_in_global) {
         lp->kpad = (int)align_up((size_t)kmax, 4);
         lp->hmax = hmax + 1;
         lp->etmax = etmax;
@@ -1629,8 +1658,10 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
         lp->off_best = (int)off; off += sizeof(int) * NFILT * lp->hmax; off = align_up(off, 16);
         lp->off_blocked = (int)off; off += sizeof(unsigned) * lp->words_blocked; off = align_up(off, 16);
         lp->off_zone = (int)off; off += sizeof(unsigned) * lp->words_zone; off = align_up(off, 16);
-        lp->off_par = (int)off; off += sizeof(uchar2) * NPAR * (size_t)lp->hmax * lp->kpad; off = align_up(off, 16);
-        lp->ref_lds = (sizeof(double) * 2 * (size_t)d->num_layers <= sizeof(uchar2) * NPAR * (size_t)lp->hmax * lp->kpad) ? 1 : 0;
+        const size_t par_bytes = sizeof(uchar2) * NPAR * (size_t)lp->hmax * lp->kpad;
+        lp->off_par = (int)off; if (!par_in_global) { off += par_bytes; off = align_up(off, 16); }
+        lp->ref_lds = (!par_in_global && sizeof(double) * 2 * (size_t)d->num_layers <= par_bytes) ? 1 : 0;
+        lp->par_glob = nullptr; lp->par_glob_stride = par_in_global ? (long long)align_up(par_bytes, 256) : 0;
         lp->off_lay = (int)off; off += sizeof(int) * 4 * (size_t)lp->hmax;
         lp->off_pos_layer = (int)off; off += sizeof(short) * MAX_POS; off = align_up(off, 16);
         lp->off_pos_veh = (int)off; off += MAX_POS; off = align_up(off, 16);
@@ -1640,7 +1671,13 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
         lp->poison = lp->poison_on ? (unsigned)strtoul(getenv("LTPL_LDS_POISON"), nullptr, 0) : 0u;
         lp->dbg = nullptr;
     };
-    make_plan(1, &h->lp1); make_plan(NUM_WAVES, &h->lp4);
+    make_plan(1, &h->lp1, false); make_plan(NUM_WAVES, &h->lp4, false);
+    const int lds_limit = 150 * 1024;
+    if (h->lp4.total > lds_limit || h->lp1.total > lds_limit || getenv("LTPL_FORCE_LONG_HORIZON")) {
+        // long planning horizons: the parent tables move to global memory, the path scratch stays in LDS
+        h->long_horizon = 1;
+        make_plan(1, &h->lp1, true); make_plan(NUM_WAVES, &h->lp4, true);
+    }
     // compile-time plan classes of the one-wave batch kernel: same arrays, hot offsets taken from the policy (PlanFx)
     auto make_fixed_plan = [&](auto plan_tag, TeamLds* lp) {
         typedef decltype(plan_tag) PL;
@@ -1666,7 +1703,7 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
         }
         lp->total = (int)off;
     };
-    if (!getenv("LTPL_NO_FIXED_PLAN")) {
+    if (!getenv("LTPL_NO_FIXED_PLAN") && !h->long_horizon) {
         if (kmax <= PlanA::c_kpad && hmax + 1 <= PlanA::c_hmax && d->num_layers >= PlanA::c_hmax) { h->plan_class = 1; make_fixed_plan(PlanA(), &h->lp1); }
         else if (kmax <= PlanB::c_kpad && hmax + 1 <= PlanB::c_hmax && d->num_layers >= PlanB::c_hmax) { h->plan_class = 2; make_fixed_plan(PlanB(), &h->lp1); }
     }
@@ -1677,20 +1714,20 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
             h->lp1.dbg = h->d_dbg; h->lp4.dbg = h->d_dbg;
         }
     }
-    if (h->lp4.total > 150 * 1024) {
-        h->err = "planning horizon too large for the LDS-resident sweep (" + std::to_string(h->lp4.total) + " B > 150 KiB)";
+    if (h->lp4.total > lds_limit || h->lp1.total > lds_limit) {
+        h->err = "planning horizon too large: the path scratch of the sweep does not fit in LDS (" + std::to_string(h->lp4.total) + " B > 150 KiB)";
         return fail(LTPL_ERR_CAPACITY);
     }
-    if (h->lp4.total > 48 * 1024) {
-        if (hipFuncSetAttribute(paths1_kernel_of(h->plan_class), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (h->lp4.total > 48 * 1024 || h->lp1.total > 48 * 1024) {
+        if (hipFuncSetAttribute(paths_kernel_of(h, 1), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 h->lp1.total) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_paths<NUM_WAVES, PlanRt>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute(paths_kernel_of(h, NUM_WAVES), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 h->lp4.total) != hipSuccess) { h->err = "cannot raise dynamic LDS limit"; return fail(LTPL_ERR_HIP); }
     }
     if (getenv("LTPL_DEBUG_OCC")) {
         int nb1 = -1, nb4 = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, paths1_kernel_of(h->plan_class), 64, (size_t)h->lp1.total);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb4, reinterpret_cast<const void*>(k_paths<NUM_WAVES, PlanRt>), WG_THREADS, (size_t)h->lp4.total);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, paths_kernel_of(h, 1), 64, (size_t)h->lp1.total);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb4, paths_kernel_of(h, NUM_WAVES), WG_THREADS, (size_t)h->lp4.total);
         fprintf(stderr, "[ltpl occ] k_paths<1> (plan class %d): %d blocks/CU at %d B LDS; k_paths<4>: %d blocks/CU at %d B LDS\n", h->plan_class, nb1, h->lp1.total, nb4, h->lp4.total);
     }
     hipDeviceProp_t prop;
@@ -1903,11 +1940,7 @@ extern "C" int ltpl_plan_paths(ltpl_handle* h, const ltpl_paths_in* in, ltpl_pat
     bind_out(static_cast<unsigned char*>(h->d_out), lo, out->cap_nodes, out->cap_pts, &dout);
     HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, li.total, hipMemcpyHostToDevice, h->stream));
     scratch_poison(h);
-    if (in->n_scen >= PIPELINE_MIN_SCEN && h->batch_nw == 1)
-        launch_paths1(h, in->n_scen, h->stream, di, dout);
-    else
-        hipLaunchKernelGGL((k_paths<NUM_WAVES, PlanRt>), dim3(in->n_scen), dim3(WG_THREADS), h->lp4.total, h->stream, h->lat, di, dout, h->lp4);
-    HIP_TRY(h, hipGetLastError());
+    if ((rc = launch_paths(h, (in->n_scen >= PIPELINE_MIN_SCEN && h->batch_nw == 1) ? 1 : NUM_WAVES, in->n_scen, h->stream, di, dout))) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, lo.total, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     dbg_report(h, "k_paths", in->n_scen);
@@ -2109,7 +2142,7 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
     t->ax = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS * (size_t)cap_pts);
     t->vel_bound = b.add(sizeof(int) * (size_t)n * LTPL_MAX_ACTIONS);
     t->too_close = b.add(sizeof(int) * (size_t)n * LTPL_MAX_ACTIONS);
-    t->pipeline = n >= PIPELINE_MIN_SCEN && !getenv("LTPL_FORCE_FUSED");
+    t->pipeline = h->long_horizon || (n >= PIPELINE_MIN_SCEN && !getenv("LTPL_FORCE_FUSED"));
     t->prep_odist = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS);
     t->prep_vobj = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS);
     t->prep_ox = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS);
@@ -2129,7 +2162,7 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
     t->vel_stride = (int)vel_scratch_bytes(t->vel_cap, false, true);
     t->vel_off = h->lp4.total;
     t->lds = (size_t)h->lp4.total + (size_t)t->vel_stride * LTPL_MAX_ACTIONS + align_up((size_t)t->vel_cap + 16, 16);
-    if (t->lds > 150 * 1024) { h->err = "fused tick exceeds the LDS budget"; return LTPL_ERR_CAPACITY; }
+    if (!t->pipeline && t->lds > 150 * 1024) { h->err = "fused tick exceeds the LDS budget"; return LTPL_ERR_CAPACITY; }
     return LTPL_OK;
 }
 
@@ -2191,12 +2224,7 @@ static int tick_pack(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_ve
 static int tick_launch_paths(ltpl_handle* h, const TickLayout& t, hipStream_t st)
 {
     if (t.dout.job_cnt) HIP_TRY(h, hipMemsetAsync(t.dout.job_cnt, 0, 2 * sizeof(int), st));
-    if (h->batch_nw == 1)
-        launch_paths1(h, t.n_scen, st, t.di, t.dout);
-    else
-        hipLaunchKernelGGL((k_paths<NUM_WAVES, PlanRt>), dim3(t.n_scen), dim3(WG_THREADS), h->lp4.total, st, h->lat, t.di, t.dout, h->lp4);
-    HIP_TRY(h, hipGetLastError());
-    return LTPL_OK;
+    return launch_paths(h, (t.n_scen >= PIPELINE_MIN_SCEN && h->batch_nw == 1) ? 1 : NUM_WAVES, t.n_scen, st, t.di, t.dout);
 }
 
 static int tick_launch_vel(ltpl_handle* h, const TickLayout& t, hipStream_t st, hipEvent_t ev_after_prep = nullptr)
@@ -2251,6 +2279,7 @@ static void tick_scatter(const unsigned char* hb, const TickLayout& t, ltpl_path
 
 static int tick_set_lds_limit(ltpl_handle* h, size_t lds, int variant)
 {
+    if (h->long_horizon) return LTPL_OK;                  // the fused kernel is not used
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(tick_kernel_of(variant)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return LTPL_OK;

@@ -46,6 +46,8 @@ struct TeamLds {                 // dynamic-LDS plan (byte offsets), computed on
     int off_path;                // path scratch, `n_path_bufs` buffers of `path_stride` bytes
     int path_stride, n_path_bufs;
     int total;
+    // long planning horizons (PlanRtG): the parent tables live in global memory, `par_glob_stride` bytes per scenario
+    unsigned char* par_glob; long long par_glob_stride;
     int ablate;                  // profiling only (LTPL_ABLATE): 1 = skip the mask, 2 = skip the sweeps, 4 = skip path assembly
     int poison_on; unsigned poison;   // testing only (LTPL_LDS_POISON=<hex word>): fill the team's LDS before phase 0, so that a read of
                                  // LDS the scenario has not written itself shows up as a parity failure instead of depending on stale data
@@ -72,6 +74,7 @@ __device__ __forceinline__ constexpr int par_tab(int f) { return f == F_PR ? 0 :
 constexpr int plan_align16(int x) { return (x + 15) / 16 * 16; }
 struct PlanRt {
     static constexpr bool fixed = false;
+    static constexpr bool par_global = false;     // parent tables in LDS
     static constexpr int par_entry = 2;           // bytes per parent entry
     static constexpr int ch1 = 4;                 // register chunks of 64 edges per layer transition (one-wave team)
 #define LTPL_PLAN_FIELD(name) static __device__ __forceinline__ int name(const TeamLds& lp) { return lp.name; }
@@ -83,6 +86,7 @@ struct PlanRt {
 template <int KPAD, int HM, int NW>
 struct PlanFx {
     static constexpr bool fixed = true;
+    static constexpr bool par_global = false;
     static constexpr int par_entry = 1;           // KPAD <= 127: the source node and the tie bit share one byte
     static constexpr int ch1 = 3;                 // 192 edges in registers: fits 128 VGPRs without spills (4 waves per SIMD)
     static constexpr int c_kpad = KPAD, c_hmax = HM;
@@ -109,6 +113,17 @@ struct PlanFx {
     LTPL_PLAN_FIELD(off_path) LTPL_PLAN_FIELD(path_stride) LTPL_PLAN_FIELD(n_path_bufs)
 #undef LTPL_PLAN_FIELD
 };
+
+// runtime plan with the parent tables in a per-scenario slab of global memory (L2 resident): planning horizons whose
+// tables do not fit in LDS next to the path scratch (e.g. 600 layers at 0.5 m layer spacing)
+struct PlanRtG : PlanRt { static constexpr bool par_global = true; };
+
+template <class P>
+__device__ __forceinline__ unsigned char* par_base(const TeamLds& lp, unsigned char* smem)
+{
+    if constexpr (P::par_global) return lp.par_glob + (size_t)blockIdx.x * (size_t)lp.par_glob_stride;
+    else return smem + P::off_par(lp);
+}
 
 template <class P>
 __device__ __forceinline__ void par_store(unsigned char* par, size_t idx, int src, int rank, int tie)
@@ -251,7 +266,7 @@ __device__ void team_resweep(const DevLat& lat, const DevPathsIn& in, const Scen
                              const TeamShared& ts, int f, int J, int lane)
 {
     double* dist = reinterpret_cast<double*>(smem + P::off_dist(lp));
-    unsigned char* par = smem + P::off_par(lp);
+    unsigned char* par = par_base<P>(lp, smem);
     int* best = reinterpret_cast<int*>(smem + P::off_best(lp));
     const unsigned* zone_bits = reinterpret_cast<const unsigned*>(smem + lp.off_zone);
     const int L = lat.L, kpad = P::kpad(lp);
@@ -290,7 +305,7 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
 {
     const int L = lat.L, hm = P::hmax(lp), N = J, s = sc.s;
     const int slot = s * LTPL_MAX_ACTIONS + a;
-    const unsigned char* par = smem + P::off_par(lp);
+    const unsigned char* par = par_base<P>(lp, smem);
     const int* best = reinterpret_cast<const int*>(smem + P::off_best(lp));
     double* kx = reinterpret_cast<double*>(pw);
     double* ky = kx + hm; double* el = ky + hm; double* mx = el + hm; double* my = mx + hm;
@@ -519,7 +534,7 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
     const unsigned* blocked_bits = reinterpret_cast<const unsigned*>(smem + lp.off_blocked);
     const unsigned* zone_bits = reinterpret_cast<const unsigned*>(smem + lp.off_zone);
     double* dist = reinterpret_cast<double*>(smem + P::off_dist(lp));
-    unsigned char* par = smem + P::off_par(lp);
+    unsigned char* par = par_base<P>(lp, smem);
     int* best = reinterpret_cast<int*>(smem + P::off_best(lp));
     unsigned* cnt_all = reinterpret_cast<unsigned*>(smem + P::off_cnt(lp));
     unsigned* widx_all = reinterpret_cast<unsigned*>(smem + P::off_widx(lp));
@@ -693,7 +708,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     unsigned* blocked_bits = reinterpret_cast<unsigned*>(smem + lp.off_blocked);
     unsigned* zone_bits = reinterpret_cast<unsigned*>(smem + lp.off_zone);
     double* dist = reinterpret_cast<double*>(smem + P::off_dist(lp));
-    unsigned char* par = smem + P::off_par(lp);
+    unsigned char* par = par_base<P>(lp, smem);
     int* best = reinterpret_cast<int*>(smem + P::off_best(lp));
     int4* lay = reinterpret_cast<int4*>(smem + P::off_lay(lp));
 
@@ -1053,6 +1068,11 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
         team_sync<NW>();
     }
 
+    if constexpr (P::par_global) {
+        // the parent tables were written with global stores: drain them before another wave of the team backtracks
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        team_sync<NW>();
+    }
     dbg_stamp(lp.dbg, 5);
     // ---- phase 5: search loop with horizon back-off (main_online_path_gen.py:187-248); uniform, every thread ---------
     int slot_valid[LTPL_MAX_ACTIONS], slot_j[LTPL_MAX_ACTIONS], slot_name[LTPL_MAX_ACTIONS], slot_red[LTPL_MAX_ACTIONS];
@@ -1110,7 +1130,10 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             any_resweep = true;
             if (wave == f % NW) team_resweep<P>(lat, in, sc, lp, smem, ts, f, Jf, lane);
         }
-        if (any_resweep) team_sync<NW>();
+        if (any_resweep) {
+            if constexpr (P::par_global) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // parent stores of the re-sweep
+            team_sync<NW>();
+        }
     }
 
     dbg_stamp(lp.dbg, 6);

@@ -153,6 +153,50 @@ def test_c5_highres_follow_ticks_match_oracle():
     compare_tick(r, vr, o, ov)
 
 
+def c5_follow_scenarios(lat, n, seed):
+    rng = np.random.default_rng(seed)
+    scen, vels = [], []
+    for _ in range(n):
+        sl = int(rng.integers(0, lat.num_layers))
+        sn = int(lat.raceline_index[sl])
+        x, y, psi, v = raceline_state(lat, float(lat.s_raceline[sl]) + rng.uniform(20.0, 80.0))
+        v = float(v) * rng.uniform(0.2, 0.5)
+        pred = np.array([[x - np.sin(psi) * v * 0.2, y + np.cos(psi) * v * 0.2]])
+        scen.append({"start_node": (sl, sn), "action_sets": True, "vehicles": [(2.5, np.vstack((np.array([[x, y]]), pred)))],
+                     "zone_gids": [], "last_nodes": None, "obj_in_const": False, "obj_besides": False, "last_action": None,
+                     "const_closest": None, "psi_s": float(lat.node_psi[lat.layer_off[sl] + sn])})
+        vels.append(np.array([v]))
+    return scen, vels
+
+
+def test_c5_full_300m_horizon_long_horizon_mode():
+    """C5 as BASELINE specifies it: 0.5 m layer spacing AND a 300 m horizon = 600 layers x 21 nodes. The parent tables no
+    longer fit in LDS next to the path scratch: ltpl_create switches to the long-horizon mode (tables in global memory,
+    velocity stage through the lane kernels). Single ticks (four-wave team) and a batch (one-wave teams) vs the oracle."""
+    from oracle.oracle_lib import OracleBackend
+    lat = c5_lattice(horizon=300.0)
+    hip, orc = _capi.HipBackend(lat), OracleBackend(lat)
+    assert hip.caps.max_path_nodes >= 601
+    scen, vels = c5_follow_scenarios(lat, 80, seed=5)
+    vel = vel_inputs(lat, scen, vels, 11)
+    n_follow = 0
+    for i in range(6):
+        b1 = _capi.PathsBatch([scen[i]], w_last_edges=[0.0, 0.5, 0.8])
+        v1 = _capi.TickVelBatch(vel.params, 1, vel.vel_plan[i:i + 1], vel.vel_est[i:i + 1],
+                                np.array([[vel.pos_x[i], vel.pos_y[i]]]), vels[i])
+        r, vr = hip.tick_batch(b1, v1)
+        o, ov = orc.tick_batch(b1, v1)
+        compare_tick(r, vr, o, ov)
+        assert int(r.n_nodes[0].max()) >= 601
+        n_follow += int(((r.action_id == _capi.ACT_FOLLOW) & (r.valid == 1)).sum())
+        compare_results(hip.plan_paths(b1), orc.plan_paths(b1), lat)
+    assert n_follow >= 3
+    batch = _capi.PathsBatch(scen, w_last_edges=[0.0, 0.5, 0.8])
+    r, vr = hip.tick_batch(batch, vel)
+    o, ov = orc.tick_batch(batch, vel)
+    compare_tick(r, vr, o, ov)
+
+
 def test_wide_lattice_serial_sweep_path():
     """More than 64 nodes per layer: the sweep takes its serial form (lane = node). Small oval, 70 nodes per layer."""
     from oracle.oracle_lib import OracleBackend

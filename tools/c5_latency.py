@@ -1,5 +1,5 @@
-"""C5 latency run: high-resolution oval (0.5 m layer spacing, 21 lateral nodes, 100 m horizon = 202 layers, see DESIGN.md
-section 7b), a slow opponent ahead so that the follow-mode velocity profile runs on every tick; single-scenario synchronous
+"""C5 latency run: high-resolution oval (0.5 m layer spacing, 21 lateral nodes; horizon in metres = first argument,
+default 300 = 600 layers = the long-horizon mode, 100 = the fused LDS-resident kernel), a slow opponent ahead so that the follow-mode velocity profile runs on every tick; single-scenario synchronous
 ltpl_tick_batch calls, host wall time including marshalling and PCIe."""
 import json
 import os
@@ -12,7 +12,9 @@ from graphbasedlocaltrajectoryplanner_amd import _capi                          
 from graphbasedlocaltrajectoryplanner_amd.scenario_gen import raceline_state               # noqa: E402
 from graphbasedlocaltrajectoryplanner_amd.synthetic_lattice import c5_lattice            # noqa: E402
 
-lat = c5_lattice()
+HORIZON = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+N_TICKS = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+lat = c5_lattice(horizon=HORIZON)
 hip = _capi.HipBackend(lat)
 rng = np.random.default_rng(2)
 singles = []
@@ -31,7 +33,7 @@ for _ in range(64):
     singles.append((b1, v1))
 res, vres = hip.new_paths_result(1), _capi.TickVelResult(1, hip.caps.max_path_pts)
 lat_us, n_follow = [], 0
-for i in range(100 + 2000):
+for i in range(100 + N_TICKS):
     b1, v1 = singles[i % 64]
     t1 = time.perf_counter()
     hip.tick_batch(b1, v1, res, vres)
