@@ -1170,9 +1170,12 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
     dbg_stamp(dbg, 1);
 }
 
-// final step of the batch velocity stage, lane per slot, no recurrence: intersection of the two follow profiles
+// final step of the batch velocity stage, no recurrence: intersection of the two follow profiles
 // (calc_vel_profile_follow.py:310), choice between follow and generic profile for reduced horizons (OTH.py:923, row 5),
-// vx = sqrt(w), ax from neighbouring points with -5 at standstill (OTH.py:925-941)
+// vx = sqrt(w), ax from neighbouring points with -5 at standstill (OTH.py:925-941). Rows are independent of each other
+// (ax_i only needs w_i, w_i+1 and the element length e_i), so the work is spread over (job, chunk of FCH rows): lane = job of
+// a tile (coalesced plane reads), blockIdx.y = row chunk; every lane writes FCH consecutive values of its slot's row.
+#define FCH 8
 __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn vin, DevTickVelOut vout, VelPlanes vp, int n_slots,
                                                   int n_scen)
 {
@@ -1183,7 +1186,9 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
     if (j >= out.job_cnt[fjob ? 1 : 0]) return;
     const int tile = fjob ? out.n_slots_pad + j : j;
     const int slot = out.job_slot[tile];
-    const int n = out.n_pts[slot], flags = vp.flags[tile];
+    const int n = out.n_pts[slot], base = (int)blockIdx.y * FCH;
+    if (base >= n) return;
+    const int flags = vp.flags[tile];
     const bool follow = fjob;
     const double* P0 = vp.P0 + tile_base(tile, vp.cap_pts);
     const double* P1 = vp.P1 + tile_base(fjob ? j : 0, vp.cap_pts);
@@ -1205,38 +1210,32 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
         const size_t o = (size_t)i * 64;
         return sel == 0 ? P0[o] : (sel == 1 ? fmin(P0[o], P1[o]) : P3[o]);
     };
-    double s_i = 0.0, w_i = value(0);
-    for (int base = 0; base < n; base += LCH) {
-        double wr[LCH], er[LCH], vv[LCH], aa[LCH];
+    double w[FCH + 1], er[FCH], vv[FCH], aa[FCH];
 #pragma unroll
-        for (int c = 0; c < LCH; ++c) {
-            const int r = base + c + 1 < n ? base + c + 1 : n - 1;
-            wr[c] = value(r); er[c] = E[(size_t)(base + c < n ? base + c : n - 1) * 64];
-        }
+    for (int c = 0; c <= FCH; ++c) w[c] = value(base + c < n ? base + c : n - 1);
 #pragma unroll
-        for (int c = 0; c < LCH; ++c) {
-            const int i = base + c;
-            const double v = sqrt(w_i);
-            double a = 0.0, w_n = 0.0;
-            if (i < n - 1) {
-                const double s_n = s_i + er[c];
-                w_n = wr[c];
-                a = (w_n - w_i) / (2.0 * (s_n - s_i));
-                if (fabs(v) <= 1e-8 && fabs(a) <= 1e-8) a = -5.0;
-                s_i = s_n;
-            }
-            vv[c] = v; aa[c] = a;
-            w_i = w_n;
-        }
-        // rows of a slot are contiguous: 16-byte stores (8-byte aligned)
+    for (int c = 0; c < FCH; ++c) er[c] = E[(size_t)(base + c < n ? base + c : n - 1) * 64];
 #pragma unroll
-        for (int c = 0; c < LCH; c += 2) {
-            const int i = base + c;
-            if (i + 1 < n) { store2_u(o_vx + i, vv[c], vv[c + 1]); store2_u(o_ax + i, aa[c], aa[c + 1]); }
-            else if (i < n) { o_vx[i] = vv[c]; o_ax[i] = aa[c]; }
+    for (int c = 0; c < FCH; ++c) {
+        const int i = base + c;
+        const double v = sqrt(w[c]);
+        double a = 0.0;
+        if (i < n - 1) {
+            // the reference divides by 2 (s_i+1 - s_i) with s the running sum of the element lengths; e_i differs from that
+            // difference by rounding only (~1e-13 relative, tolerance of ax: 1e-5)
+            a = (w[c + 1] - w[c]) / (2.0 * er[c]);
+            if (fabs(v) <= 1e-8 && fabs(a) <= 1e-8) a = -5.0;
         }
+        vv[c] = v; aa[c] = a;
     }
-    vout.vel_bound[slot] = vel_bound; vout.too_close[slot] = (flags & VF_TOO_CLOSE) ? 1 : 0;
+    // rows of a slot are contiguous: 16-byte stores (8-byte aligned)
+#pragma unroll
+    for (int c = 0; c < FCH; c += 2) {
+        const int i = base + c;
+        if (i + 1 < n) { store2_u(o_vx + i, vv[c], vv[c + 1]); store2_u(o_ax + i, aa[c], aa[c + 1]); }
+        else if (i < n) { o_vx[i] = vv[c]; o_ax[i] = aa[c]; }
+    }
+    if (blockIdx.y == 0) { vout.vel_bound[slot] = vel_bound; vout.too_close[slot] = (flags & VF_TOO_CLOSE) ? 1 : 0; }
 }
 
 // follow preparation: the wave-parallel reductions of the follow mode (projection of the object and of the ego position on
@@ -2241,7 +2240,7 @@ static int tick_launch_vel(ltpl_handle* h, const TickLayout& t, hipStream_t st, 
     hipLaunchKernelGGL(lanes_kernel_of(t.variant), dim3(nb0 + 2 * nb1), dim3(64), 0, st, h->lat, t.di, t.dout,
                        t.p, t.dvin, t.dprep, t.vp, n_slots, t.n_scen, nb0, h->lp4.dbg);
     HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL(k_vel_final, dim3(nb0 + nb1), dim3(64), 0, st, t.dout, t.dvin, t.dvout, t.vp, n_slots, t.n_scen);
+    hipLaunchKernelGGL(k_vel_final, dim3(nb0 + nb1, (t.cap_pts + FCH - 1) / FCH), dim3(64), 0, st, t.dout, t.dvin, t.dvout, t.vp, n_slots, t.n_scen);
     HIP_TRY(h, hipGetLastError());
     return LTPL_OK;
 }
