@@ -52,7 +52,9 @@ struct DevLat {
     const unsigned* edge_meta;        // [E]     source node | destination node << 8 | in-edge rank << 16
     // track bounds per layer: bound1 = refline + normvec w_right, bound2 = refline - normvec w_left, centre = (b1 + b2) / 2
     const double* b1x; const double* b1y; const double* b2x; const double* b2y; const double* ctx; const double* cty;
-    const double* edge_cx; const double* edge_cy; const double* edge_cr;   // [E] bounding circle of the edge's samples
+    const float4* edge_circ;          // [E] bounding circle of the edge's samples in fp32: (centre x, centre y, radius inflated by the
+                                      //     fp32 rounding of centre and query, first sample | #samples << 24 as bit pattern; #samples = 0: look
+                                      //     samp_ptr up) -- a conservative cull, the exact test is fp64
 };
 
 struct DevPathsIn {
@@ -1615,7 +1617,12 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
             UP(ctx, cx.data(), L.L); UP(cty, cy.data(), L.L);
         }
         // bounding circle per edge: centre of the samples' bounding box, radius = largest centre distance (inflated)
-        std::vector<double> cx((size_t)L.E), cy((size_t)L.E), cr((size_t)L.E);
+        std::vector<float4> circ((size_t)L.E);
+        double maxabs = 1.0;
+        for (int k = 0; k < L.S; ++k) maxabs = std::fmax(maxabs, std::fmax(std::fabs(d->samp_x[k]), std::fabs(d->samp_y[k])));
+        // fp32 cull: centre and obstacle position are rounded to fp32 (relative 2^-24 each) and the squared distance is
+        // formed in fp32; the radius is inflated by a bound on all of that, so no edge that the exact test would hit is lost
+        const double slack = maxabs * 4.0 * 5.960464477539063e-08 + 1.0e-4;
         for (int e = 0; e < L.E; ++e) {
             double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
             for (int k = d->samp_ptr[e]; k < d->samp_ptr[e + 1]; ++k) {
@@ -1628,9 +1635,13 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
                 const double dx = d->samp_x[k] - mx, dy = d->samp_y[k] - my;
                 r2 = std::fmax(r2, dx * dx + dy * dy);
             }
-            cx[(size_t)e] = mx; cy[(size_t)e] = my; cr[(size_t)e] = std::sqrt(r2) * (1.0 + 1.0e-9) + 1.0e-9;
+            const float rf = std::nextafter((float)(std::sqrt(r2) * (1.0 + 1.0e-5) + slack), INFINITY);
+            const int k0 = d->samp_ptr[e], ns = d->samp_ptr[e + 1] - k0;
+            const unsigned packed = (k0 < (1 << 24) && ns <= 255) ? ((unsigned)k0 | ((unsigned)ns << 24)) : 0u;
+            float pf; memcpy(&pf, &packed, sizeof(pf));
+            circ[(size_t)e] = make_float4((float)mx, (float)my, rf, pf);
         }
-        UP(edge_cx, cx.data(), L.E); UP(edge_cy, cy.data(), L.E); UP(edge_cr, cr.data(), L.E);
+        UP(edge_circ, circ.data(), L.E);
     }
 #undef UP
 

@@ -843,37 +843,44 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             while (m) {
                 // up to MQ matching positions per round, broadcast into uniform registers
                 constexpr int MQ = 2;
-                double qx[MQ], qy[MQ], qr[MQ], qs[MQ];
+                double qx[MQ], qy[MQ], qr[MQ];
+                float qxf[MQ], qyf[MQ], qsf[MQ];
 #pragma unroll
                 for (int q = 0; q < MQ; ++q) {
                     if (m) {
                         const int src_lane = __ffsll((long long)m) - 1;
                         m &= m - 1;
                         qx[q] = readlane_f64(mpx, src_lane); qy[q] = readlane_f64(mpy, src_lane);
-                        qr[q] = readlane_f64(mref, src_lane); qs[q] = readlane_f64(msq, src_lane);
-                    } else { qx[q] = 0.0; qy[q] = 0.0; qr[q] = -1.0; qs[q] = -1.0e30; }   // never near, never hit
+                        qr[q] = readlane_f64(mref, src_lane);
+                        qxf[q] = (float)qx[q]; qyf[q] = (float)qy[q];
+                        qsf[q] = (float)readlane_f64(msq, src_lane) * 1.00001f;      // rounded up: the cull stays conservative
+                    } else { qx[q] = 0.0; qy[q] = 0.0; qr[q] = -1.0; qxf[q] = 0.0f; qyf[q] = 0.0f; qsf[q] = -1.0e30f; }   // never near, never hit
                 }
                 for (int e0 = eb + wave * 64; e0 < ee; e0 += NT) {
                     const int e = e0 + lane;
                     if (e >= ee) continue;
                     int el_ = e - sc.e_base; if (el_ < 0) el_ += lat.E;
                     if ((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u) continue;       // already blocked by another object
-                    const double cx = lat.edge_cx[e], cy = lat.edge_cy[e], cr = lat.edge_cr[e];
+                    const float4 cc = lat.edge_circ[e];
                     unsigned near = 0;
 #pragma unroll
                     for (int q = 0; q < MQ; ++q) {
-                        const double dx = cx - qx[q], dy = cy - qy[q], lim = qs[q] + cr;
-                        if (dx * dx + dy * dy <= lim * lim * (1.0 + 1.0e-9)) near |= 1u << q;
+                        const float dx = cc.x - qxf[q], dy = cc.y - qyf[q], lim = qsf[q] + cc.z;
+                        if (dx * dx + dy * dy <= lim * lim * 1.00001f) near |= 1u << q;
                     }
                     if (!near) continue;
-                    const int k0 = lat.samp_ptr[e], k1 = lat.samp_ptr[e + 1];
+                    // sample range of the edge from the circle record (one dependent round trip less than via samp_ptr)
+                    const unsigned packed = __float_as_uint(cc.w);
+                    int k0 = (int)(packed & 0xffffffu), k1 = k0 + (int)(packed >> 24);
+                    if (packed >> 24 == 0u) { k0 = lat.samp_ptr[e]; k1 = lat.samp_ptr[e + 1]; }
                     bool hit = false;
-                    for (int k = k0; k < k1 && !hit; k += 4) {
-                        double xs[4], ys[4];
+                    constexpr int SG = 8;                             // samples per round trip
+                    for (int k = k0; k < k1 && !hit; k += SG) {
+                        double xs[SG], ys[SG];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) { const int kk = min(k + u, k1 - 1); xs[u] = lat.sx[kk]; ys[u] = lat.sy[kk]; }
+                        for (int u = 0; u < SG; ++u) { const int kk = min(k + u, k1 - 1); xs[u] = lat.sx[kk]; ys[u] = lat.sy[kk]; }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
+                        for (int u = 0; u < SG; ++u)
 #pragma unroll
                             for (int q = 0; q < MQ; ++q) {
                                 const double dx = xs[u] - qx[q], dy = ys[u] - qy[q];
