@@ -180,6 +180,13 @@ def main():
             if i >= 100:
                 lat_us.append((time.perf_counter() - t1) * 1e6)
         lat_us = np.array(lat_us)
+        # device-only time of one single-scenario tick (latency method): the same fused kernel launched
+        # back to back on a device-resident scenario, HIP events on the library's stream
+        device_us = None
+        if args.latency_ticks > 0:
+            hip.batch_upload(singles[0][0], singles[0][1])
+            hip.batch_run(reps=20, timed=False)
+            device_us = hip.batch_run(reps=200, timed=True) / 200 * 1e3
         out = {
             "metric": "planning ticks/s (all action primitives), " + ("Monteblanco lattice" if args.workload == "c2" else "synthetic C3 lattice"),
             "value": world * args.batch * args.steps / elapsed,
@@ -207,7 +214,8 @@ def main():
             "latency_us": {"p50": float(np.percentile(lat_us, 50)) if lat_us.size else None,
                            "p99": float(np.percentile(lat_us, 99)) if lat_us.size else None,
                            "mean": float(lat_us.mean()) if lat_us.size else None, "ticks": int(lat_us.size),
-                           "what": "one scenario per ltpl_tick_batch call, host wall time incl. marshalling + PCIe"},
+                           "device_us": device_us,
+                           "what": "one scenario per ltpl_tick_batch call, host wall time incl. marshalling + PCIe; device_us = the tick kernel alone (HIP events, back-to-back launches)"},
             "paths_per_tick": n_paths / args.batch,
         }
         if not args.no_cpu:
