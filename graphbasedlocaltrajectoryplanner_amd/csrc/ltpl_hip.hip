@@ -1346,6 +1346,7 @@ struct ltpl_handle {
     int batch_nw = 1;                // waves per scenario used for batches (LTPL_BATCH_NW)
     int plan_class = 0;              // LDS plan of the one-wave batch kernel: 0 = runtime (PlanRt), 1 = PlanA, 2 = PlanB
     int long_horizon = 0;            // 1: parent tables in global memory (PlanRtG), velocity stage always through the lane kernels
+    int nw1_min_scen = PIPELINE_MIN_SCEN;   // calls with at least this many scenarios use one-wave teams
     void* d_par = nullptr; size_t d_par_cap = 0;         // parent-table slabs of the long-horizon mode
     ltpl_caps caps{};
     std::vector<void*> dev_allocs;
@@ -1718,6 +1719,7 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
         else if (kmax <= PlanB::c_kpad && hmax + 1 <= PlanB::c_hmax && d->num_layers >= PlanB::c_hmax) { h->plan_class = 2; make_fixed_plan(PlanB(), &h->lp1); }
     }
     if (const char* e = getenv("LTPL_BATCH_NW")) h->batch_nw = atoi(e) == 4 ? 4 : 1;
+    if (const char* e = getenv("LTPL_NW1_MIN_SCEN")) h->nw1_min_scen = atoi(e) > 0 ? atoi(e) : PIPELINE_MIN_SCEN;
     if (getenv("LTPL_DEBUG_TIMING")) {
         if (hipMalloc(reinterpret_cast<void**>(&h->d_dbg), sizeof(long long) * 256 * DBG_SLOTS) == hipSuccess) {
             (void)hipMemset(h->d_dbg, 0, sizeof(long long) * 256 * DBG_SLOTS);
@@ -1950,7 +1952,7 @@ extern "C" int ltpl_plan_paths(ltpl_handle* h, const ltpl_paths_in* in, ltpl_pat
     bind_out(static_cast<unsigned char*>(h->d_out), lo, out->cap_nodes, out->cap_pts, &dout);
     HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, li.total, hipMemcpyHostToDevice, h->stream));
     scratch_poison(h);
-    if ((rc = launch_paths(h, (in->n_scen >= PIPELINE_MIN_SCEN && h->batch_nw == 1) ? 1 : NUM_WAVES, in->n_scen, h->stream, di, dout))) return rc;
+    if ((rc = launch_paths(h, (in->n_scen >= h->nw1_min_scen && h->batch_nw == 1) ? 1 : NUM_WAVES, in->n_scen, h->stream, di, dout))) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, lo.total, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     dbg_report(h, "k_paths", in->n_scen);
@@ -2234,7 +2236,7 @@ static int tick_pack(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_ve
 static int tick_launch_paths(ltpl_handle* h, const TickLayout& t, hipStream_t st)
 {
     if (t.dout.job_cnt) HIP_TRY(h, hipMemsetAsync(t.dout.job_cnt, 0, 2 * sizeof(int), st));
-    return launch_paths(h, (t.n_scen >= PIPELINE_MIN_SCEN && h->batch_nw == 1) ? 1 : NUM_WAVES, t.n_scen, st, t.di, t.dout);
+    return launch_paths(h, (t.n_scen >= h->nw1_min_scen && h->batch_nw == 1) ? 1 : NUM_WAVES, t.n_scen, st, t.di, t.dout);
 }
 
 static int tick_launch_vel(ltpl_handle* h, const TickLayout& t, hipStream_t st, hipEvent_t ev_after_prep = nullptr)
