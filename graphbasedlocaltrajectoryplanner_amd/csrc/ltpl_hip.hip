@@ -153,6 +153,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? (P::fixed ? 4 : 2) : 1)) void k
 }
 typedef PlanFx<32, 32, 1> PlanA;      // <= 32 nodes per layer, <= 31 layers of planning range (Monteblanco, stock parameters)
 typedef PlanFx<32, 40, 1> PlanB;      // <= 32 nodes per layer, <= 39 layers (synthetic C3 oval)
+typedef PlanFx<32, 32, NUM_WAVES> PlanA4;   // class A for the four-wave latency kernels (k_paths<4>, k_tick)
 
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -755,7 +756,7 @@ __device__ void tick_vel_stage(const DevLat& lat, const DevPathsIn& in, const De
     if (lane == 0) { vout.vel_bound[slot] = vel_bound; vout.too_close[slot] = too_close; }
 }
 
-template <int EM, bool AXM1>
+template <int EM, bool AXM1, class P>
 __global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, DevPathsOut out, TeamLds lp,
                                                      DevVelParams p, DevTickVelIn vin, DevTickVelOut vout,
                                                      int vel_off, int vel_stride, int vel_cap)
@@ -765,7 +766,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     VelScratch vs; double* px = nullptr; double* py = nullptr;
     if (wave < LTPL_MAX_ACTIONS) vs = carve_vel_scratch(smem + vel_off + (size_t)wave * vel_stride, vel_cap, false, true, &px, &py);
-    WavePath wp = team_paths_body<NUM_WAVES, PlanRt>(lat, in, out, lp, smem, ts, wave < LTPL_MAX_ACTIONS ? vs.kabs : nullptr,
+    WavePath wp = team_paths_body<NUM_WAVES, P>(lat, in, out, lp, smem, ts, wave < LTPL_MAX_ACTIONS ? vs.kabs : nullptr,
                                              wave < LTPL_MAX_ACTIONS ? vs.el : nullptr, px, py);
     const int s = blockIdx.x;
     // The fourth wave has no primitive of its own: it computes the unconstrained profile of the 'follow' slot
@@ -1345,6 +1346,7 @@ struct ltpl_handle {
     TeamLds lp1{}, lp4{};            // LDS plans of the path kernel: one wave / four waves per scenario
     int batch_nw = 1;                // waves per scenario used for batches (LTPL_BATCH_NW)
     int plan_class = 0;              // LDS plan of the one-wave batch kernel: 0 = runtime (PlanRt), 1 = PlanA, 2 = PlanB
+    int plan_class4 = 0;             // LDS plan of the four-wave kernels: 0 = runtime, 1 = PlanA4
     int long_horizon = 0;            // 1: parent tables in global memory (PlanRtG), velocity stage always through the lane kernels
     int nw1_min_scen = PIPELINE_MIN_SCEN;   // calls with at least this many scenarios use one-wave teams
     void* d_par = nullptr; size_t d_par_cap = 0;         // parent-table slabs of the long-horizon mode
@@ -1389,8 +1391,9 @@ static const void* paths_kernel_of(const ltpl_handle* h, int nw)
             default: return reinterpret_cast<const void*>(k_paths<1, PlanRt>);
         }
     }
-    return h->long_horizon ? reinterpret_cast<const void*>(k_paths<NUM_WAVES, PlanRtG>)
-                           : reinterpret_cast<const void*>(k_paths<NUM_WAVES, PlanRt>);
+    if (h->long_horizon) return reinterpret_cast<const void*>(k_paths<NUM_WAVES, PlanRtG>);
+    return h->plan_class4 == 1 ? reinterpret_cast<const void*>(k_paths<NUM_WAVES, PlanA4>)
+                               : reinterpret_cast<const void*>(k_paths<NUM_WAVES, PlanRt>);
 }
 
 // the path kernel with `nw` waves per scenario in the LDS plan class chosen for the lattice at ltpl_create
@@ -1417,6 +1420,7 @@ static int launch_paths(ltpl_handle* h, int nw, int n_scen, hipStream_t st, cons
             default: hipLaunchKernelGGL((k_paths<1, PlanRt>), grid, block, lp.total, st, h->lat, di, dout, lp); break;
         }
     } else if (h->long_horizon) hipLaunchKernelGGL((k_paths<NUM_WAVES, PlanRtG>), grid, block, lp.total, st, h->lat, di, dout, lp);
+    else if (h->plan_class4 == 1) hipLaunchKernelGGL((k_paths<NUM_WAVES, PlanA4>), grid, block, lp.total, st, h->lat, di, dout, lp);
     else hipLaunchKernelGGL((k_paths<NUM_WAVES, PlanRt>), grid, block, lp.total, st, h->lat, di, dout, lp);
     HIP_TRY(h, hipGetLastError());
     return LTPL_OK;
@@ -1690,9 +1694,8 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
         make_plan(1, &h->lp1, true); make_plan(NUM_WAVES, &h->lp4, true);
     }
     // compile-time plan classes of the one-wave batch kernel: same arrays, hot offsets taken from the policy (PlanFx)
-    auto make_fixed_plan = [&](auto plan_tag, TeamLds* lp) {
+    auto make_fixed_plan = [&](auto plan_tag, TeamLds* lp) {       // *lp holds the runtime plan of the same team size
         typedef decltype(plan_tag) PL;
-        *lp = h->lp1;
         lp->kpad = PL::c_kpad; lp->hmax = PL::c_hmax; lp->n_path_bufs = PL::c_n_path_bufs;
         lp->off_dist = PL::c_off_dist; lp->off_cnt = PL::c_off_cnt; lp->off_widx = PL::c_off_widx; lp->off_dumin = PL::c_off_dumin;
         lp->path_stride = PL::c_path_stride; lp->off_path = PL::c_off_path; lp->off_best = PL::c_off_best;
@@ -1715,7 +1718,10 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
         lp->total = (int)off;
     };
     if (!getenv("LTPL_NO_FIXED_PLAN") && !h->long_horizon) {
-        if (kmax <= PlanA::c_kpad && hmax + 1 <= PlanA::c_hmax && d->num_layers >= PlanA::c_hmax) { h->plan_class = 1; make_fixed_plan(PlanA(), &h->lp1); }
+        if (kmax <= PlanA::c_kpad && hmax + 1 <= PlanA::c_hmax && d->num_layers >= PlanA::c_hmax) {
+            h->plan_class = 1; make_fixed_plan(PlanA(), &h->lp1);
+            h->plan_class4 = 1; make_fixed_plan(PlanA4(), &h->lp4);
+        }
         else if (kmax <= PlanB::c_kpad && hmax + 1 <= PlanB::c_hmax && d->num_layers >= PlanB::c_hmax) { h->plan_class = 2; make_fixed_plan(PlanB(), &h->lp1); }
     }
     if (const char* e = getenv("LTPL_BATCH_NW")) h->batch_nw = atoi(e) == 4 ? 4 : 1;
@@ -2019,12 +2025,18 @@ static vel_kernel_t vel_kernel_of(int v)
         case 4: return k_vel_profile<2, false>; default: return k_vel_profile<2, true>;
     }
 }
-static tick_kernel_t tick_kernel_of(int v)
+static tick_kernel_t tick_kernel_of(int v, bool plan_a = false)
 {
+    if (plan_a)
+        switch (v) {
+            case 0: return k_tick<0, false, PlanA4>; case 1: return k_tick<0, true, PlanA4>;
+            case 2: return k_tick<1, false, PlanA4>; case 3: return k_tick<1, true, PlanA4>;
+            case 4: return k_tick<2, false, PlanA4>; default: return k_tick<2, true, PlanA4>;
+        }
     switch (v) {
-        case 0: return k_tick<0, false>; case 1: return k_tick<0, true>;
-        case 2: return k_tick<1, false>; case 3: return k_tick<1, true>;
-        case 4: return k_tick<2, false>; default: return k_tick<2, true>;
+        case 0: return k_tick<0, false, PlanRt>; case 1: return k_tick<0, true, PlanRt>;
+        case 2: return k_tick<1, false, PlanRt>; case 3: return k_tick<1, true, PlanRt>;
+        case 4: return k_tick<2, false, PlanRt>; default: return k_tick<2, true, PlanRt>;
     }
 }
 
@@ -2270,7 +2282,7 @@ static int tick_launch(ltpl_handle* h, const TickLayout& t, hipEvent_t* ev = nul
         if (ev) HIP_TRY(h, hipEventRecord(ev[3], h->stream));
         return LTPL_OK;
     }
-    hipLaunchKernelGGL(tick_kernel_of(t.variant), dim3(t.n_scen), dim3(WG_THREADS), t.lds, h->stream, h->lat, t.di, t.dout, h->lp4, t.p,
+    hipLaunchKernelGGL(tick_kernel_of(t.variant, h->plan_class4 == 1), dim3(t.n_scen), dim3(WG_THREADS), t.lds, h->stream, h->lat, t.di, t.dout, h->lp4, t.p,
                        t.dvin, t.dvout, t.vel_off, t.vel_stride, t.vel_cap);
     HIP_TRY(h, hipGetLastError());
     if (ev) { HIP_TRY(h, hipEventRecord(ev[1], h->stream)); HIP_TRY(h, hipEventRecord(ev[2], h->stream)); HIP_TRY(h, hipEventRecord(ev[3], h->stream)); }
@@ -2293,7 +2305,7 @@ static int tick_set_lds_limit(ltpl_handle* h, size_t lds, int variant)
 {
     if (h->long_horizon) return LTPL_OK;                  // the fused kernel is not used
     if (lds > 48 * 1024)
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(tick_kernel_of(variant)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(tick_kernel_of(variant, h->plan_class4 == 1)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return LTPL_OK;
 }
 
