@@ -27,6 +27,14 @@ typedef double dbl2_u __attribute__((ext_vector_type(2), aligned(8)));
 __device__ __forceinline__ void store2(double* p, double a, double b) { dbl2 v; v.x = a; v.y = b; *reinterpret_cast<dbl2*>(p) = v; }
 __device__ __forceinline__ void store2_u(double* p, double a, double b) { dbl2_u v; v.x = a; v.y = b; *reinterpret_cast<dbl2_u*>(p) = v; }
 
+// element i of a lattice array (0 <= i, array < 4 GB): the byte offset is formed in 32 bits, which lets the compiler address the
+// element as scalar base + 32-bit lane offset instead of building a 64-bit address per lane
+template <class T>
+__device__ __forceinline__ const T& at(const T* p, int i)
+{
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + (unsigned)((unsigned)i * (unsigned)sizeof(T)));
+}
+
 struct TeamLds {                 // dynamic-LDS plan (byte offsets), computed once per lattice on the host
     int kpad, hmax, etmax;
     int words_blocked, words_zone;
@@ -184,7 +192,7 @@ __device__ __forceinline__ int team_goal(const DevLat& lat, const double* dcur, 
     for (int n = lane; n < Kb; n += 64) {
         const double bestc = dcur[n];
         if (bestc < INFINITY) {
-            const double tot = bestc + lat.vgoal[v0 + n];
+            const double tot = bestc + at(lat.vgoal, v0 + n);
             if (tot < g1 || (tot == g1 && (bestc < g2 || (bestc == g2 && n < gn)))) { g1 = tot; g2 = bestc; gn = n; }
         }
     }
@@ -204,10 +212,10 @@ __device__ __forceinline__ void team_serial_node(const DevLat& lat, const Scen& 
 {
     double bestdu = INFINITY;
     bestc = INFINITY; bk = 0; bsrc = 0; tie = 0;
-    const int e0 = lat.in_ptr[v], e1 = lat.in_ptr[v + 1];
+    const int e0 = at(lat.in_ptr, v), e1 = at(lat.in_ptr, v + 1);
     for (int e = e0; e < e1; ++e) {
-        const int src = lat.edge_src8[e];
-        double c = lat.edge_cost[e];
+        const int src = at(lat.edge_src8, e);
+        double c = at(lat.edge_cost, e);
         if (f != F_PR) {
             int el_ = e - sc.e_base; if (el_ < 0) el_ += lat.E;
             if ((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u) continue;
@@ -271,14 +279,14 @@ __device__ void team_resweep(const DevLat& lat, const DevPathsIn& in, const Scen
     const unsigned* zone_bits = reinterpret_cast<const unsigned*>(smem + lp.off_zone);
     const int L = lat.L, kpad = P::kpad(lp);
     double* d0 = dist + (size_t)(f * 2) * kpad;
-    const int K0 = lat.layer_off[sc.sl + 1] - lat.layer_off[sc.sl];
+    const int K0 = at(lat.layer_off, sc.sl + 1) - at(lat.layer_off, sc.sl);
     const bool ok = sc.sn >= 0 && sc.sn < K0 &&
-                    !team_node_removed(zone_bits, lat, sc, ts.cl, ts.cn, f, sc.sl, sc.sn, lat.layer_off[sc.sl] + sc.sn);
+                    !team_node_removed(zone_bits, lat, sc, ts.cl, ts.cn, f, sc.sl, sc.sn, at(lat.layer_off, sc.sl) + sc.sn);
     for (int n = lane; n < kpad; n += 64) d0[n] = (ok && n == sc.sn) ? 0.0 : INFINITY;
     wave_sync_lds();
     for (int j = 1; j <= J; ++j) {
         int b = sc.sl + j; if (b >= L) b -= L;
-        const int v0 = lat.layer_off[b], Kb = lat.layer_off[b + 1] - v0;
+        const int v0 = at(lat.layer_off, b), Kb = at(lat.layer_off, b + 1) - v0;
         int fs, fd; double fac;
         team_factor(lat, in, sc, j, b, fs, fd, fac);
         const double* dprev = dist + (size_t)(f * 2 + ((j - 1) & 1)) * kpad;
@@ -288,7 +296,7 @@ __device__ void team_resweep(const DevLat& lat, const DevPathsIn& in, const Scen
         wave_sync_lds();
     }
     int b = sc.sl + J; if (b >= L) b -= L;
-    const int v0 = lat.layer_off[b], Kb = lat.layer_off[b + 1] - v0;
+    const int v0 = at(lat.layer_off, b), Kb = at(lat.layer_off, b + 1) - v0;
     const int g = team_goal(lat, dist + (size_t)(f * 2 + (J & 1)) * kpad, v0, Kb, lane);
     if (lane == 0) best[f * P::hmax(lp) + J] = g;
     wave_sync_lds();
@@ -360,13 +368,13 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
         if (i <= N) node = pidx[i];
         if (i >= 1 && i <= N) {
             int b = sc.sl + i; if (b >= L) b -= L;
-            if constexpr (P::par_entry == 2) e = lat.in_ptr[lat.layer_off[b] + node] + pedge[i - 1];
+            if constexpr (P::par_entry == 2) e = at(lat.in_ptr, lat.layer_off[b] + node) + pedge[i - 1];
             else {
                 // the table only holds the source NODE: look the in-edge (source -> node) up in the node's CSC segment
                 // (sorted by source): its first 16 sources in two (unaligned) 8-byte loads, longer segments serially
-                const int src = pidx[i - 1], gid = lat.layer_off[b] + node;
-                const int e1 = lat.in_ptr[gid + 1];
-                e = lat.in_ptr[gid];
+                const int src = pidx[i - 1], gid = at(lat.layer_off, b) + node;
+                const int e1 = at(lat.in_ptr, gid + 1);
+                e = at(lat.in_ptr, gid);
                 unsigned long long w0, w1;
                 __builtin_memcpy(&w0, lat.edge_src8 + e, 8); __builtin_memcpy(&w1, lat.edge_src8 + e + 8, 8);
                 const unsigned long long pat = 0x0101010101010101ull * (unsigned long long)src;
@@ -375,7 +383,7 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
                 const unsigned long long z0 = ~(((x0 & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x0 | 0x7f7f7f7f7f7f7f7full);
                 const unsigned long long z1 = ~(((x1 & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x1 | 0x7f7f7f7f7f7f7f7full);
                 int k = z0 ? (__ffsll((long long)z0) - 1) >> 3 : (z1 ? 8 + ((__ffsll((long long)z1) - 1) >> 3) : 16);
-                if (k >= 16) { k = 16; while (e + k < e1 - 1 && (int)lat.edge_src8[e + k] != src) ++k; }
+                if (k >= 16) { k = 16; while (e + k < e1 - 1 && (int)at(lat.edge_src8, e + k) != src) ++k; }
                 e += k;
             }
         }
@@ -391,16 +399,16 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
         const int i = i0 + lane;
         int take = 0, e = 0, k0 = 0, k1 = 0;
         if (i < N) {
-            e = pedge[i]; k0 = lat.samp_ptr[e]; k1 = lat.samp_ptr[e + 1];
+            e = pedge[i]; k0 = at(lat.samp_ptr, e); k1 = at(lat.samp_ptr, e + 1);
             take = (i == N - 1) ? (k1 - k0) : (k1 - k0 - 1);
         }
         int tot; const int off = wave_excl_scan(take, lane, tot);
         if (i < N) {
             pidx[i] = run + off;
-            kx[i] = lat.sx[k0]; ky[i] = lat.sy[k0]; el[i] = lat.edge_len[e];
+            kx[i] = at(lat.sx, k0); ky[i] = at(lat.sy, k0); el[i] = at(lat.edge_len, e);
             pedge[i] = k0;                                   // from here on: first sample of the segment's edge
-            if (i == 0) el[N] = lat.spsi[k0];               // heading of the first / last gathered sample (spline end slopes)
-            if (i == N - 1) { kx[N] = lat.sx[k1 - 1]; ky[N] = lat.sy[k1 - 1]; pidx[N] = run + off + take - 1; cpy[0] = lat.spsi[k1 - 1]; }
+            if (i == 0) el[N] = at(lat.spsi, k0);               // heading of the first / last gathered sample (spline end slopes)
+            if (i == N - 1) { kx[N] = at(lat.sx, k1 - 1); ky[N] = at(lat.sy, k1 - 1); pidx[N] = run + off + take - 1; cpy[0] = at(lat.spsi, k1 - 1); }
         }
         run += tot;
     }
@@ -496,7 +504,7 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
         double psi_r = atan2(-xd, yd);
         if (psi_r >= D_PI) psi_r -= 2.0 * D_PI;
         const double kap = (xd * ydd - yd * xdd) / (q * sqrt(q));
-        const double len_r = lat.slen[pedge[i] + k];
+        const double len_r = at(lat.slen, pedge[i] + k);
         store2_u(row, x, y); store2_u(row + 2, psi_r, kap); row[4] = len_r;
         if (vel_kappa) { vel_kappa[r] = kap; vel_len[r] = len_r; }
         if (out.vkap) {                                    // tiled planes of the batch velocity stage
@@ -583,8 +591,8 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
         double* dumin = reinterpret_cast<double*>(smem + P::off_dumin(lp));
         for (int ei = CH * NT + tid; ei < A.ne; ei += NT) {
             const int e = A.eb + ei;
-            double c = lat.edge_cost[e];
-            const unsigned meta = lat.edge_meta[e];
+            double c = at(lat.edge_cost, e);
+            const unsigned meta = at(lat.edge_meta, e);
             const int src = meta & 255u, dst = (meta >> 8) & 255u;
             int el_ = e - sc.e_base; if (el_ < 0) el_ += lat.E;
             const bool unbl = !((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u);
@@ -729,7 +737,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     sc.n_fac = min(in.n_last[sc.s] - 1, in.n_w_last);
     const int zone0 = in.zone_off[sc.s], zone1 = in.zone_off[sc.s + 1];
     const int const_closest = in.const_closest[sc.s], last_action = in.last_action[sc.s];
-    sc.el = lat.rng_end[sc.sl];
+    sc.el = at(lat.rng_end, sc.sl);
     sc.pos0 = in.pos_off[sc.veh0]; sc.n_pos = in.pos_off[sc.veh0 + sc.n_veh] - sc.pos0;
     sc.H = sc.el - sc.sl; if (sc.H < 0) sc.H = L - sc.sl + sc.el;
     const int H = sc.H, kpad = P::kpad(lp), hm = P::hmax(lp);
@@ -740,8 +748,8 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     // (rows beyond the planning range are harmless: the bound only depends on the lattice, so the loads do not wait for H)
     for (int j = tid; j < hm; j += NT) {
         int b = sc.sl + j; if (b >= L) b -= L;
-        const int v0 = lat.layer_off[b];
-        lay[j] = make_int4(v0, (lat.layer_off[b + 1] - v0) | (lat.layer_degmax[b] << 16), lat.layer_ebase[b], lat.layer_ebase[b + 1]);
+        const int v0 = at(lat.layer_off, b);
+        lay[j] = make_int4(v0, (at(lat.layer_off, b + 1) - v0) | (at(lat.layer_degmax, b) << 16), at(lat.layer_ebase, b), at(lat.layer_ebase, b + 1));
     }
     if (tid >= 1 && tid < LTPL_MAX_LAST_NODES) {
         int b = sc.sl + tid; if (b >= L) b -= L;
@@ -757,7 +765,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     // reference line -> LDS (aliases the parent table, which is not live before phase 4)
     double* refl = reinterpret_cast<double*>(smem + P::off_par(lp));
     if (lp.ref_lds)
-        for (int l = tid; l < L; l += NT) { refl[2 * l] = lat.ref_x[l]; refl[2 * l + 1] = lat.ref_y[l]; }
+        for (int l = tid; l < L; l += NT) { refl[2 * l] = at(lat.ref_x, l); refl[2 * l + 1] = at(lat.ref_y, l); }
     team_sync<NW>();
     {
         // offsets of the planning range from the layer table (no further dependent scalar loads)
@@ -797,7 +805,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             }
         } else {
             for (int l = l0; l < l1; ++l) {
-                const double dx = lat.ref_x[l] - px, dy = lat.ref_y[l] - py;
+                const double dx = at(lat.ref_x, l) - px, dy = at(lat.ref_y, l) - py;
                 const double d2 = dx * dx + dy * dy;
                 if (d2 < bd) { bd = d2; bl = l; }
             }
@@ -861,7 +869,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                     if (e >= ee) continue;
                     int el_ = e - sc.e_base; if (el_ < 0) el_ += lat.E;
                     if ((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u) continue;       // already blocked by another object
-                    const float4 cc = lat.edge_circ[e];
+                    const float4 cc = at(lat.edge_circ, e);
                     unsigned near = 0;
 #pragma unroll
                     for (int q = 0; q < MQ; ++q) {
@@ -872,13 +880,13 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                     // sample range of the edge from the circle record (one dependent round trip less than via samp_ptr)
                     const unsigned packed = __float_as_uint(cc.w);
                     int k0 = (int)(packed & 0xffffffu), k1 = k0 + (int)(packed >> 24);
-                    if (packed >> 24 == 0u) { k0 = lat.samp_ptr[e]; k1 = lat.samp_ptr[e + 1]; }
+                    if (packed >> 24 == 0u) { k0 = at(lat.samp_ptr, e); k1 = at(lat.samp_ptr, e + 1); }
                     bool hit = false;
                     constexpr int SG = 8;                             // samples per round trip
                     for (int k = k0; k < k1 && !hit; k += SG) {
                         double xs[SG], ys[SG];
 #pragma unroll
-                        for (int u = 0; u < SG; ++u) { const int kk = min(k + u, k1 - 1); xs[u] = lat.sx[kk]; ys[u] = lat.sy[kk]; }
+                        for (int u = 0; u < SG; ++u) { const int kk = min(k + u, k1 - 1); xs[u] = at(lat.sx, kk); ys[u] = at(lat.sy, kk); }
 #pragma unroll
                         for (int u = 0; u < SG; ++u)
 #pragma unroll
@@ -922,7 +930,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             const int v0 = ly.x, K = ly.y & 0xffff;
             double bd = INFINITY, dummy = 0.0; int bn = 0x7fffffff;
             for (int n = lane; n < K; n += 64) {
-                const double dx = lat.node_x[v0 + n] - px, dy = lat.node_y[v0 + n] - py;
+                const double dx = at(lat.node_x, v0 + n) - px, dy = at(lat.node_y, v0 + n) - py;
                 const double d2 = dx * dx + dy * dy;
                 if (d2 < bd) { bd = d2; bn = n; }
             }
@@ -1003,7 +1011,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                 const int e = ly.z + (ci * NW + wave) * 64 + lane;
                 // clamped address: a fixed number of loads in flight lets the compiler wait precisely
                 const int ec = e < ly.w ? e : ly.w - 1;
-                dr[ci].c = lat.edge_cost[ec]; dr[ci].meta = lat.edge_meta[ec];
+                dr[ci].c = at(lat.edge_cost, ec); dr[ci].meta = at(lat.edge_meta, ec);
                 int el_ = ec - sc.e_base; if (el_ < 0) el_ += lat.E;
                 bw[ci] = blocked_bits[el_ >> 5]; sh[ci] = (e < ly.w) ? (el_ & 31) : 32;
             }
