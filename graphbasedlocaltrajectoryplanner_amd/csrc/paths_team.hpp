@@ -338,7 +338,47 @@ __device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const
 
     // backtrack along the LDS parent table (lane 0), count exact ties on the way; rank of the in-edge -> pedge (as rank
     // first, resolved to edge ids by all lanes afterwards: the global in_ptr loads are then independent)
-    if (lane == 0) {
+    bool staged = false;
+    if constexpr (P::par_global) {
+        // Parent tables in global memory: a lane-0 chase would pay one global round trip per layer. Blocks of 64 table rows
+        // are copied into LDS by the whole wave (the rows of a block are contiguous per table; `kx` of the path scratch is
+        // not in use yet) and chased there.
+        const int kp = P::kpad(lp);
+        staged = (size_t)hm * sizeof(double) >= (size_t)64 * kp * 2;
+        if (staged) {
+            unsigned long long* st64 = reinterpret_cast<unsigned long long*>(kx);
+            const uchar2* st = reinterpret_cast<const uchar2*>(kx);
+            const int bj = best[f * hm + J];
+            int ties = (bj >> 30) & 1;
+            int n = bj & 0xffff;
+            for (int jhi = J; jhi >= 1; jhi -= 64) {
+                const int jlo = jhi - 63 > 1 ? jhi - 63 : 1;
+                // two contiguous segments at most: rows below the object layer come from the `default` table
+                for (int seg = 0; seg < 2; ++seg) {
+                    int ja, jb, pf;
+                    const int split = (share_prefix && jcl > jlo && jcl <= jhi) ? jcl : -1;
+                    if (split < 0) { if (seg) break; ja = jlo; jb = jhi; pf = (share_prefix && jhi < jcl) ? F_DEF : f; }
+                    else if (seg == 0) { ja = jlo; jb = split - 1; pf = F_DEF; }
+                    else { ja = split; jb = jhi; pf = f; }
+                    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(par + ((size_t)par_tab(pf) * hm + ja) * kp * 2);
+                    const int words = (jb - ja + 1) * kp / 4, w0 = (ja - jlo) * kp / 4;          // kpad is a multiple of 4
+                    for (int t = lane; t < words; t += 64) st64[w0 + t] = src[t];
+                }
+                wave_sync_lds();
+                if (lane == 0)
+                    for (int j = jhi; j >= jlo; --j) {
+                        const uchar2 pr = st[(j - jlo) * kp + n];
+                        pidx[j] = n;
+                        pedge[j - 1] = pr.y & 0x7f;
+                        ties += (pr.y >> 7) & 1;
+                        n = pr.x;
+                    }
+                wave_sync_lds();
+            }
+            if (lane == 0) { pidx[0] = n; out.n_nodes[slot] = J + 1; out.n_ties[slot] = ties; }
+        }
+    }
+    if (lane == 0 && !staged) {
         const int bj = best[f * hm + J];
         int ties = (bj >> 30) & 1;
         int n = bj & 0xffff;

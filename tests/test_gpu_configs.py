@@ -65,10 +65,12 @@ def test_c3_synthetic_lattice_matches_oracle(c3):
 
 @pytest.mark.parametrize("env", [{"LTPL_NO_FIXED_PLAN": "1"},
                                  {"LTPL_LDS_POISON": "0xfff80000"},
-                                 {"LTPL_LDS_POISON": "0x00000001", "LTPL_NO_FIXED_PLAN": "1"}])
+                                 {"LTPL_LDS_POISON": "0x00000001", "LTPL_NO_FIXED_PLAN": "1"},
+                                 {"LTPL_FORCE_LONG_HORIZON": "1"}])
 def test_batch_kernel_plan_classes_and_stale_lds(env, monteblanco, oracle_backend, monkeypatch):
     """The one-wave batch kernel exists in compile-time LDS plan classes and with a runtime plan (any lattice): both must
-    give the same bits. LTPL_LDS_POISON fills the team's LDS with a word before phase 0 -- a scenario must not depend on
+    give the same bits; so must the long-horizon mode (parent tables in global memory) when it is forced on a lattice that
+    would fit. LTPL_LDS_POISON fills the team's LDS with a word before phase 0 -- a scenario must not depend on
     what an earlier workgroup left behind."""
     from oracle.oracle_lib import OracleBackend
     from scenarios import random_scenarios
