@@ -261,7 +261,7 @@ __device__ __forceinline__ int wave_shr1_i32(int v, int first)
 // wave_shr:1, no LDS, no broadcast), so after iteration l lane l holds the final value of its step. One iteration is the
 // bare dependent chain: ~a dozen VALU instructions.
 template <int EM, bool AXM1, bool GGARR, bool BACK>
-__device__ void fb_sweep(int n, const VelScratch& vs, double cax, double cay, const DevVelParams& p, double vmax2, int lane)
+__device__ __forceinline__ void fb_sweep(int n, const VelScratch& vs, double cax, double cay, const DevVelParams& p, double vmax2, int lane)
 {
     if (n < 2) return;
     // run starts: first index of every run of positive differences of the (mirrored) profile BEFORE the sweep
@@ -334,7 +334,7 @@ __device__ void fb_sweep(int n, const VelScratch& vs, double cax, double cay, co
 
 // tph.calc_vel_profile(closed=False): vs.kabs / el / (gax, gay) hold the inputs, result in vs.w (as v^2)
 template <int EM, bool AXM1, bool GGARR>
-__device__ void fb_profile(int n, const VelScratch& vs, double cax, double cay, const DevVelParams& p, double v_max,
+__device__ __forceinline__ void fb_profile(int n, const VelScratch& vs, double cax, double cay, const DevVelParams& p, double v_max,
                            double v_start, bool has_v_end, double v_end, int lane)
 {
     if (v_start < 0.0) v_start = 0.0;
@@ -359,7 +359,7 @@ __device__ void fb_profile(int n, const VelScratch& vs, double cax, double cay, 
 
 // tph.calc_vel_profile_brake on LDS arrays: out[0..n) as v^2, zeros after standstill. Same systolic scheme as fb_sweep.
 template <int EM, bool GGARR>
-__device__ void brake_profile(int n, double* out, const VelScratch& vs, double cax, double cay, double v_start,
+__device__ __forceinline__ void brake_profile(int n, double* out, const VelScratch& vs, double cax, double cay, double v_start,
                               const DevVelParams& p, int lane)
 {
     const double icay = 1.0 / cay;
@@ -391,7 +391,7 @@ __device__ void brake_profile(int n, double* out, const VelScratch& vs, double c
 
 // out[0] = 0, out[i] = out[i - 1] + src[i - 1] for i < m, in the SEQUENTIAL summation order of np.cumsum (bit-identical),
 // executed systolically: lane l adds its element to the partial sum handed over by lane l - 1 (DPP wave_shr:1)
-__device__ void wave_cumsum_seq(const double* src, double* out, int m, int lane)
+__device__ __forceinline__ void wave_cumsum_seq(const double* src, double* out, int m, int lane)
 {
     double carry = 0.0;
     if (lane == 0 && m > 0) out[0] = 0.0;
@@ -427,7 +427,7 @@ __device__ __forceinline__ double angle3pt_dev(double ax, double ay, double bx, 
 }
 
 // get_s_coord.py:8-99 on a strided polyline in global / LDS memory, all lanes take part; every lane returns s and idx0
-__device__ double get_s_coord_dev(int n, const double* x, const double* y, int stride, const double* s_arr, int s_stride,
+__device__ __forceinline__ double get_s_coord_dev(int n, const double* x, const double* y, int stride, const double* s_arr, int s_stride,
                                   double px, double py, bool closed, int lane, int* idx0)
 {
     double bd = INFINITY, dummy = 0.0; int nb = 0x7fffffff;
@@ -461,7 +461,7 @@ struct FollowIn { double v_start, v_ego, v_obj, safety_d, obj_dist, obj_x, obj_y
 // `ext_sync`: when set, the unconstrained profile (:297-307) has been computed by ANOTHER wave of the workgroup into vs.w; the
 // function then joins that wave at a workgroup barrier instead of computing it itself (k_tick: wave 3 works for wave 0).
 template <int EM, bool AXM1, bool GGARR>
-__device__ void follow_profile(const DevLat& lat, int n, int n_el, const VelScratch& vs, double cax, double cay,
+__device__ __forceinline__ void follow_profile(const DevLat& lat, int n, int n_el, const VelScratch& vs, double cax, double cay,
                                const DevVelParams& p, const FollowIn& fi, int lane, int* too_close, int* vel_bound,
                                bool ext_sync = false)
 {
@@ -677,7 +677,7 @@ struct DevTickVelOut { double* vx; double* ax; int* vel_bound; int* too_close; }
 // cut_index_pos = 0, vel_course empty, no brake prefix (the host rejects vel_plan > v_max + 0.1, for which the
 // reference itself fails at OTH.py:919 because the prefix it computes is never merged back)
 template <int EM, bool AXM1>
-__device__ void tick_vel_stage(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const WavePath& wp,
+__device__ __forceinline__ void tick_vel_stage(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const WavePath& wp,
                                const VelScratch& vs, const double* px, const double* py, const DevVelParams& p,
                                const DevTickVelIn& vin, const DevTickVelOut& vout, int s, int slot, int lane,
                                bool helper_wave)
