@@ -52,8 +52,9 @@ def test_path_kernels_have_no_register_spills():
     import __graft_entry__ as g
     g.build_hip()
     res = g.kernel_resources(g.HIP_LIB)
-    paths = {k: v for k, v in res.items() if "k_paths" in k}
+    paths = {k: v for k, v in res.items() if "k_paths" in k or "k_tick" in k}
     assert len(paths) >= 3                                  # runtime plan (1 and 4 waves) + compile-time plan classes
     for name, r in paths.items():
         assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, name
+    assert all(r["vgpr_spill_count"] == 0 for r in res.values())
     g.check_no_register_spills(g.HIP_LIB)
