@@ -7,6 +7,12 @@ import numpy as np
 
 
 def _enc(obj, store):
+    if isinstance(obj, np.ndarray) and "__pool__" in store and obj.dtype == np.float64:
+        # packed form: all float64 arrays of a file live in ONE pool array (thousands of tiny zip members are slow and big)
+        pool = store["__pool__"]
+        off = sum(a.size for a in pool)
+        pool.append(np.ascontiguousarray(obj).reshape(-1))
+        return {"p": [off, list(obj.shape)]}
     if isinstance(obj, np.ndarray):
         key = "a%d" % len(store)
         store[key] = obj
@@ -32,6 +38,10 @@ def _dec(node, store):
     if isinstance(node, dict):
         if "@" in node:
             return store[node["@"]]
+        if "p" in node:
+            off, shape = node["p"]
+            n = int(np.prod(shape)) if len(shape) else 1
+            return store["__pool__"][off:off + n].reshape(shape).copy()
         if "d" in node:
             return {k: _dec(v, store) for k, v in node["d"]}
         if "l" in node:
@@ -41,10 +51,13 @@ def _dec(node, store):
     return node
 
 
-def save_records(path, records):
-    store = {}
+def save_records(path, records, packed=False):
+    store = {"__pool__": []} if packed else {}
     tree = _enc(records, store)
-    np.savez_compressed(path, __tree__=np.array(json.dumps(tree)), **store)
+    if packed:
+        pool = store.pop("__pool__")
+        store["__pool__"] = np.concatenate(pool) if pool else np.zeros(0)
+    np.savez_compressed(path, __tree__=np.array(json.dumps(tree, separators=(",", ":"))), **store)
 
 
 def load_records(path):

@@ -13,6 +13,16 @@ reference (imported from /root/reference over oracle/shims, see oracle/ref_env.p
   zonewall_*.npz            a full-width blocked zone plus one slow opponent (horizon back-off / reduced horizon /
                             blocked-track branches, main_online_path_gen.py:203-243, OTH.py:474-506)
   c2_exported.npz           trajectories returned by Graph_LTPL.calc_vel_profile at selected ticks
+  *_ticks.npz               (python -m oracle.gen_golden ticks) one record per planning tick at the level of
+                            OnlineTrajectoryHandler (oracle/ref_scenarios.TickRecorder): inputs of calc_paths / get_ref_idx /
+                            calc_vel_profile for EVERY tick (so that a stateful re-implementation can be driven in closed
+                            loop), node lists / cut indices / velocity digests for every tick, full stitched paths,
+                            coefficients and trajectories on selected ticks. Besides c2 / c1 / zonewall:
+                              ggdrop   free track, local_gg drops from (5, 5) to (1.5, 1.5) at tick 300: the velocity bound of
+                                       'straight' breaks -> recursive-infeasibility backup branch (OTH.py:947-1006)
+                              overtake one opponent, preference left, gg_scale 1.0 -> 0.5 at tick 200, emergency trajectory
+                                       requested: overtakes dropped for broken velocity bounds (OTH.py:945,1007-1015),
+                                       calc_brake_emergency (OTH.py:1028-1034)
 
 The reference ships no golden vectors of its own, so these recordings are the parity anchor; parity of
 the shimmed third-party arithmetic (igraph / tph) itself stays UNPINNED.
@@ -82,6 +92,49 @@ class StaticObjects(object):
         return [dict(o) for o in self.objs]
 
 
+def record_ticks(name, n_ticks, dummies_f, zones, vel_kwargs=None, action_pref=("right", "left", "straight", "follow"),
+                 full_every=25):
+    gl, clock, ltpl_obj, gb, path_dict = rs.make_planner(CACHE)
+    seam = rs.SeamRecorder(gl, gb)
+    rec = rs.TickRecorder(gl, clock, seam)
+    rs.run_loop(gl, clock, ltpl_obj, path_dict, n_ticks=n_ticks, dt=0.05, dummies=dummies_f(gl), zones=zones,
+                vel_kwargs=vel_kwargs, action_pref=action_pref)
+    ticks = rec.export(full_every=full_every)
+    rec.uninstall()
+    seam.uninstall()
+    save_records(os.path.join(GOLDEN, name + "_ticks.npz"), ticks, packed=True)
+    import collections
+    print("%s: %d ticks, %d with full arrays; offered sets %s" % (
+        name, len(ticks), sum(t['full'] is not None for t in ticks),
+        dict(collections.Counter(tuple(t['vel']['keys']) for t in ticks))))
+
+
+def main_ticks(only=None):
+    global record_ticks
+    warnings.simplefilter("ignore")
+    if only:
+        _rt = record_ticks
+        record_ticks = lambda name, *a, **k: _rt(name, *a, **k) if name in only else None      # noqa: E731
+    lat = Lattice.load(os.path.join(GOLDEN, "monteblanco_lattice.npz"))
+    Dummy = lambda gl: gl.testing_tools.src.objectlist_dummy.ObjectlistDummy      # noqa: E731
+    record_ticks("c2", 2500, lambda gl: rs.opponents_c2(gl, 8), rs.ZONE_EXAMPLE, full_every=100)
+    record_ticks("c1", 700, lambda gl: [StaticObjects(Dummy(gl)(dynamic=False).get_objectlist() + wall_objects(lat, layer=20))],
+                 None)
+    zl, zn = [], []
+    for layer in (16, 17):
+        zl += [layer] * int(lat.nodes_in_layer[layer])
+        zn += list(range(int(lat.nodes_in_layer[layer])))
+    zone = {'wall_zone': [zl, zn, np.array([[0.0, 0.0], [1.0, 1.0]]), np.array([[0.0, 0.0], [1.0, 1.0]])]}
+    record_ticks("zonewall", 420, lambda gl: [Dummy(gl)(dynamic=True, vel_scale=0.15, s0=180.0)], zone)
+    record_ticks("ggdrop", 420, lambda gl: None, None,
+                 vel_kwargs=lambda t: {'local_gg': (5.0, 5.0) if t < 300 else (1.5, 1.5)})
+    record_ticks("overtake", 600, lambda gl: [Dummy(gl)(dynamic=True, vel_scale=0.5, s0=120.0)], rs.ZONE_EXAMPLE,
+                 vel_kwargs=lambda t: {'gg_scale': 1.0 if t < 200 else 0.5, 'incl_emerg_traj': (t % 3 == 0)},
+                 action_pref=("left", "right", "straight", "follow"))
+    for f in sorted(os.listdir(GOLDEN)):
+        print("%-32s %8.2f MB" % (f, os.path.getsize(os.path.join(GOLDEN, f)) / 1e6))
+
+
 def main():
     warnings.simplefilter("ignore")
     os.makedirs(GOLDEN, exist_ok=True)
@@ -146,4 +199,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "ticks":
+        main_ticks(sys.argv[2:])
+    else:
+        main()

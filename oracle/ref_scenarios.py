@@ -162,9 +162,10 @@ def get_objects(dummies):
 
 
 def run_loop(graph_ltpl, clock, ltpl_obj, path_dict, n_ticks, dt=0.05, dummies=None, zones=None,
-             action_pref=("right", "left", "straight", "follow"), on_tick=None, extra_objects=None):
+             action_pref=("right", "left", "straight", "follow"), on_tick=None, extra_objects=None, vel_kwargs=None):
     """The example drivers' online loop with a fixed time step. Returns per-tick exported trajectory sets.
-    ``extra_objects(tick)`` may return further object-list dicts (objectlist_dummy.py:171-181 format) for that tick."""
+    ``extra_objects(tick)`` may return further object-list dicts (objectlist_dummy.py:171-181 format) for that tick;
+    ``vel_kwargs(tick)`` further keyword arguments of ``Graph_LTPL.calc_vel_profile`` (vel_max, gg_scale, ...)."""
     pos_est, vel_est = set_start(graph_ltpl, ltpl_obj, path_dict)
     traj_set = {'straight': None}
     exported = []
@@ -185,7 +186,8 @@ def run_loop(graph_ltpl, clock, ltpl_obj, path_dict, n_ticks, dt=0.05, dummies=N
                 last_path=(traj_set[sel_action][0][:, 1:3]),
                 last_vel_course=(traj_set[sel_action][0][:, 5]),
                 iter_time=dt)
-        traj_set, traj_id, _ = ltpl_obj.calc_vel_profile(pos_est=pos_est, vel_est=vel_est)
+        kw = vel_kwargs(tick) if vel_kwargs is not None else {}
+        traj_set, traj_id, _ = ltpl_obj.calc_vel_profile(pos_est=pos_est, vel_est=vel_est, **kw)
         exported.append({'sel_action': sel_action, 'pos_est': np.array(pos_est, dtype=float),
                          'vel_est': float(vel_est),
                          'traj': {k: np.array(v[0], dtype=float) for k, v in traj_set.items()},
@@ -193,3 +195,127 @@ def run_loop(graph_ltpl, clock, ltpl_obj, path_dict, n_ticks, dt=0.05, dummies=N
         if on_tick is not None:
             on_tick(tick, exported[-1])
     return exported
+
+
+class TickRecorder(object):
+    """
+    Records one dict per planning tick at the level of ``OnlineTrajectoryHandler`` (rows H1, H2, V0 of SURVEY.md §8a):
+    inputs of ``update_objects`` / ``calc_paths`` (OTH.py:272-516), the outputs of ``get_ref_idx`` (OTH.py:518-601) and
+    inputs / outputs of ``calc_vel_profile`` (OTH.py:603-1040), together with the fake-clock time the reference saw.
+    Install AFTER a SeamRecorder (if both are used) so that the zone filter content is visible; uninstall restores the
+    reference's methods.
+    """
+    P = '_OnlineTrajectoryHandler__'
+
+    def __init__(self, graph_ltpl, clock, seam_recorder=None):
+        self.gl, self.clock, self.seam = graph_ltpl, clock, seam_recorder
+        self.ticks = []
+        self._cur = None
+        self._orig = {}
+        cls = graph_ltpl.online_graph.src.OnlineTrajectoryHandler.OnlineTrajectoryHandler
+        P = self.P
+        rec = self
+
+        def wrap(name, fn):
+            self._orig[name] = getattr(cls, name)
+            setattr(cls, name, fn)
+
+        o_update, o_paths, o_ref, o_vel = cls.update_objects, cls.calc_paths, cls.get_ref_idx, cls.calc_vel_profile
+
+        def update_objects(oth, obj_veh, obj_zone):
+            rec._cur = {'obj_pos': np.array([v.get_pos() for v in obj_veh], dtype=float).reshape(-1, 2),
+                        'obj_radius': np.array([v.get_radius() for v in obj_veh], dtype=float),
+                        'obj_vel': np.array([v.get_vel() for v in obj_veh], dtype=float),
+                        'obj_pred': [np.array(v.get_prediction(), dtype=float).reshape(-1, 2) for v in obj_veh]}
+            return o_update(oth, obj_veh=obj_veh, obj_zone=obj_zone)
+
+        def calc_paths(oth, action_id_sel, idx_sel_traj):
+            cur = rec._cur if rec._cur is not None else {}
+            cur.update({'t': float(rec.clock.now), 'action_id_sel': action_id_sel, 'idx_sel_traj': int(idx_sel_traj)})
+            out = o_paths(oth, action_id_sel=action_id_sel, idx_sel_traj=idx_sel_traj)
+            path_param, start_node, nodes, const_seg = out
+            if rec.seam is not None:
+                cur['zone_layers'], cur['zone_nodes'] = copy.deepcopy(rec.seam.zone_nodes)
+            node_idx = getattr(oth, P + 'last_action_set_node_idx')
+            coeff = getattr(oth, P + 'last_action_set_coeff')
+            red = getattr(oth, P + 'last_action_set_red_len')
+            keys = list(path_param.keys())
+            cur['paths'] = {
+                'start_node': [int(start_node[0]), int(start_node[1])],
+                'keys': keys,
+                'nodes': {k: [[None if a is None else int(a), None if b is None else int(b)] for a, b in nodes[k][0]]
+                          for k in keys},
+                'node_idx': {k: [int(i) for i in node_idx[k][0]] for k in keys},
+                'n_rows': {k: int(np.shape(path_param[k][0])[0]) for k in keys},
+                'red_len': {k: bool(red[k][0]) for k in red.keys() if k in keys},
+                'const_rows': -1 if const_seg is None else int(np.shape(const_seg)[0]),
+                'closest_obj_index': getattr(oth, P + 'closest_obj_index'),
+            }
+            cur['_full_paths'] = {'path_param': {k: np.array(path_param[k][0], dtype=float) for k in keys},
+                                  'coeff': {k: np.array(coeff[k][0], dtype=float) for k in keys}}
+            rec._cur = cur
+            return out
+
+        def get_ref_idx(oth, action_id_sel, idx_sel_traj, pos_est):
+            out = o_ref(oth, action_id_sel=action_id_sel, idx_sel_traj=idx_sel_traj, pos_est=pos_est)
+            cut_index_pos, cut_layer, vel_plan, vel_course, acc_plan = out
+            rec._cur['pos_est'] = np.array(pos_est, dtype=float).reshape(-1)
+            rec._cur['ref_idx'] = {'cut_index_pos': int(cut_index_pos), 'cut_layer': int(cut_layer),
+                                   'vel_plan': float(vel_plan), 'vel_course': np.array(vel_course, dtype=float),
+                                   'acc_plan': float(acc_plan)}
+            return out
+
+        def calc_vel_profile(oth, **kw):
+            cur = rec._cur
+            cur['vel_args'] = {'vel_est': float(kw['vel_est']), 'vel_max': float(kw['vel_max']),
+                               'gg_scale': float(kw['gg_scale']), 'safety_d': float(kw['safety_d']),
+                               'ax_max_machines': np.array(kw['ax_max_machines'], dtype=float),
+                               'local_gg': [float(kw['local_gg'][0]), float(kw['local_gg'][1])]
+                               if not isinstance(kw['local_gg'], dict) else None,
+                               'incl_emerg_traj': bool(kw.get('incl_emerg_traj', False))}
+            cur['backup_available'] = getattr(oth, P + 'backup_nodes') is not None
+            out = o_vel(oth, **kw)
+            bp, ids, stamp, _ = out
+            keys = list(bp.keys())
+            cur['vel'] = {'keys': keys, 'traj_id': {k: int(v) for k, v in ids.items()},
+                          'digest': {k: [int(bp[k][0].shape[0]), float(bp[k][0][-1, 0]), float(bp[k][0][0, 5]),
+                                         float(bp[k][0][-1, 5]), float(np.sum(bp[k][0][:, 5])),
+                                         float(np.sum(bp[k][0][:, 6]))] for k in keys},
+                          'keys_after': list(getattr(oth, P + 'last_action_set_nodes').keys())}
+            cur['_full_traj'] = {k: np.array(bp[k][0], dtype=float) for k in keys}
+            rec.ticks.append(cur)
+            rec._cur = None
+            return out
+
+        wrap('update_objects', update_objects)
+        wrap('calc_paths', calc_paths)
+        wrap('get_ref_idx', get_ref_idx)
+        wrap('calc_vel_profile', calc_vel_profile)
+        self._cls = cls
+
+    def uninstall(self):
+        for name, orig in self._orig.items():
+            setattr(self._cls, name, orig)
+        self._orig = {}
+
+    def export(self, full_every=25, always_full=()):
+        """Ticks as serialisable dicts; the full arrays (stitched paths, coefficients, trajectories) are kept on every
+        ``full_every``-th tick, around every change of the offered action set and on the ticks in ``always_full``."""
+        keep = set(range(0, len(self.ticks), full_every)) | set(always_full)
+        prev = None
+        for i, t in enumerate(self.ticks):
+            sig = (tuple(t['paths']['keys']), tuple(k for k in t['vel']['keys'] if k != 'emergency'), t['action_id_sel'],
+                   tuple(sorted(t['paths']['red_len'].items())))
+            if sig != prev:
+                keep.update((max(i - 1, 0), i))
+            prev = sig
+        out = []
+        for i, t in enumerate(self.ticks):
+            d = {k: v for k, v in t.items() if not k.startswith('_')}
+            d['tick'] = i
+            d['full'] = None
+            if i in keep:
+                d['full'] = {'path_param': t['_full_paths']['path_param'], 'coeff': t['_full_paths']['coeff'],
+                             'traj': t['_full_traj']}
+            out.append(d)
+        return out
