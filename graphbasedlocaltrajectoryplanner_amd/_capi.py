@@ -13,8 +13,9 @@ from .lattice import Lattice
 
 MAX_ACTIONS = 3
 MAX_LAST_NODES = 8
-ACT_STRAIGHT, ACT_FOLLOW, ACT_LEFT, ACT_RIGHT, ACT_NONE = 0, 1, 2, 3, -1
+ACT_STRAIGHT, ACT_FOLLOW, ACT_LEFT, ACT_RIGHT, ACT_NONE, ACT_EMERGENCY = 0, 1, 2, 3, -1, 4
 ACTION_NAMES = {ACT_STRAIGHT: "straight", ACT_FOLLOW: "follow", ACT_LEFT: "left", ACT_RIGHT: "right"}
+PLANNER_MAX_KEYS = 4
 ACTION_IDS = {v: k for k, v in ACTION_NAMES.items()}
 FLAG_ACTION_SETS, FLAG_OBJ_IN_CONST, FLAG_OBJ_BESIDES, FLAG_HAS_PSI_S = 1, 2, 4, 8
 VEL_FB, VEL_BRAKE, VEL_FOLLOW = 0, 1, 2
@@ -40,7 +41,8 @@ class LatticeDesc(C.Structure):
                 ("samp_ptr", _pi32),
                 ("samp_x", _pf64), ("samp_y", _pf64), ("samp_psi", _pf64), ("samp_len", _pf64),
                 ("glob_rl", _pf64),
-                ("normvec_x", _pf64), ("normvec_y", _pf64), ("width_right", _pf64), ("width_left", _pf64)]
+                ("normvec_x", _pf64), ("normvec_y", _pf64), ("width_right", _pf64), ("width_left", _pf64),
+                ("raceline_x", _pf64), ("raceline_y", _pf64), ("node_psi", _pf64)]
 
 
 class Caps(C.Structure):
@@ -165,6 +167,9 @@ class LatticeBinding(object):
         k["normvec_y"] = _f64(lat.normvec[:, 1])
         k["width_right"] = _f64(lat.track_width_right)
         k["width_left"] = _f64(lat.track_width_left)
+        k["raceline_x"] = _f64(lat.raceline[:, 0])
+        k["raceline_y"] = _f64(lat.raceline[:, 1])
+        k["node_psi"] = _f64(lat.node_psi)
         d = self.desc = LatticeDesc()
         d.num_layers, d.num_nodes, d.num_edges = lat.num_layers, lat.num_nodes, lat.num_edges
         d.num_samples, d.num_glob_rl = lat.num_samples, lat.glob_rl.shape[0]

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/ltpl_hip.h"
+#include "planner_api.hpp"
 
 #define WG_THREADS 256
 #define PIPELINE_MIN_SCEN 64   // batches from this size on use the one-wave-per-scenario pipeline
@@ -1370,6 +1371,9 @@ struct ltpl_handle {
     int last_set = 0;
     std::vector<hipEvent_t> ev_step;          // timing events around the path kernel of every step of the last timed run
     float last_paths_ms = 0.0f; int last_paths_n = 0;
+    // host copy of the per-layer / per-node tables for the planner state machine (planner_core.hpp); empty when the
+    // descriptor came without raceline / node_psi columns
+    ltplp::HostLat hostlat; bool has_hostlat = false;
 };
 
 #define HIP_TRY(h, call)                                                                                              \
@@ -1752,6 +1756,10 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { h->err = "hipGetDeviceProperties failed"; return fail(LTPL_ERR_HIP); }
     h->caps.max_path_nodes = hmax; h->caps.max_path_pts = ptsmax; h->caps.max_horizon_edges = ehmax;
     h->caps.device = device; h->caps.num_cus = prop.multiProcessorCount; h->caps.lds_bytes_paths = h->lp1.total;
+    if (d->raceline_x && d->raceline_y && d->node_psi) {
+        std::string why;
+        h->has_hostlat = h->hostlat.init(d, h->caps.max_path_nodes, h->caps.max_path_pts, &why) == LTPL_OK;
+    }
     *out_handle = h;
     return LTPL_OK;
 }
@@ -2475,3 +2483,40 @@ extern "C" int ltpl_batch_download(ltpl_handle* h, ltpl_paths_out* out, ltpl_tic
 }
 
 static void free_resident(TickLayout* t) { delete t; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// planner (ABI v3): the OnlineTrajectoryHandler state machine of planner_core.hpp on top of the kernels above
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct HipCompute : ltplp::Compute {
+    ltpl_handle* h;
+    explicit HipCompute(ltpl_handle* handle) : h(handle) {}
+    int plan_paths(const ltpl_paths_in* in, ltpl_paths_out* out) override { return ltpl_plan_paths(h, in, out); }
+    int vel_profile(const ltpl_vel_params* p, int n, const ltpl_vel_job* jobs, ltpl_vel_result* res) override
+    {
+        return ltpl_vel_profile(h, p, n, jobs, res);
+    }
+    const char* last_error() override { return h->err.c_str(); }
+};
+}
+
+extern "C" int ltpl_planner_create(ltpl_handle* h, const ltpl_planner_config* cfg, ltpl_planner** out)
+{
+    g_create_error.clear();
+    if (!h) { g_create_error = "planner: null handle"; return LTPL_ERR_INVALID_ARG; }
+    if (!h->has_hostlat) { g_create_error = "planner: the lattice was created without raceline_x / raceline_y / node_psi"; return LTPL_ERR_UNSUPPORTED; }
+    return ltplp::api_create(new HipCompute(h), h->hostlat, cfg, out, &g_create_error);
+}
+extern "C" int ltpl_planner_destroy(ltpl_planner* p) { delete p; return LTPL_OK; }
+extern "C" int ltpl_planner_get_caps(const ltpl_planner* p, ltpl_planner_caps* c) { return ltplp::api_get_caps(p, c); }
+extern "C" const char* ltpl_planner_last_error(const ltpl_planner* p) { return p ? p->P.err.c_str() : g_create_error.c_str(); }
+extern "C" int ltpl_planner_set_start(ltpl_planner* p, int32_t scen, double x, double y, double heading, double vel,
+                                      double max_heading_offset, int32_t* in_track, int32_t* cor_heading)
+{
+    if (!p || !in_track || !cor_heading) return LTPL_ERR_INVALID_ARG;
+    return p->P.set_start(scen, x, y, heading, vel, max_heading_offset, in_track, cor_heading);
+}
+extern "C" int ltpl_planner_calc_paths(ltpl_planner* p, const ltpl_planner_paths_in* in) { return ltplp::api_calc_paths(p, in); }
+extern "C" int ltpl_planner_calc_vel_profile(ltpl_planner* p, const ltpl_planner_vel_in* in) { return ltplp::api_calc_vel_profile(p, in); }
+extern "C" int ltpl_planner_get_paths(const ltpl_planner* p, int32_t scen, ltpl_planner_paths_view* v) { return ltplp::api_get_paths(p, scen, v); }
+extern "C" int ltpl_planner_get_trajectories(const ltpl_planner* p, int32_t scen, ltpl_planner_traj_view* v) { return ltplp::api_get_trajectories(p, scen, v); }

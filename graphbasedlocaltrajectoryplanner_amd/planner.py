@@ -1,0 +1,238 @@
+"""
+ctypes binding of the planner entry points (``ltpl_planner_*``, include/ltpl_hip.h ABI v3): the iterative memory of the
+reference's ``OnlineTrajectoryHandler`` (graph_ltpl/online_graph/src/OnlineTrajectoryHandler.py:24-1040) lives in C++ behind
+the ABI, batched over ``n_scen`` independent planners on one lattice handle. One tick is two C calls:
+
+    calc_paths        = Graph_LTPL.calc_paths        (Graph_LTPL.py:300-340)
+    calc_vel_profile  = Graph_LTPL.calc_vel_profile  (Graph_LTPL.py:344-408)
+
+The accessors rebuild the reference's Python structures (dicts keyed by action name, one-element lists) from the flat views.
+"""
+import ctypes as C
+import math
+import numpy as np
+
+from . import _capi
+from ._capi import _pi32, _pf64, _p, _f64, _i32
+
+K = _capi.PLANNER_MAX_KEYS
+KEY_NAMES = dict(_capi.ACTION_NAMES)
+KEY_NAMES[_capi.ACT_EMERGENCY] = "emergency"
+KEY_IDS = {v: k for k, v in KEY_NAMES.items()}
+
+
+class PlannerConfig(C.Structure):
+    _fields_ = [("n_scen", C.c_int32), ("n_w_last", C.c_int32), ("w_last_edges", _pf64),
+                ("v_max_offset", C.c_double), ("delaycomp", C.c_double), ("calc_time_safety", C.c_double),
+                ("calc_time_buffer_len", C.c_int32), ("filt_window_width", C.c_int32),
+                ("dyn_model_exp", C.c_double), ("drag_coeff", C.c_double), ("m_veh", C.c_double),
+                ("follow_control_type", C.c_int32), ("reserved0", C.c_int32),
+                ("c_p", C.c_double), ("k_p", C.c_double), ("k_d", C.c_double), ("tan_w", C.c_double)]
+
+
+class PlannerPathsIn(C.Structure):
+    _fields_ = [("prev_action", _pi32), ("t_now", _pf64), ("veh_off", _pi32), ("pos_off", _pi32),
+                ("veh_radius", _pf64), ("veh_vel", _pf64), ("pos_x", _pf64), ("pos_y", _pf64),
+                ("zone_off", _pi32), ("zone_gid", _pi32)]
+
+
+class PlannerVelIn(C.Structure):
+    _fields_ = [("pos_est_x", _pf64), ("pos_est_y", _pf64), ("vel_est", _pf64), ("vel_max", _pf64),
+                ("gg_scale", _pf64), ("gg_ax", _pf64), ("gg_ay", _pf64), ("safety_d", _pf64),
+                ("incl_emerg_traj", _pi32), ("n_ax_max_machines", C.c_int32), ("reserved0", C.c_int32),
+                ("ax_max_machines", _pf64)]
+
+
+class PlannerCaps(C.Structure):
+    _fields_ = [("cap_rows", C.c_int32), ("cap_nodes", C.c_int32)]
+
+
+class PathsView(C.Structure):
+    _fields_ = [("n_keys", C.c_int32), ("key_id", C.c_int32 * K), ("n_rows", C.c_int32 * K), ("n_nodes", C.c_int32 * K),
+                ("red_len", C.c_int32 * K), ("start_node", C.c_int32 * 2), ("const_rows", C.c_int32),
+                ("closest_obj_index", C.c_int32),
+                ("path_param", _pf64 * K), ("coeff", _pf64 * K), ("nodes", _pi32 * K), ("node_idx", _pi32 * K)]
+
+
+class TrajView(C.Structure):
+    _fields_ = [("n_keys", C.c_int32), ("key_id", C.c_int32 * K), ("traj_id", C.c_int32 * K), ("n_rows", C.c_int32 * K),
+                ("cut_index_pos", C.c_int32), ("cut_layer", C.c_int32), ("vel_plan", C.c_double), ("acc_plan", C.c_double),
+                ("n_vel_course", C.c_int32), ("n_ids", C.c_int32), ("id_key", C.c_int32 * K), ("id_val", C.c_int32 * K),
+                ("traj", _pf64 * K), ("vel_course", _pf64)]
+
+
+# ltpl_config_online.ini of the reference (params/ltpl_config_online.ini) and the Graph_LTPL.graph_init defaults
+DEFAULT_CONFIG = dict(w_last_edges=(0.0, 0.5, 0.8), v_max_offset=0.1, delaycomp=0.1, calc_time_safety=2.0,
+                      calc_time_buffer_len=5, filt_window_width=1, dyn_model_exp=1.0, drag_coeff=0.85, m_veh=1000.0,
+                      follow_control_type="PD", follow_control_params={"c_p": 1.25, "k_d": 0.025, "k_p": 0.2})
+
+
+class Planner(object):
+    """``n_scen`` planners behind one C handle. ``lib`` / ``prefix`` / ``create`` exist so that the build container's tests
+    can bind the same class to the host-logic harness (oracle/planner_host.py); the product default is libltpl_hip.so."""
+
+    def __init__(self, backend, n_scen=1, lib=None, prefix="ltpl_planner_", create=None, **config):
+        cfg = dict(DEFAULT_CONFIG)
+        cfg.update(config)
+        self.n_scen = int(n_scen)
+        self.backend = backend
+        self.lib = lib if lib is not None else backend.lib
+        self._prefix = prefix
+        self._w_last = _f64(list(cfg["w_last_edges"]) if len(cfg["w_last_edges"]) else [0.0])
+        c = PlannerConfig()
+        c.n_scen, c.n_w_last = self.n_scen, len(cfg["w_last_edges"])
+        c.w_last_edges = _p(self._w_last, _pf64)
+        c.v_max_offset, c.delaycomp, c.calc_time_safety = cfg["v_max_offset"], cfg["delaycomp"], cfg["calc_time_safety"]
+        c.calc_time_buffer_len, c.filt_window_width = int(cfg["calc_time_buffer_len"]), int(cfg["filt_window_width"])
+        c.dyn_model_exp, c.drag_coeff, c.m_veh = cfg["dyn_model_exp"], cfg["drag_coeff"], cfg["m_veh"]
+        if cfg["follow_control_type"] not in ("PD", "PDtan"):
+            raise ValueError('Unsupported control type "' + str(cfg["follow_control_type"]) + '"!')
+        c.follow_control_type = 0 if cfg["follow_control_type"] == "PD" else 1
+        fp = cfg["follow_control_params"]
+        c.c_p, c.k_p, c.k_d, c.tan_w = fp["c_p"], fp["k_p"], fp["k_d"], fp.get("tan_w", 1.0)
+        self.handle = C.c_void_p()
+        self._declare()
+        if create is not None:
+            rc = create(C.byref(c), C.byref(self.handle))
+        else:
+            fn = self._fn("create")
+            fn.argtypes = [C.c_void_p, C.POINTER(PlannerConfig), C.POINTER(C.c_void_p)]
+            rc = fn(backend.handle, C.byref(c), C.byref(self.handle))
+        if rc != 0:
+            msg = self._fn("last_error")(None)
+            raise _capi.BackendError("ltpl_planner_create failed (%s): %s" % (_capi._STATUS.get(rc, rc), (msg or b"").decode()))
+        caps = PlannerCaps()
+        self._check(self._fn("get_caps")(self.handle, C.byref(caps)))
+        self.cap_rows, self.cap_nodes = int(caps.cap_rows), int(caps.cap_nodes)
+        # query buffers, reused by every accessor call
+        self._pp = [np.zeros((self.cap_rows, 5)) for _ in range(K)]
+        self._co = [np.zeros((self.cap_nodes, 8)) for _ in range(K)]
+        self._nd = [np.zeros((self.cap_nodes, 2), np.int32) for _ in range(K)]
+        self._ni = [np.zeros(self.cap_nodes, np.int32) for _ in range(K)]
+        self._tr = [np.zeros((self.cap_rows, 7)) for _ in range(K)]
+        self._vc = np.zeros(self.cap_rows)
+        self._pv, self._tv = PathsView(), TrajView()
+        for k in range(K):
+            self._pv.path_param[k], self._pv.coeff[k] = _p(self._pp[k], _pf64), _p(self._co[k], _pf64)
+            self._pv.nodes[k], self._pv.node_idx[k] = _p(self._nd[k], _pi32), _p(self._ni[k], _pi32)
+            self._tv.traj[k] = _p(self._tr[k], _pf64)
+        self._tv.vel_course = _p(self._vc, _pf64)
+
+    def _fn(self, name):
+        return getattr(self.lib, self._prefix + name)
+
+    def _declare(self):
+        f = self._fn
+        f("destroy").argtypes = [C.c_void_p]
+        f("get_caps").argtypes = [C.c_void_p, C.POINTER(PlannerCaps)]
+        f("last_error").argtypes = [C.c_void_p]
+        f("last_error").restype = C.c_char_p
+        f("set_start").argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                   _pi32, _pi32]
+        f("calc_paths").argtypes = [C.c_void_p, C.POINTER(PlannerPathsIn)]
+        f("calc_vel_profile").argtypes = [C.c_void_p, C.POINTER(PlannerVelIn)]
+        f("get_paths").argtypes = [C.c_void_p, C.c_int32, C.POINTER(PathsView)]
+        f("get_trajectories").argtypes = [C.c_void_p, C.c_int32, C.POINTER(TrajView)]
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._fn("last_error")(self.handle)
+            raise _capi.BackendError("ltpl_planner: %s: %s" % (_capi._STATUS.get(rc, rc), (msg or b"").decode()))
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle:
+            self._fn("destroy")(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- OnlineTrajectoryHandler.set_initial_pose ---------------------------------------------------------------------
+    def set_start(self, scen, pos, heading, vel=0.0, max_heading_offset=math.pi / 4):
+        it, ch = C.c_int32(1), C.c_int32(1)
+        self._check(self._fn("set_start")(self.handle, int(scen), float(pos[0]), float(pos[1]), float(heading), float(vel),
+                                          float(max_heading_offset), C.byref(it), C.byref(ch)))
+        return bool(it.value), bool(ch.value)
+
+    # ---- Graph_LTPL.calc_paths --------------------------------------------------------------------------------------------
+    def calc_paths(self, prev_actions, t_now, vehicles, zone_gids=None):
+        """``prev_actions``: action name per planner; ``vehicles``: per planner a list of (radius, vel, positions (k, 2) with the
+        own position first); ``zone_gids``: per planner the global node ids removed by the "overtaking_zones" filter."""
+        n = self.n_scen
+        act = _i32([KEY_IDS.get(a, _capi.ACT_NONE) if isinstance(a, str) else _capi.ACT_NONE for a in prev_actions])
+        t = _f64(np.broadcast_to(np.asarray(t_now, dtype=np.float64), (n,)))
+        veh_off, pos_off, rad, vel, px, py, zone_off, zone = [0], [0], [], [], [], [], [0], []
+        for s in range(n):
+            for radius_k, vel_k, positions in vehicles[s]:
+                positions = np.asarray(positions, dtype=np.float64).reshape(-1, 2)
+                rad.append(float(radius_k))
+                vel.append(float(vel_k))
+                px.extend(positions[:, 0].tolist())
+                py.extend(positions[:, 1].tolist())
+                pos_off.append(len(px))
+            veh_off.append(len(rad))
+            if zone_gids is not None:
+                zone.extend(int(g) for g in zone_gids[s])
+            zone_off.append(len(zone))
+        keep = [act, t, _i32(veh_off), _i32(pos_off), _f64(rad if rad else [0.0]), _f64(vel if vel else [0.0]),
+                _f64(px if px else [0.0]), _f64(py if py else [0.0]), _i32(zone_off), _i32(zone if zone else [0])]
+        i = PlannerPathsIn()
+        i.prev_action, i.t_now, i.veh_off, i.pos_off = _p(keep[0], _pi32), _p(keep[1], _pf64), _p(keep[2], _pi32), _p(keep[3], _pi32)
+        i.veh_radius, i.veh_vel, i.pos_x, i.pos_y = (_p(a, _pf64) for a in keep[4:8])
+        i.zone_off, i.zone_gid = _p(keep[8], _pi32), _p(keep[9], _pi32)
+        self._check(self._fn("calc_paths")(self.handle, C.byref(i)))
+
+    # ---- Graph_LTPL.calc_vel_profile --------------------------------------------------------------------------------------
+    def calc_vel_profile(self, pos_est, vel_est, vel_max=100.0, gg_scale=1.0, local_gg=(5.0, 5.0),
+                         ax_max_machines=((100.0, 5.0),), safety_d=30.0, incl_emerg_traj=False):
+        n = self.n_scen
+        if isinstance(local_gg, dict) or len(local_gg) != 2:
+            raise ValueError("only the constant-friction form of local_gg (tuple (ax, ay)) is supported")
+        pos = np.asarray(pos_est, dtype=np.float64).reshape(n, 2)
+
+        def bc(v):
+            return _f64(np.broadcast_to(np.asarray(v, dtype=np.float64), (n,)))
+        axm = _f64(np.atleast_2d(ax_max_machines))
+        keep = [_f64(pos[:, 0]), _f64(pos[:, 1]), bc(vel_est), bc(vel_max), bc(gg_scale), bc(local_gg[0]), bc(local_gg[1]),
+                bc(safety_d), _i32(np.broadcast_to(np.asarray(incl_emerg_traj, dtype=np.int32), (n,))), axm]
+        i = PlannerVelIn()
+        (i.pos_est_x, i.pos_est_y, i.vel_est, i.vel_max, i.gg_scale, i.gg_ax, i.gg_ay, i.safety_d) = (_p(a, _pf64) for a in keep[:8])
+        i.incl_emerg_traj = _p(keep[8], _pi32)
+        i.n_ax_max_machines, i.ax_max_machines = axm.shape[0], _p(axm, _pf64)
+        self._check(self._fn("calc_vel_profile")(self.handle, C.byref(i)))
+
+    # ---- accessors ----------------------------------------------------------------------------------------------------------
+    def paths(self, scen=0):
+        """State after calc_paths of planner ``scen``: dict with the reference's structures (OTH.py:509-516)."""
+        v = self._pv
+        self._check(self._fn("get_paths")(self.handle, int(scen), C.byref(v)))
+        out = {"keys": [], "path_param": {}, "coeff": {}, "nodes": {}, "node_idx": {}, "red_len": {},
+               "start_node": [int(v.start_node[0]), int(v.start_node[1])], "const_rows": int(v.const_rows),
+               "closest_obj_index": None if v.closest_obj_index < 0 else int(v.closest_obj_index)}
+        for k in range(v.n_keys):
+            name = KEY_NAMES[int(v.key_id[k])]
+            nr, nn = int(v.n_rows[k]), int(v.n_nodes[k])
+            out["keys"].append(name)
+            out["path_param"][name] = self._pp[k][:nr].copy()
+            out["coeff"][name] = self._co[k][:max(nn - 1, 0)].copy()
+            out["nodes"][name] = [[None if a < 0 else int(a), None if b < 0 else int(b)] for a, b in self._nd[k][:nn]]
+            out["node_idx"][name] = [int(i) for i in self._ni[k][:nn]]
+            out["red_len"][name] = bool(v.red_len[k])
+        return out
+
+    def trajectories(self, scen=0):
+        """(action_set, action_set_id, ref_idx) of planner ``scen`` after calc_vel_profile (OTH.py:1040, :601)."""
+        v = self._tv
+        self._check(self._fn("get_trajectories")(self.handle, int(scen), C.byref(v)))
+        action_set, ids = {}, {}
+        for k in range(v.n_keys):
+            name = KEY_NAMES[int(v.key_id[k])]
+            action_set[name] = [self._tr[k][:int(v.n_rows[k])].copy()]
+        for k in range(v.n_ids):
+            ids[KEY_NAMES[int(v.id_key[k])]] = int(v.id_val[k])
+        ref = {"cut_index_pos": int(v.cut_index_pos), "cut_layer": int(v.cut_layer), "vel_plan": float(v.vel_plan),
+               "acc_plan": float(v.acc_plan), "vel_course": self._vc[:int(v.n_vel_course)].copy()}
+        return action_set, ids, ref

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LTPL_ABI_VERSION 2
+#define LTPL_ABI_VERSION 3
 
 /* status codes */
 #define LTPL_OK               0
@@ -40,6 +40,7 @@ extern "C" {
 #define LTPL_ACT_LEFT     2
 #define LTPL_ACT_RIGHT    3
 #define LTPL_ACT_NONE    (-1)
+#define LTPL_ACT_EMERGENCY 4   /* key 'emergency' of the exported trajectory set (OnlineTrajectoryHandler.py:1028-1034) */
 
 #define LTPL_MAX_ACTIONS     3   /* at most 3 primitives are offered per tick (main_online_path_gen.py:128-174) */
 #define LTPL_MAX_LAST_NODES  8   /* nodes of the previous solution used for the cost discount (w_last_edges)      */
@@ -104,6 +105,12 @@ typedef struct {
     const double*  normvec_y;
     const double*  width_right;
     const double*  width_left;
+    /* ABI v3, only read by the planner entry points (ltpl_planner_*); may be NULL otherwise:
+     * race line point per layer (GraphBase.raceline, main_online_path_gen.py:86-101) and heading per node
+     * (vertex attribute psi, GraphBase.py:163-168; OnlineTrajectoryHandler.py:232-246)                              */
+    const double*  raceline_x;      /* [num_layers]                                                               */
+    const double*  raceline_y;
+    const double*  node_psi;        /* [num_nodes]                                                                */
 } ltpl_lattice_desc;
 
 typedef struct {
@@ -292,6 +299,113 @@ int ltpl_batch_run_profile(ltpl_handle* handle, int reps, float* ms_kernels);
 /* Average duration (ms) of the path kernel inside the last timed ltpl_batch_run, measured with HIP events recorded around
  * every launch of it on the handle's stream, i.e. under the same overlap with the velocity kernels as the timed region. */
 int ltpl_batch_last_paths_ms(ltpl_handle* handle, float* ms_avg);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * ABI v3 -- the planner: the iterative memory of class OnlineTrajectoryHandler
+ * (graph_ltpl/online_graph/src/OnlineTrajectoryHandler.py:24-1040) behind the C ABI, batched over n_scen independent
+ * planners that share one lattice handle (section 8f rank 2). One tick =
+ *   ltpl_planner_calc_paths        Graph_LTPL.calc_paths        (Graph_LTPL.py:300-340) = OTH.update_objects + OTH.calc_paths
+ *   ltpl_planner_calc_vel_profile  Graph_LTPL.calc_vel_profile  (Graph_LTPL.py:344-408) = OTH.get_ref_idx + OTH.calc_vel_profile
+ * Object ingestion in front of it is ltpl_process_objects; zone bookkeeping (ObjectListInterface.update_zone) stays with
+ * the caller, who passes the node ids the "overtaking_zones" filter currently removes (as for ltpl_plan_paths).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ltpl_planner ltpl_planner;
+
+#define LTPL_PLANNER_MAX_KEYS 4     /* <= 3 primitives per tick + 'emergency' */
+
+typedef struct {
+    int32_t n_scen;
+    int32_t n_w_last;               /* COST.w_last_edges                 OTH.py:109                               */
+    const double* w_last_edges;
+    double  v_max_offset;           /* ACTIONSET.v_max_offset            OTH.py:102                               */
+    double  delaycomp;              /* DELAY.delaycomp                   OTH.py:117                               */
+    double  calc_time_safety;       /* CALC_TIME.calc_time_safety        OTH.py:121                               */
+    int32_t calc_time_buffer_len;   /* CALC_TIME.calc_time_buffer_len    OTH.py:122                               */
+    int32_t filt_window_width;      /* SMOOTHING.filt_window_width       OTH.py:107 (only 1 is supported)         */
+    double  dyn_model_exp, drag_coeff, m_veh;          /* OTH.__init__ arguments -> VpForwardBackward (OTH.py:137-144) */
+    int32_t follow_control_type;    /* 0 = 'PD', 1 = 'PDtan'             OTH.py:112-114                           */
+    int32_t reserved0;
+    double  c_p, k_p, k_d, tan_w;
+} ltpl_planner_config;
+
+typedef struct {
+    const int32_t* prev_action;     /* [n_scen] LTPL_ACT_* incl. LTPL_ACT_EMERGENCY: prev_action_id (Graph_LTPL.py:300)   */
+    const double*  t_now;           /* [n_scen] the caller's time.time() (OTH.py:353-354,395)                     */
+    /* objects of the tick (output of ObjectListInterface.process_object_list): same layout as ltpl_paths_in        */
+    const int32_t* veh_off;         /* [n_scen + 1]                                                               */
+    const int32_t* pos_off;         /* [n_veh_total + 1]                                                          */
+    const double*  veh_radius;      /* [n_veh_total]                                                              */
+    const double*  veh_vel;         /* [n_veh_total] VehObject.get_vel()                                          */
+    const double*  pos_x;           /* [n_pos_total] own position first, then the prediction                      */
+    const double*  pos_y;
+    const int32_t* zone_off;        /* [n_scen + 1]                                                               */
+    const int32_t* zone_gid;        /* [n_zone_total] global node ids removed by the "overtaking_zones" filter    */
+} ltpl_planner_paths_in;
+
+typedef struct {                    /* arguments of Graph_LTPL.calc_vel_profile (Graph_LTPL.py:344-351)           */
+    const double*  pos_est_x;       /* [n_scen]                                                                   */
+    const double*  pos_est_y;
+    const double*  vel_est;
+    const double*  vel_max;         /* [n_scen] (one value per call: all entries must agree)                      */
+    const double*  gg_scale;
+    const double*  gg_ax;           /* [n_scen] constant local_gg tuple (ax, ay)                                  */
+    const double*  gg_ay;
+    const double*  safety_d;
+    const int32_t* incl_emerg_traj; /* [n_scen]                                                                   */
+    int32_t n_ax_max_machines;
+    int32_t reserved0;
+    const double*  ax_max_machines; /* [n_ax_max_machines * 2] rows [v, ax]                                       */
+} ltpl_planner_vel_in;
+
+/* Sizes a caller needs for the query buffers below: rows per (stitched) path / trajectory, nodes per path. */
+typedef struct { int32_t cap_rows; int32_t cap_nodes; } ltpl_planner_caps;
+
+typedef struct {
+    /* state after calc_paths: path_dict of Graph_LTPL.calc_paths, keys in the reference's dict order             */
+    int32_t  n_keys;
+    int32_t  key_id[LTPL_PLANNER_MAX_KEYS];
+    int32_t  n_rows[LTPL_PLANNER_MAX_KEYS];
+    int32_t  n_nodes[LTPL_PLANNER_MAX_KEYS];
+    int32_t  red_len[LTPL_PLANNER_MAX_KEYS];
+    int32_t  start_node[2];
+    int32_t  const_rows;            /* rows of const_path_seg or -1 (None)                                        */
+    int32_t  closest_obj_index;     /* -1 = None                                                                  */
+    double*  path_param[LTPL_PLANNER_MAX_KEYS];   /* caller buffers [cap_rows * 5] or NULL                        */
+    double*  coeff[LTPL_PLANNER_MAX_KEYS];        /* caller buffers [cap_nodes * 8] or NULL                       */
+    int32_t* nodes[LTPL_PLANNER_MAX_KEYS];        /* caller buffers [cap_nodes * 2] pairs (layer, node), -1 = None */
+    int32_t* node_idx[LTPL_PLANNER_MAX_KEYS];     /* caller buffers [cap_nodes]                                   */
+} ltpl_planner_paths_view;
+
+typedef struct {
+    /* result of calc_vel_profile: action_set / action_set_id of Graph_LTPL.calc_vel_profile (untrimmed)          */
+    int32_t  n_keys;
+    int32_t  key_id[LTPL_PLANNER_MAX_KEYS];
+    int32_t  traj_id[LTPL_PLANNER_MAX_KEYS];
+    int32_t  n_rows[LTPL_PLANNER_MAX_KEYS];
+    int32_t  cut_index_pos, cut_layer;            /* outputs of get_ref_idx (OTH.py:601)                          */
+    double   vel_plan, acc_plan;
+    int32_t  n_vel_course;
+    /* action_set_path_id of OTH.py:696-697,1034: one id per key of the tick INCLUDING keys dropped for a broken velocity
+     * bound (the reference never removes them from this dict)                                                    */
+    int32_t  n_ids;
+    int32_t  id_key[LTPL_PLANNER_MAX_KEYS];
+    int32_t  id_val[LTPL_PLANNER_MAX_KEYS];
+    double*  traj[LTPL_PLANNER_MAX_KEYS];         /* caller buffers [cap_rows * 7] rows [s, x, y, psi, kappa, vx, ax] or NULL */
+    double*  vel_course;                          /* caller buffer [cap_rows] or NULL                             */
+} ltpl_planner_traj_view;
+
+int ltpl_planner_create(ltpl_handle* handle, const ltpl_planner_config* cfg, ltpl_planner** out_planner);
+int ltpl_planner_destroy(ltpl_planner* planner);
+int ltpl_planner_get_caps(const ltpl_planner* planner, ltpl_planner_caps* caps);
+const char* ltpl_planner_last_error(const ltpl_planner* planner);
+/* OnlineTrajectoryHandler.set_initial_pose (OTH.py:181-270) for planner `scen` */
+int ltpl_planner_set_start(ltpl_planner* planner, int32_t scen, double x, double y, double heading, double vel,
+                           double max_heading_offset, int32_t* in_track, int32_t* cor_heading);
+int ltpl_planner_calc_paths(ltpl_planner* planner, const ltpl_planner_paths_in* in);
+int ltpl_planner_calc_vel_profile(ltpl_planner* planner, const ltpl_planner_vel_in* in);
+/* copy-out of planner `scen`'s state (fills the counts, copies the arrays whose pointers are non-NULL) */
+int ltpl_planner_get_paths(const ltpl_planner* planner, int32_t scen, ltpl_planner_paths_view* view);
+int ltpl_planner_get_trajectories(const ltpl_planner* planner, int32_t scen, ltpl_planner_traj_view* view);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,48 @@
+"""
+ORACLE / TEST INFRASTRUCTURE ONLY -- never imported by the product path.
+
+Binds ``graphbasedlocaltrajectoryplanner_amd.planner.Planner`` (the ctypes class of the product's planner entry points) to
+oracle/libltpl_planner_host.so: the product's HOST state machine (csrc/planner_core.hpp) with the oracle's CPU arithmetic
+behind it (oracle/planner_host_shim.cpp). Lets the GPU-less build container replay the recorded closed loops through the
+host logic; on the GPU box the same tests run through libltpl_hip.so.
+"""
+import ctypes as C
+import os
+import subprocess
+
+from graphbasedlocaltrajectoryplanner_amd import _capi
+from graphbasedlocaltrajectoryplanner_amd.planner import Planner, PlannerConfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libltpl_planner_host.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(HERE, "planner_host_shim.cpp"), os.path.join(HERE, "ltpl_oracle.c"),
+            os.path.join(os.path.dirname(HERE), "include", "ltpl_hip.h")]
+    csrc = os.path.join(os.path.dirname(HERE), "graphbasedlocaltrajectoryplanner_amd", "csrc")
+    srcs += [os.path.join(csrc, "planner_core.hpp"), os.path.join(csrc, "planner_api.hpp")]
+    if not force and os.path.isfile(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(s) for s in srcs):
+        return LIB
+    subprocess.check_call(["make", "-s", "-C", HERE, "-B", "libltpl_planner_host.so"])
+    return LIB
+
+
+class HostPlannerBackend(object):
+    """Stands in for HipBackend when constructing a Planner on the host-logic harness."""
+
+    def __init__(self, lattice):
+        build()
+        self.lib = C.CDLL(LIB)
+        self.lattice = lattice
+        self.binding = _capi.LatticeBinding(lattice)
+        layers, edges, pts = lattice.max_horizon()
+        self.max_nodes, self.max_pts = layers, pts
+        self.lib.oracle_planner_create.argtypes = [C.POINTER(_capi.LatticeDesc), C.c_int, C.c_int,
+                                                   C.POINTER(PlannerConfig), C.POINTER(C.c_void_p)]
+
+    def planner(self, n_scen=1, **config):
+        def create(cfg_ref, handle_ref):
+            return self.lib.oracle_planner_create(C.byref(self.binding.desc), self.max_nodes, self.max_pts, cfg_ref,
+                                                  handle_ref)
+        return Planner(self, n_scen=n_scen, lib=self.lib, prefix="oracle_planner_", create=create, **config)

@@ -1,0 +1,60 @@
+// ORACLE / TEST INFRASTRUCTURE ONLY -- never linked into or loaded by the product path.
+//
+// The product's host state machine (graphbasedlocaltrajectoryplanner_amd/csrc/planner_core.hpp: the C++ restatement of the
+// reference's OnlineTrajectoryHandler) bound to the ORACLE's CPU arithmetic (oracle_plan_paths / oracle_vel_profile of
+// ltpl_oracle.c) instead of the HIP kernels. Purpose: the GPU-less build container can drive the host logic through the
+// recorded closed loops of tests/golden/*_ticks.npz (`-m "not gpu"` tests cover "the host logic"). On the GPU box the same
+// recordings run through libltpl_hip.so (`-m gpu`). The exported names carry the prefix oracle_planner_ so that they can
+// never be mistaken for the product's ltpl_planner_* symbols.
+#include "../graphbasedlocaltrajectoryplanner_amd/csrc/planner_api.hpp"
+
+extern "C" {
+int oracle_plan_paths(const ltpl_lattice_desc* d, const ltpl_paths_in* in, ltpl_paths_out* out);
+int oracle_vel_profile(const ltpl_lattice_desc* d, const ltpl_vel_params* params, int n_jobs, const ltpl_vel_job* jobs,
+                       ltpl_vel_result* results);
+}
+
+namespace {
+struct OracleCompute : ltplp::Compute {
+    const ltpl_lattice_desc* d;          // owned by the caller (Python keeps the arrays alive)
+    std::string err;
+    explicit OracleCompute(const ltpl_lattice_desc* desc) : d(desc) {}
+    int plan_paths(const ltpl_paths_in* in, ltpl_paths_out* out) override
+    {
+        const int rc = oracle_plan_paths(d, in, out);
+        if (rc) err = "oracle_plan_paths failed";
+        return rc;
+    }
+    int vel_profile(const ltpl_vel_params* p, int n, const ltpl_vel_job* jobs, ltpl_vel_result* res) override
+    {
+        const int rc = oracle_vel_profile(d, p, n, jobs, res);
+        if (rc) err = "oracle_vel_profile failed";
+        return rc;
+    }
+    const char* last_error() override { return err.c_str(); }
+};
+std::string g_err;
+}
+
+extern "C" {
+int oracle_planner_create(const ltpl_lattice_desc* d, int max_path_nodes, int max_path_pts, const ltpl_planner_config* cfg,
+                          ltpl_planner** out)
+{
+    ltplp::HostLat lat;
+    int rc = lat.init(d, max_path_nodes, max_path_pts, &g_err);
+    if (rc) return rc;
+    return ltplp::api_create(new OracleCompute(d), lat, cfg, out, &g_err);
+}
+int oracle_planner_destroy(ltpl_planner* p) { delete p; return LTPL_OK; }
+int oracle_planner_get_caps(const ltpl_planner* p, ltpl_planner_caps* c) { return ltplp::api_get_caps(p, c); }
+const char* oracle_planner_last_error(const ltpl_planner* p) { return p ? p->P.err.c_str() : g_err.c_str(); }
+int oracle_planner_set_start(ltpl_planner* p, int32_t scen, double x, double y, double heading, double vel, double mho,
+                             int32_t* in_track, int32_t* cor_heading)
+{
+    return p ? p->P.set_start(scen, x, y, heading, vel, mho, in_track, cor_heading) : LTPL_ERR_INVALID_ARG;
+}
+int oracle_planner_calc_paths(ltpl_planner* p, const ltpl_planner_paths_in* in) { return ltplp::api_calc_paths(p, in); }
+int oracle_planner_calc_vel_profile(ltpl_planner* p, const ltpl_planner_vel_in* in) { return ltplp::api_calc_vel_profile(p, in); }
+int oracle_planner_get_paths(const ltpl_planner* p, int32_t scen, ltpl_planner_paths_view* v) { return ltplp::api_get_paths(p, scen, v); }
+int oracle_planner_get_trajectories(const ltpl_planner* p, int32_t scen, ltpl_planner_traj_view* v) { return ltplp::api_get_trajectories(p, scen, v); }
+}

@@ -210,6 +210,7 @@ class TickRecorder(object):
     def __init__(self, graph_ltpl, clock, seam_recorder=None):
         self.gl, self.clock, self.seam = graph_ltpl, clock, seam_recorder
         self.ticks = []
+        self.start = None
         self._cur = None
         self._orig = {}
         cls = graph_ltpl.online_graph.src.OnlineTrajectoryHandler.OnlineTrajectoryHandler
@@ -287,6 +288,21 @@ class TickRecorder(object):
             rec._cur = None
             return out
 
+        o_init = cls.set_initial_pose
+
+        def set_initial_pose(oth, start_pos, start_heading, start_vel=0.0, max_heading_offset=np.pi / 4):
+            out = o_init(oth, start_pos=start_pos, start_heading=start_heading, start_vel=start_vel,
+                         max_heading_offset=max_heading_offset)
+            pp = getattr(oth, P + 'last_action_set_path_param')
+            rec.start = {'pos': np.array(start_pos, dtype=float).reshape(-1), 'heading': float(np.squeeze(start_heading)),
+                         'vel': float(start_vel), 'max_heading_offset': float(max_heading_offset),
+                         'in_track': bool(out[0]), 'cor_heading': bool(out[1]),
+                         'start_node': [int(v) for v in getattr(oth, P + 'start_node')],
+                         'path_param': np.array(pp['straight'][0], dtype=float),
+                         'coeff': np.array(getattr(oth, P + 'last_action_set_coeff')['straight'][0], dtype=float)}
+            return out
+
+        wrap('set_initial_pose', set_initial_pose)
         wrap('update_objects', update_objects)
         wrap('calc_paths', calc_paths)
         wrap('get_ref_idx', get_ref_idx)
@@ -313,6 +329,7 @@ class TickRecorder(object):
         for i, t in enumerate(self.ticks):
             d = {k: v for k, v in t.items() if not k.startswith('_')}
             d['tick'] = i
+            d['start'] = self.start if i == 0 else None
             d['full'] = None
             if i in keep:
                 d['full'] = {'path_param': t['_full_paths']['path_param'], 'coeff': t['_full_paths']['coeff'],

@@ -1,0 +1,134 @@
+"""
+Closed-loop replay of the tick-level recordings (tests/golden/*_ticks.npz, recorded from the unmodified reference by
+oracle/gen_golden.py) through a planner (``graphbasedlocaltrajectoryplanner_amd.planner.Planner``): every tick feeds the
+recorded INPUTS of OnlineTrajectoryHandler (objects, selected action, clock, pose / velocity estimate, velocity arguments)
+and compares what the reference produced on that tick:
+
+  every tick      start node, offered keys, node lists + node indices + reduced flags (bit-exact), rows per path, the outputs of
+                  get_ref_idx (cut indices bit-exact, vel_plan / vel_course 1e-5), trajectory keys and ids, per-trajectory
+                  digests (rows, s_end, vx[0], vx[-1], sum vx) to 1e-5
+  selected ticks  the full stitched paths, spline coefficients and trajectories [s, x, y, psi, kappa, vx, ax] to 1e-5 relative
+
+The planner carries its own state from tick to tick (nothing is re-synchronised from the recording), so any divergence of the
+state machine shows up and compounds.
+"""
+import numpy as np
+
+from helpers import assert_close_rel, REL_TOL, KAPPA_FLOOR, load_golden
+
+
+def vehicles_of_tick(t):
+    out = []
+    for k in range(len(t['obj_radius'])):
+        pos = np.asarray(t['obj_pos'][k], dtype=float).reshape(1, 2)
+        pred = np.asarray(t['obj_pred'][k], dtype=float).reshape(-1, 2)
+        out.append((float(t['obj_radius'][k]), float(t['obj_vel'][k]), np.vstack((pos, pred))))
+    return out
+
+
+def zone_gids_of_tick(lat, t):
+    gids = []
+    for l, n in zip(t.get('zone_layers', ()), t.get('zone_nodes', ())):
+        l, n = int(l), int(n)
+        if 0 <= l < lat.num_layers and 0 <= n < lat.nodes_in_layer[l]:
+            gids.append(int(lat.layer_off[l]) + n)
+    return sorted(set(gids))
+
+
+def check_traj(got, exp, what):
+    assert got.shape == exp.shape, "%s: shape %s vs %s" % (what, got.shape, exp.shape)
+    if exp.shape[0] == 0:
+        return
+    for col, name in enumerate(("s", "x", "y", "psi", "kappa", "vx", "ax")):
+        if name == "psi":
+            d = np.abs(np.mod(got[:, col] - exp[:, col] + np.pi, 2 * np.pi) - np.pi)
+            assert float(d.max()) <= REL_TOL * np.pi, "%s psi" % what
+        elif name == "ax":
+            scale = max(float(np.max(np.abs(exp[:, 5]))) ** 2 / 2.0, 5.0)
+            assert float(np.max(np.abs(got[:, col] - exp[:, col]))) <= 1e-5 * scale, "%s ax: %g" % (
+                what, float(np.max(np.abs(got[:, col] - exp[:, col]))))
+        elif name == "kappa":
+            assert_close_rel(got[:, col], exp[:, col], what="%s kappa" % what, floor=KAPPA_FLOOR)
+        else:
+            assert_close_rel(got[:, col], exp[:, col], what="%s %s" % (what, name))
+
+
+def replay(planner, lat, ticks, scen=0, n_ticks=None, others=None):
+    """Drive planner ``scen`` through ``ticks``; ``others``: callable(tick) -> (prev_actions, vehicles, zones, pos, vel,
+    kwargs lists) filler for the remaining planners of a batch (default: replicate the recorded inputs)."""
+    n = planner.n_scen
+    st = ticks[0]['start']
+    for s in range(n):
+        in_track, cor = planner.set_start(s, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+        assert (in_track, cor) == (st['in_track'], st['cor_heading'])
+    p0 = planner.paths(scen)
+    assert p0['start_node'] == st['start_node']
+    assert_close_rel(p0['path_param']['straight'][:, 0:2], st['path_param'][:, 0:2], what="start spline xy")
+    assert_close_rel(p0['path_param']['straight'][:, 4], st['path_param'][:, 4], what="start spline el")
+    assert_close_rel(p0['coeff']['straight'], st['coeff'], what="start spline coeff") if p0['coeff']['straight'].size else None
+    seen = {'full': 0, 'keys': set(), 'backup': 0, 'dropped': 0, 'emergency': 0}
+    for t in ticks[:n_ticks]:
+        what = "tick %d" % t['tick']
+        veh = vehicles_of_tick(t)
+        zg = zone_gids_of_tick(lat, t)
+        planner.calc_paths([t['action_id_sel']] * n, [t['t']] * n, [veh] * n, [zg] * n)
+        got = planner.paths(scen)
+        exp = t['paths']
+        assert got['start_node'] == exp['start_node'], "%s: start node %s vs %s" % (what, got['start_node'], exp['start_node'])
+        assert got['keys'] == exp['keys'], "%s: keys %s vs %s" % (what, got['keys'], exp['keys'])
+        assert got['const_rows'] == exp['const_rows'], "%s: const rows %d vs %d" % (what, got['const_rows'], exp['const_rows'])
+        assert got['closest_obj_index'] == exp['closest_obj_index'], "%s: closest object" % what
+        for k in exp['keys']:
+            assert got['nodes'][k] == exp['nodes'][k], "%s/%s: node list" % (what, k)
+            assert got['node_idx'][k] == exp['node_idx'][k], "%s/%s: node_idx" % (what, k)
+            assert got['path_param'][k].shape[0] == exp['n_rows'][k], "%s/%s: rows" % (what, k)
+            if k in exp['red_len']:
+                assert got['red_len'][k] == exp['red_len'][k], "%s/%s: reduced flag" % (what, k)
+        full = t['full']
+        if full is not None:
+            for k in exp['keys']:
+                pp, epp = got['path_param'][k], full['path_param'][k]
+                assert_close_rel(pp[:, 0:2], epp[:, 0:2], what="%s/%s xy" % (what, k))
+                d = np.abs(np.mod(pp[:, 2] - epp[:, 2] + np.pi, 2 * np.pi) - np.pi)
+                assert float(d.max()) <= REL_TOL * np.pi, "%s/%s psi" % (what, k)
+                assert_close_rel(pp[:, 3], epp[:, 3], what="%s/%s kappa" % (what, k), floor=KAPPA_FLOOR)
+                assert_close_rel(pp[:, 4], epp[:, 4], what="%s/%s el" % (what, k))
+                assert_close_rel(got['coeff'][k], full['coeff'][k], what="%s/%s coeff" % (what, k))
+        va = t['vel_args']
+        planner.calc_vel_profile([t['pos_est']] * n, va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'],
+                                 local_gg=tuple(va['local_gg']), ax_max_machines=va['ax_max_machines'],
+                                 safety_d=va['safety_d'], incl_emerg_traj=va['incl_emerg_traj'])
+        traj, ids, ref = planner.trajectories(scen)
+        er = t['ref_idx']
+        assert ref['cut_index_pos'] == er['cut_index_pos'] and ref['cut_layer'] == er['cut_layer'], \
+            "%s: cut (%d, %d) vs (%d, %d)" % (what, ref['cut_index_pos'], ref['cut_layer'], er['cut_index_pos'], er['cut_layer'])
+        assert abs(ref['vel_plan'] - er['vel_plan']) <= 1e-5 * max(abs(er['vel_plan']), 1.0), "%s: vel_plan" % what
+        assert abs(ref['acc_plan'] - er['acc_plan']) <= 1e-5 * max(abs(er['acc_plan']), 5.0), "%s: acc_plan" % what
+        assert ref['vel_course'].shape == er['vel_course'].shape, "%s: vel_course length" % what
+        if er['vel_course'].size:
+            assert np.max(np.abs(ref['vel_course'] - er['vel_course'])) <= 1e-5 * max(float(np.max(np.abs(er['vel_course']))), 1.0)
+        ev = t['vel']
+        assert list(traj.keys()) == ev['keys'], "%s: trajectory keys %s vs %s" % (what, list(traj.keys()), ev['keys'])
+        assert ids == ev['traj_id'], "%s: trajectory ids" % what
+        for k in ev['keys']:
+            dg = ev['digest'][k]
+            tr = traj[k][0]
+            assert tr.shape[0] == dg[0], "%s/%s: trajectory rows %d vs %d" % (what, k, tr.shape[0], dg[0])
+            vs = max(abs(dg[4]) / max(dg[0], 1), 1.0)
+            assert abs(tr[-1, 0] - dg[1]) <= 1e-5 * max(abs(dg[1]), 1.0), "%s/%s: s_end" % (what, k)
+            assert abs(tr[0, 5] - dg[2]) <= 1e-5 * max(vs, abs(dg[2])), "%s/%s: vx[0] %g vs %g" % (what, k, tr[0, 5], dg[2])
+            assert abs(tr[-1, 5] - dg[3]) <= 1e-5 * max(vs, abs(dg[3])), "%s/%s: vx[-1]" % (what, k)
+            assert abs(float(np.sum(tr[:, 5])) - dg[4]) <= 1e-5 * max(abs(dg[4]), 1.0), "%s/%s: sum vx %g vs %g" % (
+                what, k, float(np.sum(tr[:, 5])), dg[4])
+        if full is not None:
+            for k in ev['keys']:
+                check_traj(traj[k][0], full['traj'][k], "%s/%s" % (what, k))
+            seen['full'] += 1
+        seen['keys'].update(ev['keys'])
+        seen['dropped'] += len([k for k in exp['keys'] if k not in ev['keys']])
+        seen['emergency'] += int('emergency' in ev['keys'])
+    return seen
+
+
+def load_ticks(name):
+    return load_golden(name + "_ticks.npz")

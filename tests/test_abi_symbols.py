@@ -18,7 +18,8 @@ def test_header_declares_the_expected_entry_points():
     syms = declared_symbols()
     for must in ("ltpl_create", "ltpl_destroy", "ltpl_plan_paths", "ltpl_vel_profile", "ltpl_tick_batch",
                  "ltpl_last_error", "ltpl_version", "ltpl_get_caps", "ltpl_batch_upload", "ltpl_batch_run",
-                 "ltpl_batch_download"):
+                 "ltpl_batch_download", "ltpl_planner_create", "ltpl_planner_calc_paths", "ltpl_planner_calc_vel_profile",
+                 "ltpl_planner_set_start", "ltpl_planner_get_paths", "ltpl_planner_get_trajectories"):
         assert must in syms
 
 
@@ -28,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(lib_path)
     for sym in declared_symbols():
         assert hasattr(lib, sym), "libltpl_hip.so does not export %s" % sym
-    assert lib.ltpl_version() == 2
+    assert lib.ltpl_version() == 3
 
 
 def test_product_fails_loudly_without_library(monteblanco, tmp_path):
@@ -41,7 +42,7 @@ def test_product_package_never_imports_oracle():
     pkg = os.path.join(ROOT, "graphbasedlocaltrajectoryplanner_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("oracle/", "").replace("the oracle", "") or f == "__init__.py", \
                     "%s mentions the oracle" % f
