@@ -387,6 +387,18 @@ def make_vel_jobs(jobs):
     return jarr, rarr, outs, keep
 
 
+def pack_const_segment_args(const_path_seg, pos_est, vehicles):
+    """ctypes arguments (seg, n_rows, pos_est, n_veh, x, y, radius) of ltpl_const_segment_test + keep-alive list."""
+    seg = None if const_path_seg is None else _f64(np.asarray(const_path_seg, dtype=np.float64)[:, :5])
+    n_rows = 0 if seg is None else seg.shape[0]
+    pos = None if pos_est is None else _f64(np.asarray(pos_est, dtype=np.float64).reshape(-1)[:2])
+    vx = _f64([float(p[0][0]) for _, p in vehicles] or [0.0])
+    vy = _f64([float(p[0][1]) for _, p in vehicles] or [0.0])
+    vr = _f64([float(r) for r, _ in vehicles] or [0.0])
+    return (None if seg is None else _p(seg, _pf64), n_rows, None if pos is None else _p(pos, _pf64), len(vehicles),
+            _p(vx, _pf64), _p(vy, _pf64), _p(vr, _pf64), None, (seg, pos, vx, vy, vr))
+
+
 def default_library_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libltpl_hip.so")
 
@@ -434,6 +446,8 @@ class HipBackend(object):
         L.ltpl_batch_run_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
         L.ltpl_batch_last_paths_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.ltpl_process_objects.argtypes = [C.c_void_p, C.POINTER(ObjectsIn), C.POINTER(ObjectsOut)]
+        L.ltpl_const_segment_test.argtypes = [C.c_void_p, _pf64, C.c_int32, _pf64, C.c_int32, _pf64, _pf64, _pf64,
+                                              _pi32, _pi32]
 
     def _check(self, rc):
         if rc != 0:
@@ -460,6 +474,15 @@ class HipBackend(object):
             result = self.new_paths_result(batch.n_scen)
         self._check(self.lib.ltpl_plan_paths(self.handle, C.byref(batch.struct), C.byref(result.struct)))
         return result
+
+    def const_segment_test(self, const_path_seg, pos_est, vehicles):
+        """(obj_in_const_path, object_besides_const_path, closest object index | None) of main_online_path_gen.py:76-122;
+        ``vehicles`` = [(radius, positions (k, 2) own position first)]."""
+        args = pack_const_segment_args(const_path_seg, pos_est, vehicles)
+        flags, closest = C.c_int32(0), C.c_int32(-1)
+        self._check(self.lib.ltpl_const_segment_test(self.handle, *args[:7], C.byref(flags), C.byref(closest)))
+        return (bool(flags.value & FLAG_OBJ_IN_CONST), bool(flags.value & FLAG_OBJ_BESIDES),
+                None if closest.value < 0 else int(closest.value))
 
     # ---- object ingestion ----
     def process_objects(self, x, y, theta, v, length, dt=0.2):

@@ -1338,6 +1338,7 @@ __global__ __launch_bounds__(64) void k_process_objects(DevLat lat, int n_obj, d
 static thread_local std::string g_create_error;
 struct TickLayout;
 static void free_resident(TickLayout* t);
+static int self_test(struct ltpl_handle* h, const ltpl_lattice_desc* d);
 
 struct ltpl_handle {
     int device = 0;
@@ -1760,6 +1761,9 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
         std::string why;
         h->has_hostlat = h->hostlat.init(d, h->caps.max_path_nodes, h->caps.max_path_pts, &why) == LTPL_OK;
     }
+    if (!getenv("LTPL_NO_SELFTEST")) {
+        if ((rc = self_test(h, d)) != LTPL_OK) return fail(rc);
+    }
     *out_handle = h;
     return LTPL_OK;
 }
@@ -1776,6 +1780,16 @@ struct Arena {
     size_t size = 0;
     size_t add(size_t bytes) { size_t o = size; size = align_up(size + bytes, 16); return o; }
 };
+
+// The device-resident batch of ltpl_batch_upload points into the staging buffers (d_in / d_out / d_planes). Every other
+// entry point reuses (and may reallocate) them, so it drops the resident batch first: a later ltpl_batch_run / _download then
+// fails with "no resident batch" instead of reading overwritten or freed memory.
+static void drop_resident(ltpl_handle* h)
+{
+    if (h->resident || h->resident2) (void)hipDeviceSynchronize();
+    free_resident(h->resident); h->resident = nullptr;
+    free_resident(h->resident2); h->resident2 = nullptr;
+}
 
 static int ensure(ltpl_handle* h, void** hp, size_t* hcap, void** dp, size_t* dcap, size_t need)
 {
@@ -1946,11 +1960,20 @@ static void scratch_poison(ltpl_handle* h)
         hipLaunchKernelGGL(k_scratch_poison, dim3(256 * 64), dim3(64), 0, h->stream, (unsigned)strtoul(e, nullptr, 0), (unsigned*)nullptr);
 }
 
+static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_out* out, int force_nw);
+
 extern "C" int ltpl_plan_paths(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_out* out)
+{
+    return plan_paths_impl(h, in, out, 0);
+}
+
+// force_nw: 0 = choose by batch size, 1 / NUM_WAVES = one-wave batch kernel / four-wave latency kernel (self-test)
+static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_out* out, int force_nw)
 {
     if (!h) return LTPL_ERR_INVALID_ARG;
     if (!out) { h->err = "null output"; return LTPL_ERR_INVALID_ARG; }
     HIP_TRY(h, hipSetDevice(h->device));
+    drop_resident(h);
     InLayout li;
     int rc = validate_and_layout(h, in, &li);
     if (rc) return rc;
@@ -1966,7 +1989,8 @@ extern "C" int ltpl_plan_paths(ltpl_handle* h, const ltpl_paths_in* in, ltpl_pat
     bind_out(static_cast<unsigned char*>(h->d_out), lo, out->cap_nodes, out->cap_pts, &dout);
     HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, li.total, hipMemcpyHostToDevice, h->stream));
     scratch_poison(h);
-    if ((rc = launch_paths(h, (in->n_scen >= h->nw1_min_scen && h->batch_nw == 1) ? 1 : NUM_WAVES, in->n_scen, h->stream, di, dout))) return rc;
+    const int nw = force_nw ? force_nw : ((in->n_scen >= h->nw1_min_scen && h->batch_nw == 1) ? 1 : NUM_WAVES);
+    if ((rc = launch_paths(h, nw, in->n_scen, h->stream, di, dout))) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, lo.total, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     dbg_report(h, "k_paths", in->n_scen);
@@ -1981,6 +2005,7 @@ extern "C" int ltpl_process_objects(ltpl_handle* h, const ltpl_objects_in* in, l
         !out->on_track || !out->pred_x || !out->pred_y || !out->radius) { h->err = "null argument or n_obj < 1"; return LTPL_ERR_INVALID_ARG; }
     if (!h->lat.ctx) { h->err = "the lattice was created without track bounds (normvec / width_right / width_left)"; return LTPL_ERR_UNSUPPORTED; }
     HIP_TRY(h, hipSetDevice(h->device));
+    drop_resident(h);
     const size_t n = (size_t)in->n_obj;
     Arena ain, aout;
     const size_t o_x = ain.add(8 * n), o_y = ain.add(8 * n), o_t = ain.add(8 * n), o_v = ain.add(8 * n), o_l = ain.add(8 * n);
@@ -2065,6 +2090,7 @@ extern "C" int ltpl_vel_profile(ltpl_handle* h, const ltpl_vel_params* vp, int n
     if (!h) return LTPL_ERR_INVALID_ARG;
     if (n_jobs < 1 || !jobs || !results) { h->err = "no jobs"; return LTPL_ERR_INVALID_ARG; }
     HIP_TRY(h, hipSetDevice(h->device));
+    drop_resident(h);
     // pooled layout: [axm table][jobs][kappa | el | gg per job] ; outputs: [flags][vx per job]
     Arena ain, aout;
     const size_t o_axm = ain.add(sizeof(double) * 2 * (size_t)(vp ? vp->n_ax_max_machines : 1));
@@ -2323,6 +2349,7 @@ extern "C" int ltpl_tick_batch(ltpl_handle* h, const ltpl_paths_in* in, const lt
     if (!h) return LTPL_ERR_INVALID_ARG;
     if (!out || !vout) { h->err = "null output"; return LTPL_ERR_INVALID_ARG; }
     HIP_TRY(h, hipSetDevice(h->device));
+    drop_resident(h);
     TickLayout t;
     int rc = tick_prepare(h, in, vin, out->cap_nodes, out->cap_pts, &t);
     if (rc) return rc;
@@ -2346,7 +2373,7 @@ extern "C" int ltpl_batch_upload(ltpl_handle* h, const ltpl_paths_in* in, const 
 {
     if (!h) return LTPL_ERR_INVALID_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
-    delete h->resident; h->resident = nullptr;
+    drop_resident(h);
     TickLayout* t = new TickLayout();
     int rc = tick_prepare(h, in, vin, cap_nodes, cap_pts, t);
     if (rc) { delete t; return rc; }
@@ -2359,7 +2386,6 @@ extern "C" int ltpl_batch_upload(ltpl_handle* h, const ltpl_paths_in* in, const 
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->resident = t;
     h->last_set = 0;
-    delete h->resident2; h->resident2 = nullptr;
     if (t->pipeline && !getenv("LTPL_NO_OVERLAP")) {
         // second buffer set for the two-stream software pipeline of ltpl_batch_run
         if (t->out_total > h->d_out2_cap) {
@@ -2485,6 +2511,66 @@ extern "C" int ltpl_batch_download(ltpl_handle* h, ltpl_paths_out* out, ltpl_tic
 static void free_resident(TickLayout* t) { delete t; }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// self-test at ltpl_create: the one-wave batch kernel and the four-wave latency kernel are two differently scheduled builds
+// of the same source (different register budgets, LDS plans and synchronisation); 64 probe scenarios derived from the
+// lattice itself (an obstacle on the race line four layers ahead: mask, three filters, tie-break rounds) must come out
+// IDENTICAL from both, otherwise the handle is refused. Guards against a toolchain that miscompiles one of them
+//  for lattices no parity test has seen. LTPL_NO_SELFTEST=1 skips it.
+// ---------------------------------------------------------------------------------------------------------------------
+static int self_test(ltpl_handle* h, const ltpl_lattice_desc* d)
+{
+    const int n = 64, L = d->num_layers, A = LTPL_MAX_ACTIONS;
+    std::vector<int> sl(n), sn(n), flags(n, LTPL_FLAG_ACTION_SETS), la(n, LTPL_ACT_NONE), cc(n, -1), veh_off(n + 1), pos_off(n + 1),
+        zone_off(n + 1, 0), zone(1, 0), n_last(n, 0), ll((size_t)n * LTPL_MAX_LAST_NODES, -1), ln((size_t)n * LTPL_MAX_LAST_NODES, -1);
+    std::vector<double> psi(n, 0.0), rad(n, 2.5), px(n), py(n), w(1, 0.0);
+    for (int i = 0; i < n; ++i) {
+        sl[i] = (int)(((long long)i * L) / n); sn[i] = d->raceline_index[sl[i]];
+        const int ol = (sl[i] + 4) % L, g = d->layer_node_off[ol] + d->raceline_index[ol];
+        px[i] = d->node_x[g]; py[i] = d->node_y[g];
+        veh_off[i] = i; pos_off[i] = i;
+        if (i % 4 == 3) flags[i] |= LTPL_FLAG_OBJ_BESIDES;            // constant-segment template: follow + left + right on `default`
+    }
+    veh_off[n] = n; pos_off[n] = n;
+    ltpl_paths_in in; memset(&in, 0, sizeof(in));
+    in.n_scen = n; in.n_w_last = 0; in.w_last_edges = w.data(); in.start_layer = sl.data(); in.start_node = sn.data();
+    in.flags = flags.data(); in.last_action = la.data(); in.const_closest = cc.data(); in.psi_s = psi.data();
+    in.veh_off = veh_off.data(); in.pos_off = pos_off.data(); in.veh_radius = rad.data(); in.pos_x = px.data(); in.pos_y = py.data();
+    in.zone_off = zone_off.data(); in.zone_gid = zone.data(); in.n_last = n_last.data(); in.last_layer = ll.data(); in.last_node = ln.data();
+    const int cn = h->caps.max_path_nodes, cp = h->caps.max_path_pts;
+    struct Out {
+        std::vector<int> end_layer, coi, con, n_actions, action_id, valid, reduced, goal_layer, n_nodes, n_pts, n_ties, nodes, node_idx;
+        std::vector<double> coeff, pp; ltpl_paths_out o;
+    };
+    auto make = [&](Out& O) {
+        O.end_layer.assign(n, 0); O.coi.assign(n, 0); O.con.assign((size_t)n * 2, 0); O.n_actions.assign(n, 0);
+        for (auto* v : {&O.action_id, &O.valid, &O.reduced, &O.goal_layer, &O.n_nodes, &O.n_pts, &O.n_ties}) v->assign((size_t)n * A, 0);
+        O.nodes.assign((size_t)n * A * cn, 0); O.node_idx.assign((size_t)n * A * cn, 0);
+        O.coeff.assign((size_t)n * A * cn * 8, 0.0); O.pp.assign((size_t)n * A * cp * 5, 0.0);
+        memset(&O.o, 0, sizeof(O.o));
+        O.o.cap_nodes = cn; O.o.cap_pts = cp; O.o.end_layer = O.end_layer.data(); O.o.closest_obj_index = O.coi.data();
+        O.o.closest_obj_node = O.con.data(); O.o.n_actions = O.n_actions.data(); O.o.action_id = O.action_id.data();
+        O.o.valid = O.valid.data(); O.o.reduced = O.reduced.data(); O.o.goal_layer = O.goal_layer.data(); O.o.n_nodes = O.n_nodes.data();
+        O.o.n_pts = O.n_pts.data(); O.o.n_ties = O.n_ties.data(); O.o.nodes = O.nodes.data(); O.o.node_idx = O.node_idx.data();
+        O.o.coeff = O.coeff.data(); O.o.path_param = O.pp.data();
+    };
+    Out a, b; make(a); make(b);
+    int rc = plan_paths_impl(h, &in, &a.o, 1);
+    if (rc) return rc;
+    if ((rc = plan_paths_impl(h, &in, &b.o, NUM_WAVES))) return rc;
+    bool same = a.n_actions == b.n_actions && a.action_id == b.action_id && a.valid == b.valid && a.reduced == b.reduced &&
+                a.n_nodes == b.n_nodes && a.n_pts == b.n_pts && a.n_ties == b.n_ties && a.coi == b.coi;
+    int n_paths = 0;
+    for (size_t slot = 0; same && slot < (size_t)n * A; ++slot) {
+        if (!a.valid[slot]) continue;
+        ++n_paths;
+        for (int i = 0; i < a.n_nodes[slot]; ++i) same = same && a.nodes[slot * cn + i] == b.nodes[slot * cn + i];
+    }
+    if (!same) { h->err = "self-test failed: the one-wave batch kernel and the four-wave kernel disagree on the probe scenarios"; return LTPL_ERR_HIP; }
+    if (n_paths == 0) { h->err = "self-test failed: no path found on any probe scenario"; return LTPL_ERR_HIP; }
+    return LTPL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // planner (ABI v3): the OnlineTrajectoryHandler state machine of planner_core.hpp on top of the kernels above
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
@@ -2498,6 +2584,19 @@ struct HipCompute : ltplp::Compute {
     }
     const char* last_error() override { return h->err.c_str(); }
 };
+}
+
+extern "C" int ltpl_const_segment_test(const ltpl_handle* h, const double* seg, int32_t n_rows, const double* pos_est, int32_t n_veh,
+                                       const double* veh_x, const double* veh_y, const double* veh_radius, int32_t* flags_out,
+                                       int32_t* closest_out)
+{
+    if (!h || !flags_out || !closest_out || n_veh < 0 || n_rows < 0) return LTPL_ERR_INVALID_ARG;
+    if (!h->has_hostlat) return LTPL_ERR_UNSUPPORTED;
+    int in_const, besides, closest;
+    ltplp::const_segment_test(h->hostlat, n_rows > 0 ? seg : nullptr, n_rows, pos_est, n_veh, veh_x, veh_y, veh_radius, &in_const, &besides, &closest);
+    *flags_out = (in_const ? LTPL_FLAG_OBJ_IN_CONST : 0) | (besides ? LTPL_FLAG_OBJ_BESIDES : 0);
+    *closest_out = closest;
+    return LTPL_OK;
 }
 
 extern "C" int ltpl_planner_create(ltpl_handle* h, const ltpl_planner_config* cfg, ltpl_planner** out)
@@ -2517,6 +2616,7 @@ extern "C" int ltpl_planner_set_start(ltpl_planner* p, int32_t scen, double x, d
     return p->P.set_start(scen, x, y, heading, vel, max_heading_offset, in_track, cor_heading);
 }
 extern "C" int ltpl_planner_calc_paths(ltpl_planner* p, const ltpl_planner_paths_in* in) { return ltplp::api_calc_paths(p, in); }
+extern "C" int ltpl_planner_get_ref_idx(ltpl_planner* p, const double* px, const double* py) { return (p && px && py) ? p->P.get_ref_idx(px, py) : LTPL_ERR_INVALID_ARG; }
 extern "C" int ltpl_planner_calc_vel_profile(ltpl_planner* p, const ltpl_planner_vel_in* in) { return ltplp::api_calc_vel_profile(p, in); }
 extern "C" int ltpl_planner_get_paths(const ltpl_planner* p, int32_t scen, ltpl_planner_paths_view* v) { return ltplp::api_get_paths(p, scen, v); }
 extern "C" int ltpl_planner_get_trajectories(const ltpl_planner* p, int32_t scen, ltpl_planner_traj_view* v) { return ltplp::api_get_trajectories(p, scen, v); }

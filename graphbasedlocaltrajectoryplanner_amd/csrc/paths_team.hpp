@@ -143,9 +143,11 @@ __device__ __forceinline__ void par_store(unsigned char* par, size_t idx, int sr
 struct TeamShared {
     int closest_idx, cl, cn, have_cn;          // written by wave 0 in phase 3
     int start_ok[NFILT];
-    // previous-solution cost discount per layer transition j (gen_local_node_template.py:154-162), filled in phase 0
-    int fac_src[LTPL_MAX_LAST_NODES], fac_dst[LTPL_MAX_LAST_NODES];
+    // previous-solution cost discount (gen_local_node_template.py:154-162), filled in phase 0: pair i of the node list applies
+    // to the transition into the layer at distance fac_j[i] from the start layer (-1: outside the planning range)
+    int fac_j[LTPL_MAX_LAST_NODES], fac_src[LTPL_MAX_LAST_NODES], fac_dst[LTPL_MAX_LAST_NODES];
     double fac[LTPL_MAX_LAST_NODES];
+    int fac_jmax;
 };
 
 // uniform per-scenario state, computed redundantly by every wave (scalar registers)
@@ -254,17 +256,18 @@ __device__ __forceinline__ bool team_relax_layer(const DevLat& lat, const DevPat
     return __ballot(any) != 0ull;
 }
 
-// cost discount along the previous solution (gen_local_node_template.py:154-162) for the transition j-1 -> j
+// cost discount along the previous solution (gen_local_node_template.py:154-162) for the transition j-1 -> j: pair i of
+// the node list (factor w_last_edges[i]) applies to whatever transition its two nodes span -- normally i = j - 1 (the list
+// starts at the start node, OTH.py:393), but the seam accepts any alignment (GraphBase.factor_edge_cost, GraphBase.py:478-512)
 __device__ __forceinline__ void team_factor(const DevLat& lat, const DevPathsIn& in, const Scen& sc, int j, int b,
                                             int& fac_src, int& fac_dst, double& fac)
 {
     fac_src = -1; fac_dst = -1; fac = 1.0;
-    if (j - 1 < sc.n_fac) {
-        const int* ll = in.last_layer + (size_t)sc.s * LTPL_MAX_LAST_NODES;
-        const int* ln = in.last_node + (size_t)sc.s * LTPL_MAX_LAST_NODES;
-        int pb = b - 1; if (pb < 0) pb += lat.L;
-        if (ll[j - 1] == pb && ll[j] == b) { fac_src = ln[j - 1]; fac_dst = ln[j]; fac = in.w_last[j - 1]; }
-    }
+    const int* ll = in.last_layer + (size_t)sc.s * LTPL_MAX_LAST_NODES;
+    const int* ln = in.last_node + (size_t)sc.s * LTPL_MAX_LAST_NODES;
+    int pb = b - 1; if (pb < 0) pb += lat.L;
+    for (int i = 0; i < sc.n_fac; ++i)
+        if (ll[i] == pb && ll[i + 1] == b) { fac_src = ln[i]; fac_dst = ln[i + 1]; fac = in.w_last[i]; break; }
 }
 
 // Re-sweep of one filter up to layer J straight from global memory (reduced-horizon paths only: the goal node of a
@@ -791,11 +794,22 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
         const int v0 = at(lat.layer_off, b);
         lay[j] = make_int4(v0, (at(lat.layer_off, b + 1) - v0) | (at(lat.layer_degmax, b) << 16), at(lat.layer_ebase, b), at(lat.layer_ebase, b + 1));
     }
-    if (tid >= 1 && tid < LTPL_MAX_LAST_NODES) {
-        int b = sc.sl + tid; if (b >= L) b -= L;
-        int fs, fd; double fac;
-        team_factor(lat, in, sc, tid, b, fs, fd, fac);
-        ts.fac_src[tid] = fs; ts.fac_dst[tid] = fd; ts.fac[tid] = fac;
+    if (tid < LTPL_MAX_LAST_NODES) {
+        // pair tid of the previous solution: which transition of the planning range does it span?
+        int fj = -1, fs = -1, fd = -1; double fac = 1.0;
+        if (tid < sc.n_fac) {
+            const int* ll = in.last_layer + (size_t)sc.s * LTPL_MAX_LAST_NODES;
+            const int* ln = in.last_node + (size_t)sc.s * LTPL_MAX_LAST_NODES;
+            const int la = ll[tid], lb = ll[tid + 1];
+            int nx = la + 1; if (nx >= L) nx -= L;
+            int jj = lb - sc.sl; if (jj < 0) jj += L;
+            if (la >= 0 && la < L && lb == nx && jj >= 1 && jj <= sc.H) { fj = jj; fs = ln[tid]; fd = ln[tid + 1]; fac = in.w_last[tid]; }
+        }
+        ts.fac_j[tid] = fj; ts.fac_src[tid] = fs; ts.fac_dst[tid] = fd; ts.fac[tid] = fac;
+        int mx = fj;
+#pragma unroll
+        for (int m = 1; m < LTPL_MAX_LAST_NODES; m <<= 1) { const int o = __shfl_xor(mx, m); mx = o > mx ? o : mx; }
+        if (tid == 0) ts.fac_jmax = mx;
     }
     // vehicle of every position (radius lookup in phase 2)
     for (int k = tid; k < sc.n_veh; k += NT) {
@@ -980,7 +994,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
         if (lane == 0) { ts.closest_idx = ci; ts.cl = cl; ts.cn = cn; ts.have_cn = have; }
     }
     team_sync<NW>();
-    const int t_cl = ts.cl, t_cn = ts.cn, t_have = ts.have_cn;
+    const int t_cl = ts.cl, t_cn = ts.cn, t_have = ts.have_cn, fac_jmax = ts.fac_jmax;
     // action template (uniform, every thread)
     int n_act = 0, filt[LTPL_MAX_ACTIONS], nm0[LTPL_MAX_ACTIONS];
     int closest_idx = ts.closest_idx;
@@ -1067,7 +1081,10 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             A.j = j; A.b = b; A.v0 = ly.x; A.Kb = ly.y & 0xffff; A.ne = ly.w - ly.z; A.eb = ly.z; A.kpad = kpad; A.hm = hm; A.cur = j & 1; A.prv = (j - 1) & 1;
             A.H = H; A.cl_hit = (b == t_cl) ? 1 : 0; A.cn = t_cn;
             A.fs = -1; A.fd = -1; A.fac = 1.0;
-            if (j - 1 < sc.n_fac) { A.fs = ts.fac_src[j]; A.fd = ts.fac_dst[j]; A.fac = ts.fac[j]; }
+            if (j <= fac_jmax) {
+                for (int i = 0; i < sc.n_fac; ++i)
+                    if (ts.fac_j[i] == j) { A.fs = ts.fac_src[i]; A.fd = ts.fac_dst[i]; A.fac = ts.fac[i]; break; }
+            }
             // filters that advance through this layer; left / right read `default`'s frontier in their first own layer
             unsigned actm = 0;
             if ((need >> F_PR) & 1u) actm |= 1u << F_PR;

@@ -133,6 +133,37 @@ inline Foot project_on_polyline(const Poly& p, double qx, double qy, bool closed
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// constant-segment test in front of seam (1) (main_online_path_gen.py:76-122): is an object beside / on the part of the last
+// path that stays constant? `seg` = rows [x, y, psi, kappa, el] of const_path_seg, `pos_est` = 2 doubles or null
+// ---------------------------------------------------------------------------------------------------------------------
+inline void const_segment_test(const HostLat& lat, const double* seg, int seg_rows, const double* pos_est, int n_veh,
+                               const double* veh_x, const double* veh_y, const double* veh_radius, int* in_const, int* besides,
+                               int* closest)
+{
+    *in_const = 0; *besides = 0; *closest = -1;
+    if (!seg || seg_rows < 2) return;
+    Poly rl{lat.race_x.data(), lat.race_y.data(), 1, lat.L};
+    auto s_rl = [&](int i) { return lat.s_rl[(size_t)i]; };
+    const double sx = pos_est ? pos_est[0] : seg[0], sy = pos_est ? pos_est[1] : seg[1];
+    const double s_start = project_on_polyline(rl, sx, sy, true, true, s_rl, lat.L).s;
+    const double s_end = project_on_polyline(rl, seg[(size_t)(seg_rows - 1) * 5], seg[(size_t)(seg_rows - 1) * 5 + 1], true, true, s_rl, lat.L).s;
+    double smallest = kInf;
+    for (int k = 0; k < n_veh; ++k) {
+        const double s_obj = project_on_polyline(rl, veh_x[k], veh_y[k], true, true, s_rl, lat.L).s;
+        if ((s_start <= s_obj && s_obj <= s_end) || (s_start > s_end && (s_obj > s_start || s_obj < s_end))) {
+            *besides = 1;
+            const double od = s_obj < s_start ? s_obj + lat.s_rl[(size_t)lat.L - 1] - s_start : s_obj - s_start;
+            if (*closest < 0 || od < smallest) { *closest = k; smallest = od; }          // :96,113
+            const double ref = std::pow(veh_radius[k] + lat.veh_width / 2, 2);
+            for (int i = 0; i < seg_rows; ++i) {
+                const double d2 = std::pow(seg[(size_t)i * 5] - veh_x[k], 2) + std::pow(seg[(size_t)i * 5 + 1] - veh_y[k], 2);
+                if (d2 <= ref) { *in_const = 1; break; }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // state
 // ---------------------------------------------------------------------------------------------------------------------
 #define LTPLP_NONE (-1)
@@ -175,6 +206,7 @@ struct Scn {
     int loc_path_start_idx = 0, start_node_idx = 0;
     // outputs of the last get_ref_idx
     int cut_index_pos = 0, cut_layer = 0; double vel_plan = 0.0, acc_plan = 0.0; std::vector<double> vel_course;
+    bool ref_done = false;                                  // get_ref_idx already ran for the current tick
     std::vector<std::pair<int, int>> path_ids;              // action_set_path_id of the last tick (key, id), dropped keys included
 
     Traj* find_last(int id) { for (auto& t : last) if (t.id == id) return &t; return nullptr; }
@@ -319,33 +351,12 @@ struct Planner {
         return LTPL_OK;
     }
 
-    // -----------------------------------------------------------------------------------------------------------------
-    // constant-segment test in front of seam (1) (main_online_path_gen.py:76-122)
-    // -----------------------------------------------------------------------------------------------------------------
     void const_segment_test(const Scn& S, const double* seg, int seg_rows, int* in_const, int* besides, int* closest) const
     {
-        *in_const = 0; *besides = 0; *closest = -1;
-        if (!seg || seg_rows < 2) return;
-        Poly rl{lat.race_x.data(), lat.race_y.data(), 1, lat.L};
-        auto s_rl = [&](int i) { return lat.s_rl[(size_t)i]; };
-        const double sx = S.has_pos ? S.pos_est[0] : seg[0], sy = S.has_pos ? S.pos_est[1] : seg[1];
-        const double s_start = project_on_polyline(rl, sx, sy, true, true, s_rl, lat.L).s;
-        const double s_end = project_on_polyline(rl, seg[(size_t)(seg_rows - 1) * 5], seg[(size_t)(seg_rows - 1) * 5 + 1], true, true, s_rl, lat.L).s;
-        double smallest = kInf;
-        for (size_t k = 0; k < S.veh.size(); ++k) {
-            const ObjVeh& v = S.veh[k];
-            const double s_obj = project_on_polyline(rl, v.x, v.y, true, true, s_rl, lat.L).s;
-            if ((s_start <= s_obj && s_obj <= s_end) || (s_start > s_end && (s_obj > s_start || s_obj < s_end))) {
-                *besides = 1;
-                const double od = s_obj < s_start ? s_obj + lat.s_rl[(size_t)lat.L - 1] - s_start : s_obj - s_start;
-                if (*closest < 0 || od < smallest) { *closest = (int)k; smallest = od; }      // :96,113
-                const double ref = std::pow(v.radius + lat.veh_width / 2, 2);
-                for (int i = 0; i < seg_rows; ++i) {
-                    const double d2 = std::pow(seg[(size_t)i * 5] - v.x, 2) + std::pow(seg[(size_t)i * 5 + 1] - v.y, 2);
-                    if (d2 <= ref) { *in_const = 1; break; }
-                }
-            }
-        }
+        std::vector<double> vx(S.veh.size()), vy(S.veh.size()), vr(S.veh.size());
+        for (size_t k = 0; k < S.veh.size(); ++k) { vx[k] = S.veh[k].x; vy[k] = S.veh[k].y; vr[k] = S.veh[k].radius; }
+        ltplp::const_segment_test(lat, seg, seg_rows, S.has_pos ? S.pos_est : nullptr, (int)S.veh.size(), vx.data(), vy.data(), vr.data(),
+                                  in_const, besides, closest);
     }
 
     // -----------------------------------------------------------------------------------------------------------------
@@ -591,6 +602,13 @@ struct Planner {
         S.last_cut_idx = S.cut_index_pos - cut_index_layer;
     }
 
+    // get_ref_idx as its own call (Graph_LTPL.py:380-383 calls it right before calc_vel_profile); calc_vel_profile then reuses it
+    int get_ref_idx(const double* px, const double* py)
+    {
+        for (size_t s = 0; s < sc.size(); ++s) { ref_idx(sc[s], px[s], py[s]); sc[s].ref_done = true; }
+        return LTPL_OK;
+    }
+
     // -----------------------------------------------------------------------------------------------------------------
     // OTH.calc_vel_profile (OTH.py:603-1040), batched: all seam-(2) jobs of a stage go out in one launch
     // -----------------------------------------------------------------------------------------------------------------
@@ -657,7 +675,8 @@ struct Planner {
         for (int s = 0; s < n; ++s) {
             Scn& S = sc[(size_t)s];
             const VelReq& R = req[s];
-            ref_idx(S, R.pos_x, R.pos_y);
+            if (!S.ref_done) ref_idx(S, R.pos_x, R.pos_y);
+            S.ref_done = false;
             S.traj_base_id += 10;
             // VpForwardBackward.update_dyn_parameters (:65-84)
             if (!S.has_old_gg) { S.old_gg_scale = R.gg_scale; S.has_old_gg = true; }

@@ -199,6 +199,11 @@ class Lattice(object):
         Build the SoA lattice from a (reference) ``GraphBase`` through its public API only: ``get_edges`` (648),
         ``get_edge`` (444), ``get_node_info`` (221) and the public attributes of GraphBase.py:93-119.
         """
+        if not getattr(gb, "virt_goal_node", True):
+            # GraphBase.search_graph_layer's else-branch (GraphBase.py:896-927: race-line node first, then its neighbours one by
+            # one) is a different search; this backend always searches to the virtual goal vertex of the end layer
+            raise ValueError("lattices built with virt_goal_n=False (params/ltpl_config_offline.ini:25) are not supported: "
+                             "the backend implements the virtual-goal-node search only")
         L = int(gb.num_layers)
         nodes_in_layer = np.array([gb.nodes_in_layer[l] for l in range(L)], dtype=np.int32)
         layer_off = np.zeros(L + 1, dtype=np.int64)

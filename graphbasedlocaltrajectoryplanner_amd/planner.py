@@ -130,6 +130,7 @@ class Planner(object):
         f("set_start").argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                    _pi32, _pi32]
         f("calc_paths").argtypes = [C.c_void_p, C.POINTER(PlannerPathsIn)]
+        f("get_ref_idx").argtypes = [C.c_void_p, _pf64, _pf64]
         f("calc_vel_profile").argtypes = [C.c_void_p, C.POINTER(PlannerVelIn)]
         f("get_paths").argtypes = [C.c_void_p, C.c_int32, C.POINTER(PathsView)]
         f("get_trajectories").argtypes = [C.c_void_p, C.c_int32, C.POINTER(TrajView)]
@@ -184,6 +185,14 @@ class Planner(object):
         i.veh_radius, i.veh_vel, i.pos_x, i.pos_y = (_p(a, _pf64) for a in keep[4:8])
         i.zone_off, i.zone_gid = _p(keep[8], _pi32), _p(keep[9], _pi32)
         self._check(self._fn("calc_paths")(self.handle, C.byref(i)))
+
+    def get_ref_idx(self, pos_est, scen=0):
+        """OnlineTrajectoryHandler.get_ref_idx (OTH.py:518-601) for all planners; returns planner ``scen``'s 5-tuple."""
+        pos = np.asarray(pos_est, dtype=np.float64).reshape(self.n_scen, 2)
+        px, py = _f64(pos[:, 0]), _f64(pos[:, 1])
+        self._check(self._fn("get_ref_idx")(self.handle, _p(px, _pf64), _p(py, _pf64)))
+        ref = self.trajectories(scen)[2]
+        return ref["cut_index_pos"], ref["cut_layer"], ref["vel_plan"], ref["vel_course"], ref["acc_plan"]
 
     # ---- Graph_LTPL.calc_vel_profile --------------------------------------------------------------------------------------
     def calc_vel_profile(self, pos_est, vel_est, vel_max=100.0, gg_scale=1.0, local_gg=(5.0, 5.0),

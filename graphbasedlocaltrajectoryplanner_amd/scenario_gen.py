@@ -85,13 +85,15 @@ def random_scenarios(lat, n, seed, n_veh=8, lateral=True, zone_prob=0.3, last_pr
 SAMPLE_ZONE = ([64] * 7 + [65] * 7 + [66] * 7, list(range(7)) * 3)     # main_std_example.py:90-91
 
 
-def c2_scenarios(lat, n, seed=1, n_opp=8):
+def c2_scenarios(lat, n, seed=1, n_opp=8, lead_gap=None):
     """
     Batch of independent C2 scenarios: the std-example opponent set -- ``n_opp`` race-line
     followers at s0_k = 250 + 280 k with vel_scale_k = 0.30 + 0.05 (k mod 4), 0.2 s constant-velocity prediction
     (O = 2 n_opp obstacle positions) -- phase-shifted by rng.uniform(0, track length); ego start layer
     rng.integers(0, L) on the race-line node; the sample zone of main_std_example.py; previous solution = race-line
     nodes (cost discount w_last_edges), constant-segment heading = node heading. Returns (scenarios, vehicle speeds).
+    ``lead_gap=(lo, hi)``: the phase shift is chosen such that opponent 0 drives rng.uniform(lo, hi) metres ahead of the ego
+    (every scenario then has an object inside the planning horizon: the [follow, left, right] template is live).
     """
     rng = np.random.default_rng(seed)
     L = lat.num_layers
@@ -103,6 +105,8 @@ def c2_scenarios(lat, n, seed=1, n_opp=8):
         shift = rng.uniform(0.0, track_len)
         sl = int(rng.integers(0, L))
         sn = int(lat.raceline_index[sl])
+        if lead_gap is not None:
+            shift = float(lat.s_raceline[sl]) + rng.uniform(lead_gap[0], lead_gap[1]) - 250.0
         vehicles, vv = [], []
         for k in range(n_opp):
             s_k = 250.0 + 280.0 * k + shift

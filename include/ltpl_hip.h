@@ -275,6 +275,13 @@ int ltpl_version(void);
 /* --- seam (1): main_online_path_gen.py:11 ------------------------------------------------------------------------- */
 int ltpl_plan_paths(ltpl_handle* handle, const ltpl_paths_in* in, ltpl_paths_out* out);
 
+/* --- constant-segment test in front of seam (1): main_online_path_gen.py:76-122 (host side, O(#objects) projections on the
+ *     race line). seg = rows [x, y, psi, kappa, el] of const_path_seg (n_rows may be 0), pos_est = 2 doubles or NULL;
+ *     flags_out receives LTPL_FLAG_OBJ_IN_CONST | LTPL_FLAG_OBJ_BESIDES bits, closest_out the object index or -1 ---------- */
+int ltpl_const_segment_test(const ltpl_handle* handle, const double* seg, int32_t n_rows, const double* pos_est, int32_t n_veh,
+                            const double* veh_x, const double* veh_y, const double* veh_radius, int32_t* flags_out,
+                            int32_t* closest_out);
+
 /* --- object ingestion: ObjectListInterface.py:75-153, check_inside_bounds.py:7-59 --------------------------------- */
 int ltpl_process_objects(ltpl_handle* handle, const ltpl_objects_in* in, ltpl_objects_out* out);
 
@@ -287,6 +294,9 @@ int ltpl_tick_batch(ltpl_handle* handle, const ltpl_paths_in* in, const ltpl_tic
                     ltpl_paths_out* out, ltpl_tick_vel_out* vout);
 
 /* Device-resident variant for benchmarks: upload the batch once, replay the fused kernel, download on demand.
+ * The resident batch lives in the handle's staging buffers: ANY other entry point on the same handle (ltpl_plan_paths,
+ * ltpl_tick_batch, ltpl_vel_profile, ltpl_process_objects, the planner calls) drops it, after which ltpl_batch_run /
+ * ltpl_batch_download return LTPL_ERR_INVALID_ARG ("no resident batch") until the next ltpl_batch_upload.
  * ltpl_batch_run enqueues `reps` launches on the handle's stream and, when ms_total != NULL, brackets them with HIP
  * events on that stream and waits. */
 int ltpl_batch_upload(ltpl_handle* handle, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin,
@@ -402,6 +412,9 @@ const char* ltpl_planner_last_error(const ltpl_planner* planner);
 int ltpl_planner_set_start(ltpl_planner* planner, int32_t scen, double x, double y, double heading, double vel,
                            double max_heading_offset, int32_t* in_track, int32_t* cor_heading);
 int ltpl_planner_calc_paths(ltpl_planner* planner, const ltpl_planner_paths_in* in);
+/* OnlineTrajectoryHandler.get_ref_idx (OTH.py:518-601) on its own; optional -- ltpl_planner_calc_vel_profile runs it when it was
+ * not called for the tick. Results: cut_index_pos .. vel_course of ltpl_planner_traj_view. */
+int ltpl_planner_get_ref_idx(ltpl_planner* planner, const double* pos_est_x, const double* pos_est_y);
 int ltpl_planner_calc_vel_profile(ltpl_planner* planner, const ltpl_planner_vel_in* in);
 /* copy-out of planner `scen`'s state (fills the counts, copies the arrays whose pointers are non-NULL) */
 int ltpl_planner_get_paths(const ltpl_planner* planner, int32_t scen, ltpl_planner_paths_view* view);

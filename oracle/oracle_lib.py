@@ -69,6 +69,22 @@ class OracleBackend(object):
                                                 rarr))
         return [(outs[i], bool(rarr[i].too_close), bool(rarr[i].vel_bound)) for i in range(len(jobs))]
 
+    def const_segment_test(self, const_path_seg, pos_est, vehicles):
+        """Host logic of the product (csrc/planner_core.hpp) through the test harness library; no device arithmetic involved."""
+        from oracle import planner_host
+        if not hasattr(self, "_host_lib"):
+            planner_host.build()
+            self._host_lib = C.CDLL(planner_host.LIB)
+            self._host_lib.oracle_const_segment_test.argtypes = [
+                C.POINTER(_capi.LatticeDesc), _capi._pf64, C.c_int32, _capi._pf64, C.c_int32, _capi._pf64, _capi._pf64,
+                _capi._pf64, _capi._pi32, _capi._pi32]
+        args = _capi.pack_const_segment_args(const_path_seg, pos_est, vehicles)
+        flags, closest = C.c_int32(0), C.c_int32(-1)
+        self._check(self._host_lib.oracle_const_segment_test(C.byref(self.binding.desc), *args[:7], C.byref(flags),
+                                                             C.byref(closest)))
+        return (bool(flags.value & _capi.FLAG_OBJ_IN_CONST), bool(flags.value & _capi.FLAG_OBJ_BESIDES),
+                None if closest.value < 0 else int(closest.value))
+
     def process_objects(self, x, y, theta, v, length, dt=0.2):
         i, o, arrays, keep = _capi.make_objects(x, y, theta, v, length, dt)
         if i.n_obj > 0:
