@@ -45,6 +45,20 @@ inline int api_calc_paths(ltpl_planner* p, const ltpl_planner_paths_in* in)
                            in->zone_off, in->zone_gid);
 }
 
+inline int api_calc_paths_begin(ltpl_planner* p, const ltpl_planner_paths_in* in)
+{
+    if (!p) return LTPL_ERR_INVALID_ARG;
+    if (!in || !in->prev_action || !in->t_now || !in->veh_off || !in->pos_off) return p->P.fail(LTPL_ERR_INVALID_ARG, "planner: null input");
+    return p->P.calc_paths_begin(in->prev_action, in->t_now, in->veh_off, in->pos_off, in->veh_radius, in->veh_vel, in->pos_x, in->pos_y);
+}
+
+inline int api_calc_paths_finish(ltpl_planner* p, const int32_t* zone_off, const int32_t* zone_gid)
+{
+    if (!p) return LTPL_ERR_INVALID_ARG;
+    if (!zone_off) return p->P.fail(LTPL_ERR_INVALID_ARG, "planner: null input");
+    return p->P.calc_paths_finish(zone_off, zone_gid);
+}
+
 inline int api_calc_vel_profile(ltpl_planner* p, const ltpl_planner_vel_in* in)
 {
     if (!p) return LTPL_ERR_INVALID_ARG;

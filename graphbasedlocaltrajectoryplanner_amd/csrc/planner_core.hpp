@@ -511,14 +511,24 @@ struct Planner {
         return LTPL_OK;
     }
 
-    int calc_paths(const int* prev_action, const double* t_now, const int* veh_off, const int* pos_off, const double* veh_radius,
-                   const double* veh_vel, const double* pos_x, const double* pos_y, const int* zone_off, const int* zone_gid)
+    // calc_paths in two halves so that a caller that owns the zone bookkeeping (gen_local_node_template.py:42-99 needs the start
+    // node of THIS search) can step in between: begin = OTH.update_objects + OTH.py:308-414, finish = seam (1) + OTH.py:429-513
+    std::vector<int> b_veh_off, b_pos_off; std::vector<double> b_radius, b_px, b_py;
+    bool began = false;
+
+    int calc_paths_begin(const int* prev_action, const double* t_now, const int* veh_off, const int* pos_off, const double* veh_radius,
+                         const double* veh_vel, const double* pos_x, const double* pos_y)
     {
-        const int n = (int)sc.size(), A = LTPL_MAX_ACTIONS, cn = lat.max_path_nodes, cp = lat.max_path_pts;
+        const int n = (int)sc.size();
         p_start_layer.assign((size_t)n, 0); p_start_node.assign((size_t)n, 0); p_flags.assign((size_t)n, 0);
         p_last_action.assign((size_t)n, LTPL_ACT_NONE); p_const_closest.assign((size_t)n, -1); p_psi_s.assign((size_t)n, 0.0);
         p_n_last.assign((size_t)n, 0);
         p_last_layer.assign((size_t)n * LTPL_MAX_LAST_NODES, -1); p_last_node.assign((size_t)n * LTPL_MAX_LAST_NODES, -1);
+        if (veh_off[0] != 0 || pos_off[0] != 0) return fail(LTPL_ERR_INVALID_ARG, "offset arrays must start at 0");
+        const int nv = veh_off[n], np_ = pos_off[nv];
+        b_veh_off.assign(veh_off, veh_off + n + 1); b_pos_off.assign(pos_off, pos_off + nv + 1);
+        b_radius.assign(veh_radius, veh_radius + nv); b_px.assign(pos_x, pos_x + np_); b_py.assign(pos_y, pos_y + np_);
+        b_radius.push_back(0.0); b_px.push_back(0.0); b_py.push_back(0.0);          // never empty
         // OTH.update_objects (OTH.py:272-287)
         for (int s = 0; s < n; ++s) {
             Scn& S = sc[(size_t)s];
@@ -534,13 +544,22 @@ struct Planner {
             int rc = paths_pre(s, prev_action[s], t_now[s]);
             if (rc) return rc;
         }
+        began = true;
+        return LTPL_OK;
+    }
+
+    int calc_paths_finish(const int* zone_off, const int* zone_gid)
+    {
+        if (!began) return fail(LTPL_ERR_INVALID_ARG, "planner: calc_paths_finish without calc_paths_begin");
+        began = false;
+        const int n = (int)sc.size(), A = LTPL_MAX_ACTIONS, cn = lat.max_path_nodes, cp = lat.max_path_pts;
         ltpl_paths_in in; std::memset(&in, 0, sizeof(in));
         in.n_scen = n; in.n_w_last = (int)cfg.w_last.size();
         static const double zero = 0.0;
         in.w_last_edges = cfg.w_last.empty() ? &zero : cfg.w_last.data();
         in.start_layer = p_start_layer.data(); in.start_node = p_start_node.data(); in.flags = p_flags.data();
         in.last_action = p_last_action.data(); in.const_closest = p_const_closest.data(); in.psi_s = p_psi_s.data();
-        in.veh_off = veh_off; in.pos_off = pos_off; in.veh_radius = veh_radius; in.pos_x = pos_x; in.pos_y = pos_y;
+        in.veh_off = b_veh_off.data(); in.pos_off = b_pos_off.data(); in.veh_radius = b_radius.data(); in.pos_x = b_px.data(); in.pos_y = b_py.data();
         in.zone_off = zone_off; in.zone_gid = zone_gid;
         in.n_last = p_n_last.data(); in.last_layer = p_last_layer.data(); in.last_node = p_last_node.data();
         o_end_layer.resize((size_t)n); o_coi.resize((size_t)n); o_con.resize((size_t)n * 2); o_n_actions.resize((size_t)n);
@@ -558,6 +577,14 @@ struct Planner {
         if (rc) return fail_cmp(rc);
         for (int s = 0; s < n; ++s) if ((rc = paths_post(s))) return rc;
         return LTPL_OK;
+    }
+
+    int calc_paths(const int* prev_action, const double* t_now, const int* veh_off, const int* pos_off, const double* veh_radius,
+                   const double* veh_vel, const double* pos_x, const double* pos_y, const int* zone_off, const int* zone_gid)
+    {
+        int rc = calc_paths_begin(prev_action, t_now, veh_off, pos_off, veh_radius, veh_vel, pos_x, pos_y);
+        if (rc) return rc;
+        return calc_paths_finish(zone_off, zone_gid);
     }
 
     // -----------------------------------------------------------------------------------------------------------------

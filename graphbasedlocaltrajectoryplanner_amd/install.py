@@ -29,9 +29,10 @@ from .vp_forward_backward import VpForwardBackward
 class Session(object):
     """State shared by the two patched seams of one ``graph_ltpl`` module: one backend per GraphBase instance."""
 
-    def __init__(self, backend_factory=None, device=-1):
+    def __init__(self, backend_factory=None, device=-1, clock=None):
         self.backend_factory = backend_factory
         self.device = device
+        self.clock = clock        # object with .time(); None = the time module (tests pass the reference's fake clock)
         self._by_gb = {}          # id(graph_base) -> (graph_base, Lattice, backend, OnlinePathGenerator)
         self.current = None       # most recently bound entry (what a VpForwardBackward constructed next will use)
         self.originals = {}
@@ -64,12 +65,20 @@ class Session(object):
                    w_last_edges=w_last_edges)
 
 
-def install(graph_ltpl, backend_factory=None, device=-1) -> Session:
+def install(graph_ltpl, backend_factory=None, device=-1, mode="seams", clock=None) -> Session:
     """
-    Patch the two seams of an already imported ``graph_ltpl`` package (the unmodified reference). Returns the Session;
-    ``uninstall(session)`` restores the reference's own implementations.
+    Patch an already imported ``graph_ltpl`` package (the unmodified reference). Returns the Session; ``uninstall(session)``
+    restores the reference's own implementations.
+
+    mode="seams"    seam (1) ``main_online_path_gen`` and seam (2) ``VpForwardBackward`` are replaced; the reference's own
+                    ``OnlineTrajectoryHandler`` keeps the iterative memory in Python
+    mode="planner"  additionally the class ``OnlineTrajectoryHandler`` itself (constructed at Graph_LTPL.py:221-227) is replaced
+                    by ``oth_adapter.PlannerOnlineTrajectoryHandler``: the state machine runs in C++ behind ``ltpl_planner_*``
+                     -- a tick is a handful of C calls
     """
-    session = Session(backend_factory=backend_factory, device=device)
+    if mode not in ("seams", "planner"):
+        raise ValueError("install(): mode must be 'seams' or 'planner'")
+    session = Session(backend_factory=backend_factory, device=device, clock=clock)
     mopg_mod = graph_ltpl.online_graph.src.main_online_path_gen
     vp_mod = graph_ltpl.online_graph.src.VpForwardBackward
     oth_cls = graph_ltpl.online_graph.src.OnlineTrajectoryHandler.OnlineTrajectoryHandler
@@ -106,6 +115,16 @@ def install(graph_ltpl, backend_factory=None, device=-1) -> Session:
     oli_cls = oli_mod.ObjectListInterface
     session.originals["oli_process"] = (oli_cls, "process_object_list", oli_cls.process_object_list)
     oli_cls.process_object_list = make_process_object_list(oli_mod, session)
+
+    if mode == "planner":
+        from .oth_adapter import PlannerOnlineTrajectoryHandler
+        oth_mod = graph_ltpl.online_graph.src.OnlineTrajectoryHandler
+
+        class BoundPlannerOTH(PlannerOnlineTrajectoryHandler):
+            pass
+        BoundPlannerOTH.session = session
+        session.originals["oth_cls"] = (oth_mod, "OnlineTrajectoryHandler", oth_mod.OnlineTrajectoryHandler)
+        oth_mod.OnlineTrajectoryHandler = BoundPlannerOTH
     return session
 
 

@@ -130,6 +130,8 @@ class Planner(object):
         f("set_start").argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                    _pi32, _pi32]
         f("calc_paths").argtypes = [C.c_void_p, C.POINTER(PlannerPathsIn)]
+        f("calc_paths_begin").argtypes = [C.c_void_p, C.POINTER(PlannerPathsIn)]
+        f("calc_paths_finish").argtypes = [C.c_void_p, _pi32, _pi32]
         f("get_ref_idx").argtypes = [C.c_void_p, _pf64, _pf64]
         f("calc_vel_profile").argtypes = [C.c_void_p, C.POINTER(PlannerVelIn)]
         f("get_paths").argtypes = [C.c_void_p, C.c_int32, C.POINTER(PathsView)]
@@ -159,13 +161,11 @@ class Planner(object):
         return bool(it.value), bool(ch.value)
 
     # ---- Graph_LTPL.calc_paths --------------------------------------------------------------------------------------------
-    def calc_paths(self, prev_actions, t_now, vehicles, zone_gids=None):
-        """``prev_actions``: action name per planner; ``vehicles``: per planner a list of (radius, vel, positions (k, 2) with the
-        own position first); ``zone_gids``: per planner the global node ids removed by the "overtaking_zones" filter."""
+    def _pack_paths_in(self, prev_actions, t_now, vehicles, zone_gids):
         n = self.n_scen
         act = _i32([KEY_IDS.get(a, _capi.ACT_NONE) if isinstance(a, str) else _capi.ACT_NONE for a in prev_actions])
         t = _f64(np.broadcast_to(np.asarray(t_now, dtype=np.float64), (n,)))
-        veh_off, pos_off, rad, vel, px, py, zone_off, zone = [0], [0], [], [], [], [], [0], []
+        veh_off, pos_off, rad, vel, px, py = [0], [0], [], [], [], []
         for s in range(n):
             for radius_k, vel_k, positions in vehicles[s]:
                 positions = np.asarray(positions, dtype=np.float64).reshape(-1, 2)
@@ -175,16 +175,42 @@ class Planner(object):
                 py.extend(positions[:, 1].tolist())
                 pos_off.append(len(px))
             veh_off.append(len(rad))
-            if zone_gids is not None:
-                zone.extend(int(g) for g in zone_gids[s])
-            zone_off.append(len(zone))
+        zone_off, zone = self._pack_zones(zone_gids)
         keep = [act, t, _i32(veh_off), _i32(pos_off), _f64(rad if rad else [0.0]), _f64(vel if vel else [0.0]),
-                _f64(px if px else [0.0]), _f64(py if py else [0.0]), _i32(zone_off), _i32(zone if zone else [0])]
+                _f64(px if px else [0.0]), _f64(py if py else [0.0]), zone_off, zone]
         i = PlannerPathsIn()
         i.prev_action, i.t_now, i.veh_off, i.pos_off = _p(keep[0], _pi32), _p(keep[1], _pf64), _p(keep[2], _pi32), _p(keep[3], _pi32)
         i.veh_radius, i.veh_vel, i.pos_x, i.pos_y = (_p(a, _pf64) for a in keep[4:8])
         i.zone_off, i.zone_gid = _p(keep[8], _pi32), _p(keep[9], _pi32)
+        return i, keep
+
+    def _pack_zones(self, zone_gids):
+        zone_off, zone = [0], []
+        for s in range(self.n_scen):
+            if zone_gids is not None:
+                zone.extend(int(g) for g in zone_gids[s])
+            zone_off.append(len(zone))
+        return _i32(zone_off), _i32(zone if zone else [0])
+
+    def calc_paths(self, prev_actions, t_now, vehicles, zone_gids=None):
+        """``prev_actions``: action name per planner; ``vehicles``: per planner a list of (radius, vel, positions (k, 2) with the
+        own position first); ``zone_gids``: per planner the global node ids removed by the "overtaking_zones" filter."""
+        i, keep = self._pack_paths_in(prev_actions, t_now, vehicles, zone_gids)
         self._check(self._fn("calc_paths")(self.handle, C.byref(i)))
+
+    def calc_paths_begin(self, prev_actions, t_now, vehicles):
+        """First half of calc_paths: objects in, start nodes determined (read them with ``start_nodes()``)."""
+        i, keep = self._pack_paths_in(prev_actions, t_now, vehicles, None)
+        self._check(self._fn("calc_paths_begin")(self.handle, C.byref(i)))
+
+    def calc_paths_finish(self, zone_gids=None):
+        zone_off, zone = self._pack_zones(zone_gids)
+        self._check(self._fn("calc_paths_finish")(self.handle, _p(zone_off, _pi32), _p(zone, _pi32)))
+
+    def start_node(self, scen=0):
+        v = PathsView()                                    # counts only: no buffers attached
+        self._check(self._fn("get_paths")(self.handle, int(scen), C.byref(v)))
+        return [int(v.start_node[0]), int(v.start_node[1])]
 
     def get_ref_idx(self, pos_est, scen=0):
         """OnlineTrajectoryHandler.get_ref_idx (OTH.py:518-601) for all planners; returns planner ``scen``'s 5-tuple."""

@@ -1,7 +1,7 @@
 """
 Launcher: run an UNMODIFIED example script of the reference against the MI355X backend.
 
-    python -m graphbasedlocaltrajectoryplanner_amd.run [--ticks N] [--device D] [--extra-path DIR] main_std_example.py
+    python -m graphbasedlocaltrajectoryplanner_amd.run [--ticks N] [--device D] [--mode planner|seams] [--extra-path DIR] main_std_example.py
 
 What it does, in this order:
   1. puts the script's directory (the reference checkout: it holds the ``graph_ltpl`` package, ``params/``, ``inputs/``)
@@ -26,6 +26,9 @@ def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m graphbasedlocaltrajectoryplanner_amd.run")
     ap.add_argument("--ticks", type=int, default=0, help="stop after N planning ticks (0 = run the script's own loop)")
     ap.add_argument("--device", type=int, default=-1)
+    ap.add_argument("--mode", choices=("planner", "seams"), default="planner",
+                    help="planner = the OnlineTrajectoryHandler state machine runs in C++ behind ltpl_planner_* (default); "
+                         "seams = only main_online_path_gen / VpForwardBackward are replaced")
     ap.add_argument("--extra-path", action="append", default=[], help="additional sys.path entries (dependencies)")
     ap.add_argument("script")
     ap.add_argument("script_args", nargs=argparse.REMAINDER)
@@ -45,7 +48,7 @@ def main(argv=None):
 
     import graph_ltpl
     from .install import install
-    session = install(graph_ltpl, device=args.device)
+    session = install(graph_ltpl, device=args.device, mode=args.mode)
 
     cls = graph_ltpl.Graph_LTPL.Graph_LTPL
     orig = cls.calc_vel_profile

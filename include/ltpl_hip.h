@@ -412,6 +412,11 @@ const char* ltpl_planner_last_error(const ltpl_planner* planner);
 int ltpl_planner_set_start(ltpl_planner* planner, int32_t scen, double x, double y, double heading, double vel,
                            double max_heading_offset, int32_t* in_track, int32_t* cor_heading);
 int ltpl_planner_calc_paths(ltpl_planner* planner, const ltpl_planner_paths_in* in);
+/* The same call in two halves for callers that own the zone bookkeeping (gen_local_node_template.py:42-99 decides on the
+ * START NODE OF THIS SEARCH): _begin = OTH.update_objects + OTH.py:308-414 (the zone members of `in` are ignored; the start
+ * nodes are then visible through ltpl_planner_get_paths), _finish = seam (1) + OTH.py:429-513 with the zone node ids. */
+int ltpl_planner_calc_paths_begin(ltpl_planner* planner, const ltpl_planner_paths_in* in);
+int ltpl_planner_calc_paths_finish(ltpl_planner* planner, const int32_t* zone_off, const int32_t* zone_gid);
 /* OnlineTrajectoryHandler.get_ref_idx (OTH.py:518-601) on its own; optional -- ltpl_planner_calc_vel_profile runs it when it was
  * not called for the tick. Results: cut_index_pos .. vel_course of ltpl_planner_traj_view. */
 int ltpl_planner_get_ref_idx(ltpl_planner* planner, const double* pos_est_x, const double* pos_est_y);

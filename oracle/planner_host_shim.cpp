@@ -65,6 +65,8 @@ int oracle_planner_set_start(ltpl_planner* p, int32_t scen, double x, double y, 
     return p ? p->P.set_start(scen, x, y, heading, vel, mho, in_track, cor_heading) : LTPL_ERR_INVALID_ARG;
 }
 int oracle_planner_calc_paths(ltpl_planner* p, const ltpl_planner_paths_in* in) { return ltplp::api_calc_paths(p, in); }
+int oracle_planner_calc_paths_begin(ltpl_planner* p, const ltpl_planner_paths_in* in) { return ltplp::api_calc_paths_begin(p, in); }
+int oracle_planner_calc_paths_finish(ltpl_planner* p, const int32_t* zo, const int32_t* zg) { return ltplp::api_calc_paths_finish(p, zo, zg); }
 int oracle_planner_get_ref_idx(ltpl_planner* p, const double* px, const double* py) { return (p && px && py) ? p->P.get_ref_idx(px, py) : LTPL_ERR_INVALID_ARG; }
 int oracle_planner_calc_vel_profile(ltpl_planner* p, const ltpl_planner_vel_in* in) { return ltplp::api_calc_vel_profile(p, in); }
 int oracle_planner_get_paths(const ltpl_planner* p, int32_t scen, ltpl_planner_paths_view* v) { return ltplp::api_get_paths(p, scen, v); }

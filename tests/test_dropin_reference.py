@@ -23,17 +23,32 @@ pytestmark = [pytest.mark.reference,
 CACHE = os.path.join(ROOT, "oracle", "_cache")
 
 
-def run(scenario, n_ticks, patched):
+class OracleWithPlanner(object):
+    """Backend factory for mode="planner" in the GPU-less container: seam-level calls go to the oracle, the planner entry
+    points to the host-logic harness (product state machine + oracle arithmetic)."""
+
+    def __new__(cls, lat):
+        from oracle.oracle_lib import OracleBackend
+        from oracle.planner_host import HostPlannerBackend
+        b = OracleBackend(lat)
+        host = HostPlannerBackend(lat)
+        b.planner = host.planner
+        b._host_planner_backend = host
+        return b
+
+
+def run(scenario, n_ticks, patched, mode="seams"):
     from oracle import ref_scenarios as rs
     from oracle.oracle_lib import OracleBackend
     from graphbasedlocaltrajectoryplanner_amd.install import install, uninstall
     warnings.simplefilter("ignore")
     session = None
     if patched:
-        graph_ltpl, _ = ref_env.load_reference()
-        session = install(graph_ltpl, backend_factory=OracleBackend)
+        graph_ltpl, clock = ref_env.load_reference()
+        session = install(graph_ltpl, backend_factory=OracleBackend if mode == "seams" else OracleWithPlanner, mode=mode,
+                          clock=clock)
     try:
-        gl, clock, ltpl_obj, gb, path_dict = rs.make_planner(CACHE)
+        gl, clock, ltpl_obj, gb, path_dict = rs.make_planner(CACHE, clock=session.clock if session is not None else None)
         if scenario == "c2":
             dummies, zones = rs.opponents_c2(gl, 8), rs.ZONE_EXAMPLE
         else:   # a slow opponent in front of a full-width zone: follow / back-off / reduced horizon branches
@@ -54,10 +69,11 @@ def run(scenario, n_ticks, patched):
             uninstall(session)
 
 
-@pytest.mark.parametrize("scenario,n_ticks", [("c2", 160), ("zonewall", 140)])
-def test_closed_loop_matches_unmodified_reference(scenario, n_ticks):
+@pytest.mark.parametrize("scenario,n_ticks,mode", [("c2", 160, "seams"), ("zonewall", 140, "seams"),
+                                                   ("c2", 400, "planner"), ("zonewall", 200, "planner")])
+def test_closed_loop_matches_unmodified_reference(scenario, n_ticks, mode):
     ref = run(scenario, n_ticks, patched=False)
-    got = run(scenario, n_ticks, patched=True)
+    got = run(scenario, n_ticks, patched=True, mode=mode)
     assert len(ref) == len(got) == n_ticks
     seen = set()
     for t, (a, b) in enumerate(zip(ref, got)):
@@ -82,7 +98,8 @@ def test_closed_loop_matches_unmodified_reference(scenario, n_ticks):
         assert "follow" in seen and seen & {"left", "right"}
 
 
-def test_launcher_runs_unmodified_std_example(tmp_path, monkeypatch):
+@pytest.mark.parametrize("launcher_mode", ["planner", "seams"])
+def test_launcher_runs_unmodified_std_example(tmp_path, monkeypatch, launcher_mode):
     """`python -m graphbasedlocaltrajectoryplanner_amd.run --ticks N main_std_example.py` on a scratch checkout (the
     example writes logs / the graph cache next to itself, and /root/reference is read-only). The script itself is the
     reference's file, byte for byte; only install()'s default backend factory is swapped for the oracle (no GPU here)."""
@@ -103,19 +120,21 @@ def test_launcher_runs_unmodified_std_example(tmp_path, monkeypatch):
     real_install = inst.install
     sessions = []
 
-    def install_with_oracle(graph_ltpl, backend_factory=None, device=-1):
-        sessions.append(real_install(graph_ltpl, backend_factory=OracleBackend, device=device))
+    def install_with_oracle(graph_ltpl, backend_factory=None, device=-1, mode="seams", clock=None):
+        sessions.append(real_install(graph_ltpl, backend_factory=OracleBackend if mode == "seams" else OracleWithPlanner,
+                                     device=device, mode=mode, clock=clock))
         return sessions[-1]
     monkeypatch.setattr(inst, "install", install_with_oracle)
     saved_path, saved_argv = list(sys.path), list(sys.argv)
     try:
         with pytest.raises(SystemExit) as exc:
-            launcher.main(["--ticks", "40", "--extra-path", os.path.join(ROOT, "oracle", "shims"),
+            launcher.main(["--ticks", "40", "--mode", launcher_mode, "--extra-path", os.path.join(ROOT, "oracle", "shims"),
                            str(tmp_path / "main_std_example.py")])
         assert exc.value.code == 0
         assert sessions and sessions[0].current is not None
-        gen = sessions[0].current[3]
-        assert gen.last_result is not None and int(gen.last_result.n_actions[0]) >= 1
+        if launcher_mode == "seams":
+            gen = sessions[0].current[3]
+            assert gen.last_result is not None and int(gen.last_result.n_actions[0]) >= 1
     finally:
         sys.path[:], sys.argv[:] = saved_path, saved_argv
         if sessions:

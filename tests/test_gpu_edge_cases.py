@@ -78,3 +78,51 @@ def test_batch_sizes_around_the_team_switch(monteblanco, hip_backend, oracle_bac
             if ref.valid[s, a]:
                 nn = int(ref.n_nodes[s, a])
                 assert np.array_equal(res.nodes[s, a, :nn], ref.nodes[s, a, :nn])
+
+
+def test_previous_solution_discount_with_any_alignment(monteblanco, hip_backend, oracle_backend):
+    """last_solution_nodes need not start on the start layer (GraphBase.factor_edge_cost discounts whatever edges the node pairs
+    span, GraphBase.py:478-512): shifted lists must give the oracle's paths, in the batch kernel and in the four-wave kernel."""
+    from scenarios import random_scenarios
+    lat = monteblanco
+    L = lat.num_layers
+    scen, _ = random_scenarios(lat, 96, seed=4242, last_prob=1.0)
+    rng = np.random.default_rng(7)
+    for i, sc in enumerate(scen):
+        sl, sn = sc["start_node"]
+        d = int(rng.integers(0, 4)) if i % 3 else 0           # two thirds start 1..3 layers behind the start node
+        nodes, cur = [], sn
+        for j in range(0, d + 5):
+            l2 = (sl + j) % L
+            if j > 0:
+                cands = [nn for nn in range(lat.nodes_in_layer[l2]) if lat.find_edge((l2 - 1) % L, cur, l2, nn) >= 0]
+                if not cands:
+                    break
+                cur = int(cands[int(rng.integers(0, len(cands)))])
+            nodes.append([l2, cur])
+        sc["last_nodes"] = nodes[d:]
+    for chunk in (scen, scen[:7]):                             # >= 64 scenarios: batch kernel; fewer: four-wave kernel
+        batch = _capi.PathsBatch(chunk, w_last_edges=[0.0, 0.5, 0.8])
+        res, ref = hip_backend.plan_paths(batch), oracle_backend.plan_paths(batch)
+        for name in ("n_actions", "action_id", "valid", "reduced", "n_nodes", "n_pts"):
+            assert np.array_equal(getattr(res, name), getattr(ref, name)), name
+        for s in range(len(chunk)):
+            for a in range(int(ref.n_actions[s])):
+                if ref.valid[s, a]:
+                    nn = int(ref.n_nodes[s, a])
+                    assert np.array_equal(res.nodes[s, a, :nn], ref.nodes[s, a, :nn]), (s, a)
+
+
+def test_resident_batch_is_dropped_by_other_entry_points(monteblanco, hip_backend):
+    """ltpl_batch_run after another entry point reused the staging buffers must fail loudly, not read stale memory."""
+    from scenarios import random_scenarios
+    scen, vels = random_scenarios(monteblanco, 64, seed=5)
+    batch = _capi.PathsBatch(scen, w_last_edges=[0.0, 0.5, 0.8])
+    params = _capi.VelParamSet(len_veh=monteblanco.veh_length)
+    pos = np.array([monteblanco.node_pos[monteblanco.layer_off[s['start_node'][0]] + s['start_node'][1]] for s in scen])
+    vel = _capi.TickVelBatch(params, 64, np.full(64, 20.0), np.full(64, 20.0), pos, np.concatenate(vels))
+    hip_backend.batch_upload(batch, vel)
+    hip_backend.batch_run(reps=1, timed=False)
+    hip_backend.plan_paths(_capi.PathsBatch(scen[:3], w_last_edges=[0.0, 0.5, 0.8]))
+    with pytest.raises(_capi.BackendError):
+        hip_backend.batch_run(reps=1, timed=False)

@@ -3,7 +3,7 @@
 #   tools/pmc_pass.sh <tag> "<COUNTER1 COUNTER2 ...>" [bench args]
 set -u
 TAG=$1; CTRS=$2; shift 2
-ARGS=${@:-"--steps 20 --warmup 3 --no-cpu --latency-ticks 0"}
+ARGS=${@:-"--steps 20 --warmup 3 --no-cpu --latency-ticks 0 --exact-steps --no-extra"}
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_${TAG}
 mkdir -p $OUT

@@ -5,7 +5,7 @@
 # Counters are collected in their own passes with --kernel-trace only (no sys/hip/hsa trace domains).
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:-"--steps 50 --warmup 5 --no-cpu --latency-ticks 200"}
+ARGS=${@:-"--steps 50 --warmup 5 --no-cpu --latency-ticks 200 --dropin-ticks 300 --exact-steps --no-extra"}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_${TAG}
 mkdir -p $OUT
