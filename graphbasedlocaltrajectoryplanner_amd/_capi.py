@@ -446,6 +446,7 @@ class HipBackend(object):
         L.ltpl_batch_run_profile.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
         L.ltpl_batch_last_paths_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.ltpl_process_objects.argtypes = [C.c_void_p, C.POINTER(ObjectsIn), C.POINTER(ObjectsOut)]
+        L.ltpl_raceline_s.argtypes = [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_double)]
         L.ltpl_const_segment_test.argtypes = [C.c_void_p, _pf64, C.c_int32, _pf64, C.c_int32, _pf64, _pf64, _pf64,
                                               _pi32, _pi32]
 
@@ -483,6 +484,12 @@ class HipBackend(object):
         self._check(self.lib.ltpl_const_segment_test(self.handle, *args[:7], C.byref(flags), C.byref(closest)))
         return (bool(flags.value & FLAG_OBJ_IN_CONST), bool(flags.value & FLAG_OBJ_BESIDES),
                 None if closest.value < 0 else int(closest.value))
+
+    def raceline_s(self, pos):
+        """Global s coordinate of ``pos`` on the race line (get_s_coord with closed=True, Graph_LTPL.py:436-440)."""
+        s = C.c_double(0.0)
+        self._check(self.lib.ltpl_raceline_s(self.handle, float(pos[0]), float(pos[1]), C.byref(s)))
+        return float(s.value)
 
     # ---- object ingestion ----
     def process_objects(self, x, y, theta, v, length, dt=0.2):

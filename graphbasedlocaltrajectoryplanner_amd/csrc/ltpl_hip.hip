@@ -2599,6 +2599,14 @@ extern "C" int ltpl_const_segment_test(const ltpl_handle* h, const double* seg, 
     return LTPL_OK;
 }
 
+extern "C" int ltpl_raceline_s(const ltpl_handle* h, double x, double y, double* s_out)
+{
+    if (!h || !s_out) return LTPL_ERR_INVALID_ARG;
+    if (!h->has_hostlat) return LTPL_ERR_UNSUPPORTED;
+    *s_out = ltplp::raceline_s(h->hostlat, x, y);
+    return LTPL_OK;
+}
+
 extern "C" int ltpl_planner_create(ltpl_handle* h, const ltpl_planner_config* cfg, ltpl_planner** out)
 {
     g_create_error.clear();

@@ -132,6 +132,13 @@ inline Foot project_on_polyline(const Poly& p, double qx, double qy, bool closed
     return f;
 }
 
+// s coordinate of a position on the (closed) race line, one point per layer (get_s_coord with s_array = s_raceline)
+inline double raceline_s(const HostLat& lat, double x, double y)
+{
+    Poly rl{lat.race_x.data(), lat.race_y.data(), 1, lat.L};
+    return project_on_polyline(rl, x, y, true, true, [&](int i) { return lat.s_rl[(size_t)i]; }, lat.L).s;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // constant-segment test in front of seam (1) (main_online_path_gen.py:76-122): is an object beside / on the part of the last
 // path that stays constant? `seg` = rows [x, y, psi, kappa, el] of const_path_seg, `pos_est` = 2 doubles or null

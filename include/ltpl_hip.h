@@ -282,6 +282,10 @@ int ltpl_const_segment_test(const ltpl_handle* handle, const double* seg, int32_
                             const double* veh_x, const double* veh_y, const double* veh_radius, int32_t* flags_out,
                             int32_t* closest_out);
 
+/* --- global s coordinate of a position on the race line: get_s_coord(ref_line=raceline, s_array=s_raceline, closed=True)
+ *     (get_s_coord.py:8-99; call sites Graph_LTPL.py:436-440 for the log row, main_online_path_gen.py:86-101) ------------- */
+int ltpl_raceline_s(const ltpl_handle* handle, double x, double y, double* s_out);
+
 /* --- object ingestion: ObjectListInterface.py:75-153, check_inside_bounds.py:7-59 --------------------------------- */
 int ltpl_process_objects(ltpl_handle* handle, const ltpl_objects_in* in, ltpl_objects_out* out);
 

@@ -69,8 +69,7 @@ class OracleBackend(object):
                                                 rarr))
         return [(outs[i], bool(rarr[i].too_close), bool(rarr[i].vel_bound)) for i in range(len(jobs))]
 
-    def const_segment_test(self, const_path_seg, pos_est, vehicles):
-        """Host logic of the product (csrc/planner_core.hpp) through the test harness library; no device arithmetic involved."""
+    def _host(self):
         from oracle import planner_host
         if not hasattr(self, "_host_lib"):
             planner_host.build()
@@ -78,6 +77,18 @@ class OracleBackend(object):
             self._host_lib.oracle_const_segment_test.argtypes = [
                 C.POINTER(_capi.LatticeDesc), _capi._pf64, C.c_int32, _capi._pf64, C.c_int32, _capi._pf64, _capi._pf64,
                 _capi._pf64, _capi._pi32, _capi._pi32]
+            self._host_lib.oracle_raceline_s.argtypes = [C.POINTER(_capi.LatticeDesc), C.c_double, C.c_double,
+                                                         C.POINTER(C.c_double)]
+        return self._host_lib
+
+    def raceline_s(self, pos):
+        s = C.c_double(0.0)
+        self._check(self._host().oracle_raceline_s(C.byref(self.binding.desc), float(pos[0]), float(pos[1]), C.byref(s)))
+        return float(s.value)
+
+    def const_segment_test(self, const_path_seg, pos_est, vehicles):
+        """Host logic of the product (csrc/planner_core.hpp) through the test harness library; no device arithmetic involved."""
+        self._host()
         args = _capi.pack_const_segment_args(const_path_seg, pos_est, vehicles)
         flags, closest = C.c_int32(0), C.c_int32(-1)
         self._check(self._host_lib.oracle_const_segment_test(C.byref(self.binding.desc), *args[:7], C.byref(flags),

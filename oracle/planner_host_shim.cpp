@@ -56,6 +56,13 @@ int oracle_const_segment_test(const ltpl_lattice_desc* d, const double* seg, int
     *closest_out = closest;
     return LTPL_OK;
 }
+int oracle_raceline_s(const ltpl_lattice_desc* d, double x, double y, double* s_out)
+{
+    ltplp::HostLat lat;
+    if (lat.init(d, 0, 0, &g_err)) return LTPL_ERR_UNSUPPORTED;
+    *s_out = ltplp::raceline_s(lat, x, y);
+    return LTPL_OK;
+}
 int oracle_planner_destroy(ltpl_planner* p) { delete p; return LTPL_OK; }
 int oracle_planner_get_caps(const ltpl_planner* p, ltpl_planner_caps* c) { return ltplp::api_get_caps(p, c); }
 const char* oracle_planner_last_error(const ltpl_planner* p) { return p ? p->P.err.c_str() : g_err.c_str(); }
