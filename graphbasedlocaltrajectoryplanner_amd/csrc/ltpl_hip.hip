@@ -43,6 +43,7 @@ struct DevLat {
     const int* in_ptr; const int* edge_src; const double* edge_cost; const double* edge_len; const int* samp_ptr;
     const double* sx; const double* sy; const double* spsi; const double* slen;
     const double* glob_rl;
+    const double* grx; const double* gry;   // x / y columns of glob_rl as contiguous arrays (coalesced scans)
     // derived at ltpl_create
     const int* rng_end;               // [L]     end layer of the planning range that starts in layer l
     const int* layer_ebase;           // [L + 1] first edge INTO layer l (= in_ptr[layer_off[l]]); [L] = E
@@ -87,6 +88,12 @@ struct DevPathsOut {
 __device__ __forceinline__ void dbg_stamp(long long* dbg, int k)
 {
     if (dbg && (threadIdx.x & 63) == 0 && blockIdx.x < 256) dbg[(size_t)blockIdx.x * DBG_SLOTS + (threadIdx.x >> 6) * 16 + k] = clock64();
+}
+
+// LTPL_DEBUG_TIMING for the lane kernel: `row` selects one of 256 sample rows (generic / follow / unconstrained blocks)
+__device__ __forceinline__ void vl_stamp(long long* dbg, int row, int k)
+{
+    if (dbg && (threadIdx.x & 63) == 0 && row >= 0 && row < 256) dbg[(size_t)row * DBG_SLOTS + k] = clock64();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -407,6 +414,25 @@ __device__ __forceinline__ void wave_cumsum_seq(const double* src, double* out, 
     wave_sync_lds();
 }
 
+// out[0] = 0, out[i] = sum of src[0 .. i-1] for i < m as a wave-parallel prefix sum (log-step shuffles, 64 elements per round).
+// NOT the summation order of np.cumsum: used where the arc length only enters results with a 1e-5 tolerance (distance to the
+// object in the batch follow preparation), never where indices are derived from it.
+__device__ __forceinline__ void wave_cumsum_par(const double* src, double* out, int m, int lane)
+{
+    double carry = 0.0;
+    if (lane == 0 && m > 0) out[0] = 0.0;
+    for (int base = 0; base < m - 1; base += 64) {
+        const int i = base + lane;
+        const double e = i < m - 1 ? src[i] : 0.0;
+        double x = e;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const double y = __shfl_up(x, d); if (lane >= d) x += y; }
+        if (i < m - 1) out[i + 1] = carry + x;
+        carry += __shfl(x, 63);
+    }
+    wave_sync_lds();
+}
+
 // first index i in [0, m) with pred(i), or m (wave-parallel search; pred is evaluated per lane)
 template <typename Pred>
 __device__ __forceinline__ int wave_find_first(int m, int lane, Pred pred)
@@ -427,6 +453,23 @@ __device__ __forceinline__ double angle3pt_dev(double ax, double ay, double bx, 
     return ang;
 }
 
+// get_s_coord.py:34-47 picks the neighbour of the closest point by comparing |angle3pt(nb, pos, neighbour)|. The wrapped
+// difference of two atan2 values is the angle between u = nb - pos and v = neighbour - pos in [0, pi], and the cosine is
+// monotone there: |ang1| > |ang2|  <=>  u.v1 / |v1| < u.v2 / |v2|  (|u| cancels). Two dot products and two square roots instead
+// of four atan2 (~600 instructions per projection). Degenerate vectors (pos on a polyline point) take the atan2 form.
+// Returns -1 / 0 / +1 for |ang1| < / == / > |ang2|.
+__device__ __forceinline__ int angle_order_dev(double nx, double ny, double px, double py, double x1, double y1, double x2, double y2)
+{
+    const double ux = nx - px, uy = ny - py, v1x = x1 - px, v1y = y1 - py, v2x = x2 - px, v2y = y2 - py;
+    const double n1 = v1x * v1x + v1y * v1y, n2 = v2x * v2x + v2y * v2y, nu = ux * ux + uy * uy;
+    if (!(n1 > 0.0) || !(n2 > 0.0) || !(nu > 0.0)) {
+        const double a1 = fabs(angle3pt_dev(nx, ny, px, py, x1, y1)), a2 = fabs(angle3pt_dev(nx, ny, px, py, x2, y2));
+        return a1 > a2 ? 1 : (a1 < a2 ? -1 : 0);
+    }
+    const double c1 = (ux * v1x + uy * v1y) * sqrt(n2), c2 = (ux * v2x + uy * v2y) * sqrt(n1);
+    return c1 < c2 ? 1 : (c1 > c2 ? -1 : 0);
+}
+
 // get_s_coord.py:8-99 on a strided polyline in global / LDS memory, all lanes take part; every lane returns s and idx0
 __device__ __forceinline__ double get_s_coord_dev(int n, const double* x, const double* y, int stride, const double* s_arr, int s_stride,
                                   double px, double py, bool closed, int lane, int* idx0)
@@ -444,16 +487,39 @@ __device__ __forceinline__ double get_s_coord_dev(int n, const double* x, const 
     const double nx = x[(size_t)nb * stride], ny = y[(size_t)nb * stride];
     const double x1 = x[(size_t)i1 * stride], y1 = y[(size_t)i1 * stride];
     const double x2 = x[(size_t)i2 * stride], y2 = y[(size_t)i2 * stride];
-    const double ang1 = fabs(angle3pt_dev(nx, ny, px, py, x1, y1));
-    const double ang2 = fabs(angle3pt_dev(nx, ny, px, py, x2, y2));
+    const int ord = angle_order_dev(nx, ny, px, py, x1, y1, x2, y2);
     double ax, ay, bx, by;
-    if (ang1 > ang2) { ax = x1; ay = y1; bx = nx; by = ny; } else { ax = nx; ay = ny; bx = x2; by = y2; }
+    if (ord > 0) { ax = x1; ay = y1; bx = nx; by = ny; } else { ax = nx; ay = ny; bx = x2; by = y2; }
     const double t = ((px - ax) * (bx - ax) + (py - ay) * (by - ay)) / ((bx - ax) * (bx - ax) + (by - ay) * (by - ay));
     const double fx = ax + t * (bx - ax), fy = ay + t * (by - ay);
     const double ds = sqrt((ax - fx) * (ax - fx) + (ay - fy) * (ay - fy));
-    const double s = (ang1 > ang2 ? s_arr[(size_t)i1 * s_stride] : s_arr[(size_t)nb * s_stride]) + ds;
-    if (idx0) *idx0 = (ang1 >= ang2) ? i1 : nb;
+    const double s = (ord > 0 ? s_arr[(size_t)i1 * s_stride] : s_arr[(size_t)nb * s_stride]) + ds;
+    if (idx0) *idx0 = (ord >= 0) ? i1 : nb;
     return s;
+}
+
+// Index pair start of the global race line segment an object is projected on (calc_vel_profile_follow.py:172-176:
+// get_s_coord(closed=True, only the first index is used). All 2 x ceil(G / 64) loads of a lane are independent: four points per
+// round trip from the contiguous x / y copies instead of one strided load per iteration.
+__device__ __forceinline__ int globrl_index_dev(const DevLat& lat, double px, double py, int lane)
+{
+    const int G = lat.G - 1;
+    double bd = INFINITY, dummy = 0.0; int nb = 0x7fffffff;
+    for (int i0 = 0; i0 < G; i0 += 256) {
+        double xs[4], ys[4]; int id[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * 64 + lane; id[u] = i < G ? i : G - 1; xs[u] = at(lat.grx, id[u]); ys[u] = at(lat.gry, id[u]); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double dx = xs[u] - px, dy = ys[u] - py, d2 = dx * dx + dy * dy;
+            if (d2 < bd) { bd = d2; nb = id[u]; }
+        }
+    }
+    wave_min3(bd, dummy, nb);
+    int i1 = nb - 1; if (i1 < 0) i1 += G;
+    int i2 = nb + 1; if (i2 > G - 1) i2 = 0;
+    const int ord = angle_order_dev(at(lat.grx, nb), at(lat.gry, nb), px, py, at(lat.grx, i1), at(lat.gry, i1), at(lat.grx, i2), at(lat.gry, i2));
+    return ord >= 0 ? i1 : nb;
 }
 
 struct FollowIn { double v_start, v_ego, v_obj, safety_d, obj_dist, obj_x, obj_y; };
@@ -484,8 +550,7 @@ __device__ __forceinline__ void follow_profile(const DevLat& lat, int n, int n_e
     // opponent: closest point of the global race line (:172-179), brake scan with ggv [100, 14, 14] (:134,185-199)
     const int G = lat.G - 1;
     const double* grl = lat.glob_rl;
-    int idx_s_opp = 0;
-    (void)get_s_coord_dev(G, grl + 1, grl + 2, 5, grl, 5, fi.obj_x, fi.obj_y, true, lane, &idx_s_opp);
+    const int idx_s_opp = globrl_index_dev(lat, fi.obj_x, fi.obj_y, lane);
     const double vel0 = grl[(size_t)idx_s_opp * 5 + 4];
     const double vel_start = fi.v_obj < vel0 ? fi.v_obj : vel0;                          // :182
     double opp_stop = 0.0, wopp = vel_start * vel_start;
@@ -825,6 +890,8 @@ struct VelPlanes {              // tiled planes (doubles), tile index = job inde
     double* P2;                 // ego brake profile (follow)                                           n_scen_pad tiles
     double* P3;                 // segment profile (follow), afterwards the generic profile of a reduced-horizon follow job
     int* flags;                 // per tile: VF_* bits
+    int* fseg;                  // per follow job [2]: n_decel (-1: everything from the brake profile), stop_idx -- composition of
+                                // "vx_profile" (:289 / :294) from P2 / P3 / zeros, done by k_vel_final (VF_COMPOSE)
     int cap_pts;
 };
 
@@ -847,107 +914,120 @@ __device__ __forceinline__ double fast_div(double a, double b)
 #define LCH 8      // rows per register chunk: all loads of a chunk are issued before the chunk's recurrence steps
 
 // tph.calc_vel_profile(closed=False) for one lane: rows [off, off + n) of the path, result into plane D (as v^2).
-// Rows are processed in register chunks of LCH so that a lane pays one memory latency per chunk, not per step.
+// Rows are processed in register chunks of LCH; the rows of the NEXT chunk are requested before the current chunk's recurrence
+// steps run (double buffer). Two things keep the compiler's s_waitcnt placement tight (measured: a per-step vmcnt(0) -- i.e. a
+// full store acknowledgement per row -- made the kernel 8x slower than its instruction count):
+//   * the function is force-inlined into the kernel, so the planes are addressed with GLOBAL instructions (an out-of-line copy
+//     takes them by reference as generic pointers -> FLAT loads / stores, which always wait on vmcnt(0) and lgkmcnt(0));
+//   * a recurrence step is branch-free (selects instead of `if (active)`), so a chunk is one basic block and the waits are
+//     counted exactly: the stores of a chunk stay in flight while the next chunk's operands are awaited.
 template <int EM, bool AXM1>
-__device__ void lane_fb_profile(const LaneProf& L, double* D, int off, int n, double cax, double cay,
-                                const DevVelParams& p, const double* axm_tab, double v_max, double v_start,
-                                bool has_v_end, double v_end)
+__device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, int off, int n, double cax, double cay,
+                                                const DevVelParams& p, const double* axm_tab, double v_max, double v_start,
+                                                bool has_v_end, double v_end)
 {
     if (v_start < 0.0) v_start = 0.0;
     if (has_v_end && v_end < 0.0) v_end = 0.0;
     const double vmax2 = v_max * v_max, icay = 1.0 / cay, axm1 = axm_tab[1], dm = p.drag_m, axa = fabs(cax);
+    const double vend2 = has_v_end ? v_end * v_end : INFINITY;
     const double* Kp = L.K + (size_t)off * 64; const double* Ep = L.E + (size_t)off * 64;
     double* Dp = D + (size_t)off * 64;
-    // ---- lateral-limit speed + forward sweep (accel_forw) in one pass -------------------------------------------------
     double kabs_i = Kp[0], e_i = Ep[0];
     double wi = fast_div(cay, kabs_i);
     if (!(wi < vmax2)) wi = vmax2;
     if (wi > v_start * v_start) wi = v_start * v_start;
     Dp[0] = wi;
     if (n < 2) return;
+    // ---- lateral-limit speed + forward sweep (accel_forw) in one pass -------------------------------------------------
     {
         double orig_i = wi;
         bool active = false, prev_acc = false;
-        for (int base = 0; base < n - 1; base += LCH) {
-            double kr[LCH], er[LCH];
+        double kr[LCH], er[LCH], kn[LCH], en[LCH];
 #pragma unroll
-            for (int c = 0; c < LCH; ++c) {
-                const int r = base + 1 + c < n ? base + 1 + c : n - 1;
-                kr[c] = Kp[(size_t)r * 64]; er[c] = Ep[(size_t)r * 64];
+        for (int c = 0; c < LCH; ++c) { const int r = 1 + c < n ? 1 + c : n - 1; kr[c] = Kp[(size_t)r * 64]; er[c] = Ep[(size_t)r * 64]; }
+        for (int base = 0; base < n - 1; base += LCH) {
+#pragma unroll
+            for (int c = 0; c < LCH; ++c) {                    // operands of the next chunk (clamped rows: harmless re-reads at the end)
+                const int r = base + LCH + 1 + c < n ? base + LCH + 1 + c : n - 1;
+                kn[c] = Kp[(size_t)r * 64]; en[c] = Ep[(size_t)r * 64];
             }
 #pragma unroll
             for (int c = 0; c < LCH; ++c) {
                 const int i = base + c;
-                if (i < n - 1) {
-                    double w0n = fast_div(cay, kr[c]);
-                    if (!(w0n < vmax2)) w0n = vmax2;
-                    const bool acc = w0n - orig_i > 0.0;
-                    if (acc && !prev_acc) active = true;
-                    prev_acc = acc;
-                    double wnext = w0n;
-                    if (active) {
-                        const double kq_i = kabs_i * icay;
-                        double wn;
-                        if constexpr (EM == 1 && AXM1) {
-                            const double te = 2.0 * e_i;
-                            const double A0 = 1.0 - te * dm, A1 = A0 - te * (axa * kq_i), B1 = te * axa, B2 = te * axm1;
-                            wn = fmax(fmin(fmax(fma(A1, wi, B1), A0 * wi), fma(A0, wi, B2)), 0.0);
-                        } else {
-                            const double a = ax_poss_w<EM, AXM1, VMODE_ACCEL_FORW>(wi, kq_i, cax, p, axm_tab, axm1);
-                            wn = fmax(wi + 2.0 * a * e_i, 0.0);
-                        }
-                        if (wn < w0n) wnext = wn;
-                        active = !(wn > vmax2);
-                    }
-                    if (has_v_end && i + 1 == n - 1 && wnext > v_end * v_end) wnext = v_end * v_end;
-                    Dp[(size_t)(i + 1) * 64] = wnext;
-                    orig_i = w0n; wi = wnext; kabs_i = kr[c]; e_i = er[c];
+                const bool valid = i < n - 1;
+                double w0n = fast_div(cay, kr[c]);
+                w0n = (w0n < vmax2) ? w0n : vmax2;
+                const bool acc = w0n - orig_i > 0.0;
+                const bool act = active || (acc && !prev_acc);
+                const double kq_i = kabs_i * icay;
+                double wn;
+                if constexpr (EM == 1 && AXM1) {
+                    const double te = 2.0 * e_i;
+                    const double A0 = 1.0 - te * dm, A1 = A0 - te * (axa * kq_i), B1 = te * axa, B2 = te * axm1;
+                    wn = fmax(fmin(fmax(fma(A1, wi, B1), A0 * wi), fma(A0, wi, B2)), 0.0);
+                } else {
+                    const double a = ax_poss_w<EM, AXM1, VMODE_ACCEL_FORW>(wi, kq_i, cax, p, axm_tab, axm1);
+                    wn = fmax(wi + 2.0 * a * e_i, 0.0);
                 }
+                double wnext = (act && wn < w0n) ? wn : w0n;
+                const bool act_out = act && !(wn > vmax2);
+                wnext = (i + 1 == n - 1 && wnext > vend2) ? vend2 : wnext;
+                if (valid) Dp[(size_t)(i + 1) * 64] = wnext;
+                active = valid ? act_out : active; prev_acc = valid ? acc : prev_acc;
+                orig_i = valid ? w0n : orig_i; wi = valid ? wnext : wi; kabs_i = valid ? kr[c] : kabs_i; e_i = valid ? er[c] : e_i;
             }
+#pragma unroll
+            for (int c = 0; c < LCH; ++c) { kr[c] = kn[c]; er[c] = en[c]; }
         }
     }
     // ---- backward sweep (decel_backw), mirrored indices; with a constant gg the unmirrored-gg quirk is void --------------
     {
         double orig_i = wi;
         bool active = false, prev_acc = false;
+        double kr[LCH], er[LCH], wr[LCH], kn[LCH], en[LCH], wq[LCH];
+#pragma unroll
+        for (int c = 0; c < LCH; ++c) {
+            const int r = n - 2 - c >= 0 ? n - 2 - c : 0;
+            kr[c] = Kp[(size_t)r * 64]; er[c] = Ep[(size_t)r * 64]; wr[c] = Dp[(size_t)r * 64];
+        }
         for (int base = 0; base < n - 1; base += LCH) {
-            double kr[LCH], er[LCH], wr[LCH];
+            // rows of the next chunk are not written by this chunk's steps (a step only rewrites its own row n - 2 - i)
 #pragma unroll
             for (int c = 0; c < LCH; ++c) {
-                const int r = n - 2 - base - c >= 0 ? n - 2 - base - c : 0;
-                kr[c] = Kp[(size_t)r * 64]; er[c] = Ep[(size_t)r * 64]; wr[c] = Dp[(size_t)r * 64];
+                const int r = n - 2 - base - LCH - c >= 0 ? n - 2 - base - LCH - c : 0;
+                kn[c] = Kp[(size_t)r * 64]; en[c] = Ep[(size_t)r * 64]; wq[c] = Dp[(size_t)r * 64];
             }
 #pragma unroll
             for (int c = 0; c < LCH; ++c) {
                 const int i = base + c;
-                if (i < n - 1) {
-                    const double wold = wr[c], e_b = er[c];
-                    const bool acc = wold - orig_i > 0.0;
-                    if (acc && !prev_acc) active = true;
-                    prev_acc = acc;
-                    double wnext = wold;
-                    if (active) {
-                        const double kq_i = kabs_i * icay, kq_n = kr[c] * icay;
-                        double wn;
-                        if constexpr (EM == 1 && AXM1) {
-                            const double te = 2.0 * e_b;
-                            const double A0 = 1.0 + te * dm, A1 = A0 - te * (axa * kq_i), B1 = te * axa;
-                            const double C0 = te * dm, C1 = C0 - te * (axa * kq_n), D1 = te * axa;
-                            wn = fmax(fmax(fma(A1, wi, B1), A0 * wi), 0.0);
-                            const double t0 = fma(C0, wn, wi), t1 = fma(C1, wn, wi + D1);
-                            wn = fmin(fmax(fmax(t1, t0), 0.0), wn);
-                        } else {
-                            const double a = ax_poss_w<EM, AXM1, VMODE_DECEL_BACKW>(wi, kq_i, cax, p, axm_tab, axm1);
-                            wn = fmax(wi + 2.0 * a * e_b, 0.0);
-                            const double a2 = ax_poss_w<EM, AXM1, VMODE_DECEL_BACKW>(wn, kq_n, cax, p, axm_tab, axm1);
-                            wn = fmin(fmax(wi + 2.0 * a2 * e_b, 0.0), wn);
-                        }
-                        if (wn < wold) { wnext = wn; Dp[(size_t)(n - 2 - i) * 64] = wn; }
-                        active = !(wn > vmax2);
-                    }
-                    orig_i = wold; wi = wnext; kabs_i = kr[c];
+                const bool valid = i < n - 1;
+                const double wold = wr[c], e_b = er[c];
+                const bool acc = wold - orig_i > 0.0;
+                const bool act = active || (acc && !prev_acc);
+                const double kq_i = kabs_i * icay, kq_n = kr[c] * icay;
+                double wn;
+                if constexpr (EM == 1 && AXM1) {
+                    const double te = 2.0 * e_b;
+                    const double A0 = 1.0 + te * dm, A1 = A0 - te * (axa * kq_i), B1 = te * axa;
+                    const double C0 = te * dm, C1 = C0 - te * (axa * kq_n), D1 = te * axa;
+                    wn = fmax(fmax(fma(A1, wi, B1), A0 * wi), 0.0);
+                    const double t0 = fma(C0, wn, wi), t1 = fma(C1, wn, wi + D1);
+                    wn = fmin(fmax(fmax(t1, t0), 0.0), wn);
+                } else {
+                    const double a = ax_poss_w<EM, AXM1, VMODE_DECEL_BACKW>(wi, kq_i, cax, p, axm_tab, axm1);
+                    wn = fmax(wi + 2.0 * a * e_b, 0.0);
+                    const double a2 = ax_poss_w<EM, AXM1, VMODE_DECEL_BACKW>(wn, kq_n, cax, p, axm_tab, axm1);
+                    wn = fmin(fmax(wi + 2.0 * a2 * e_b, 0.0), wn);
                 }
+                const bool take = act && wn < wold;
+                const double wnext = take ? wn : wold;
+                if (valid && take) Dp[(size_t)(n - 2 - i) * 64] = wn;
+                const bool act_out = act && !(wn > vmax2);
+                active = valid ? act_out : active; prev_acc = valid ? acc : prev_acc;
+                orig_i = valid ? wold : orig_i; wi = valid ? wnext : wi; kabs_i = valid ? kr[c] : kabs_i;
             }
+#pragma unroll
+            for (int c = 0; c < LCH; ++c) { kr[c] = kn[c]; er[c] = en[c]; wr[c] = wq[c]; }
         }
     }
 }
@@ -956,6 +1036,7 @@ __device__ void lane_fb_profile(const LaneProf& L, double* D, int off, int n, do
 #define VF_TOO_CLOSE    2
 #define VF_HAS_GENERIC  4
 #define VF_BOUND_GENERIC 8
+#define VF_COMPOSE 16
 
 // the generic forward-backward profile of a slot (OTH.py:834-903) into plane D; returns its vel_bound flag
 template <int EM, bool AXM1>
@@ -1003,7 +1084,8 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
     if ((b < nbG && b * 64 >= cntG) || (b >= nbG && ((b - nbG) % nbF) * 64 >= cntF)) return;
     for (int i = lane; i < 2 * p.n_axm; i += 64) axm_tab[i] = p.axm[i];
     __syncthreads();
-    dbg_stamp(dbg, 0);
+    const int drow = b < nbG ? (b < 64 ? b : -1) : (b < nbG + nbF ? (b - nbG < 64 ? 64 + b - nbG : -1) : (b - nbG - nbF < 64 ? 128 + b - nbG - nbF : -1));
+    vl_stamp(dbg, drow, 0);
     const double cax = vin.gg_ax, cay = vin.gg_ay, icay = 1.0 / cay;
     const int fbase = out.n_slots_pad;
     if (b >= nbG + nbF) {
@@ -1014,6 +1096,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
         LaneProf L; L.K = vp.K + tile_base(fbase + j, vp.cap_pts); L.E = vp.E + tile_base(fbase + j, vp.cap_pts);
         lane_fb_profile<EM, AXM1>(L, vp.P1 + tile_base(j, vp.cap_pts), 0, out.n_pts[slot], cax, cay, p, axm_tab, p.v_max,
                                   vin.vel_plan[slot / LTPL_MAX_ACTIONS], false, 0.0);
+        vl_stamp(dbg, drow, 6);
         return;
     }
     const bool fjob = b >= nbG;
@@ -1078,19 +1161,24 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
                 }
             }
         }
+        vl_stamp(dbg, drow, 1);
         // one pass over the path rows: ego brake profile -> P2 (:152-159), ego stop distance (:162-166), first index at
         // or below the control speed (:254), arc length and stop index (:203-209)
         const double s_stop = obj_dist - safety_d + opp_stop;                            // :206
         double ego_stop = 0.0, s_run = 0.0, s_last = 0.0; int first_le = -1, stop_idx = 0;
         {
             double w = v_start * v_start; bool braking = true, counting = true, searching = true;
-            for (int base = 0; base < n; base += LCH) {
-                double kr[LCH], er[LCH];
+            double kr[LCH], er[LCH], kn[LCH], en[LCH];
+            auto load_rows = [&](int base, double (&k)[LCH], double (&e)[LCH]) {
 #pragma unroll
                 for (int c = 0; c < LCH; ++c) {
                     const int r = base + c < n ? base + c : n - 1;
-                    kr[c] = L.K[(size_t)r * 64]; er[c] = L.E[(size_t)r * 64];
+                    k[c] = L.K[(size_t)r * 64]; e[c] = L.E[(size_t)r * 64];
                 }
+            };
+            load_rows(0, kr, er);
+            for (int base = 0; base < n; base += LCH) {
+                if (base + LCH < n) load_rows(base + LCH, kn, en);         // next chunk in flight during this chunk's steps
 #pragma unroll
                 for (int c = 0; c < LCH; ++c) {
                     const int i = base + c;
@@ -1116,20 +1204,33 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
                         }
                     }
                 }
+#pragma unroll
+                for (int c = 0; c < LCH; ++c) { kr[c] = kn[c]; er[c] = en[c]; }
             }
         }
+        vl_stamp(dbg, drow, 2);
         double v_end = 0.0;
         if (s_stop > s_last) {                                                           // :212-221
+            // the stop point lies beyond the path: end velocity = race-line velocity where the opponent's remaining brake
+            // distance is used up; the element lengths are fetched LCH at a time (one round trip per chunk, not per step)
             const double s_ends = opp_stop - (s_stop - s_last);
-            int idx = 0; double summed = 0.0;
-            while (summed < s_ends && idx < G) {
-                int j = idx + idx_s_opp; if (j >= G) j -= G;
-                summed += grl[(size_t)(j + 1) * 5] - grl[(size_t)j * 5];
-                ++idx;
+            int idx = 0; double summed = 0.0; bool run = summed < s_ends;
+            while (run) {
+                double dl[LCH];
+#pragma unroll
+                for (int c = 0; c < LCH; ++c) {
+                    int j = idx + c + idx_s_opp; j = j % G;
+                    dl[c] = grl[(size_t)(j + 1) * 5] - grl[(size_t)j * 5];
+                }
+#pragma unroll
+                for (int c = 0; c < LCH; ++c)
+                    if (run) { if (summed < s_ends && idx < G) { summed += dl[c]; ++idx; } else run = false; }
+                if (run && !(summed < s_ends && idx < G)) run = false;
             }
             int j = (idx % G) + idx_s_opp; if (j >= G) j -= G;
             v_end = grl[(size_t)j * 5 + 4];
         }
+        vl_stamp(dbg, drow, 3);
         int idx_c = 0, n_decel = 0; const bool two_seg = ego_stop < s_stop;
         if (two_seg) {                                                                   // :247-292
             double vcs = v_start;
@@ -1148,8 +1249,12 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
             const double first_v = (n_decel - 1 > 0) ? sqrt(P2[0]) : sqrt(P3[0]);
             if (fabs(first_v - v_start) > 1.0) vel_bound = 0;
         }
-        // "vx_profile" (:289 / :294) -> P0, chunked
-        for (int base = 0; base < n; base += LCH) {
+        vl_stamp(dbg, drow, 4);
+        // "vx_profile" (:289 / :294) = brake profile in front, segment profile up to the stop index, zeros behind. Normally only
+        // described (two indices) and composed by the row-parallel final kernel; a reduced-horizon follow job needs P3 for its
+        // generic profile, so there the composition is materialised in P0 here.
+        if (!reduced) { vp.fseg[2 * j] = two_seg ? n_decel : -1; vp.fseg[2 * j + 1] = stop_idx; flags |= VF_COMPOSE; }
+        else for (int base = 0; base < n; base += LCH) {
             double a[LCH];
 #pragma unroll
             for (int c = 0; c < LCH; ++c) {
@@ -1160,6 +1265,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
 #pragma unroll
             for (int c = 0; c < LCH; ++c) if (base + c < n) P0[(size_t)(base + c) * 64] = a[c];
         }
+        vl_stamp(dbg, drow, 5);
         if (!vel_bound) flags &= ~VF_BOUND_FOLLOW;
         if (reduced) {                                                                   // OTH.py:834-923 on top of follow
             flags |= VF_HAS_GENERIC;
@@ -1171,7 +1277,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
             flags |= VF_BOUND_GENERIC;
     }
     vp.flags[tile] = flags;
-    dbg_stamp(dbg, 1);
+    vl_stamp(dbg, drow, 6);
 }
 
 // final step of the batch velocity stage, no recurrence: intersection of the two follow profiles
@@ -1196,8 +1302,11 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
     const bool follow = fjob;
     const double* P0 = vp.P0 + tile_base(tile, vp.cap_pts);
     const double* P1 = vp.P1 + tile_base(fjob ? j : 0, vp.cap_pts);
+    const double* P2 = vp.P2 + tile_base(fjob ? j : 0, vp.cap_pts);
     const double* P3 = vp.P3 + tile_base(fjob ? j : 0, vp.cap_pts);
     const double* E = vp.E + tile_base(tile, vp.cap_pts);
+    const bool compose = follow && (flags & VF_COMPOSE);
+    const int nd = compose ? vp.fseg[2 * j] : 0, stop_idx = compose ? vp.fseg[2 * j + 1] : 0;
     int vel_bound = follow ? ((flags & VF_BOUND_FOLLOW) ? 1 : 0) : ((flags & VF_BOUND_GENERIC) ? 1 : 0);
     int sel = follow ? 1 : 0;                     // 0: P0, 1: min(P0, P1), 2: P3
     if (follow && (flags & VF_HAS_GENERIC)) {
@@ -1212,6 +1321,10 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
     double* o_ax = vout.ax + (size_t)slot * out.cap_pts;
     auto value = [&](int i) {
         const size_t o = (size_t)i * 64;
+        if (compose) {                                     // sel == 1: min("vx_profile", unconstrained profile)
+            const double a = (nd < 0 || i < nd - 1) ? P2[o] : (i > stop_idx ? 0.0 : P3[o]);
+            return fmin(a, P1[o]);
+        }
         return sel == 0 ? P0[o] : (sel == 1 ? fmin(P0[o], P1[o]) : P3[o]);
     };
     double w[FCH + 1], er[FCH], vv[FCH], aa[FCH];
@@ -1249,7 +1362,7 @@ __device__ void follow_prep(const DevLat& lat, const DevPathsIn& in, const DevPa
                             const DevVelPrep& prep, int n, double* s_arr, const double* el, const double* px,
                             const double* py, int s, int slot, int lane)
 {
-    wave_cumsum_seq(el, s_arr, n + 1, lane);
+    wave_cumsum_par(el, s_arr, n + 1, lane);
     const int ci = out.closest_obj_index[s], v0 = in.veh_off[s];
     double ox, oy, vobj, odist;
     if (ci < 0 || ci >= in.veh_off[s + 1] - v0) { odist = 0.0; vobj = 0.0; ox = vin.pos_est_x[s]; oy = vin.pos_est_y[s]; }
@@ -1260,19 +1373,19 @@ __device__ void follow_prep(const DevLat& lat, const DevPathsIn& in, const DevPa
         const double s_sta = get_s_coord_dev(n, px, py, 1, s_arr, 1, vin.pos_est_x[s], vin.pos_est_y[s], false, lane, nullptr);
         odist = s_obj - s_sta;
     }
-    int idx = 0;
-    (void)get_s_coord_dev(lat.G - 1, lat.glob_rl + 1, lat.glob_rl + 2, 5, lat.glob_rl, 5, ox, oy, true, lane, &idx);
+    const int idx = globrl_index_dev(lat, ox, oy, lane);
     if (lane == 0) { prep.obj_dist[slot] = odist; prep.v_obj[slot] = vobj; prep.obj_x[slot] = ox; prep.obj_y[slot] = oy; prep.idx_s_opp[slot] = idx; }
 }
 
-// follow preparation as its own small kernel between the path kernel and the lane kernel: one wave per action slot,
-// slots without a valid 'follow' path exit at once. The path rows are re-read from the path kernel's output.
+// follow preparation as its own small kernel between the path kernel and the lane kernel: one wave per FOLLOW JOB (job table
+// of the path kernel; the count is only known on the device, so the grid is the upper bound n_scen and the rest exits at once).
+// A job is a chain of dependent global round trips with little arithmetic: many short-lived blocks in flight hide that better
+// than a grid-stride loop (measured: 141 us vs 199 us per 32 768 scenarios). The path rows are re-read from the path kernel's output.
 __global__ __launch_bounds__(64) void k_follow_prep(DevLat lat, DevPathsIn in, DevPathsOut out, DevTickVelIn vin,
                                                     DevVelPrep prep, int n_slots)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
-    // one wave per FOLLOW JOB (job table of the path kernel); n_slots = upper bound of the grid
     if ((int)blockIdx.x >= out.job_cnt[1]) return;
     const int slot = out.job_slot[out.n_slots_pad + blockIdx.x];
     const int n = out.n_pts[slot];
@@ -1455,6 +1568,30 @@ static void dbg_report(ltpl_handle* h, const char* what, int n_blocks)
 
 
 
+static void dbg_report_lanes(ltpl_handle* h)
+{
+    if (!h->d_dbg) return;
+    std::vector<long long> v((size_t)256 * DBG_SLOTS);
+    if (hipMemcpy(v.data(), h->d_dbg, v.size() * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+    const char* names[3] = {"generic", "follow (controlled)", "follow (unconstrained)"};
+    for (int g = 0; g < 3; ++g) {
+        fprintf(stderr, "[ltpl dbg] k_vel_lanes %-24s mean cycles between stamps 0-1-2-3-4-5-6, total:", names[g]);
+        double tot = 0; int tc = 0;
+        for (int k = 0; k < 6; ++k) {
+            double acc = 0; int cnt = 0;
+            for (int r = 0; r < 64; ++r) {
+                const long long* row = &v[(size_t)(g * 64 + r) * DBG_SLOTS];
+                int k2 = k + 1; while (k2 < 7 && row[k2] == 0) ++k2;
+                if (row[k] > 0 && k2 < 7 && row[k2] > row[k] && (k2 == k + 1)) { acc += (double)(row[k2] - row[k]); ++cnt; }
+            }
+            fprintf(stderr, " %9.0f", cnt ? acc / cnt : 0.0);
+        }
+        for (int r = 0; r < 64; ++r) { const long long* row = &v[(size_t)(g * 64 + r) * DBG_SLOTS]; if (row[0] > 0 && row[6] > row[0]) { tot += (double)(row[6] - row[0]); ++tc; } }
+        fprintf(stderr, " | %9.0f (%d rows)\n", tc ? tot / tc : 0.0, tc);
+    }
+    (void)hipMemset(h->d_dbg, 0, v.size() * sizeof(long long));
+}
+
 template <typename T>
 static int upload(ltpl_handle* h, const T* src, size_t n, const T** dst)
 {
@@ -1591,6 +1728,11 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
     UP(edge_len, d->edge_len, L.E); UP(samp_ptr, d->samp_ptr, L.E + 1);
     UP(sx, d->samp_x, L.S); UP(sy, d->samp_y, L.S); UP(spsi, d->samp_psi, L.S); UP(slen, d->samp_len, L.S);
     UP(glob_rl, d->glob_rl, (size_t)L.G * 5);
+    {
+        std::vector<double> gx((size_t)L.G), gy((size_t)L.G);
+        for (int k = 0; k < L.G; ++k) { gx[(size_t)k] = d->glob_rl[(size_t)k * 5 + 1]; gy[(size_t)k] = d->glob_rl[(size_t)k * 5 + 2]; }
+        UP(grx, gx.data(), L.G); UP(gry, gy.data(), L.G);
+    }
     {
         // derived tables: planning range per start layer, first edge into every layer, byte-wide edge sources
         std::vector<int> ebase((size_t)L.L + 1);
@@ -2212,7 +2354,7 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
     {
         const size_t tiles = (size_t)t->n_slots_pad + (size_t)t->n_scen_pad;
         t->planes_bytes = t->pipeline ? sizeof(double) * (size_t)cap_pts * (3 * tiles + 3 * (size_t)t->n_scen_pad)
-                                            + sizeof(int) * (2 * tiles + 16) : 0;
+                                            + sizeof(int) * (2 * tiles + 16 + 2 * (size_t)t->n_scen_pad) : 0;
     }
     t->prep_off = 0; t->prep_stride = 0;
     t->lds_prep = align_up(sizeof(double) * 4 * (size_t)(cap_pts + 2), 16);      // k_follow_prep: el, x, y, s
@@ -2242,7 +2384,7 @@ static void tick_bind_outputs(TickLayout* t, unsigned char* dob, double* planes)
         t->vp.K = planes; t->vp.E = planes + per_all; t->vp.P0 = planes + 2 * per_all;
         t->vp.P1 = planes + 3 * per_all; t->vp.P2 = t->vp.P1 + per_scen; t->vp.P3 = t->vp.P2 + per_scen;
         int* ints = reinterpret_cast<int*>(t->vp.P3 + per_scen);
-        t->vp.flags = ints; t->dout.job_slot = ints + tiles; t->dout.job_cnt = ints + 2 * tiles;
+        t->vp.flags = ints; t->dout.job_slot = ints + tiles; t->dout.job_cnt = ints + 2 * tiles; t->vp.fseg = ints + 2 * tiles + 16;
         t->dout.n_slots_pad = t->n_slots_pad;
         t->vp.cap_pts = t->cap_pts;
         t->dout.vkap = t->vp.K; t->dout.vlen = t->vp.E;
@@ -2362,7 +2504,7 @@ extern "C" int ltpl_tick_batch(ltpl_handle* h, const ltpl_paths_in* in, const lt
     if ((rc = tick_launch(h, t))) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, t.out_total, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    dbg_report(h, "k_tick", in->n_scen);
+    if (t.pipeline) dbg_report_lanes(h); else dbg_report(h, "k_tick", in->n_scen);
     tick_scatter(static_cast<const unsigned char*>(h->h_out), t, out, vout);
     return LTPL_OK;
 }
