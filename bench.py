@@ -299,8 +299,18 @@ def worker(args):
             tp = time.perf_counter()
             for _ in range(5):
                 hip.tick_batch(bpc, vpc, rpc, vrpc)
-            extra["pcie_inclusive"] = {"ticks_per_s": npc * 5 / (time.perf_counter() - tp), "scenarios_per_call": npc,
-                                       "what": "ltpl_tick_batch with host buffers in and out (H2D, kernels, D2H, scatter)"}
+            slab_rate = npc * 5 / (time.perf_counter() - tp)
+            comp = hip.new_compact_trajectories(npc, max_rows=115)
+            hip.tick_batch_compact(bpc, vpc, comp)
+            tp = time.perf_counter()
+            for _ in range(10):
+                hip.tick_batch_compact(bpc, vpc, comp)
+            extra["pcie_inclusive"] = {"ticks_per_s": npc * 10 / (time.perf_counter() - tp), "scenarios_per_call": npc,
+                                       "rows_per_trajectory": 115, "bytes_out_per_tick": float(comp.struct.total_rows) * 56 / npc,
+                                       "capacity_slab_ticks_per_s": slab_rate,
+                                       "what": "ltpl_tick_batch_compact: host buffers in, trajectories [s,x,y,psi,kappa,vx,ax] "
+                                               "(115 export rows, Graph_LTPL.py:401-406) packed on the device and DMA-written into "
+                                               "page-locked host memory; capacity_slab_* = ltpl_tick_batch with full capacity slabs"}
         out = {
             "metric": "planning ticks/s (all action primitives), " + ("Monteblanco lattice" if args.workload == "c2" else "synthetic C3 lattice"),
             "value": world * args.batch * timed_steps / elapsed,

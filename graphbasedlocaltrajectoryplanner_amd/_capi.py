@@ -120,6 +120,57 @@ def make_objects(x, y, theta, v, length, dt=0.2):
     return i, out, {k: a[:n] for k, a in o.items()}, arrs
 
 
+class TrajOut(C.Structure):
+    _fields_ = [("max_rows", C.c_int32), ("reserved0", C.c_int32), ("capacity_rows", C.c_int64),
+                ("action_id", _pi32), ("n_rows", _pi32), ("vel_bound", _pi32), ("reduced", _pi32),
+                ("row_off", C.POINTER(C.c_int64)), ("rows", _pf64), ("total_rows", C.c_int64)]
+
+
+class CompactTrajectories(object):
+    """Caller buffers of ``ltpl_tick_batch_compact``: packed rows [s, x, y, psi, kappa, vx, ax] in page-locked host memory
+    (``ltpl_host_alloc``) + per-slot tables. ``trajectories(s)`` rebuilds the dict Graph_LTPL.calc_vel_profile returns."""
+
+    def __init__(self, lib, n_scen, capacity_rows, max_rows=115):
+        self.lib, self.n_scen, self.capacity_rows = lib, int(n_scen), int(capacity_rows)
+        n_slots = self.n_scen * MAX_ACTIONS
+        self.action_id = np.zeros(n_slots, np.int32)
+        self.n_rows = np.zeros(n_slots, np.int32)
+        self.vel_bound = np.zeros(n_slots, np.int32)
+        self.reduced = np.zeros(n_slots, np.int32)
+        self.row_off = np.zeros(n_slots, np.int64)
+        lib.ltpl_host_alloc.restype = C.c_void_p
+        lib.ltpl_host_alloc.argtypes = [C.c_size_t]
+        lib.ltpl_host_free.argtypes = [C.c_void_p]
+        self._ptr = lib.ltpl_host_alloc(self.capacity_rows * 7 * 8)
+        if not self._ptr:
+            raise BackendError("ltpl_host_alloc failed")
+        self.rows = np.ctypeslib.as_array((C.c_double * (self.capacity_rows * 7)).from_address(self._ptr)).reshape(-1, 7)
+        s = self.struct = TrajOut()
+        s.max_rows, s.capacity_rows = int(max_rows), self.capacity_rows
+        s.action_id, s.n_rows, s.vel_bound, s.reduced = (_p(a, _pi32) for a in (self.action_id, self.n_rows, self.vel_bound,
+                                                                                  self.reduced))
+        s.row_off = self.row_off.ctypes.data_as(C.POINTER(C.c_int64))
+        s.rows = C.cast(self._ptr, _pf64)
+
+    def trajectories(self, scen):
+        out = {}
+        for a in range(MAX_ACTIONS):
+            k = scen * MAX_ACTIONS + a
+            if self.n_rows[k] > 0:
+                o = int(self.row_off[k])
+                out[ACTION_NAMES[int(self.action_id[k])]] = [self.rows[o:o + int(self.n_rows[k])]]
+        return out
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                self.rows = None
+                self.lib.ltpl_host_free(self._ptr)
+                self._ptr = None
+        except Exception:
+            pass
+
+
 class TickVelOut(C.Structure):
     _fields_ = [("vx", _pf64), ("ax", _pf64), ("vel_bound", _pi32), ("too_close", _pi32)]
 
@@ -440,6 +491,7 @@ class HipBackend(object):
                                        C.POINTER(VelResult)]
         L.ltpl_tick_batch.argtypes = [C.c_void_p, C.POINTER(PathsIn), C.POINTER(TickVelIn), C.POINTER(PathsOut),
                                       C.POINTER(TickVelOut)]
+        L.ltpl_tick_batch_compact.argtypes = [C.c_void_p, C.POINTER(PathsIn), C.POINTER(TickVelIn), C.POINTER(TrajOut)]
         L.ltpl_batch_upload.argtypes = [C.c_void_p, C.POINTER(PathsIn), C.POINTER(TickVelIn), C.c_int32, C.c_int32]
         L.ltpl_batch_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
         L.ltpl_batch_download.argtypes = [C.c_void_p, C.POINTER(PathsOut), C.POINTER(TickVelOut)]
@@ -515,6 +567,15 @@ class HipBackend(object):
         self._check(self.lib.ltpl_tick_batch(self.handle, C.byref(batch.struct), C.byref(vel.struct),
                                              C.byref(result.struct), C.byref(vresult.struct)))
         return result, vresult
+
+    def new_compact_trajectories(self, n_scen, max_rows=115, capacity_rows=None):
+        cap = capacity_rows if capacity_rows is not None else n_scen * MAX_ACTIONS * (max_rows if max_rows > 0 else self.caps.max_path_pts)
+        return CompactTrajectories(self.lib, n_scen, cap, max_rows)
+
+    def tick_batch_compact(self, batch: PathsBatch, vel: TickVelBatch, out: "CompactTrajectories"):
+        """Fused tick with the compact result form: only the trajectory rows in use cross PCIe (ltpl_tick_batch_compact)."""
+        self._check(self.lib.ltpl_tick_batch_compact(self.handle, C.byref(batch.struct), C.byref(vel.struct), C.byref(out.struct)))
+        return out
 
     def batch_upload(self, batch: PathsBatch, vel: TickVelBatch):
         self._check(self.lib.ltpl_batch_upload(self.handle, C.byref(batch.struct), C.byref(vel.struct),

@@ -1398,6 +1398,64 @@ __global__ __launch_bounds__(64) void k_follow_prep(DevLat lat, DevPathsIn in, D
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// compact trajectory export (ltpl_tick_batch_compact): rows [s, x, y, psi, kappa, vx, ax] of the valid slots, back to back
+// ---------------------------------------------------------------------------------------------------------------------
+// rows kept per slot and their exclusive prefix (one block; n_slots <= a few hundred thousand)
+__global__ __launch_bounds__(1024) void k_compact_offsets(const int* valid, const int* n_pts, int n_slots, int max_rows,
+                                                          int* rows_out, long long* off_out, long long* total)
+{
+    __shared__ long long part[1024];
+    const int t = threadIdx.x, per = (n_slots + 1023) / 1024;
+    const int a = t * per, b = a + per < n_slots ? a + per : n_slots;
+    long long sum = 0;
+    for (int i = a; i < b; ++i) {
+        int r = valid[i] ? n_pts[i] : 0;
+        if (max_rows > 0 && r > max_rows) r = max_rows;
+        rows_out[i] = r; sum += r;
+    }
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const long long v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    long long run = part[t] - sum;
+    for (int i = a; i < b; ++i) { off_out[i] = run; run += rows_out[i]; }
+    if (t == 1023) *total = part[1023];
+}
+
+// one wave per slot: s = [0, cumsum(el[:-1])] (OTH.py:743, wave-parallel prefix), then the seven columns of every kept row
+__global__ __launch_bounds__(64) void k_compact_rows(DevPathsOut out, DevTickVelOut vout, const int* rows_kept, const long long* off,
+                                                     double* dst, long long capacity_rows)
+{
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    const int n = rows_kept[slot];
+    if (n <= 0) return;
+    const long long o = off[slot];
+    if (o + n > capacity_rows) return;
+    const double* pp = out.path_param + (size_t)slot * out.cap_pts * 5;
+    const double* vx = vout.vx + (size_t)slot * out.cap_pts;
+    const double* ax = vout.ax + (size_t)slot * out.cap_pts;
+    double carry = 0.0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const double e = (i < n) ? pp[(size_t)i * 5 + 4] : 0.0;
+        double x = e;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const double y = __shfl_up(x, d); if (lane >= d) x += y; }
+        if (i < n) {
+            double* r = dst + (size_t)(o + i) * 7;
+            r[0] = carry + (x - e);
+            r[1] = pp[(size_t)i * 5]; r[2] = pp[(size_t)i * 5 + 1]; r[3] = pp[(size_t)i * 5 + 2]; r[4] = pp[(size_t)i * 5 + 3];
+            r[5] = vx[i]; r[6] = ax[i];
+        }
+        carry += __shfl(x, 63);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // object ingestion: ObjectListInterface.process_object_list (ObjectListInterface.py:75-153)
 // ---------------------------------------------------------------------------------------------------------------------
 // One lane per object: closest centre-line point (first minimum), the neighbour with the larger opening angle
@@ -2506,6 +2564,75 @@ extern "C" int ltpl_tick_batch(ltpl_handle* h, const ltpl_paths_in* in, const lt
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (t.pipeline) dbg_report_lanes(h); else dbg_report(h, "k_tick", in->n_scen);
     tick_scatter(static_cast<const unsigned char*>(h->h_out), t, out, vout);
+    return LTPL_OK;
+}
+
+extern "C" void* ltpl_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void ltpl_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+extern "C" int ltpl_tick_batch_compact(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin, ltpl_traj_out* out)
+{
+    if (!h) return LTPL_ERR_INVALID_ARG;
+    if (!out || !out->rows || !out->action_id || !out->n_rows || !out->vel_bound || !out->reduced || !out->row_off || out->capacity_rows < 0) {
+        h->err = "null output"; return LTPL_ERR_INVALID_ARG;
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    drop_resident(h);
+    TickLayout t;
+    int rc = tick_prepare(h, in, vin, h->caps.max_path_nodes, h->caps.max_path_pts, &t);
+    if (rc) return rc;
+    const size_t n_slots = (size_t)in->n_scen * LTPL_MAX_ACTIONS;
+    // device scratch behind the regular output slab: rows kept, offsets, total, packed rows
+    Arena b; b.size = t.out_total;
+    const size_t o_rows = b.add(sizeof(int) * n_slots), o_off = b.add(sizeof(long long) * n_slots), o_tot = b.add(sizeof(long long));
+    const size_t o_pack = b.add(sizeof(double) * 7 * (size_t)out->capacity_rows);
+    if ((rc = ensure(h, &h->h_in, &h->h_in_cap, &h->d_in, &h->d_in_cap, t.in_total))) return rc;
+    // host staging only for the small per-slot arrays (+ the packed rows when the caller's buffer is not page-locked)
+    hipPointerAttribute_t attr; bool pinned = false;
+    if (hipPointerGetAttributes(&attr, out->rows) == hipSuccess) pinned = attr.type == hipMemoryTypeHost;
+    else (void)hipGetLastError();
+    const size_t small_bytes = sizeof(int) * n_slots * 4 + sizeof(long long) * (n_slots + 1) + 64;
+    const size_t h_need = small_bytes + (pinned ? 0 : sizeof(double) * 7 * (size_t)out->capacity_rows);
+    if ((rc = ensure(h, &h->h_out, &h->h_out_cap, &h->d_out, &h->d_out_cap, b.size > h_need ? b.size : h_need))) return rc;
+    if ((rc = tick_pack(h, in, vin, &t, static_cast<unsigned char*>(h->h_in), static_cast<unsigned char*>(h->d_in),
+                        static_cast<unsigned char*>(h->d_out)))) return rc;
+    if ((rc = tick_set_lds_limit(h, t.lds, t.variant))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, t.in_total, hipMemcpyHostToDevice, h->stream));
+    if ((rc = tick_launch(h, t))) return rc;
+    unsigned char* dob = static_cast<unsigned char*>(h->d_out);
+    int* d_rows = reinterpret_cast<int*>(dob + o_rows); long long* d_off = reinterpret_cast<long long*>(dob + o_off);
+    long long* d_tot = reinterpret_cast<long long*>(dob + o_tot); double* d_pack = reinterpret_cast<double*>(dob + o_pack);
+    hipLaunchKernelGGL(k_compact_offsets, dim3(1), dim3(1024), 0, h->stream, t.dout.valid, t.dout.n_pts, (int)n_slots, out->max_rows, d_rows, d_off, d_tot);
+    hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)n_slots), dim3(64), 0, h->stream, t.dout, t.dvout, d_rows, d_off, d_pack, (long long)out->capacity_rows);
+    HIP_TRY(h, hipGetLastError());
+    // small arrays first (they tell how many packed bytes there are)
+    unsigned char* hb = static_cast<unsigned char*>(h->h_out);
+    int* h_rows = reinterpret_cast<int*>(hb); int* h_act = h_rows + n_slots; int* h_vb = h_act + n_slots; int* h_red = h_vb + n_slots;
+    long long* h_off = reinterpret_cast<long long*>(h_red + n_slots + 2); long long* h_tot = h_off + n_slots;
+    HIP_TRY(h, hipMemcpyAsync(h_rows, d_rows, sizeof(int) * n_slots, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h_act, t.dout.action_id, sizeof(int) * n_slots, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h_vb, t.dvout.vel_bound, sizeof(int) * n_slots, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h_red, t.dout.reduced, sizeof(int) * n_slots, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h_off, d_off, sizeof(long long) * n_slots, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h_tot, d_tot, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const long long total = *h_tot;
+    out->total_rows = total;
+    if (total > out->capacity_rows) { h->err = "ltpl_traj_out.capacity_rows too small (total_rows holds the need)"; return LTPL_ERR_CAPACITY; }
+    double* h_pack = pinned ? out->rows : reinterpret_cast<double*>(hb + small_bytes);
+    if (total > 0) {
+        HIP_TRY(h, hipMemcpyAsync(h_pack, d_pack, sizeof(double) * 7 * (size_t)total, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (!pinned) memcpy(out->rows, h_pack, sizeof(double) * 7 * (size_t)total);
+    }
+    memcpy(out->n_rows, h_rows, sizeof(int) * n_slots); memcpy(out->action_id, h_act, sizeof(int) * n_slots);
+    memcpy(out->vel_bound, h_vb, sizeof(int) * n_slots); memcpy(out->reduced, h_red, sizeof(int) * n_slots);
+    memcpy(out->row_off, h_off, sizeof(long long) * n_slots);
     return LTPL_OK;
 }
 

@@ -297,6 +297,28 @@ int ltpl_vel_profile(ltpl_handle* handle, const ltpl_vel_params* params, int n_j
 int ltpl_tick_batch(ltpl_handle* handle, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin,
                     ltpl_paths_out* out, ltpl_tick_vel_out* vout);
 
+/* Compact result form of ltpl_tick_batch for callers that only need what Graph_LTPL.calc_vel_profile hands out (the
+ * trajectory set, Graph_LTPL.py:396-408): rows [s, x, y, psi, kappa, vx, ax] of every valid action slot, trimmed to max_rows
+ * (EXPORT.nmbr_export_points) and packed back to back on the DEVICE, so that only the bytes in use cross PCIe (the capacity
+ * slabs of ltpl_paths_out / ltpl_tick_vel_out are mostly padding). `rows` may be any host memory; memory from ltpl_host_alloc
+ * (page-locked) is written by DMA directly, other memory goes through the handle's staging buffer. */
+typedef struct {
+    int32_t  max_rows;              /* rows kept per trajectory, 0 = all                                          */
+    int32_t  reserved0;
+    int64_t  capacity_rows;         /* capacity of `rows` in rows of 7 doubles                                    */
+    /* per scenario and action slot, index s * LTPL_MAX_ACTIONS + a */
+    int32_t* action_id;             /* LTPL_ACT_* or LTPL_ACT_NONE                                                */
+    int32_t* n_rows;                /* 0 = no trajectory in this slot                                             */
+    int32_t* vel_bound;             /* OTH.py:906-911                                                             */
+    int32_t* reduced;               /* action_set_red_len                                                         */
+    int64_t* row_off;               /* first row of the slot in `rows`                                            */
+    double*  rows;                  /* [total_rows * 7]                                                           */
+    int64_t  total_rows;            /* out                                                                        */
+} ltpl_traj_out;
+int ltpl_tick_batch_compact(ltpl_handle* handle, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin, ltpl_traj_out* out);
+void* ltpl_host_alloc(size_t bytes);      /* page-locked host memory for ltpl_traj_out.rows; NULL on failure      */
+void  ltpl_host_free(void* p);
+
 /* Device-resident variant for benchmarks: upload the batch once, replay the fused kernel, download on demand.
  * The resident batch lives in the handle's staging buffers: ANY other entry point on the same handle (ltpl_plan_paths,
  * ltpl_tick_batch, ltpl_vel_profile, ltpl_process_objects, the planner calls) drops it, after which ltpl_batch_run /

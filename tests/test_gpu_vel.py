@@ -134,3 +134,35 @@ def test_tick_paths_equal_plan_paths(monteblanco, hip_backend):
     res1 = hip_backend.plan_paths(batch)
     for name in ("nodes", "node_idx", "coeff", "path_param", "valid", "action_id", "n_pts", "reduced", "n_ties"):
         assert np.array_equal(getattr(res, name), getattr(res1, name)), name
+
+
+def test_compact_trajectories_equal_the_slab_outputs(monteblanco, hip_backend):
+    """ltpl_tick_batch_compact packs exactly the rows ltpl_tick_batch returns (trimmed to max_rows), for a batch on the
+    one-wave pipeline and for a small batch on the fused kernel; s is the running sum of the element lengths (OTH.py:743)."""
+    from scenarios import random_scenarios
+    lat = monteblanco
+    for n in (96, 5):
+        scen, vels = random_scenarios(lat, n, seed=31 + n)
+        batch = _capi.PathsBatch(scen, w_last_edges=[0.0, 0.5, 0.8])
+        params = _capi.VelParamSet(len_veh=lat.veh_length)
+        pos = np.array([lat.node_pos[lat.layer_off[s['start_node'][0]] + s['start_node'][1]] for s in scen])
+        vel = _capi.TickVelBatch(params, n, np.full(n, 25.0), np.full(n, 25.0), pos, np.concatenate(vels))
+        res, vres = hip_backend.tick_batch(batch, vel)
+        comp = hip_backend.new_compact_trajectories(n, max_rows=115)
+        hip_backend.tick_batch_compact(batch, vel, comp)
+        assert comp.struct.total_rows == int(np.minimum(res.n_pts * res.valid, 115).sum())
+        for s in range(n):
+            tr = comp.trajectories(s)
+            names = [_capi.ACTION_NAMES[int(res.action_id[s, a])] for a in range(int(res.n_actions[s])) if res.valid[s, a]]
+            assert list(tr.keys()) == names
+            for a in range(int(res.n_actions[s])):
+                if not res.valid[s, a]:
+                    continue
+                m = min(int(res.n_pts[s, a]), 115)
+                t = tr[_capi.ACTION_NAMES[int(res.action_id[s, a])]][0]
+                assert t.shape == (m, 7)
+                assert np.array_equal(t[:, 1:5], res.path_param[s, a, :m, 0:4])
+                assert np.array_equal(t[:, 5], vres.vx[s, a, :m]) and np.array_equal(t[:, 6], vres.ax[s, a, :m])
+                s_ref = np.concatenate(([0.0], np.cumsum(res.path_param[s, a, :m - 1, 4])))
+                assert_close_rel(t[:, 0], s_ref, what="s column")
+                assert comp.vel_bound[s * 3 + a] == vres.vel_bound[s, a] and comp.reduced[s * 3 + a] == res.reduced[s, a]

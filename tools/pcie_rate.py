@@ -1,5 +1,5 @@
-"""PCIe-inclusive throughput of the host-buffer entry point: ltpl_tick_batch on a batch of C2 scenarios, host wall time per
-call including packing, H2D, kernels, D2H and unpacking (never the bench `value`)."""
+"""PCIe-inclusive rate of the host-buffer entry points on one MI355X: ltpl_tick_batch (capacity slabs) vs ltpl_tick_batch_compact
+(trajectory rows in use, packed on the device, DMA into page-locked memory). Prints one JSON line."""
 import json
 import os
 import sys
@@ -15,12 +15,18 @@ lat = Lattice.load(os.path.join(ROOT, "tests", "golden", "monteblanco_lattice.np
 hip = _capi.HipBackend(lat)
 scen, batch, vel = bench.make_batch(lat, n, seed=1)
 res, vres = hip.new_paths_result(n), _capi.TickVelResult(n, hip.caps.max_path_pts)
-for _ in range(3):
+hip.tick_batch(batch, vel, res, vres)
+t0 = time.perf_counter()
+for _ in range(5):
     hip.tick_batch(batch, vel, res, vres)
-t0 = time.perf_counter(); reps = 10
-for _ in range(reps):
-    hip.tick_batch(batch, vel, res, vres)
-el = (time.perf_counter() - t0) / reps
-out_bytes = sum(a.nbytes for a in (res.nodes, res.node_idx, res.coeff, res.path_param, vres.vx, vres.ax))
-print(json.dumps({"batch": n, "ms_per_call": el * 1e3, "ticks_per_s_pcie_inclusive": n / el,
-                  "output_bytes_per_call": out_bytes, "output_GBps": out_bytes / el / 1e9}))
+slab = n * 5 / (time.perf_counter() - t0)
+out = {"scenarios_per_call": n, "capacity_slab_ticks_per_s": slab}
+for rows in (115, 0):
+    comp = hip.new_compact_trajectories(n, max_rows=rows)
+    hip.tick_batch_compact(batch, vel, comp)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        hip.tick_batch_compact(batch, vel, comp)
+    out["compact_%s_ticks_per_s" % (rows or "all_rows")] = n * 10 / (time.perf_counter() - t0)
+    out["compact_%s_bytes_per_tick" % (rows or "all_rows")] = float(comp.struct.total_rows) * 56 / n
+print(json.dumps(out))
