@@ -191,8 +191,6 @@ class LatticeBinding(object):
     """Keeps the column arrays alive that a ``ltpl_lattice_desc`` points to."""
 
     def __init__(self, lat: Lattice):
-        if not lat.closed:
-            raise ValueError("only closed tracks are supported by this version of the backend")
         self.lat = lat
         k = self.keep = {}
         k["layer_node_off"] = _i32(lat.layer_off)

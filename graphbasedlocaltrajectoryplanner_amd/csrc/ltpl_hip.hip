@@ -36,6 +36,7 @@
 struct DevLat {
     int L, V, E, S, G;
     int mode;
+    int closed;                       // GraphBase.closed; open tracks: the planning range is clamped to the last layer
     double min_plan_horizon, veh_width, sampled_resolution, lat_offset, vel_decrease_lat, veh_length;
     const int* layer_off; const int* rl_idx;
     const double* s_rl; const double* ref_x; const double* ref_y; const double* vel_rl;
@@ -1546,6 +1547,7 @@ struct ltpl_handle {
     // host copy of the per-layer / per-node tables for the planner state machine (planner_core.hpp); empty when the
     // descriptor came without raceline / node_psi columns
     ltplp::HostLat hostlat; bool has_hostlat = false;
+    std::vector<int> rng_end_host;   // planning range end per start layer, -1 = no planning range (end of an open track)
 };
 
 #define HIP_TRY(h, call)                                                                                              \
@@ -1695,17 +1697,23 @@ static int horizon_stats(const ltpl_lattice_desc* d, int* hmax, int* ehmax, int*
     rng_end->assign((size_t)L, 0);
     for (int sl = 0; sl < L; ++sl) {
         int el;
-        if (d->plan_horizon_mode == 0) {
+        if (d->plan_horizon_mode == 0) {                             // gen_local_node_template.py:104-124
             double des = d->s_raceline[sl] + d->min_plan_horizon;
-            if (des > d->s_raceline[L - 1]) des -= d->s_raceline[L - 1];
+            if (des > d->s_raceline[L - 1]) { if (d->closed) des -= d->s_raceline[L - 1]; else des = d->s_raceline[L - 1]; }
             int lo = 0, hi = L;
             while (lo < hi) { int mid = (lo + hi) / 2; if (d->s_raceline[mid] < des) lo = mid + 1; else hi = mid; }
             el = lo;
-        } else el = (sl + (int)d->min_plan_horizon) % L;
-        if (el >= L) { *why = "planning horizon runs past the last layer (track shorter than the horizon?)"; return LTPL_ERR_UNSUPPORTED; }
+        } else if (d->closed) el = (sl + (int)d->min_plan_horizon) % L;
+        else el = std::max(sl + (int)d->min_plan_horizon, L - 1);    // :131-133 (sic: max)
+        if (el >= L) {
+            if (!d->closed) { (*rng_end)[(size_t)sl] = -1; continue; }   // the reference fails for this start layer (GraphBase.py:889)
+            *why = "planning horizon runs past the last layer (track shorter than the horizon?)"; return LTPL_ERR_UNSUPPORTED;
+        }
         (*rng_end)[(size_t)sl] = el;
         int H = el - sl; if (H < 0) H = L - sl + el;
-        if (H <= 0 || H >= L - 1) { *why = "planning range covers the whole track; not supported"; return LTPL_ERR_UNSUPPORTED; }
+        if (!d->closed) {
+            if (H <= 0) { (*rng_end)[(size_t)sl] = -1; continue; }       // last layer of an open track: empty planning range
+        } else if (H <= 0 || H >= L - 1) { *why = "planning range covers the whole track; not supported"; return LTPL_ERR_UNSUPPORTED; }
         int eh = 0, nh = d->layer_node_off[sl + 1] - d->layer_node_off[sl], pts = 1;
         for (int j = 1; j <= H; ++j) {
             int b = (sl + j) % L;
@@ -1752,7 +1760,6 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
 {
     g_create_error.clear();
     if (!d || !out_handle) { g_create_error = "null argument"; return LTPL_ERR_INVALID_ARG; }
-    if (!d->closed) { g_create_error = "only closed tracks are supported"; return LTPL_ERR_UNSUPPORTED; }
     if (d->num_layers < 4 || d->num_nodes < 1 || d->num_edges < 1) { g_create_error = "empty lattice"; return LTPL_ERR_INVALID_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "no HIP device visible"; return LTPL_ERR_NO_DEVICE; }
@@ -1763,18 +1770,20 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
     std::vector<int> rng_end;
     int rc = horizon_stats(d, &hmax, &ehmax, &nhmax, &ptsmax, &kmax, &degmax, &etmax, &rng_end, &g_create_error);
     if (rc) return rc;
+    if (hmax < 2) { g_create_error = "no start layer with a planning range"; return LTPL_ERR_INVALID_ARG; }
     if (etmax > 65535) { g_create_error = "more than 65535 edges in one layer transition"; return LTPL_ERR_CAPACITY; }
     if (kmax > 255 || degmax > 127) { g_create_error = "more than 255 nodes per layer or 127 in-edges per node"; return LTPL_ERR_CAPACITY; }
 
     ltpl_handle* h = new ltpl_handle();
     h->device = device;
+    h->rng_end_host = rng_end;
     auto fail = [&](int code) { g_create_error = h->err; ltpl_destroy(h); return code; };
     if (hipSetDevice(device) != hipSuccess) { h->err = "hipSetDevice failed"; return fail(LTPL_ERR_HIP); }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return fail(LTPL_ERR_HIP); }
 
     DevLat& L = h->lat;
     L.L = d->num_layers; L.V = d->num_nodes; L.E = d->num_edges; L.S = d->num_samples; L.G = d->num_glob_rl;
-    L.mode = d->plan_horizon_mode; L.min_plan_horizon = d->min_plan_horizon; L.veh_width = d->veh_width;
+    L.mode = d->plan_horizon_mode; L.closed = d->closed ? 1 : 0; L.min_plan_horizon = d->min_plan_horizon; L.veh_width = d->veh_width;
     L.sampled_resolution = d->sampled_resolution; L.lat_offset = d->lat_offset;
     L.vel_decrease_lat = d->vel_decrease_lat; L.veh_length = d->veh_length;
 #define UP(field, src, n) if ((rc = upload(h, src, (size_t)(n), &L.field)) != LTPL_OK) return fail(rc)
@@ -2029,6 +2038,7 @@ static int validate_and_layout(ltpl_handle* h, const ltpl_paths_in* in, InLayout
     for (int s = 0; s < n; ++s) {
         const int sl = in->start_layer[s];
         if (sl < 0 || sl >= h->lat.L) { h->err = "start_layer out of range"; return LTPL_ERR_INVALID_ARG; }
+        if (h->rng_end_host[(size_t)sl] < 0) { h->err = "start layer without a planning range (end of an open track)"; return LTPL_ERR_INVALID_ARG; }
         const int nv = in->veh_off[s + 1] - in->veh_off[s];
         if (nv < 0 || nv > MAX_VEH) { h->err = "more than 96 vehicles in one scenario"; return LTPL_ERR_CAPACITY; }
         const int np = in->pos_off[in->veh_off[s + 1]] - in->pos_off[in->veh_off[s]];
@@ -2793,7 +2803,9 @@ static int self_test(ltpl_handle* h, const ltpl_lattice_desc* d)
         zone_off(n + 1, 0), zone(1, 0), n_last(n, 0), ll((size_t)n * LTPL_MAX_LAST_NODES, -1), ln((size_t)n * LTPL_MAX_LAST_NODES, -1);
     std::vector<double> psi(n, 0.0), rad(n, 2.5), px(n), py(n), w(1, 0.0);
     for (int i = 0; i < n; ++i) {
-        sl[i] = (int)(((long long)i * L) / n); sn[i] = d->raceline_index[sl[i]];
+        sl[i] = (int)(((long long)i * L) / n);
+        while (h->rng_end_host[(size_t)sl[i]] < 0 && sl[i] > 0) --sl[i];     // open tracks: the last layer(s) have no planning range
+        sn[i] = d->raceline_index[sl[i]];
         const int ol = (sl[i] + 4) % L, g = d->layer_node_off[ol] + d->raceline_index[ol];
         px[i] = d->node_x[g]; py[i] = d->node_y[g];
         veh_off[i] = i; pos_off[i] = i;

@@ -1164,7 +1164,8 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                 if (found || !(nm == LTPL_ACT_FOLLOW || nm == LTPL_ACT_STRAIGHT)) break;
                 mod_j -= 1;
             }
-            const bool reduced = mod_j != H;
+            // main_online_path_gen.py:223-224: also when an open track's planning range ends in the last layer
+            const bool reduced = mod_j != H || (!lat.closed && sc.el == L - 1);
             int goal = sc.sl + mod_j; if (goal >= L) goal -= L;
             if (reduced) {
                 const int cl = t_cl, sl = sc.sl;

@@ -166,7 +166,9 @@ class Lattice(object):
         for s in range(L):
             e = self.horizon_end_layer(s)
             dist = e - s if e >= s else L - s + e
-            if dist <= 0:
+            if dist <= 0 or e >= L:
+                if not self.closed:
+                    continue                # open track: no planning range from the last layer(s)
                 dist = L
             layers = [(s + j) % L for j in range(1, dist + 1)]
             best_layers = max(best_layers, dist + 1)

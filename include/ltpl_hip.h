@@ -64,7 +64,7 @@ typedef struct {
     int32_t num_edges;
     int32_t num_samples;
     int32_t num_glob_rl;            /* rows of glob_rl                                                            */
-    int32_t closed;                 /* GraphBase.closed (only closed tracks are supported in this version)        */
+    int32_t closed;                 /* GraphBase.closed; 0 = open track (planning range clamped to the last layer)   */
     int32_t plan_horizon_mode;      /* 0 = 'distance', 1 = 'layers'        gen_local_node_template.py:104-133     */
     int32_t reserved0;
     double  min_plan_horizon;

@@ -135,6 +135,73 @@ def main_ticks(only=None):
         print("%-32s %8.2f MB" % (f, os.path.getsize(os.path.join(GOLDEN, f)) / 1e6))
 
 
+def main_open():
+    """Open (unclosed) track: rows 40..339 of the Monteblanco race line as its own track (the reference decides `closed` from the
+    distance between the first and the last point, main_offline_callback.py:90-93). One slow opponent ahead, the ego drives to the
+    end of the track: clamped planning range (gen_local_node_template.py:112-133), reduced-horizon flag at the last layer
+    (main_online_path_gen.py:223-224), blocked-track branch when the range runs out.
+      open_lattice.npz, open_path_calls.npz, open_vel_calls.npz, open_ticks.npz"""
+    warnings.simplefilter("ignore")
+    from oracle import ref_env
+    src = ref_env.REFERENCE_ROOT + "/inputs/traj_ltpl_cl/traj_ltpl_cl_monteblanco.csv"
+    lines = open(src).read().split("\n")
+    hdr = [ln for ln in lines if ln.startswith("#")]
+    rows = [ln for ln in lines if ln and not ln.startswith("#")]
+    os.makedirs(CACHE, exist_ok=True)
+    csv_path = os.path.join(CACHE, "traj_ltpl_cl_openmb.csv")
+    with open(csv_path, "w") as fh:
+        fh.write("\n".join(hdr + rows[40:340]) + "\n")
+    gl, clock = ref_env.load_reference()
+    path_dict = ref_env.default_path_dict(CACHE, "monteblanco")
+    path_dict['globtraj_input_path'] = csv_path
+    path_dict['graph_store_path'] = os.path.join(CACHE, "stored_graph_openmb.pckl")
+    ltpl_obj = gl.Graph_LTPL.Graph_LTPL(path_dict=path_dict, visual_mode=False, log_to_file=False)
+    ltpl_obj.graph_init()
+    gb = ltpl_obj._Graph_LTPL__graph_base
+    assert not gb.closed
+    lat = Lattice.from_graph_base(gb)
+    lat.save(os.path.join(GOLDEN, "open_lattice.npz"))
+    print("open lattice: L=%d V=%d E=%d S=%d closed=%s" % (lat.num_layers, lat.num_nodes, lat.num_edges, lat.num_samples, lat.closed))
+    seam = rs.SeamRecorder(gl, gb)
+    rec = rs.TickRecorder(gl, clock, seam)
+    Dummy = gl.testing_tools.src.objectlist_dummy.ObjectlistDummy
+
+    class TrackObject(object):            # slow vehicle on the open track's own race line
+        def __init__(self, s0, v):
+            self.s, self.v = s0, v
+
+        def get_objectlist(self):
+            g = gb.glob_rl
+            self.s = min(self.s + self.v * 0.05, float(g[-2, 0]))
+            i = int(np.searchsorted(g[:, 0], self.s)) - 1
+            i = max(0, min(i, g.shape[0] - 2))
+            t = (self.s - g[i, 0]) / (g[i + 1, 0] - g[i, 0])
+            x, y = g[i, 1] + t * (g[i + 1, 1] - g[i, 1]), g[i, 2] + t * (g[i + 1, 2] - g[i, 2])
+            psi = np.arctan2(g[i + 1, 2] - g[i, 2], g[i + 1, 1] - g[i, 1]) - np.pi / 2
+            return [{'X': float(x), 'Y': float(y), 'theta': float(psi), 'type': 'physical', 'id': 1, 'length': 5.0,
+                     'v': float(self.v)}]
+    n_done = [0]
+    try:
+        rs.run_loop(gl, clock, ltpl_obj, path_dict, n_ticks=900, dt=0.05, dummies=[TrackObject(120.0, 12.0)], zones=None,
+                    on_tick=lambda i, e: n_done.__setitem__(0, i + 1))
+    except Exception as e:      # the reference runs out of track eventually; everything up to there is recorded
+        print("open loop stopped after %d ticks: %s: %s" % (n_done[0], type(e).__name__, e))
+    ticks = rec.export(full_every=25)
+    n = len(ticks)
+    sel = select_path_ticks(seam.path_calls[:n], every=20)
+    save_records(os.path.join(GOLDEN, "open_path_calls.npz"), [dict(seam.path_calls[i], tick=i) for i in sel])
+    vsel = select_vel_calls(seam.vel_calls, every=17)
+    save_records(os.path.join(GOLDEN, "open_vel_calls.npz"), [seam.vel_calls[i] for i in vsel])
+    save_records(os.path.join(GOLDEN, "open_ticks.npz"), ticks, packed=True)
+    import collections
+    print("open: %d ticks, %d path calls kept, %d vel calls kept; offered sets %s; reduced %s; last start layers %s" % (
+        n, len(sel), len(vsel), dict(collections.Counter(tuple(t['vel']['keys']) for t in ticks)),
+        dict(collections.Counter(tuple(sorted(t['paths']['red_len'].items())) for t in ticks)),
+        [t['paths']['start_node'][0] for t in ticks[-5:]]))
+    rec.uninstall()
+    seam.uninstall()
+
+
 def main():
     warnings.simplefilter("ignore")
     os.makedirs(GOLDEN, exist_ok=True)
@@ -199,7 +266,9 @@ def main():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "ticks":
+    if len(sys.argv) > 1 and sys.argv[1] == "open":
+        main_open()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ticks":
         main_ticks(sys.argv[2:])
     else:
         main()

@@ -112,3 +112,27 @@ def test_path_invariants_full_batch(monteblanco, hip_backend):
                 assert np.hypot(*(pp[idx[i], 0:2] - g)) < 1e-6
             checked += 1
     assert checked > 100
+
+
+def test_hip_matches_reference_recordings_on_an_open_track(open_lattice, hip_open, oracle_open):
+    """Unclosed track: recordings of the unmodified reference + random scenarios against the oracle, incl. start layers close to
+    the end of the track (clamped planning range, reduced-horizon flag) on both kernel forms."""
+    recs = load_golden("open_path_calls.npz")
+    gen = OnlinePathGenerator(open_lattice, hip_open)
+    scen = [replay_path_call(gen, r) for r in recs]
+    res = hip_open.plan_paths(_capi.PathsBatch(scen, w_last_edges=recs[0]['w_last_edges']))
+    for i, rec in enumerate(recs):
+        check_path_output(res.action_sets(i, rec['start_node'][0], open_lattice.num_layers), rec, what="open tick %d" % rec['tick'])
+    L = open_lattice.num_layers
+    rnd, _ = random_scenarios(open_lattice, 200, seed=77)
+    rnd = [s for s in rnd if s['start_node'][0] < L - 1][:128]
+    for k, s in enumerate(rnd[:40]):                     # force start layers near the end of the track
+        sl = L - 2 - (k % 12)
+        s['start_node'] = (sl, int(open_lattice.raceline_index[sl]))
+        s['last_nodes'] = None
+    for chunk in (rnd, rnd[:9]):
+        batch = _capi.PathsBatch(chunk, w_last_edges=[0.0, 0.5, 0.8])
+        compare_results(hip_open.plan_paths(batch), oracle_open.plan_paths(batch), open_lattice)
+    with pytest.raises(_capi.BackendError):              # the last layer has no planning range
+        bad = dict(rnd[0]); bad['start_node'] = (L - 1, 0)
+        hip_open.plan_paths(_capi.PathsBatch([bad], w_last_edges=[0.0, 0.5, 0.8]))

@@ -17,3 +17,16 @@ def test_oracle_matches_reference_recordings(monteblanco, oracle_backend, fixtur
         res = oracle_backend.plan_paths(batch)
         out6 = res.action_sets(0, rec['start_node'][0], monteblanco.num_layers)
         check_path_output(out6, rec, what="%s tick %d" % (fixture, rec['tick']))
+
+
+def test_oracle_matches_reference_recordings_on_an_open_track(open_lattice, oracle_open):
+    """Unclosed track (gen_local_node_template.py:112-133 clamps the planning range, main_online_path_gen.py:223-224 raises the
+    reduced-horizon flag at the last layer): recordings of the unmodified reference on rows 40..339 of the Monteblanco line."""
+    recs = load_golden("open_path_calls.npz")
+    gen = OnlinePathGenerator(open_lattice, oracle_open)
+    assert not open_lattice.closed and len(recs) > 30
+    assert any(any(r['out']['red_len'].values()) for r in recs)
+    for rec in recs:
+        sc = replay_path_call(gen, rec)
+        res = oracle_open.plan_paths(_capi.PathsBatch([sc], w_last_edges=rec['w_last_edges']))
+        check_path_output(res.action_sets(0, rec['start_node'][0], open_lattice.num_layers), rec, what="open tick %d" % rec['tick'])

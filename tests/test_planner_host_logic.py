@@ -56,3 +56,12 @@ def test_recordings_cover_the_rare_v0_branches():
     assert n_backup > 50
     ov = pr.load_ticks("overtake")
     assert sum(1 for t in ov if set(t['paths']['keys']) - set(t['vel']['keys'])) > 50
+
+
+def test_closed_loop_replay_on_an_open_track(open_lattice):
+    """900 ticks of the unmodified reference on an unclosed track, up to the end of the track (reduced horizon at the last layer)."""
+    from oracle.planner_host import HostPlannerBackend
+    ticks = pr.load_ticks("open")
+    seen = pr.replay(HostPlannerBackend(open_lattice).planner(1), open_lattice, ticks)
+    assert {"straight", "follow", "right"} <= seen['keys'] and seen['full'] >= 15
+    assert sum(1 for t in ticks if any(t['paths']['red_len'].values())) > 100
