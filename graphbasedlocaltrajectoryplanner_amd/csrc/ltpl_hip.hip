@@ -153,8 +153,11 @@ struct WavePath { int valid; int n_pts; int n_nodes; int name; int reduced; int 
 // this kernel that spilled VGPRs to scratch produced wrong parents on gfx950; __graft_entry__.build() rejects such builds).
 // Runtime plan (any lattice): 2 waves per SIMD = 256 VGPRs. Compile-time plan (three register chunks of edges): 4 waves per
 // SIMD = 128 VGPRs.
+#ifndef LTPL_RT_WAVES
+#define LTPL_RT_WAVES 2              // -DLTPL_RT_WAVES=4 builds the spilling variant studied in tools/ubench/spill_study
+#endif
 template <int NW, class P>
-__global__ __launch_bounds__(64 * NW, (NW == 1 ? (P::fixed ? 4 : 2) : 1)) void k_paths(DevLat lat, DevPathsIn in, DevPathsOut out, TeamLds lp)
+__global__ __launch_bounds__(64 * NW, (NW == 1 ? (P::fixed ? 4 : LTPL_RT_WAVES) : 1)) void k_paths(DevLat lat, DevPathsIn in, DevPathsOut out, TeamLds lp)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ TeamShared ts;

@@ -173,9 +173,16 @@ __device__ __forceinline__ void team_sync()
 {
     if constexpr (NW == 1) {
         // one wave: DS operations of a wave execute in order, so only the compiler has to be kept from reordering
+#ifdef LTPL_WG_FENCE                     // spill study (tools/ubench/spill_study): workgroup-scope fences + explicit LDS drain
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
     } else {
         // LDS-only workgroup barrier: the team only exchanges data through LDS, so outstanding GLOBAL loads (the edge
         // prefetch of the next layer) must not be drained here -- __syncthreads() would wait for vmcnt(0) as well
@@ -270,10 +277,15 @@ __device__ __forceinline__ void team_factor(const DevLat& lat, const DevPathsIn&
         if (ll[i] == pb && ll[i + 1] == b) { fac_src = ln[i]; fac_dst = ln[i + 1]; fac = in.w_last[i]; break; }
 }
 
+#ifdef LTPL_NOINLINE_ASSEMBLE
+#define LTPL_RESWEEP_ATTR __attribute__((noinline))
+#else
+#define LTPL_RESWEEP_ATTR __forceinline__
+#endif
 // Re-sweep of one filter up to layer J straight from global memory (reduced-horizon paths only: the goal node of a
 // layer in front of the planning horizon is needed). Parents are rewritten with identical values.
 template <class P>
-__device__ void team_resweep(const DevLat& lat, const DevPathsIn& in, const Scen& sc, const TeamLds& lp, unsigned char* smem,
+__device__ LTPL_RESWEEP_ATTR void team_resweep(const DevLat& lat, const DevPathsIn& in, const Scen& sc, const TeamLds& lp, unsigned char* smem,
                              const TeamShared& ts, int f, int J, int lane)
 {
     double* dist = reinterpret_cast<double*>(smem + P::off_dist(lp));
@@ -308,8 +320,16 @@ __device__ void team_resweep(const DevLat& lat, const DevPathsIn& in, const Scen
 // ---------------------------------------------------------------------------------------------------------------------
 // phase 6: assemble primitive `a` (one wave): backtrack, gather, spline, re-sampling (main_online_path_gen.py:250-328)
 // ---------------------------------------------------------------------------------------------------------------------
+// Always inlined. An out-of-line copy (the compiler's own choice for the larger plan classes in round 1) takes the kernel-argument
+// structs by reference -- they are then copied to private memory -- and, inside the one-wave kernel, ran into wrong results when
+// the caller also spilled registers (spill study, DESIGN.md section 4.1: LTPL_NOINLINE_ASSEMBLE reproduces it).
+#ifdef LTPL_NOINLINE_ASSEMBLE
+#define LTPL_ASSEMBLE_ATTR __attribute__((noinline))
+#else
+#define LTPL_ASSEMBLE_ATTR __forceinline__
+#endif
 template <class P>
-__device__ WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const Scen& sc,
+__device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const Scen& sc,
                                   const TeamLds& lp, unsigned char* smem, int a, int f, int J, int name, int reduced,
                                   int jcl, bool share_prefix, int lane, unsigned char* pw,
                                   double* vel_kappa, double* vel_len, double* vel_x, double* vel_y)
