@@ -2793,6 +2793,116 @@ extern "C" int ltpl_batch_download(ltpl_handle* h, ltpl_paths_out* out, ltpl_tic
 static void free_resident(TickLayout* t) { delete t; }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// offline lattice build: every candidate edge of a track in one launch, lane = edge
+// ---------------------------------------------------------------------------------------------------------------------
+struct DevOfflineIn {
+    int n_edges, cap; double step, kmax_turn;
+    const double* sx; const double* sy; const double* spsi; const double* ex; const double* ey; const double* epsi;
+    const double* kmax_vel; const int* rl_edge; const double* given;
+};
+struct DevOfflineOut { int* n_samples; int* valid; double* coeff; double* length; double* kavg; double* krange; double* samples; };
+
+__global__ __launch_bounds__(64) void k_offline_edges(DevOfflineIn in, DevOfflineOut out)
+{
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= in.n_edges) return;
+    double cx[4], cy[4];
+    if (in.rl_edge[e]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cx[k] = in.given[(size_t)e * 8 + k]; cy[k] = in.given[(size_t)e * 8 + 4 + k]; }
+    } else {
+        // tph.calc_splines on two points with heading constraints (gen_edges.py:80-84): cubic Hermite segment, end slopes scaled
+        // by the chord length (psi = 0 is north, hence + pi / 2)
+        const double x0 = in.sx[e], y0 = in.sy[e], x1 = in.ex[e], y1 = in.ey[e];
+        const double el = sqrt((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0));
+        const double tx0 = cos(in.spsi[e] + D_PI / 2) * el, ty0 = sin(in.spsi[e] + D_PI / 2) * el;
+        const double tx1 = cos(in.epsi[e] + D_PI / 2) * el, ty1 = sin(in.epsi[e] + D_PI / 2) * el;
+        cx[0] = x0; cx[1] = tx0; cx[2] = 3.0 * (x1 - x0) - 2.0 * tx0 - tx1; cx[3] = -2.0 * (x1 - x0) + tx0 + tx1;
+        cy[0] = y0; cy[1] = ty0; cy[2] = 3.0 * (y1 - y0) - 2.0 * ty0 - ty1; cy[3] = -2.0 * (y1 - y0) + ty0 + ty1;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { out.coeff[(size_t)e * 8 + k] = cx[k]; out.coeff[(size_t)e * 8 + 4 + k] = cy[k]; }
+    auto px = [&](double t) { return cx[0] + cx[1] * t + cx[2] * (t * t) + cx[3] * (t * t * t); };
+    auto py = [&](double t) { return cy[0] + cy[1] * t + cy[2] * (t * t) + cy[3] * (t * t * t); };
+    // tph.calc_spline_lengths: polyline over 15 uniform-t points
+    double len = 0.0;
+    {
+        double lx = px(0.0), ly = py(0.0);
+        for (int i = 1; i < 15; ++i) {
+            const double t = i == 14 ? 1.0 : (double)i * (1.0 / 14.0);
+            const double qx = px(t), qy = py(t);
+            len += sqrt((qx - lx) * (qx - lx) + (qy - ly) * (qy - ly));
+            lx = qx; ly = qy;
+        }
+    }
+    const int n = (int)ceil(len / in.step) + 1;                  // tph.interp_splines(stepsize_approx, incl_last_point=True)
+    out.n_samples[e] = n;
+    if (n > in.cap || n < 2) { out.valid[e] = 0; out.length[e] = 0.0; out.kavg[e] = 0.0; out.krange[e] = 0.0; return; }
+    double* S = out.samples + (size_t)e * in.cap * 5;
+    const double lin_step = len / (double)(n - 1);
+    const double kmax_v = in.kmax_vel[e], kmax_t = in.kmax_turn;
+    bool ok = true; double sum_abs = 0.0, kmin = INFINITY, kmax = -INFINITY, slen = 0.0, lx = 0.0, ly = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const bool last = i == n - 1;
+        const double t = last ? 1.0 : ((double)i * lin_step) / len;
+        double x = px(t), y = py(t);
+        if (last) { x = ((cx[0] + cx[1]) + cx[2]) + cx[3]; y = ((cy[0] + cy[1]) + cy[2]) + cy[3]; }
+        const double xd = cx[1] + 2.0 * cx[2] * t + 3.0 * cx[3] * (t * t), yd = cy[1] + 2.0 * cy[2] * t + 3.0 * cy[3] * (t * t);
+        const double xdd = 2.0 * cx[2] + 6.0 * cx[3] * t, ydd = 2.0 * cy[2] + 6.0 * cy[3] * t;
+        const double psi = normalize_psi_dev(atan2(yd, xd) - D_PI / 2);
+        const double q = xd * xd + yd * yd;
+        const double kap = (xd * ydd - yd * xdd) / (q * sqrt(q));
+        double* r = S + (size_t)i * 5;
+        r[0] = x; r[1] = y; r[2] = psi; r[3] = kap; r[4] = 0.0;
+        if (i > 0) { const double el = sqrt((x - lx) * (x - lx) + (y - ly) * (y - ly)); S[(size_t)(i - 1) * 5 + 4] = el; slen += el; }
+        lx = x; ly = y;
+        const double ka = fabs(kap);
+        ok = ok && ka <= kmax_t && ka <= kmax_v;
+        sum_abs += ka; kmin = kap < kmin ? kap : kmin; kmax = kap > kmax ? kap : kmax;
+    }
+    out.valid[e] = (ok || in.rl_edge[e]) ? 1 : 0;
+    out.length[e] = slen; out.kavg[e] = sum_abs / (double)n; out.krange[e] = fabs(kmax - kmin);
+}
+
+extern "C" int ltpl_offline_edges(int device, const ltpl_offline_edges_in* in, ltpl_offline_edges_out* out)
+{
+    g_create_error.clear();
+    if (!in || !out || in->n_edges < 1 || in->cap_samples < 2 || !(in->stepsize_approx > 0.0)) { g_create_error = "offline edges: invalid argument"; return LTPL_ERR_INVALID_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "no HIP device visible"; return LTPL_ERR_NO_DEVICE; }
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= ndev || hipSetDevice(device) != hipSuccess) { g_create_error = "device index out of range"; return LTPL_ERR_NO_DEVICE; }
+    const size_t n = (size_t)in->n_edges, cap = (size_t)in->cap_samples;
+    Arena ai, ao;
+    const size_t o_sx = ai.add(8 * n), o_sy = ai.add(8 * n), o_sp = ai.add(8 * n), o_ex = ai.add(8 * n), o_ey = ai.add(8 * n), o_ep = ai.add(8 * n),
+                 o_kv = ai.add(8 * n), o_rl = ai.add(4 * n), o_gc = ai.add(64 * n);
+    const size_t q_ns = ao.add(4 * n), q_va = ao.add(4 * n), q_co = ao.add(64 * n), q_le = ao.add(8 * n), q_ka = ao.add(8 * n), q_kr = ao.add(8 * n),
+                 q_sa = ao.add(8 * 5 * cap * n);
+    unsigned char *di = nullptr, *dobuf = nullptr;
+    auto fail = [&](const char* why) { g_create_error = why; if (di) (void)hipFree(di); if (dobuf) (void)hipFree(dobuf); return LTPL_ERR_HIP; };
+    if (hipMalloc(reinterpret_cast<void**>(&di), ai.size) != hipSuccess) return fail("offline edges: hipMalloc failed");
+    if (hipMalloc(reinterpret_cast<void**>(&dobuf), ao.size) != hipSuccess) return fail("offline edges: hipMalloc failed");
+    auto up = [&](size_t off, const void* src, size_t bytes) { return hipMemcpy(di + off, src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
+    if (!up(o_sx, in->start_x, 8 * n) || !up(o_sy, in->start_y, 8 * n) || !up(o_sp, in->start_psi, 8 * n) || !up(o_ex, in->end_x, 8 * n) ||
+        !up(o_ey, in->end_y, 8 * n) || !up(o_ep, in->end_psi, 8 * n) || !up(o_kv, in->kappa_max_vel, 8 * n) || !up(o_rl, in->raceline_edge, 4 * n) ||
+        !up(o_gc, in->given_coeff, 64 * n)) return fail("offline edges: upload failed");
+    DevOfflineIn d; d.n_edges = in->n_edges; d.cap = in->cap_samples; d.step = in->stepsize_approx; d.kmax_turn = in->kappa_max_turn;
+    d.sx = reinterpret_cast<double*>(di + o_sx); d.sy = reinterpret_cast<double*>(di + o_sy); d.spsi = reinterpret_cast<double*>(di + o_sp);
+    d.ex = reinterpret_cast<double*>(di + o_ex); d.ey = reinterpret_cast<double*>(di + o_ey); d.epsi = reinterpret_cast<double*>(di + o_ep);
+    d.kmax_vel = reinterpret_cast<double*>(di + o_kv); d.rl_edge = reinterpret_cast<int*>(di + o_rl); d.given = reinterpret_cast<double*>(di + o_gc);
+    DevOfflineOut o; o.n_samples = reinterpret_cast<int*>(dobuf + q_ns); o.valid = reinterpret_cast<int*>(dobuf + q_va);
+    o.coeff = reinterpret_cast<double*>(dobuf + q_co); o.length = reinterpret_cast<double*>(dobuf + q_le); o.kavg = reinterpret_cast<double*>(dobuf + q_ka);
+    o.krange = reinterpret_cast<double*>(dobuf + q_kr); o.samples = reinterpret_cast<double*>(dobuf + q_sa);
+    hipLaunchKernelGGL(k_offline_edges, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, d, o);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail("offline edges: kernel failed");
+    auto down = [&](void* dst, size_t off, size_t bytes) { return hipMemcpy(dst, dobuf + off, bytes, hipMemcpyDeviceToHost) == hipSuccess; };
+    if (!down(out->n_samples, q_ns, 4 * n) || !down(out->valid, q_va, 4 * n) || !down(out->coeff, q_co, 64 * n) || !down(out->length, q_le, 8 * n) ||
+        !down(out->kappa_avg, q_ka, 8 * n) || !down(out->kappa_range, q_kr, 8 * n) || !down(out->samples, q_sa, 8 * 5 * cap * n)) return fail("offline edges: download failed");
+    (void)hipFree(di); (void)hipFree(dobuf);
+    return LTPL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // self-test at ltpl_create: the one-wave batch kernel and the four-wave latency kernel are two differently scheduled builds
 // of the same source (different register budgets, LDS plans and synchronisation); 64 probe scenarios derived from the
 // lattice itself (an obstacle on the race line four layers ahead: mask, three filters, tie-break rounds) must come out

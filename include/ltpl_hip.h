@@ -337,6 +337,42 @@ int ltpl_batch_run_profile(ltpl_handle* handle, int reps, float* ms_kernels);
 int ltpl_batch_last_paths_ms(ltpl_handle* handle, float* ms_avg);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Offline lattice build: the per-edge arithmetic of gen_edges.py:11-164 (two-point cubic from node
+ * pose to node pose, arc-length sampling tph.interp_splines(stepsize_approx), heading / curvature tph.calc_head_curv_an,
+ * turn-radius / velocity filter :127-140), of GraphBase.update_edge (element lengths, spline length, GraphBase.py:421-436) and
+ * the curvature terms of gen_offline_cost.py:57-62 for ALL candidate edges of a track in one launch (lane = edge). Needs no
+ * lattice handle. The host side (node skeleton, pruning, assembly) is graphbasedlocaltrajectoryplanner_amd/offline_build.py.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t n_edges;
+    int32_t cap_samples;            /* capacity per edge of ltpl_offline_edges_out.samples                        */
+    double  stepsize_approx;        /* SAMPLING.stepsize_approx                                                   */
+    double  kappa_max_turn;         /* 1 / VEHICLE.veh_turn                                                       */
+    const double*  start_x;         /* [n_edges] pose of the start node                                           */
+    const double*  start_y;
+    const double*  start_psi;
+    const double*  end_x;           /* [n_edges] pose of the end node                                             */
+    const double*  end_y;
+    const double*  end_psi;
+    const double*  kappa_max_vel;   /* [n_edges] 10 / (vel_raceline[start layer] * min_vel_race)^2   gen_edges.py:131-132 */
+    const int32_t* raceline_edge;   /* [n_edges] 1: race line node -> race line node: coefficients are GIVEN (closed spline
+                                                 through the race line, gen_edges.py:40-42,75-78) and the filter does not apply */
+    const double*  given_coeff;     /* [n_edges * 8] x a0..a3, y a0..a3 (only read where raceline_edge != 0)      */
+} ltpl_offline_edges_in;
+
+typedef struct {
+    int32_t* n_samples;             /* [n_edges]  (> cap_samples: the edge did not fit, samples not written)      */
+    int32_t* valid;                 /* [n_edges]  1 = kept by the curvature filter                                */
+    double*  coeff;                 /* [n_edges * 8]                                                              */
+    double*  length;                /* [n_edges]  spline_length = sum of the element lengths                      */
+    double*  kappa_avg;             /* [n_edges]  sum |kappa| / n_samples                  gen_offline_cost.py:57 */
+    double*  kappa_range;           /* [n_edges]  |max kappa - min kappa|                  gen_offline_cost.py:61 */
+    double*  samples;               /* [n_edges * cap_samples * 5] rows x, y, psi, kappa, el_length               */
+} ltpl_offline_edges_out;
+
+int ltpl_offline_edges(int device, const ltpl_offline_edges_in* in, ltpl_offline_edges_out* out);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * ABI v3 -- the planner: the iterative memory of class OnlineTrajectoryHandler
  * (graph_ltpl/online_graph/src/OnlineTrajectoryHandler.py:24-1040) behind the C ABI, batched over n_scen independent
  * planners that share one lattice handle (section 8f rank 2). One tick =
