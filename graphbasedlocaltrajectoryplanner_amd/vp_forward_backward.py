@@ -56,23 +56,17 @@ class VpForwardBackward(object):
 
     def check_brake_prefix(self, vel_plan: float, vel_course: np.ndarray, kappa: np.ndarray, el_lengths: np.ndarray,
                            loc_gg: np.ndarray) -> tuple:
-        """VpForwardBackward.py:86-139"""
-        if vel_plan > (self.__vel_max + 0.1):
-            self.__log.info("Applying deceleration in order to break to new v_max!")
-            gg_brake = loc_gg * self.__old_gg_scale
-            vx_decel = self.__brake(gg_brake, kappa, el_lengths, vel_plan)
-            idx = np.argmax(vx_decel <= self.__vel_max)
-            if idx == 0:
-                idx = len(vx_decel) - 1
-            vx_prefix = np.concatenate((vel_course, vx_decel[:idx]))
-            pref_idx = idx
-            vel_start = vx_decel[idx]
-        else:
-            vx_prefix = vel_course
-            pref_idx = 0
-            vel_start = vel_plan
+        """VpForwardBackward.py:86-139: (velocity prefix, number of prefix points behind vel_course, start velocity of the profile).
+        Only when the planned velocity exceeds the (lowered) maximum: brake with the friction scale of the PREVIOUS ticks until the
+        maximum is met; that scale only advances while no such braking phase is pending."""
+        if not vel_plan > self.__vel_max + 0.1:
             self.__old_gg_scale = self.__gg_scale
-        return vx_prefix, pref_idx, vel_start
+            return vel_course, 0, vel_plan
+        self.__log.info("Applying deceleration in order to break to new v_max!")
+        decel = self.__brake(loc_gg * self.__old_gg_scale, kappa, el_lengths, vel_plan)
+        below = np.flatnonzero(decel <= self.__vel_max)
+        cut = int(below[0]) if below.size and below[0] > 0 else len(decel) - 1      # np.argmax == 0 -> last point (:124-126)
+        return np.concatenate((vel_course, decel[:cut])), cut, decel[cut]
 
     def calc_vel_profile_follow(self, kappa: np.ndarray, el_lengths: np.ndarray, loc_gg: np.array, v_start: float,
                                 v_ego: float, v_obj: float, safety_d: float, obj_dist: float,
