@@ -50,13 +50,18 @@ class Caps(C.Structure):
                 ("device", C.c_int32), ("num_cus", C.c_int32), ("lds_bytes_paths", C.c_int32)]
 
 
+# The per-call INPUT structs declare their pointer members as plain addresses (c_void_p) and are filled with
+# ndarray.ctypes.data: a typed ctypes pointer per array (ndarray.ctypes.data_as) costs ~4 us, and a tick packs ~25 of them.
+_vp = C.c_void_p
+
+
 class PathsIn(C.Structure):
-    _fields_ = [("n_scen", C.c_int32), ("n_w_last", C.c_int32), ("w_last_edges", _pf64),
-                ("start_layer", _pi32), ("start_node", _pi32), ("flags", _pi32), ("last_action", _pi32),
-                ("const_closest", _pi32), ("psi_s", _pf64),
-                ("veh_off", _pi32), ("pos_off", _pi32), ("veh_radius", _pf64), ("pos_x", _pf64), ("pos_y", _pf64),
-                ("zone_off", _pi32), ("zone_gid", _pi32),
-                ("n_last", _pi32), ("last_layer", _pi32), ("last_node", _pi32)]
+    _fields_ = [("n_scen", C.c_int32), ("n_w_last", C.c_int32), ("w_last_edges", _vp),
+                ("start_layer", _vp), ("start_node", _vp), ("flags", _vp), ("last_action", _vp),
+                ("const_closest", _vp), ("psi_s", _vp),
+                ("veh_off", _vp), ("pos_off", _vp), ("veh_radius", _vp), ("pos_x", _vp), ("pos_y", _vp),
+                ("zone_off", _vp), ("zone_gid", _vp),
+                ("n_last", _vp), ("last_layer", _vp), ("last_node", _vp)]
 
 
 class PathsOut(C.Structure):
@@ -91,8 +96,8 @@ class VelResult(C.Structure):
 class TickVelIn(C.Structure):
     _fields_ = [("params", C.POINTER(VelParams)), ("gg_ax", C.c_double), ("gg_ay", C.c_double),
                 ("gg_brake_scale", C.c_double), ("safety_d", C.c_double), ("v_max_offset", C.c_double),
-                ("vel_plan", _pf64), ("vel_est", _pf64), ("pos_est_x", _pf64), ("pos_est_y", _pf64),
-                ("veh_vel", _pf64)]
+                ("vel_plan", _vp), ("vel_est", _vp), ("pos_est_x", _vp), ("pos_est_y", _vp),
+                ("veh_vel", _vp)]
 
 
 class ObjectsIn(C.Structure):
@@ -321,12 +326,10 @@ class PathsBatch(object):
             raise ValueError("w_last_edges longer than %d entries is not supported" % (MAX_LAST_NODES - 1))
         s = self.struct = PathsIn()
         s.n_scen, s.n_w_last = n, self.n_w_last
-        s.w_last_edges = _p(self.w_last, _pf64)
+        s.w_last_edges = self.w_last.ctypes.data
         for name in ("start_layer", "start_node", "flags", "last_action", "const_closest", "veh_off", "pos_off",
-                     "zone_off", "zone_gid", "n_last", "last_layer", "last_node"):
-            setattr(s, name, _p(getattr(self, name), _pi32))
-        for name in ("psi_s", "veh_radius", "pos_x", "pos_y"):
-            setattr(s, name, _p(getattr(self, name), _pf64))
+                     "zone_off", "zone_gid", "n_last", "last_layer", "last_node", "psi_s", "veh_radius", "pos_x", "pos_y"):
+            setattr(s, name, getattr(self, name).ctypes.data)
 
 
 class PathsResult(object):
@@ -384,9 +387,9 @@ class TickVelBatch(object):
         s.params = C.pointer(params.struct)
         s.gg_ax, s.gg_ay, s.gg_brake_scale = float(gg[0]), float(gg[1]), float(gg_brake_scale)
         s.safety_d, s.v_max_offset = float(safety_d), float(v_max_offset)
-        s.vel_plan, s.vel_est = _p(self.vel_plan, _pf64), _p(self.vel_est, _pf64)
-        s.pos_est_x, s.pos_est_y = _p(self.pos_x, _pf64), _p(self.pos_y, _pf64)
-        s.veh_vel = _p(self.veh_vel, _pf64)
+        s.vel_plan, s.vel_est = self.vel_plan.ctypes.data, self.vel_est.ctypes.data
+        s.pos_est_x, s.pos_est_y = self.pos_x.ctypes.data, self.pos_y.ctypes.data
+        s.veh_vel = self.veh_vel.ctypes.data
 
 
 class TickVelResult(object):

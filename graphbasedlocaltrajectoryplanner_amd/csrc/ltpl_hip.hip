@@ -75,7 +75,7 @@ struct DevPathsOut {
     int* end_layer; int* closest_obj_index; int* closest_obj_node; int* n_actions;
     int* action_id; int* valid; int* reduced; int* goal_layer; int* n_nodes; int* n_pts; int* n_ties;
     int* nodes; int* node_idx; double* coeff; double* path_param;
-    double* vkap; double* vlen;      // optional tiled planes (|kappa|, element length) for the batch velocity stage
+    float2* vke;                     // optional tiled plane (|kappa|, element length) as fp32 pairs for the batch velocity stage
     // job compaction of the batch velocity stage (all nullptr outside the pipeline): every valid path takes a job index
     // from a counter of its class (0 = generic forward-backward profile, 1 = follow); its planes are tiled by JOB, so
     // the lanes of a velocity wave (64 consecutive jobs of one class) are all busy and equally long
@@ -534,7 +534,7 @@ struct FollowIn { double v_start, v_ego, v_obj, safety_d, obj_dist, obj_x, obj_y
 template <int EM, bool AXM1, bool GGARR>
 __device__ __forceinline__ void follow_profile(const DevLat& lat, int n, int n_el, const VelScratch& vs, double cax, double cay,
                                const DevVelParams& p, const FollowIn& fi, int lane, int* too_close, int* vel_bound,
-                               bool ext_sync = false)
+                               bool ext_sync = false, bool skip_free = false)
 {
     int vb = 1;
     const double control_d = p.c_p * fi.safety_d + p.len_veh;                            // :141
@@ -656,6 +656,12 @@ __device__ __forceinline__ void follow_profile(const DevLat& lat, int n, int n_e
         wave_sync_lds();
     }
     // complete profile (:297-307) and intersection (:310)
+    if (skip_free) {                                           // LTPL_VEL_FOLLOW_CONTROLLED: the caller intersects (:297-310)
+        for (int i = lane; i < n; i += 64) vs.w[i] = vs.wc[i];
+        wave_sync_lds();
+        *too_close = tc; *vel_bound = vb;
+        return;
+    }
     if (ext_sync) __syncthreads();                             // the helper wave has written vs.w
     else fb_profile<EM, AXM1, GGARR>(n, vs, cax, cay, p, v_max, fi.v_start, false, 0.0, lane);
     for (int i = lane; i < n; i += 64) { const double a = vs.wc[i], b = vs.w[i]; vs.w[i] = a < b ? a : b; }
@@ -728,7 +734,8 @@ __global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p, 
     } else {
         FollowIn fi; fi.v_start = jb.v_start; fi.v_ego = jb.v_ego; fi.v_obj = jb.v_obj; fi.safety_d = jb.safety_d;
         fi.obj_dist = jb.obj_dist; fi.obj_x = jb.obj_x; fi.obj_y = jb.obj_y;
-        follow_profile<EM, AXM1, true>(lat, n, jb.n_el, vs, 1.0, 1.0, p, fi, lane, &too_close, &vel_bound);
+        follow_profile<EM, AXM1, true>(lat, n, jb.n_el, vs, 1.0, 1.0, p, fi, lane, &too_close, &vel_bound, false,
+                                       jb.mode == LTPL_VEL_FOLLOW_CONTROLLED);
     }
     dbg_stamp(dbg, 2);
     for (int i = lane; i < n; i += 64) out_pool[jb.off_out + i] = sqrt(vs.w[i]);
@@ -888,7 +895,8 @@ struct DevVelPrep {             // per-slot scalars produced by k_follow_prep (f
 };
 
 struct VelPlanes {              // tiled planes (doubles), tile index = job index: generic jobs [0, n_slots_pad), follow jobs behind
-    double* K; double* E;       // |kappa|, element length          (written by the path kernel)   n_slots_pad + n_scen_pad tiles
+    float2* KE;                 // (|kappa|, element length) as an fp32 pair: ONE 8-byte load per row and lane (the operands only enter
+                                // results with a 1e-5 tolerance; the profile state itself stays fp64)   n_slots_pad + n_scen_pad tiles
     double* P0;                 // type 0 result: follow -> "vx_profile" (:289/:294), else the generic profile     (same size)
     double* P1;                 // type 1 result: unconstrained profile of a follow job                n_scen_pad tiles
     double* P2;                 // ego brake profile (follow)                                           n_scen_pad tiles
@@ -902,7 +910,7 @@ struct VelPlanes {              // tiled planes (doubles), tile index = job inde
 __device__ __forceinline__ size_t tile_base(int idx, int cap_pts) { return ((size_t)(idx >> 6) * cap_pts) * 64 + (idx & 63); }
 
 struct LaneProf {
-    const double* K; const double* E;     // tile-strided: element i at [i * 64]
+    const float2* KE;                     // tile-strided: element i at [i * 64]
 };
 
 // a / b with the hardware reciprocal and two Newton steps (~1 ulp; the velocity stage is checked to 1e-5 relative). b = 0
@@ -916,6 +924,8 @@ __device__ __forceinline__ double fast_div(double a, double b)
 }
 
 #define LCH 8      // rows per register chunk: all loads of a chunk are issued before the chunk's recurrence steps
+#define LCHF 16    // forward sweep of lane_fb_profile: one 8-byte (|kappa|, el) load per row -> 16 rows per chunk in 32 registers
+#define LCHB 12    // backward sweep: (|kappa|, el) + the fp64 profile state per row
 
 // tph.calc_vel_profile(closed=False) for one lane: rows [off, off + n) of the path, result into plane D (as v^2).
 // Rows are processed in register chunks of LCH; the rows of the NEXT chunk are requested before the current chunk's recurrence
@@ -934,9 +944,9 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
     if (has_v_end && v_end < 0.0) v_end = 0.0;
     const double vmax2 = v_max * v_max, icay = 1.0 / cay, axm1 = axm_tab[1], dm = p.drag_m, axa = fabs(cax);
     const double vend2 = has_v_end ? v_end * v_end : INFINITY;
-    const double* Kp = L.K + (size_t)off * 64; const double* Ep = L.E + (size_t)off * 64;
+    const float2* KEp = L.KE + (size_t)off * 64;
     double* Dp = D + (size_t)off * 64;
-    double kabs_i = Kp[0], e_i = Ep[0];
+    double kabs_i = (double)KEp[0].x, e_i = (double)KEp[0].y;
     double wi = fast_div(cay, kabs_i);
     if (!(wi < vmax2)) wi = vmax2;
     if (wi > v_start * v_start) wi = v_start * v_start;
@@ -946,20 +956,21 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
     {
         double orig_i = wi;
         bool active = false, prev_acc = false;
-        double kr[LCH], er[LCH], kn[LCH], en[LCH];
+        float2 kr[LCHF], kn[LCHF];
 #pragma unroll
-        for (int c = 0; c < LCH; ++c) { const int r = 1 + c < n ? 1 + c : n - 1; kr[c] = Kp[(size_t)r * 64]; er[c] = Ep[(size_t)r * 64]; }
-        for (int base = 0; base < n - 1; base += LCH) {
+        for (int c = 0; c < LCHF; ++c) { const int r = 1 + c < n ? 1 + c : n - 1; kr[c] = KEp[(size_t)r * 64]; }
+        for (int base = 0; base < n - 1; base += LCHF) {
 #pragma unroll
-            for (int c = 0; c < LCH; ++c) {                    // operands of the next chunk (clamped rows: harmless re-reads at the end)
-                const int r = base + LCH + 1 + c < n ? base + LCH + 1 + c : n - 1;
-                kn[c] = Kp[(size_t)r * 64]; en[c] = Ep[(size_t)r * 64];
+            for (int c = 0; c < LCHF; ++c) {                   // operands of the next chunk (clamped rows: harmless re-reads at the end)
+                const int r = base + LCHF + 1 + c < n ? base + LCHF + 1 + c : n - 1;
+                kn[c] = KEp[(size_t)r * 64];
             }
 #pragma unroll
-            for (int c = 0; c < LCH; ++c) {
+            for (int c = 0; c < LCHF; ++c) {
                 const int i = base + c;
                 const bool valid = i < n - 1;
-                double w0n = fast_div(cay, kr[c]);
+                const double k_c = (double)kr[c].x, e_c = (double)kr[c].y;
+                double w0n = fast_div(cay, k_c);
                 w0n = (w0n < vmax2) ? w0n : vmax2;
                 const bool acc = w0n - orig_i > 0.0;
                 const bool act = active || (acc && !prev_acc);
@@ -978,37 +989,37 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
                 wnext = (i + 1 == n - 1 && wnext > vend2) ? vend2 : wnext;
                 if (valid) Dp[(size_t)(i + 1) * 64] = wnext;
                 active = valid ? act_out : active; prev_acc = valid ? acc : prev_acc;
-                orig_i = valid ? w0n : orig_i; wi = valid ? wnext : wi; kabs_i = valid ? kr[c] : kabs_i; e_i = valid ? er[c] : e_i;
+                orig_i = valid ? w0n : orig_i; wi = valid ? wnext : wi; kabs_i = valid ? k_c : kabs_i; e_i = valid ? e_c : e_i;
             }
 #pragma unroll
-            for (int c = 0; c < LCH; ++c) { kr[c] = kn[c]; er[c] = en[c]; }
+            for (int c = 0; c < LCHF; ++c) kr[c] = kn[c];
         }
     }
     // ---- backward sweep (decel_backw), mirrored indices; with a constant gg the unmirrored-gg quirk is void --------------
     {
         double orig_i = wi;
         bool active = false, prev_acc = false;
-        double kr[LCH], er[LCH], wr[LCH], kn[LCH], en[LCH], wq[LCH];
+        float2 kr[LCHB], kn[LCHB]; double wr[LCHB], wq[LCHB];
 #pragma unroll
-        for (int c = 0; c < LCH; ++c) {
+        for (int c = 0; c < LCHB; ++c) {
             const int r = n - 2 - c >= 0 ? n - 2 - c : 0;
-            kr[c] = Kp[(size_t)r * 64]; er[c] = Ep[(size_t)r * 64]; wr[c] = Dp[(size_t)r * 64];
+            kr[c] = KEp[(size_t)r * 64]; wr[c] = Dp[(size_t)r * 64];
         }
-        for (int base = 0; base < n - 1; base += LCH) {
+        for (int base = 0; base < n - 1; base += LCHB) {
             // rows of the next chunk are not written by this chunk's steps (a step only rewrites its own row n - 2 - i)
 #pragma unroll
-            for (int c = 0; c < LCH; ++c) {
-                const int r = n - 2 - base - LCH - c >= 0 ? n - 2 - base - LCH - c : 0;
-                kn[c] = Kp[(size_t)r * 64]; en[c] = Ep[(size_t)r * 64]; wq[c] = Dp[(size_t)r * 64];
+            for (int c = 0; c < LCHB; ++c) {
+                const int r = n - 2 - base - LCHB - c >= 0 ? n - 2 - base - LCHB - c : 0;
+                kn[c] = KEp[(size_t)r * 64]; wq[c] = Dp[(size_t)r * 64];
             }
 #pragma unroll
-            for (int c = 0; c < LCH; ++c) {
+            for (int c = 0; c < LCHB; ++c) {
                 const int i = base + c;
                 const bool valid = i < n - 1;
-                const double wold = wr[c], e_b = er[c];
+                const double wold = wr[c], e_b = (double)kr[c].y, k_c = (double)kr[c].x;
                 const bool acc = wold - orig_i > 0.0;
                 const bool act = active || (acc && !prev_acc);
-                const double kq_i = kabs_i * icay, kq_n = kr[c] * icay;
+                const double kq_i = kabs_i * icay, kq_n = k_c * icay;
                 double wn;
                 if constexpr (EM == 1 && AXM1) {
                     const double te = 2.0 * e_b;
@@ -1028,10 +1039,10 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
                 if (valid && take) Dp[(size_t)(n - 2 - i) * 64] = wn;
                 const bool act_out = act && !(wn > vmax2);
                 active = valid ? act_out : active; prev_acc = valid ? acc : prev_acc;
-                orig_i = valid ? wold : orig_i; wi = valid ? wnext : wi; kabs_i = valid ? kr[c] : kabs_i;
+                orig_i = valid ? wold : orig_i; wi = valid ? wnext : wi; kabs_i = valid ? k_c : kabs_i;
             }
 #pragma unroll
-            for (int c = 0; c < LCH; ++c) { kr[c] = kn[c]; er[c] = en[c]; wr[c] = wq[c]; }
+            for (int c = 0; c < LCHB; ++c) { kr[c] = kn[c]; wr[c] = wq[c]; }
         }
     }
 }
@@ -1056,9 +1067,9 @@ __device__ int lane_generic_profile(const DevLat& lat, const DevPathsOut& out, c
     if (reduced) {
         v_end = 0.0;
         double spl_len = 0.0;
-        for (int i = 0; i < n - 1; ++i) spl_len += L.E[(size_t)i * 64];
+        for (int i = 0; i < n - 1; ++i) spl_len += (double)L.KE[(size_t)i * 64].y;
         int first = -1; double c = 0.0;
-        for (int i = 0; i < n - 1; ++i) { c += L.E[(size_t)i * 64]; if (first < 0 && !(c < (spl_len - 5.0))) first = i; }
+        for (int i = 0; i < n - 1; ++i) { c += (double)L.KE[(size_t)i * 64].y; if (first < 0 && !(c < (spl_len - 5.0))) first = i; }
         v_idx = (first < 0 ? 0 : first) + 1;
         if (v_idx == 1 && n > 1) v_idx = n;
     } else {
@@ -1097,7 +1108,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
         const int j = (b - nbG - nbF) * 64 + lane;
         if (j >= cntF) return;
         const int slot = out.job_slot[fbase + j];
-        LaneProf L; L.K = vp.K + tile_base(fbase + j, vp.cap_pts); L.E = vp.E + tile_base(fbase + j, vp.cap_pts);
+        LaneProf L; L.KE = vp.KE + tile_base(fbase + j, vp.cap_pts);
         lane_fb_profile<EM, AXM1>(L, vp.P1 + tile_base(j, vp.cap_pts), 0, out.n_pts[slot], cax, cay, p, axm_tab, p.v_max,
                                   vin.vel_plan[slot / LTPL_MAX_ACTIONS], false, 0.0);
         vl_stamp(dbg, drow, 6);
@@ -1110,7 +1121,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
     const int slot = out.job_slot[tile];
     const int s = slot / LTPL_MAX_ACTIONS;
     const int n = out.n_pts[slot];
-    LaneProf L; L.K = vp.K + tile_base(tile, vp.cap_pts); L.E = vp.E + tile_base(tile, vp.cap_pts);
+    LaneProf L; L.KE = vp.KE + tile_base(tile, vp.cap_pts);
     double* P0 = vp.P0 + tile_base(tile, vp.cap_pts);
     double* P2 = vp.P2 + tile_base(fjob ? j : 0, vp.cap_pts);
     double* P3 = vp.P3 + tile_base(fjob ? j : 0, vp.cap_pts);
@@ -1177,7 +1188,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
 #pragma unroll
                 for (int c = 0; c < LCH; ++c) {
                     const int r = base + c < n ? base + c : n - 1;
-                    k[c] = L.K[(size_t)r * 64]; e[c] = L.E[(size_t)r * 64];
+                    const float2 ke = L.KE[(size_t)r * 64]; k[c] = (double)ke.x; e[c] = (double)ke.y;
                 }
             };
             load_rows(0, kr, er);
@@ -1308,7 +1319,7 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
     const double* P1 = vp.P1 + tile_base(fjob ? j : 0, vp.cap_pts);
     const double* P2 = vp.P2 + tile_base(fjob ? j : 0, vp.cap_pts);
     const double* P3 = vp.P3 + tile_base(fjob ? j : 0, vp.cap_pts);
-    const double* E = vp.E + tile_base(tile, vp.cap_pts);
+    const float2* KE = vp.KE + tile_base(tile, vp.cap_pts);
     const bool compose = follow && (flags & VF_COMPOSE);
     const int nd = compose ? vp.fseg[2 * j] : 0, stop_idx = compose ? vp.fseg[2 * j + 1] : 0;
     int vel_bound = follow ? ((flags & VF_BOUND_FOLLOW) ? 1 : 0) : ((flags & VF_BOUND_GENERIC) ? 1 : 0);
@@ -1335,7 +1346,7 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
 #pragma unroll
     for (int c = 0; c <= FCH; ++c) w[c] = value(base + c < n ? base + c : n - 1);
 #pragma unroll
-    for (int c = 0; c < FCH; ++c) er[c] = E[(size_t)(base + c < n ? base + c : n - 1) * 64];
+    for (int c = 0; c < FCH; ++c) er[c] = (double)KE[(size_t)(base + c < n ? base + c : n - 1) * 64].y;
 #pragma unroll
     for (int c = 0; c < FCH; ++c) {
         const int i = base + c;
@@ -1550,6 +1561,7 @@ struct ltpl_handle {
     // host copy of the per-layer / per-node tables for the planner state machine (planner_core.hpp); empty when the
     // descriptor came without raceline / node_psi columns
     ltplp::HostLat hostlat; bool has_hostlat = false;
+    int zc_out = 0;                  // small calls: kernels write their outputs straight into the page-locked host buffer (no D2H copy)
     std::vector<int> rng_end_host;   // planning range end per start layer, -1 = no planning range (end of an open track)
 };
 
@@ -1942,6 +1954,8 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
         else if (kmax <= PlanB::c_kpad && hmax + 1 <= PlanB::c_hmax && d->num_layers >= PlanB::c_hmax) { h->plan_class = 2; make_fixed_plan(PlanB(), &h->lp1); }
     }
     if (const char* e = getenv("LTPL_BATCH_NW")) h->batch_nw = atoi(e) == 4 ? 4 : 1;
+    h->zc_out = 1;
+    if (const char* e = getenv("LTPL_ZC_OUT")) h->zc_out = atoi(e);
     if (const char* e = getenv("LTPL_NW1_MIN_SCEN")) h->nw1_min_scen = atoi(e) > 0 ? atoi(e) : PIPELINE_MIN_SCEN;
     if (getenv("LTPL_DEBUG_TIMING")) {
         if (hipMalloc(reinterpret_cast<void**>(&h->d_dbg), sizeof(long long) * 256 * DBG_SLOTS) == hipSuccess) {
@@ -2133,7 +2147,7 @@ static void bind_out(unsigned char* db, const OutLayout& lo, int cap_nodes, int 
     d->n_ties = reinterpret_cast<int*>(db + lo.n_ties); d->nodes = reinterpret_cast<int*>(db + lo.nodes);
     d->node_idx = reinterpret_cast<int*>(db + lo.node_idx); d->coeff = reinterpret_cast<double*>(db + lo.coeff);
     d->path_param = reinterpret_cast<double*>(db + lo.path_param);
-    d->vkap = nullptr; d->vlen = nullptr; d->job_cnt = nullptr; d->job_slot = nullptr; d->n_slots_pad = 0;
+    d->vke = nullptr; d->job_cnt = nullptr; d->job_slot = nullptr; d->n_slots_pad = 0;
 }
 
 static void scatter_out(const unsigned char* hb, const OutLayout& lo, int n, ltpl_paths_out* out)
@@ -2199,12 +2213,15 @@ static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_o
     if ((rc = ensure(h, &h->h_out, &h->h_out_cap, &h->d_out, &h->d_out_cap, lo.total))) return rc;
     DevPathsIn di; DevPathsOut dout;
     pack_in(in, li, static_cast<unsigned char*>(h->h_in), static_cast<const unsigned char*>(h->d_in), &di);
-    bind_out(static_cast<unsigned char*>(h->d_out), lo, out->cap_nodes, out->cap_pts, &dout);
+    // small calls (latency path): the output slab is the page-locked host buffer itself (device-accessible under unified
+    // addressing): the kernel's stores cross PCIe as posted writes, no D2H copy is enqueued
+    const bool zc = h->zc_out && in->n_scen <= 8;
+    bind_out(static_cast<unsigned char*>(zc ? h->h_out : h->d_out), lo, out->cap_nodes, out->cap_pts, &dout);
     HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, li.total, hipMemcpyHostToDevice, h->stream));
     scratch_poison(h);
     const int nw = force_nw ? force_nw : ((in->n_scen >= h->nw1_min_scen && h->batch_nw == 1) ? 1 : NUM_WAVES);
     if ((rc = launch_paths(h, nw, in->n_scen, h->stream, di, dout))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, lo.total, hipMemcpyDeviceToHost, h->stream));
+    if (!zc) HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, lo.total, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     dbg_report(h, "k_paths", in->n_scen);
     scatter_out(static_cast<const unsigned char*>(h->h_out), lo, in->n_scen, out);
@@ -2314,7 +2331,7 @@ extern "C" int ltpl_vel_profile(ltpl_handle* h, const ltpl_vel_params* vp, int n
     for (int j = 0; j < n_jobs; ++j) {
         const ltpl_vel_job& jb = jobs[j];
         if (jb.n < 1 || !jb.kappa || !jb.loc_gg || !results[j].vx) { h->err = "job without data"; return LTPL_ERR_INVALID_ARG; }
-        if (jb.mode == LTPL_VEL_FOLLOW) { if (jb.n_el < jb.n) { h->err = "follow: el_lengths shorter than kappa"; return LTPL_ERR_INVALID_ARG; } }
+        if (jb.mode == LTPL_VEL_FOLLOW || jb.mode == LTPL_VEL_FOLLOW_CONTROLLED) { if (jb.n_el < jb.n) { h->err = "follow: el_lengths shorter than kappa"; return LTPL_ERR_INVALID_ARG; } }
         else if (jb.mode == LTPL_VEL_FB || jb.mode == LTPL_VEL_BRAKE) {
             if (jb.n_el != jb.n - 1) { h->err = "kappa must have the length of el_lengths + 1"; return LTPL_ERR_INVALID_ARG; }
         } else { h->err = "unknown velocity mode"; return LTPL_ERR_INVALID_ARG; }
@@ -2354,12 +2371,13 @@ extern "C" int ltpl_vel_profile(ltpl_handle* h, const ltpl_vel_params* vp, int n
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, ain.size, hipMemcpyHostToDevice, h->stream));
-    unsigned char* dob = static_cast<unsigned char*>(h->d_out);
+    const bool zc = h->zc_out && n_jobs <= 16;
+    unsigned char* dob = static_cast<unsigned char*>(zc ? h->h_out : h->d_out);
     hipLaunchKernelGGL(kern, dim3(n_jobs), dim3(64), lds, h->stream, h->lat, p,
                        reinterpret_cast<const DevVelJob*>(db + o_jobs), reinterpret_cast<const double*>(db + o_pool),
                        reinterpret_cast<double*>(dob + o_vx), reinterpret_cast<int*>(dob + o_flags), cap, h->lp4.dbg);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, aout.size, hipMemcpyDeviceToHost, h->stream));
+    if (!zc) HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, aout.size, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     dbg_report(h, "k_vel_profile", n_jobs);
     const unsigned char* ho = static_cast<const unsigned char*>(h->h_out);
@@ -2452,13 +2470,13 @@ static void tick_bind_outputs(TickLayout* t, unsigned char* dob, double* planes)
     if (t->pipeline && planes) {
         const size_t tiles = (size_t)t->n_slots_pad + (size_t)t->n_scen_pad;
         const size_t per_all = (size_t)t->cap_pts * tiles, per_scen = (size_t)t->cap_pts * (size_t)t->n_scen_pad;
-        t->vp.K = planes; t->vp.E = planes + per_all; t->vp.P0 = planes + 2 * per_all;
+        t->vp.KE = reinterpret_cast<float2*>(planes); t->vp.P0 = planes + 2 * per_all;       // (the second plane-sized region is unused)
         t->vp.P1 = planes + 3 * per_all; t->vp.P2 = t->vp.P1 + per_scen; t->vp.P3 = t->vp.P2 + per_scen;
         int* ints = reinterpret_cast<int*>(t->vp.P3 + per_scen);
         t->vp.flags = ints; t->dout.job_slot = ints + tiles; t->dout.job_cnt = ints + 2 * tiles; t->vp.fseg = ints + 2 * tiles + 16;
         t->dout.n_slots_pad = t->n_slots_pad;
         t->vp.cap_pts = t->cap_pts;
-        t->dout.vkap = t->vp.K; t->dout.vlen = t->vp.E;
+        t->dout.vke = t->vp.KE;
     }
 }
 

@@ -570,9 +570,9 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
         const double len_r = at(lat.slen, pedge[i] + k);
         store2_u(row, x, y); store2_u(row + 2, psi_r, kap); row[4] = len_r;
         if (vel_kappa) { vel_kappa[r] = kap; vel_len[r] = len_r; }
-        if (out.vkap) {                                    // tiled planes of the batch velocity stage
+        if (out.vke) {                                    // tiled planes of the batch velocity stage
             const size_t o = (((size_t)(vtile >> 6) * out.cap_pts) + r) * 64 + (vtile & 63);
-            out.vkap[o] = fabs(kap); out.vlen[o] = len_r;
+            out.vke[o] = make_float2((float)fabs(kap), (float)len_r);
         }
         if (vel_x) { vel_x[r] = x; vel_y[r] = y; }
     }

@@ -653,7 +653,7 @@ struct Planner {
         int cut_index_layer = 0;
         int n = 0, vel_idx = 0, pref_idx = 0, v_idx = 0;
         double vel_start = 0.0;
-        int job_follow = -1, job_fb = -1, job_backup = -1;
+        int job_follow = -1, job_free = -1, job_fb = -1, job_backup = -1;
         bool generic = false, has_fb = false;
         int too_close = 0, vel_bound = 1;
         std::vector<double> bp;         // result rows of 7
@@ -782,10 +782,13 @@ struct Planner {
                         const double s_sta = project_on_polyline(pl, S.pos_est[0], S.pos_est[1], false, true, s_at, m).s;
                         obj_dist = s_obj - s_sta;
                     }
-                    const int j = make_job(LTPL_VEL_FOLLOW, pref, m, m - pref, W.vel_start, false, 0.0);
+                    // the two halves of the follow mode are independent (calc_vel_profile_follow.py:151-294 vs :297-307): two
+                    // jobs = two waves in parallel on the device, intersected in stage B (:310)
+                    const int j = make_job(LTPL_VEL_FOLLOW_CONTROLLED, pref, m, m - pref, W.vel_start, false, 0.0);
                     jobs[(size_t)j].v_ego = R.vel_est; jobs[(size_t)j].v_obj = v_obj; jobs[(size_t)j].safety_d = R.safety_d;
                     jobs[(size_t)j].obj_dist = obj_dist; jobs[(size_t)j].obj_x = ox; jobs[(size_t)j].obj_y = oy;
                     W.job_follow = j;
+                    W.job_free = make_job(LTPL_VEL_FB, pref, m, m - pref - 1, W.vel_start, false, 0.0);
                 }
                 if (T.id != LTPL_ACT_FOLLOW || T.red_len) {                                // :834-903
                     W.generic = true;
@@ -830,7 +833,14 @@ struct Planner {
                     const ltpl_vel_result& r = res[(size_t)W.job_follow];
                     W.too_close = r.too_close; W.vel_bound = r.vel_bound;
                     vx_follow = S.vel_course;
-                    vx_follow.insert(vx_follow.end(), bufs[(size_t)W.job_follow].out.begin(), bufs[(size_t)W.job_follow].out.end());
+                    {
+                        std::vector<double> f = bufs[(size_t)W.job_follow].out;
+                        if (W.job_free >= 0) {
+                            const std::vector<double>& u = bufs[(size_t)W.job_free].out;          // np.minimum(vx_profile, vx_compl) (:310)
+                            for (size_t i = 0; i < f.size() && i < u.size(); ++i) f[i] = f[i] < u[i] ? f[i] : u[i];
+                        }
+                        vx_follow.insert(vx_follow.end(), f.begin(), f.end());
+                    }
                     if ((int)vx_follow.size() > m) vx_follow.resize((size_t)m);
                     if ((int)vx_follow.size() != m) return fail(LTPL_ERR_INVALID_ARG, "planner: follow profile shorter than the path (the reference raises at OTH.py:830)");
                     have_bp = true;

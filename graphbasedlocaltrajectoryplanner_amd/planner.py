@@ -30,17 +30,22 @@ class PlannerConfig(C.Structure):
                 ("c_p", C.c_double), ("k_p", C.c_double), ("k_d", C.c_double), ("tan_w", C.c_double)]
 
 
+# Per-tick input structs: the pointer members are declared as plain addresses (c_void_p) and filled with ndarray.ctypes.data --
+# building a typed ctypes pointer per array (ndarray.ctypes.data_as) costs ~4 us each, i.e. more than the C call's own host work.
+_vp = C.c_void_p
+
+
 class PlannerPathsIn(C.Structure):
-    _fields_ = [("prev_action", _pi32), ("t_now", _pf64), ("veh_off", _pi32), ("pos_off", _pi32),
-                ("veh_radius", _pf64), ("veh_vel", _pf64), ("pos_x", _pf64), ("pos_y", _pf64),
-                ("zone_off", _pi32), ("zone_gid", _pi32)]
+    _fields_ = [("prev_action", _vp), ("t_now", _vp), ("veh_off", _vp), ("pos_off", _vp),
+                ("veh_radius", _vp), ("veh_vel", _vp), ("pos_x", _vp), ("pos_y", _vp),
+                ("zone_off", _vp), ("zone_gid", _vp)]
 
 
 class PlannerVelIn(C.Structure):
-    _fields_ = [("pos_est_x", _pf64), ("pos_est_y", _pf64), ("vel_est", _pf64), ("vel_max", _pf64),
-                ("gg_scale", _pf64), ("gg_ax", _pf64), ("gg_ay", _pf64), ("safety_d", _pf64),
-                ("incl_emerg_traj", _pi32), ("n_ax_max_machines", C.c_int32), ("reserved0", C.c_int32),
-                ("ax_max_machines", _pf64)]
+    _fields_ = [("pos_est_x", _vp), ("pos_est_y", _vp), ("vel_est", _vp), ("vel_max", _vp),
+                ("gg_scale", _vp), ("gg_ax", _vp), ("gg_ay", _vp), ("safety_d", _vp),
+                ("incl_emerg_traj", _vp), ("n_ax_max_machines", C.c_int32), ("reserved0", C.c_int32),
+                ("ax_max_machines", _vp)]
 
 
 class PlannerCaps(C.Structure):
@@ -131,8 +136,8 @@ class Planner(object):
                                    _pi32, _pi32]
         f("calc_paths").argtypes = [C.c_void_p, C.POINTER(PlannerPathsIn)]
         f("calc_paths_begin").argtypes = [C.c_void_p, C.POINTER(PlannerPathsIn)]
-        f("calc_paths_finish").argtypes = [C.c_void_p, _pi32, _pi32]
-        f("get_ref_idx").argtypes = [C.c_void_p, _pf64, _pf64]
+        f("calc_paths_finish").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        f("get_ref_idx").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         f("calc_vel_profile").argtypes = [C.c_void_p, C.POINTER(PlannerVelIn)]
         f("get_paths").argtypes = [C.c_void_p, C.c_int32, C.POINTER(PathsView)]
         f("get_trajectories").argtypes = [C.c_void_p, C.c_int32, C.POINTER(TrajView)]
@@ -162,35 +167,37 @@ class Planner(object):
 
     # ---- Graph_LTPL.calc_paths --------------------------------------------------------------------------------------------
     def _pack_paths_in(self, prev_actions, t_now, vehicles, zone_gids):
+        # plain lists + one array conversion per column: for the handful of objects of a tick this is several times faster than
+        # per-vehicle NumPy operations (small-array overhead dominates)
         n = self.n_scen
-        act = _i32([KEY_IDS.get(a, _capi.ACT_NONE) if isinstance(a, str) else _capi.ACT_NONE for a in prev_actions])
-        t = _f64(np.broadcast_to(np.asarray(t_now, dtype=np.float64), (n,)))
-        veh_off, pos_off, rad, vel, px, py = [0], [0], [], [], [], []
+        act = np.array([KEY_IDS.get(a, _capi.ACT_NONE) if isinstance(a, str) else _capi.ACT_NONE for a in prev_actions], np.int32)
+        t = np.array(t_now, np.float64).reshape(-1) if np.ndim(t_now) else np.full(n, float(t_now))
+        rad, vel, px, py, pos_off, veh_off = [], [], [], [], [0], [0]
         for s in range(n):
-            for radius_k, vel_k, positions in vehicles[s]:
-                positions = np.asarray(positions, dtype=np.float64).reshape(-1, 2)
-                rad.append(float(radius_k))
-                vel.append(float(vel_k))
-                px.extend(positions[:, 0].tolist())
-                py.extend(positions[:, 1].tolist())
+            for r, v, pos in vehicles[s]:
+                rad.append(r)
+                vel.append(v)
+                for x, y in (pos.tolist() if isinstance(pos, np.ndarray) else pos):
+                    px.append(x)
+                    py.append(y)
                 pos_off.append(len(px))
             veh_off.append(len(rad))
         zone_off, zone = self._pack_zones(zone_gids)
-        keep = [act, t, _i32(veh_off), _i32(pos_off), _f64(rad if rad else [0.0]), _f64(vel if vel else [0.0]),
-                _f64(px if px else [0.0]), _f64(py if py else [0.0]), zone_off, zone]
+        keep = [act, t, np.array(veh_off, np.int32), np.array(pos_off, np.int32), np.array(rad or [0.0], np.float64),
+                np.array(vel or [0.0], np.float64), np.array(px or [0.0], np.float64), np.array(py or [0.0], np.float64), zone_off, zone]
         i = PlannerPathsIn()
-        i.prev_action, i.t_now, i.veh_off, i.pos_off = _p(keep[0], _pi32), _p(keep[1], _pf64), _p(keep[2], _pi32), _p(keep[3], _pi32)
-        i.veh_radius, i.veh_vel, i.pos_x, i.pos_y = (_p(a, _pf64) for a in keep[4:8])
-        i.zone_off, i.zone_gid = _p(keep[8], _pi32), _p(keep[9], _pi32)
+        (i.prev_action, i.t_now, i.veh_off, i.pos_off, i.veh_radius, i.veh_vel, i.pos_x, i.pos_y, i.zone_off,
+         i.zone_gid) = [a.ctypes.data for a in keep]
         return i, keep
 
     def _pack_zones(self, zone_gids):
         zone_off, zone = [0], []
         for s in range(self.n_scen):
             if zone_gids is not None:
-                zone.extend(int(g) for g in zone_gids[s])
+                z = zone_gids[s]
+                zone.extend(z.tolist() if isinstance(z, np.ndarray) else z)
             zone_off.append(len(zone))
-        return _i32(zone_off), _i32(zone if zone else [0])
+        return np.array(zone_off, np.int32), np.array(zone or [0], np.int32)
 
     def calc_paths(self, prev_actions, t_now, vehicles, zone_gids=None):
         """``prev_actions``: action name per planner; ``vehicles``: per planner a list of (radius, vel, positions (k, 2) with the
@@ -205,7 +212,7 @@ class Planner(object):
 
     def calc_paths_finish(self, zone_gids=None):
         zone_off, zone = self._pack_zones(zone_gids)
-        self._check(self._fn("calc_paths_finish")(self.handle, _p(zone_off, _pi32), _p(zone, _pi32)))
+        self._check(self._fn("calc_paths_finish")(self.handle, zone_off.ctypes.data, zone.ctypes.data))
 
     def start_node(self, scen=0):
         v = PathsView()                                    # counts only: no buffers attached
@@ -216,7 +223,7 @@ class Planner(object):
         """OnlineTrajectoryHandler.get_ref_idx (OTH.py:518-601) for all planners; returns planner ``scen``'s 5-tuple."""
         pos = np.asarray(pos_est, dtype=np.float64).reshape(self.n_scen, 2)
         px, py = _f64(pos[:, 0]), _f64(pos[:, 1])
-        self._check(self._fn("get_ref_idx")(self.handle, _p(px, _pf64), _p(py, _pf64)))
+        self._check(self._fn("get_ref_idx")(self.handle, px.ctypes.data, py.ctypes.data))
         ref = self.trajectories(scen)[2]
         return ref["cut_index_pos"], ref["cut_layer"], ref["vel_plan"], ref["vel_course"], ref["acc_plan"]
 
@@ -229,14 +236,14 @@ class Planner(object):
         pos = np.asarray(pos_est, dtype=np.float64).reshape(n, 2)
 
         def bc(v):
-            return _f64(np.broadcast_to(np.asarray(v, dtype=np.float64), (n,)))
+            return np.array([v], np.float64) if n == 1 and np.ndim(v) == 0 else _f64(np.broadcast_to(np.asarray(v, dtype=np.float64), (n,)))
         axm = _f64(np.atleast_2d(ax_max_machines))
         keep = [_f64(pos[:, 0]), _f64(pos[:, 1]), bc(vel_est), bc(vel_max), bc(gg_scale), bc(local_gg[0]), bc(local_gg[1]),
-                bc(safety_d), _i32(np.broadcast_to(np.asarray(incl_emerg_traj, dtype=np.int32), (n,))), axm]
+                bc(safety_d), np.ascontiguousarray(np.broadcast_to(np.asarray(incl_emerg_traj, dtype=np.int32), (n,))), axm]
         i = PlannerVelIn()
-        (i.pos_est_x, i.pos_est_y, i.vel_est, i.vel_max, i.gg_scale, i.gg_ax, i.gg_ay, i.safety_d) = (_p(a, _pf64) for a in keep[:8])
-        i.incl_emerg_traj = _p(keep[8], _pi32)
-        i.n_ax_max_machines, i.ax_max_machines = axm.shape[0], _p(axm, _pf64)
+        (i.pos_est_x, i.pos_est_y, i.vel_est, i.vel_max, i.gg_scale, i.gg_ax, i.gg_ay, i.safety_d, i.incl_emerg_traj) = \
+            [a.ctypes.data for a in keep[:9]]
+        i.n_ax_max_machines, i.ax_max_machines = axm.shape[0], axm.ctypes.data
         self._check(self._fn("calc_vel_profile")(self.handle, C.byref(i)))
 
     # ---- accessors ----------------------------------------------------------------------------------------------------------
@@ -253,8 +260,11 @@ class Planner(object):
             out["keys"].append(name)
             out["path_param"][name] = self._pp[k][:nr].copy()
             out["coeff"][name] = self._co[k][:max(nn - 1, 0)].copy()
-            out["nodes"][name] = [[None if a < 0 else int(a), None if b < 0 else int(b)] for a, b in self._nd[k][:nn]]
-            out["node_idx"][name] = [int(i) for i in self._ni[k][:nn]]
+            nodes = self._nd[k][:nn].tolist()
+            if nn and nodes[0][0] < 0:                          # the start spline's pseudo node [None, None] (OTH.py:267)
+                nodes = [[None if a < 0 else a, None if b < 0 else b] for a, b in nodes]
+            out["nodes"][name] = nodes
+            out["node_idx"][name] = self._ni[k][:nn].tolist()
             out["red_len"][name] = bool(v.red_len[k])
         return out
 

@@ -182,6 +182,10 @@ typedef struct {
 #define LTPL_VEL_FB      0   /* VpForwardBackward.calc_vel_profile  :194-227 -> tph.calc_vel_profile(closed=False) */
 #define LTPL_VEL_BRAKE   1   /* tph.calc_vel_profile_brake behind check_brake_prefix :115-122, calc_vel_brake_em  */
 #define LTPL_VEL_FOLLOW  2   /* VpForwardBackward.calc_vel_profile_follow :141-192 -> calc_vel_profile_follow.py  */
+#define LTPL_VEL_FOLLOW_CONTROLLED 3   /* the same without the final intersection with the unconstrained profile
+                                          (calc_vel_profile_follow.py:78-294 only): a caller that wants the two independent halves of
+                                          the follow mode in parallel submits this job + an LTPL_VEL_FB job without v_end and takes
+                                          the element-wise minimum (:297-310) itself                                          */
 
 typedef struct {
     double  dyn_model_exp;          /* VpForwardBackward.__init__ :22-29                                          */
