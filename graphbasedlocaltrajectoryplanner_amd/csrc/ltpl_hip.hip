@@ -924,8 +924,15 @@ __device__ __forceinline__ double fast_div(double a, double b)
 }
 
 #define LCH 8      // rows per register chunk: all loads of a chunk are issued before the chunk's recurrence steps
+#ifndef LCHF
 #define LCHF 16    // forward sweep of lane_fb_profile: one 8-byte (|kappa|, el) load per row -> 16 rows per chunk in 32 registers
+#endif
+#ifndef LCHA
+#define LCHA 16    // affine case, forward sweep: rows per register chunk
+#endif
+#ifndef LCHB
 #define LCHB 12    // backward sweep: (|kappa|, el) + the fp64 profile state per row
+#endif
 
 // tph.calc_vel_profile(closed=False) for one lane: rows [off, off + n) of the path, result into plane D (as v^2).
 // Rows are processed in register chunks of LCH; the rows of the NEXT chunk are requested before the current chunk's recurrence
@@ -938,7 +945,7 @@ __device__ __forceinline__ double fast_div(double a, double b)
 template <int EM, bool AXM1>
 __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, int off, int n, double cax, double cay,
                                                 const DevVelParams& p, const double* axm_tab, double v_max, double v_start,
-                                                bool has_v_end, double v_end)
+                                                bool has_v_end, double v_end, long long* dbg = nullptr, int drow = -1)
 {
     if (v_start < 0.0) v_start = 0.0;
     if (has_v_end && v_end < 0.0) v_end = 0.0;
@@ -946,14 +953,60 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
     const double vend2 = has_v_end ? v_end * v_end : INFINITY;
     const float2* KEp = L.KE + (size_t)off * 64;
     double* Dp = D + (size_t)off * 64;
-    double kabs_i = (double)KEp[0].x, e_i = (double)KEp[0].y;
-    double wi = fast_div(cay, kabs_i);
-    if (!(wi < vmax2)) wi = vmax2;
+    const float2 rec0 = KEp[0];
+    double kabs_i = (double)rec0.x, e_i = (double)rec0.y;
+    double wi = fmin(cay * (double)__builtin_amdgcn_rcpf(rec0.x), vmax2);
     if (wi > v_start * v_start) wi = v_start * v_start;
     Dp[0] = wi;
     if (n < 2) return;
     // ---- lateral-limit speed + forward sweep (accel_forw) in one pass -------------------------------------------------
-    {
+    if constexpr (EM == 1 && AXM1) {
+        // Affine case (exponent 1, one-row machine table). A velocity wave is alone on its SIMD and issues one instruction every
+        // ~13 cycles whether or not it depends on the previous one (measured: 610 cycles per row for ~50 instructions; splitting
+        // a chunk into independent coefficient work and a short dependent chain changed nothing), so the step is written for
+        // the smallest instruction COUNT:  w' = max(A0 w + te min(max(axa - g w, 0), axm), 0)  with te = 2 e, A0 = 1 - te dm,
+        // g = axa |kappa| / ay  -- algebraically the reference's min(tyre, machine) - drag step; the limit speed comes from the
+        // fp32 hardware reciprocal of |kappa| (no fp64 division), full chunks run without the `valid` selects (the partial chunk at the end has them).
+        const double axg = axa * icay;
+        double orig_p = wi, g_p = kabs_i * axg, e_p = e_i;      // operands of the row in front of the current step
+        bool active = false, prev_acc = false;
+        float2 kr[LCHA], kn[LCHA];
+        const int nst = n - 1;
+#pragma unroll
+        for (int c = 0; c < LCHA; ++c) { const int r = 1 + c < n ? 1 + c : n - 1; kr[c] = KEp[(size_t)r * 64]; }
+        auto step = [&](const float2& rec, int i, bool valid) {
+            const double w0n = fmin(cay * (double)__builtin_amdgcn_rcpf(rec.x), vmax2);    // 1 / |kappa| in fp32 (1 ulp), inf on straights
+            const bool acc = w0n > orig_p;
+            const bool act = active || (acc && !prev_acc);
+            const double te = e_p + e_p;
+            const double u = fmin(fmax(fma(-g_p, wi, axa), 0.0), axm1);
+            const double wn = fmax(fma(te, u, fma(-(te * dm), wi, wi)), 0.0);
+            const double wnext = (act && wn < w0n) ? wn : w0n;
+            if (valid) {
+                Dp[(size_t)(i + 1) * 64] = wnext;
+                active = act && !(wn > vmax2); prev_acc = acc;
+                wi = wnext; orig_p = w0n; g_p = (double)rec.x * axg; e_p = (double)rec.y;
+            }
+        };
+        int base = 0;
+        for (; base + LCHA <= nst; base += LCHA) {
+#pragma unroll
+            for (int c = 0; c < LCHA; ++c) {                   // operands of the next chunk (clamped rows: harmless re-reads at the end)
+                const int r = base + LCHA + 1 + c < n ? base + LCHA + 1 + c : n - 1;
+                kn[c] = KEp[(size_t)r * 64];
+            }
+#pragma unroll
+            for (int c = 0; c < LCHA; ++c) step(kr[c], base + c, true);
+#pragma unroll
+            for (int c = 0; c < LCHA; ++c) kr[c] = kn[c];
+        }
+        if (base < nst) {
+#pragma unroll
+            for (int c = 0; c < LCHA; ++c) step(kr[c], base + c, base + c < nst);
+        }
+        if (wi > vend2) { wi = vend2; Dp[(size_t)(n - 1) * 64] = wi; }            // the end-velocity clamp of the last step
+        kabs_i = (double)KEp[(size_t)(n - 1) * 64].x;                             // |kappa| of the last row (start of the backward sweep)
+    } else {
         double orig_i = wi;
         bool active = false, prev_acc = false;
         float2 kr[LCHF], kn[LCHF];
@@ -963,7 +1016,11 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #pragma unroll
             for (int c = 0; c < LCHF; ++c) {                   // operands of the next chunk (clamped rows: harmless re-reads at the end)
                 const int r = base + LCHF + 1 + c < n ? base + LCHF + 1 + c : n - 1;
+#ifdef LTPL_EXP_NOLOAD
+                kn[c] = make_float2(0.01f + 1e-6f * (float)r, 2.0f);
+#else
                 kn[c] = KEp[(size_t)r * 64];
+#endif
             }
 #pragma unroll
             for (int c = 0; c < LCHF; ++c) {
@@ -987,7 +1044,9 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
                 double wnext = (act && wn < w0n) ? wn : w0n;
                 const bool act_out = act && !(wn > vmax2);
                 wnext = (i + 1 == n - 1 && wnext > vend2) ? vend2 : wnext;
+#ifndef LTPL_EXP_NOSTORE
                 if (valid) Dp[(size_t)(i + 1) * 64] = wnext;
+#endif
                 active = valid ? act_out : active; prev_acc = valid ? acc : prev_acc;
                 orig_i = valid ? w0n : orig_i; wi = valid ? wnext : wi; kabs_i = valid ? k_c : kabs_i; e_i = valid ? e_c : e_i;
             }
@@ -995,8 +1054,55 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
             for (int c = 0; c < LCHF; ++c) kr[c] = kn[c];
         }
     }
+    vl_stamp(dbg, drow, 8);
     // ---- backward sweep (decel_backw), mirrored indices; with a constant gg the unmirrored-gg quirk is void --------------
-    {
+    if constexpr (EM == 1 && AXM1) {
+        // same form: w1 = max(A0 w + te max(axa - g_i w, 0), 0), w' = min(max(te dm w1 + w + te max(axa - g_n w1, 0), 0), w1),
+        // A0 = 1 + te dm (no machine limit under braking)
+        const double axg = axa * icay;
+        double orig_p = wi, g_p = kabs_i * axg;
+        bool active = false, prev_acc = false;
+        float2 kr[LCHB], kn[LCHB]; double wr[LCHB], wq[LCHB];
+        const int nst = n - 1;
+#pragma unroll
+        for (int c = 0; c < LCHB; ++c) {
+            const int r = n - 2 - c >= 0 ? n - 2 - c : 0;
+            kr[c] = KEp[(size_t)r * 64]; wr[c] = Dp[(size_t)r * 64];
+        }
+        auto step = [&](const float2& rec, double wold, int i, bool valid) {
+            const bool acc = wold > orig_p;
+            const bool act = active || (acc && !prev_acc);
+            const double te = 2.0 * (double)rec.y, tdm = te * dm, g_n = (double)rec.x * axg;
+            const double w1 = fmax(fma(te, fmax(fma(-g_p, wi, axa), 0.0), fma(tdm, wi, wi)), 0.0);
+            const double wn = fmin(fmax(fma(te, fmax(fma(-g_n, w1, axa), 0.0), fma(tdm, w1, wi)), 0.0), w1);
+            const bool take = act && wn < wold;
+            const double wnext = take ? wn : wold;
+            if (valid) {
+                // only rows the sweep lowers are rewritten: an unconditional store per row made the sweep 1.5x slower (gfx9 counts
+                // loads and stores in ONE in-order vmcnt, so every wait for prefetched rows also waits for the older stores)
+                if (take) Dp[(size_t)(n - 2 - i) * 64] = wn;
+                active = act && !(wn > vmax2); prev_acc = acc;
+                wi = wnext; orig_p = wold; g_p = g_n;
+            }
+        };
+        int base = 0;
+        for (; base + LCHB <= nst; base += LCHB) {
+            // rows of the next chunk are not written by this chunk's steps (a step only rewrites its own row n - 2 - i)
+#pragma unroll
+            for (int c = 0; c < LCHB; ++c) {
+                const int r = n - 2 - base - LCHB - c >= 0 ? n - 2 - base - LCHB - c : 0;
+                kn[c] = KEp[(size_t)r * 64]; wq[c] = Dp[(size_t)r * 64];
+            }
+#pragma unroll
+            for (int c = 0; c < LCHB; ++c) step(kr[c], wr[c], base + c, true);
+#pragma unroll
+            for (int c = 0; c < LCHB; ++c) { kr[c] = kn[c]; wr[c] = wq[c]; }
+        }
+        if (base < nst) {
+#pragma unroll
+            for (int c = 0; c < LCHB; ++c) step(kr[c], wr[c], base + c, base + c < nst);
+        }
+    } else {
         double orig_i = wi;
         bool active = false, prev_acc = false;
         float2 kr[LCHB], kn[LCHB]; double wr[LCHB], wq[LCHB];
@@ -1110,7 +1216,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
         const int slot = out.job_slot[fbase + j];
         LaneProf L; L.KE = vp.KE + tile_base(fbase + j, vp.cap_pts);
         lane_fb_profile<EM, AXM1>(L, vp.P1 + tile_base(j, vp.cap_pts), 0, out.n_pts[slot], cax, cay, p, axm_tab, p.v_max,
-                                  vin.vel_plan[slot / LTPL_MAX_ACTIONS], false, 0.0);
+                                  vin.vel_plan[slot / LTPL_MAX_ACTIONS], false, 0.0, dbg, drow);
         vl_stamp(dbg, drow, 6);
         return;
     }
@@ -1298,118 +1404,183 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
 // final step of the batch velocity stage, no recurrence: intersection of the two follow profiles
 // (calc_vel_profile_follow.py:310), choice between follow and generic profile for reduced horizons (OTH.py:923, row 5),
 // vx = sqrt(w), ax from neighbouring points with -5 at standstill (OTH.py:925-941). Rows are independent of each other
-// (ax_i only needs w_i, w_i+1 and the element length e_i), so the work is spread over (job, chunk of FCH rows): lane = job of
-// a tile (coalesced plane reads), blockIdx.y = row chunk; every lane writes FCH consecutive values of its slot's row.
-#define FCH 8
+// (ax_i only needs w_i, w_i+1 and the element length e_i), so the work is spread over (tile of 64 jobs, chunk of FCH rows).
+// Two lane mappings in one wave: the planes are tiled by job, so they are READ with lane = job (one coalesced 512-byte line per
+// row); the outputs are rows of a slot, so they are WRITTEN with lane = (job, pair of rows) after a transposition through LDS: one
+// store instruction covers 8 jobs x 128 contiguous bytes instead of 64 jobs x 16 bytes on 64 different lines (round 2: 122 us ->
+// see DESIGN.md section 6; the stores of the lane = job form kept the address units busy, not HBM).
+#define FCH 16
+#define FPITCH (FCH + 2)           // doubles per job row in LDS (16-byte aligned pairs, odd multiple of 16 bytes: conflict-free b128 access)
 __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn vin, DevTickVelOut vout, VelPlanes vp, int n_slots,
                                                   int n_scen)
 {
+    __shared__ __align__(16) double tbuf[32 * FPITCH];     // 32 jobs at a time: 4.5 KB, so that many blocks fit next to a resident path kernel
+    __shared__ int s_slot[64], s_n[64];
     // blocks [0, nbG): generic jobs, [nbG, nbG + nbF): follow jobs; slots without a path were initialised by the path kernel
     const int nbG = (n_slots + 63) / 64;
     const bool fjob = (int)blockIdx.x >= nbG;
-    const int j = (fjob ? blockIdx.x - nbG : blockIdx.x) * 64 + threadIdx.x;
-    if (j >= out.job_cnt[fjob ? 1 : 0]) return;
+    const int lane = threadIdx.x;
+    const int j = (fjob ? blockIdx.x - nbG : blockIdx.x) * 64 + lane;
+    const int cnt = out.job_cnt[fjob ? 1 : 0];
+    const int base = (int)blockIdx.y * FCH;
+    if ((j - lane) >= cnt) return;                                      // whole tile without jobs (uniform)
+    const bool have = j < cnt;
     const int tile = fjob ? out.n_slots_pad + j : j;
-    const int slot = out.job_slot[tile];
-    const int n = out.n_pts[slot], base = (int)blockIdx.y * FCH;
-    if (base >= n) return;
-    const int flags = vp.flags[tile];
-    const bool follow = fjob;
-    const double* P0 = vp.P0 + tile_base(tile, vp.cap_pts);
-    const double* P1 = vp.P1 + tile_base(fjob ? j : 0, vp.cap_pts);
-    const double* P2 = vp.P2 + tile_base(fjob ? j : 0, vp.cap_pts);
-    const double* P3 = vp.P3 + tile_base(fjob ? j : 0, vp.cap_pts);
-    const float2* KE = vp.KE + tile_base(tile, vp.cap_pts);
-    const bool compose = follow && (flags & VF_COMPOSE);
-    const int nd = compose ? vp.fseg[2 * j] : 0, stop_idx = compose ? vp.fseg[2 * j + 1] : 0;
-    int vel_bound = follow ? ((flags & VF_BOUND_FOLLOW) ? 1 : 0) : ((flags & VF_BOUND_GENERIC) ? 1 : 0);
-    int sel = follow ? 1 : 0;                     // 0: P0, 1: min(P0, P1), 2: P3
-    if (follow && (flags & VF_HAS_GENERIC)) {
-        vel_bound = (flags & VF_BOUND_GENERIC) ? 1 : 0;
-        sel = 2;
-        if (n >= 6) {
-            const double f5 = fmin(P0[5 * 64], P1[5 * 64]);
-            if (sqrt(f5) < sqrt(P3[5 * 64])) sel = 1;
+    const int slot = have ? out.job_slot[tile] : 0;
+    const int n = have ? out.n_pts[slot] : 0;
+    s_slot[lane] = slot; s_n[lane] = n;
+    const bool act = have && base < n;
+    if (__ballot(act) == 0ull) return;                                  // uniform
+    double vv[FCH], aa[FCH];
+    if (act) {
+        const int flags = vp.flags[tile];
+        const bool follow = fjob;
+        const double* P0 = vp.P0 + tile_base(tile, vp.cap_pts);
+        const double* P1 = vp.P1 + tile_base(fjob ? j : 0, vp.cap_pts);
+        const double* P2 = vp.P2 + tile_base(fjob ? j : 0, vp.cap_pts);
+        const double* P3 = vp.P3 + tile_base(fjob ? j : 0, vp.cap_pts);
+        const float2* KE = vp.KE + tile_base(tile, vp.cap_pts);
+        const bool compose = follow && (flags & VF_COMPOSE);
+        const int nd = compose ? vp.fseg[2 * j] : 0, stop_idx = compose ? vp.fseg[2 * j + 1] : 0;
+        int vel_bound = follow ? ((flags & VF_BOUND_FOLLOW) ? 1 : 0) : ((flags & VF_BOUND_GENERIC) ? 1 : 0);
+        int sel = follow ? 1 : 0;                     // 0: P0, 1: min(P0, P1), 2: P3
+        if (follow && (flags & VF_HAS_GENERIC)) {
+            vel_bound = (flags & VF_BOUND_GENERIC) ? 1 : 0;
+            sel = 2;
+            if (n >= 6) {
+                const double f5 = fmin(P0[5 * 64], P1[5 * 64]);
+                if (sqrt(f5) < sqrt(P3[5 * 64])) sel = 1;
+            }
         }
-    }
-    double* o_vx = vout.vx + (size_t)slot * out.cap_pts;
-    double* o_ax = vout.ax + (size_t)slot * out.cap_pts;
-    auto value = [&](int i) {
-        const size_t o = (size_t)i * 64;
-        if (compose) {                                     // sel == 1: min("vx_profile", unconstrained profile)
-            const double a = (nd < 0 || i < nd - 1) ? P2[o] : (i > stop_idx ? 0.0 : P3[o]);
-            return fmin(a, P1[o]);
+        auto value = [&](int i) {
+            const size_t o = (size_t)i * 64;
+            if (compose) {                                     // sel == 1: min("vx_profile", unconstrained profile)
+                const double a = (nd < 0 || i < nd - 1) ? P2[o] : (i > stop_idx ? 0.0 : P3[o]);
+                return fmin(a, P1[o]);
+            }
+            return sel == 0 ? P0[o] : (sel == 1 ? fmin(P0[o], P1[o]) : P3[o]);
+        };
+        double w[FCH + 1], er[FCH];
+#pragma unroll
+        for (int c = 0; c <= FCH; ++c) w[c] = value(base + c < n ? base + c : n - 1);
+#pragma unroll
+        for (int c = 0; c < FCH; ++c) er[c] = (double)KE[(size_t)(base + c < n ? base + c : n - 1) * 64].y;
+#pragma unroll
+        for (int c = 0; c < FCH; ++c) {
+            const int i = base + c;
+            const double v = sqrt(w[c]);
+            double a = 0.0;
+            if (i < n - 1) {
+                // the reference divides by 2 (s_i+1 - s_i) with s the running sum of the element lengths; e_i differs from that
+                // difference by rounding only (~1e-13 relative, tolerance of ax: 1e-5)
+                a = (w[c + 1] - w[c]) / (2.0 * er[c]);
+                if (fabs(v) <= 1e-8 && fabs(a) <= 1e-8) a = -5.0;
+            }
+            vv[c] = v; aa[c] = a;
         }
-        return sel == 0 ? P0[o] : (sel == 1 ? fmin(P0[o], P1[o]) : P3[o]);
-    };
-    double w[FCH + 1], er[FCH], vv[FCH], aa[FCH];
+        if (blockIdx.y == 0) { vout.vel_bound[slot] = vel_bound; vout.too_close[slot] = (flags & VF_TOO_CLOSE) ? 1 : 0; }
+    } else {
 #pragma unroll
-    for (int c = 0; c <= FCH; ++c) w[c] = value(base + c < n ? base + c : n - 1);
+        for (int c = 0; c < FCH; ++c) { vv[c] = 0.0; aa[c] = 0.0; }
+    }
+    // transposition: lane = job writes its FCH values as one LDS row; lane = (job q of a group of 8, pair of rows) reads 16 bytes
+    // and stores them to the slot's row (8-byte aligned 16-byte stores; rows of a slot are contiguous)
+    const int q = lane >> 3, piece = lane & 7;
 #pragma unroll
-    for (int c = 0; c < FCH; ++c) er[c] = (double)KE[(size_t)(base + c < n ? base + c : n - 1) * 64].y;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int half = pass & 1;                                      // jobs [32 half, 32 half + 32)
+        double* dst_base = pass < 2 ? vout.vx : vout.ax;
+        if ((lane >> 5) == half) {
 #pragma unroll
-    for (int c = 0; c < FCH; ++c) {
-        const int i = base + c;
-        const double v = sqrt(w[c]);
-        double a = 0.0;
-        if (i < n - 1) {
-            // the reference divides by 2 (s_i+1 - s_i) with s the running sum of the element lengths; e_i differs from that
-            // difference by rounding only (~1e-13 relative, tolerance of ax: 1e-5)
-            a = (w[c + 1] - w[c]) / (2.0 * er[c]);
-            if (fabs(v) <= 1e-8 && fabs(a) <= 1e-8) a = -5.0;
+            for (int c = 0; c < FCH; c += 2) store2(&tbuf[(lane & 31) * FPITCH + c], pass < 2 ? vv[c] : aa[c], pass < 2 ? vv[c + 1] : aa[c + 1]);
         }
-        vv[c] = v; aa[c] = a;
-    }
-    // rows of a slot are contiguous: 16-byte stores (8-byte aligned)
+        wave_sync_lds();
 #pragma unroll
-    for (int c = 0; c < FCH; c += 2) {
-        const int i = base + c;
-        if (i + 1 < n) { store2_u(o_vx + i, vv[c], vv[c + 1]); store2_u(o_ax + i, aa[c], aa[c + 1]); }
-        else if (i < n) { o_vx[i] = vv[c]; o_ax[i] = aa[c]; }
+        for (int k = 0; k < 4; ++k) {
+            const int jl = k * 8 + q, jj = half * 32 + jl;
+            const int nn = s_n[jj], i = base + 2 * piece;
+            if (i >= nn) continue;
+            const dbl2 v = *reinterpret_cast<const dbl2*>(&tbuf[jl * FPITCH + 2 * piece]);
+            double* o = dst_base + (size_t)s_slot[jj] * out.cap_pts + i;
+            if (i + 1 < nn) store2_u(o, v.x, v.y); else o[0] = v.x;
+        }
+        wave_sync_lds();
     }
-    if (blockIdx.y == 0) { vout.vel_bound[slot] = vel_bound; vout.too_close[slot] = (flags & VF_TOO_CLOSE) ? 1 : 0; }
 }
 
 // follow preparation: the wave-parallel reductions of the follow mode (projection of the object and of the ego position on
 // the path, OTH.py:774-784; projection of the object on the global race line, calc_vel_profile_follow.py:172-176) so that
-// the lane kernel only runs recurrences
-__device__ void follow_prep(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const DevTickVelIn& vin,
-                            const DevVelPrep& prep, int n, double* s_arr, const double* el, const double* px,
-                            const double* py, int s, int slot, int lane)
+// the lane kernel only runs recurrences. No LDS: the path rows are read straight from the path kernel's output (L2 resident) --
+// both projections share one pass over the points and one pass over the element lengths (the arc length is only needed at the
+// two foot points: a masked wave sum instead of a prefix array). Round 2: with 11 KB of LDS per job the kernel fitted 14 waves
+// per CU (2 next to a resident path kernel), which made it the slowest stage of the overlapped pipeline.
+__device__ __forceinline__ void follow_prep(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const DevTickVelIn& vin,
+                                            const DevVelPrep& prep, int n, const double* pp, int s, int slot, int lane,
+                                            long long* dbg = nullptr, int drow = -1)
 {
-    wave_cumsum_par(el, s_arr, n + 1, lane);
     const int ci = out.closest_obj_index[s], v0 = in.veh_off[s];
-    double ox, oy, vobj, odist;
-    if (ci < 0 || ci >= in.veh_off[s + 1] - v0) { odist = 0.0; vobj = 0.0; ox = vin.pos_est_x[s]; oy = vin.pos_est_y[s]; }
-    else {
-        const int pp = in.pos_off[v0 + ci];
-        ox = in.pos_x[pp]; oy = in.pos_y[pp]; vobj = vin.veh_vel[v0 + ci];
-        const double s_obj = get_s_coord_dev(n, px, py, 1, s_arr, 1, ox, oy, false, lane, nullptr);
-        const double s_sta = get_s_coord_dev(n, px, py, 1, s_arr, 1, vin.pos_est_x[s], vin.pos_est_y[s], false, lane, nullptr);
-        odist = s_obj - s_sta;
-    }
+    const bool have = !(ci < 0 || ci >= in.veh_off[s + 1] - v0);
+    const double ex = vin.pos_est_x[s], ey = vin.pos_est_y[s];
+    double ox = ex, oy = ey, vobj = 0.0, odist = 0.0;
+    if (have) { const int q = in.pos_off[v0 + ci]; ox = in.pos_x[q]; oy = in.pos_y[q]; vobj = vin.veh_vel[v0 + ci]; }
+    vl_stamp(dbg, drow, 1);
     const int idx = globrl_index_dev(lat, ox, oy, lane);
+    vl_stamp(dbg, drow, 2);
+    if (have) {
+        // closest path point of the object and of the ego position (first minimum, like np.argmin)
+        double bo = INFINITY, be = INFINITY, d0 = 0.0, d1 = 0.0; int no = 0x7fffffff, ne = 0x7fffffff;
+        for (int i = lane; i < n; i += 64) {
+            const double x = pp[(size_t)i * 5], y = pp[(size_t)i * 5 + 1];
+            const double ao = (x - ox) * (x - ox) + (y - oy) * (y - oy), ae = (x - ex) * (x - ex) + (y - ey) * (y - ey);
+            if (ao < bo) { bo = ao; no = i; }
+            if (ae < be) { be = ae; ne = i; }
+        }
+        wave_min3(bo, d0, no); wave_min3(be, d1, ne);
+        vl_stamp(dbg, drow, 3);
+        // get_s_coord.py:34-99 (closed = False) for one query: index whose arc length is needed and the distance to add
+        auto foot = [&](int nb, double px, double py, int* is, double* ds) {
+            const int i1 = nb - 1 > 0 ? nb - 1 : 0, i2 = nb + 1 < n - 1 ? nb + 1 : n - 1;
+            const double nx = pp[(size_t)nb * 5], ny = pp[(size_t)nb * 5 + 1];
+            const double x1 = pp[(size_t)i1 * 5], y1 = pp[(size_t)i1 * 5 + 1], x2 = pp[(size_t)i2 * 5], y2 = pp[(size_t)i2 * 5 + 1];
+            const int ord = angle_order_dev(nx, ny, px, py, x1, y1, x2, y2);
+            double ax, ay, bx, by;
+            if (ord > 0) { ax = x1; ay = y1; bx = nx; by = ny; } else { ax = nx; ay = ny; bx = x2; by = y2; }
+            const double t = ((px - ax) * (bx - ax) + (py - ay) * (by - ay)) / ((bx - ax) * (bx - ax) + (by - ay) * (by - ay));
+            const double fx = ax + t * (bx - ax), fy = ay + t * (by - ay);
+            *ds = sqrt((ax - fx) * (ax - fx) + (ay - fy) * (ay - fy));
+            *is = ord > 0 ? i1 : nb;
+        };
+        int io, ie; double dso, dse;
+        foot(no, ox, oy, &io, &dso); foot(ne, ex, ey, &ie, &dse);
+        vl_stamp(dbg, drow, 4);
+        // s[i] = sum of el[0 .. i-1] at the two indices (wave-parallel sum: the distance has a 1e-5 tolerance)
+        double so = 0.0, se = 0.0;
+        for (int i = lane; i < n; i += 64) {
+            const double e = pp[(size_t)i * 5 + 4];
+            so += i < io ? e : 0.0; se += i < ie ? e : 0.0;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { so += __shfl_xor(so, m); se += __shfl_xor(se, m); }
+        odist = (so + dso) - (se + dse);
+    }
     if (lane == 0) { prep.obj_dist[slot] = odist; prep.v_obj[slot] = vobj; prep.obj_x[slot] = ox; prep.obj_y[slot] = oy; prep.idx_s_opp[slot] = idx; }
+    vl_stamp(dbg, drow, 5);
 }
 
 // follow preparation as its own small kernel between the path kernel and the lane kernel: one wave per FOLLOW JOB (job table
 // of the path kernel; the count is only known on the device, so the grid is the upper bound n_scen and the rest exits at once).
 // A job is a chain of dependent global round trips with little arithmetic: many short-lived blocks in flight hide that better
-// than a grid-stride loop (measured: 141 us vs 199 us per 32 768 scenarios). The path rows are re-read from the path kernel's output.
+// than a grid-stride loop (measured: 141 us vs 199 us per 32 768 scenarios).
 __global__ __launch_bounds__(64) void k_follow_prep(DevLat lat, DevPathsIn in, DevPathsOut out, DevTickVelIn vin,
-                                                    DevVelPrep prep, int n_slots)
+                                                    DevVelPrep prep, int n_slots, long long* dbg)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
+    const int drow = blockIdx.x < 64 ? 192 + (int)blockIdx.x : -1;      // LTPL_DEBUG_TIMING: rows 192 .. 255 of the stamp table
+    vl_stamp(dbg, drow, 0);
     if ((int)blockIdx.x >= out.job_cnt[1]) return;
     const int slot = out.job_slot[out.n_slots_pad + blockIdx.x];
-    const int n = out.n_pts[slot];
-    const int c1 = out.cap_pts + 2;
-    double* sel = reinterpret_cast<double*>(smem); double* sx = sel + c1; double* sy = sx + c1; double* ss = sy + c1;
-    const double* pp = out.path_param + (size_t)slot * out.cap_pts * 5;
-    for (int i = lane; i < n; i += 64) { sx[i] = pp[(size_t)i * 5]; sy[i] = pp[(size_t)i * 5 + 1]; sel[i] = pp[(size_t)i * 5 + 4]; }
-    wave_sync_lds();
-    follow_prep(lat, in, out, vin, prep, n, ss, sel, sx, sy, slot / LTPL_MAX_ACTIONS, slot, lane);
+    follow_prep(lat, in, out, vin, prep, out.n_pts[slot], out.path_param + (size_t)slot * out.cap_pts * 5, slot / LTPL_MAX_ACTIONS, slot, lane,
+                dbg, drow);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1561,6 +1732,9 @@ struct ltpl_handle {
     // host copy of the per-layer / per-node tables for the planner state machine (planner_core.hpp); empty when the
     // descriptor came without raceline / node_psi columns
     ltplp::HostLat hostlat; bool has_hostlat = false;
+    int scratch_poison_on = 0; unsigned scratch_poison_word = 0;   // LTPL_SCRATCH_POISON (testing)
+    int force_fused = 0, no_overlap = 0;                            // LTPL_FORCE_FUSED, LTPL_NO_OVERLAP (measurement switches)
+    int zc_in = 0;                   // small calls: kernels read their inputs straight from the page-locked staging buffer (no H2D copy)
     int zc_out = 0;                  // small calls: kernels write their outputs straight into the page-locked host buffer (no D2H copy)
     std::vector<int> rng_end_host;   // planning range end per start layer, -1 = no planning range (end of an open track)
 };
@@ -1649,6 +1823,20 @@ static void dbg_report_lanes(ltpl_handle* h)
     std::vector<long long> v((size_t)256 * DBG_SLOTS);
     if (hipMemcpy(v.data(), h->d_dbg, v.size() * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return;
     const char* names[3] = {"generic", "follow (controlled)", "follow (unconstrained)"};
+    {
+        double acc = 0; int cnt = 0;
+        for (int r = 0; r < 64; ++r) { const long long* row = &v[(size_t)(128 + r) * DBG_SLOTS]; if (row[0] > 0 && row[8] > row[0]) { acc += (double)(row[8] - row[0]); ++cnt; } }
+        fprintf(stderr, "[ltpl dbg] k_vel_lanes unconstrained profile: forward sweep %9.0f cycles (%d rows)\n", cnt ? acc / cnt : 0.0, cnt);
+    }
+    {
+        fprintf(stderr, "[ltpl dbg] k_follow_prep mean cycles between stamps 0-1-2-3-4-5 (inputs | race line scan | path scan | foot points | sums):");
+        for (int k = 0; k < 5; ++k) {
+            double acc = 0; int cnt = 0;
+            for (int r = 0; r < 64; ++r) { const long long* row = &v[(size_t)(192 + r) * DBG_SLOTS]; if (row[k] > 0 && row[k + 1] > row[k]) { acc += (double)(row[k + 1] - row[k]); ++cnt; } }
+            fprintf(stderr, " %8.0f", cnt ? acc / cnt : 0.0);
+        }
+        fprintf(stderr, "\n");
+    }
     for (int g = 0; g < 3; ++g) {
         fprintf(stderr, "[ltpl dbg] k_vel_lanes %-24s mean cycles between stamps 0-1-2-3-4-5-6, total:", names[g]);
         double tot = 0; int tc = 0;
@@ -1956,6 +2144,11 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
     if (const char* e = getenv("LTPL_BATCH_NW")) h->batch_nw = atoi(e) == 4 ? 4 : 1;
     h->zc_out = 1;
     if (const char* e = getenv("LTPL_ZC_OUT")) h->zc_out = atoi(e);
+    if (const char* e = getenv("LTPL_ZC_IN")) h->zc_in = atoi(e);
+    // environment switches are read ONCE here: getenv() in a per-tick entry point costs microseconds in a process with a large environment
+    if (const char* e = getenv("LTPL_SCRATCH_POISON")) { h->scratch_poison_on = 1; h->scratch_poison_word = (unsigned)strtoul(e, nullptr, 0); }
+    h->force_fused = getenv("LTPL_FORCE_FUSED") ? 1 : 0;
+    h->no_overlap = getenv("LTPL_NO_OVERLAP") ? 1 : 0;
     if (const char* e = getenv("LTPL_NW1_MIN_SCEN")) h->nw1_min_scen = atoi(e) > 0 ? atoi(e) : PIPELINE_MIN_SCEN;
     if (getenv("LTPL_DEBUG_TIMING")) {
         if (hipMalloc(reinterpret_cast<void**>(&h->d_dbg), sizeof(long long) * 256 * DBG_SLOTS) == hipSuccess) {
@@ -2183,8 +2376,8 @@ __global__ __launch_bounds__(64) void k_scratch_poison(unsigned pattern, unsigne
 
 static void scratch_poison(ltpl_handle* h)
 {
-    if (const char* e = getenv("LTPL_SCRATCH_POISON"))
-        hipLaunchKernelGGL(k_scratch_poison, dim3(256 * 64), dim3(64), 0, h->stream, (unsigned)strtoul(e, nullptr, 0), (unsigned*)nullptr);
+    if (h->scratch_poison_on)
+        hipLaunchKernelGGL(k_scratch_poison, dim3(256 * 64), dim3(64), 0, h->stream, h->scratch_poison_word, (unsigned*)nullptr);
 }
 
 static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_out* out, int force_nw);
@@ -2199,6 +2392,7 @@ static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_o
 {
     if (!h) return LTPL_ERR_INVALID_ARG;
     if (!out) { h->err = "null output"; return LTPL_ERR_INVALID_ARG; }
+    LTPL_PROF(prof_pack, "plan_paths.validate+pack");
     HIP_TRY(h, hipSetDevice(h->device));
     drop_resident(h);
     InLayout li;
@@ -2212,18 +2406,31 @@ static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_o
     if ((rc = ensure(h, &h->h_in, &h->h_in_cap, &h->d_in, &h->d_in_cap, li.total))) return rc;
     if ((rc = ensure(h, &h->h_out, &h->h_out_cap, &h->d_out, &h->d_out_cap, lo.total))) return rc;
     DevPathsIn di; DevPathsOut dout;
-    pack_in(in, li, static_cast<unsigned char*>(h->h_in), static_cast<const unsigned char*>(h->d_in), &di);
+    const bool zci = h->zc_in && in->n_scen <= 8;
+    pack_in(in, li, static_cast<unsigned char*>(h->h_in), static_cast<const unsigned char*>(zci ? h->h_in : h->d_in), &di);
     // small calls (latency path): the output slab is the page-locked host buffer itself (device-accessible under unified
     // addressing): the kernel's stores cross PCIe as posted writes, no D2H copy is enqueued
     const bool zc = h->zc_out && in->n_scen <= 8;
     bind_out(static_cast<unsigned char*>(zc ? h->h_out : h->d_out), lo, out->cap_nodes, out->cap_pts, &dout);
-    HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, li.total, hipMemcpyHostToDevice, h->stream));
+    prof_pack.stop();
+    LTPL_PROF(prof_enq, "plan_paths.enqueue");
+    {
+        LTPL_PROF(prof_h2d, "plan_paths.enqueue.h2d");
+        if (!zci) HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, li.total, hipMemcpyHostToDevice, h->stream));
+    }
     scratch_poison(h);
     const int nw = force_nw ? force_nw : ((in->n_scen >= h->nw1_min_scen && h->batch_nw == 1) ? 1 : NUM_WAVES);
-    if ((rc = launch_paths(h, nw, in->n_scen, h->stream, di, dout))) return rc;
+    {
+        LTPL_PROF(prof_l, "plan_paths.enqueue.launch");
+        if ((rc = launch_paths(h, nw, in->n_scen, h->stream, di, dout))) return rc;
+    }
     if (!zc) HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, lo.total, hipMemcpyDeviceToHost, h->stream));
+    prof_enq.stop();
+    LTPL_PROF(prof_sync, "plan_paths.sync");
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    prof_sync.stop();
     dbg_report(h, "k_paths", in->n_scen);
+    LTPL_PROF(prof_sc, "plan_paths.scatter");
     scatter_out(static_cast<const unsigned char*>(h->h_out), lo, in->n_scen, out);
     return LTPL_OK;
 }
@@ -2319,6 +2526,7 @@ extern "C" int ltpl_vel_profile(ltpl_handle* h, const ltpl_vel_params* vp, int n
 {
     if (!h) return LTPL_ERR_INVALID_ARG;
     if (n_jobs < 1 || !jobs || !results) { h->err = "no jobs"; return LTPL_ERR_INVALID_ARG; }
+    LTPL_PROF(prof_pack, "vel_profile.validate+pack");
     HIP_TRY(h, hipSetDevice(h->device));
     drop_resident(h);
     // pooled layout: [axm table][jobs][kappa | el | gg per job] ; outputs: [flags][vx per job]
@@ -2355,7 +2563,8 @@ extern "C" int ltpl_vel_profile(ltpl_handle* h, const ltpl_vel_params* vp, int n
     if ((rc = ensure(h, &h->h_in, &h->h_in_cap, &h->d_in, &h->d_in_cap, ain.size))) return rc;
     if ((rc = ensure(h, &h->h_out, &h->h_out_cap, &h->d_out, &h->d_out_cap, aout.size))) return rc;
     unsigned char* hb = static_cast<unsigned char*>(h->h_in);
-    unsigned char* db = static_cast<unsigned char*>(h->d_in);
+    const bool zci = h->zc_in && n_jobs <= 16;
+    unsigned char* db = static_cast<unsigned char*>(zci ? h->h_in : h->d_in);
     DevVelParams p;
     if ((rc = make_vel_params(h, vp, reinterpret_cast<const double*>(db + o_axm), &p))) return rc;
     memcpy(hb + o_axm, vp->ax_max_machines, sizeof(double) * 2 * (size_t)vp->n_ax_max_machines);
@@ -2370,7 +2579,9 @@ extern "C" int ltpl_vel_profile(ltpl_handle* h, const ltpl_vel_params* vp, int n
     vel_kernel_t kern = vel_kernel_of(vel_variant(vp));
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, ain.size, hipMemcpyHostToDevice, h->stream));
+    prof_pack.stop();
+    LTPL_PROF(prof_enq, "vel_profile.enqueue");
+    if (!zci) HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, ain.size, hipMemcpyHostToDevice, h->stream));
     const bool zc = h->zc_out && n_jobs <= 16;
     unsigned char* dob = static_cast<unsigned char*>(zc ? h->h_out : h->d_out);
     hipLaunchKernelGGL(kern, dim3(n_jobs), dim3(64), lds, h->stream, h->lat, p,
@@ -2378,8 +2589,12 @@ extern "C" int ltpl_vel_profile(ltpl_handle* h, const ltpl_vel_params* vp, int n
                        reinterpret_cast<double*>(dob + o_vx), reinterpret_cast<int*>(dob + o_flags), cap, h->lp4.dbg);
     HIP_TRY(h, hipGetLastError());
     if (!zc) HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, aout.size, hipMemcpyDeviceToHost, h->stream));
+    prof_enq.stop();
+    LTPL_PROF(prof_sync, "vel_profile.sync");
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    prof_sync.stop();
     dbg_report(h, "k_vel_profile", n_jobs);
+    LTPL_PROF(prof_sc, "vel_profile.scatter");
     const unsigned char* ho = static_cast<const unsigned char*>(h->h_out);
     const int* flags = reinterpret_cast<const int*>(ho + o_flags);
     const double* vx = reinterpret_cast<const double*>(ho + o_vx);
@@ -2400,7 +2615,7 @@ struct TickLayout {
     int variant;
     // two-kernel batch pipeline (n_scen >= PIPELINE_MIN_SCEN)
     bool pipeline; size_t prep_odist, prep_vobj, prep_ox, prep_oy, prep_idx; size_t planes_bytes;
-    DevVelPrep dprep; int prep_off, prep_stride; size_t lds_prep;
+    DevVelPrep dprep; int prep_off, prep_stride;
     VelPlanes vp{}; int n_slots_pad = 0, n_scen_pad = 0;
 };
 
@@ -2431,7 +2646,7 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
     t->ax = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS * (size_t)cap_pts);
     t->vel_bound = b.add(sizeof(int) * (size_t)n * LTPL_MAX_ACTIONS);
     t->too_close = b.add(sizeof(int) * (size_t)n * LTPL_MAX_ACTIONS);
-    t->pipeline = h->long_horizon || (n >= PIPELINE_MIN_SCEN && !getenv("LTPL_FORCE_FUSED"));
+    t->pipeline = h->long_horizon || (n >= PIPELINE_MIN_SCEN && !h->force_fused);
     t->prep_odist = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS);
     t->prep_vobj = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS);
     t->prep_ox = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS);
@@ -2446,7 +2661,6 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
                                             + sizeof(int) * (2 * tiles + 16 + 2 * (size_t)t->n_scen_pad) : 0;
     }
     t->prep_off = 0; t->prep_stride = 0;
-    t->lds_prep = align_up(sizeof(double) * 4 * (size_t)(cap_pts + 2), 16);      // k_follow_prep: el, x, y, s
     t->vel_cap = h->caps.max_path_pts;
     t->vel_stride = (int)vel_scratch_bytes(t->vel_cap, false, true);
     t->vel_off = h->lp4.total;
@@ -2521,8 +2735,8 @@ static int tick_launch_vel(ltpl_handle* h, const TickLayout& t, hipStream_t st, 
     // slots without a path: vel_bound = too_close = 0 (the job kernels only touch slots that own a job)
     HIP_TRY(h, hipMemsetAsync(t.dvout.vel_bound, 0, sizeof(int) * (size_t)t.n_scen * LTPL_MAX_ACTIONS, st));
     HIP_TRY(h, hipMemsetAsync(t.dvout.too_close, 0, sizeof(int) * (size_t)t.n_scen * LTPL_MAX_ACTIONS, st));
-    hipLaunchKernelGGL(k_follow_prep, dim3(t.n_scen), dim3(64), t.lds_prep, st, h->lat, t.di, t.dout,
-                       t.dvin, t.dprep, t.n_scen);
+    hipLaunchKernelGGL(k_follow_prep, dim3(t.n_scen), dim3(64), 0, st, h->lat, t.di, t.dout,
+                       t.dvin, t.dprep, t.n_scen, h->lp4.dbg);
     HIP_TRY(h, hipGetLastError());
     if (ev_after_prep) HIP_TRY(h, hipEventRecord(ev_after_prep, st));
     const int n_slots = t.n_scen * LTPL_MAX_ACTIONS;
@@ -2686,7 +2900,7 @@ extern "C" int ltpl_batch_upload(ltpl_handle* h, const ltpl_paths_in* in, const 
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->resident = t;
     h->last_set = 0;
-    if (t->pipeline && !getenv("LTPL_NO_OVERLAP")) {
+    if (t->pipeline && !h->no_overlap) {
         // second buffer set for the two-stream software pipeline of ltpl_batch_run
         if (t->out_total > h->d_out2_cap) {
             if (h->d_out2) (void)hipFree(h->d_out2);

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/ltpl_hip.h"
+#include "host_prof.hpp"
 
 namespace ltplp {
 
@@ -548,6 +549,7 @@ struct Planner {
                 S.veh.push_back(std::move(o));
             }
             S.closest_obj_index = -1;
+            LTPL_PROF(prof_pre, "planner.paths_pre");
             int rc = paths_pre(s, prev_action[s], t_now[s]);
             if (rc) return rc;
         }
@@ -582,6 +584,7 @@ struct Planner {
         out.coeff = o_coeff.data(); out.path_param = o_pp.data();
         int rc = cmp->plan_paths(&in, &out);
         if (rc) return fail_cmp(rc);
+        LTPL_PROF(prof_post, "planner.paths_post");
         for (int s = 0; s < n; ++s) if ((rc = paths_post(s))) return rc;
         return LTPL_OK;
     }
@@ -693,6 +696,7 @@ struct Planner {
     int calc_vel_profile(const VelReq* req, const double* ax_max_machines, int n_axm, const double* /*t_now*/)
     {
         const int n = (int)sc.size();
+        LTPL_PROF(prof_a, "planner.vel_stage_A");
         if (cfg.filt_window_width != 1) return fail(LTPL_ERR_UNSUPPORTED, "planner: SMOOTHING.filt_window_width != 1 is not supported");
         ltpl_vel_params vp; std::memset(&vp, 0, sizeof(vp));
         vp.dyn_model_exp = cfg.dyn_model_exp; vp.drag_coeff = cfg.drag_coeff; vp.m_veh = cfg.m_veh; vp.len_veh = lat.veh_length;
@@ -816,8 +820,10 @@ struct Planner {
                 work.push_back(std::move(W));
             }
         }
+        prof_a.stop();
         int rc = run_jobs(vp, jobs, bufs, res);
         if (rc) return rc;
+        LTPL_PROF(prof_b, "planner.vel_stage_B");
 
         // ---- stage B: assemble trajectories (:824-941), decide keep / drop / backup (:943-1015) ---------------------------
         std::vector<ltpl_vel_job> jobs2; std::vector<JobBuf> bufs2; std::vector<ltpl_vel_result> res2;
@@ -893,7 +899,9 @@ struct Planner {
                 }
             } else W.drop = true;
         }
+        prof_b.stop();
         if ((rc = run_jobs(vp, jobs2, bufs2, res2))) return rc;
+        LTPL_PROF(prof_c, "planner.vel_stage_C");
 
         // ---- stage C: backup trajectories, commit, emergency profile ---------------------------------------------------------
         std::vector<ltpl_vel_job> jobs3; std::vector<JobBuf> bufs3; std::vector<ltpl_vel_result> res3;

@@ -1,0 +1,19 @@
+"""In-kernel phase cycle counts of the path kernel (LTPL_DEBUG_TIMING=1, shader-clock ticks, blocks 0..255 of the launch).
+Stamps: 0 start | 1 scenario set-up | 2 closest layer per position | 3 edge mask | 4 closest object / template |
+5 sweeps | 6 goal / horizon decisions | 7 path assembly.   tools/dbg_paths_timing.py [n_scen] [workload]"""
+import os
+import sys
+os.environ["LTPL_DEBUG_TIMING"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench                                                                  # noqa: E402
+from graphbasedlocaltrajectoryplanner_amd import _capi                        # noqa: E402
+from graphbasedlocaltrajectoryplanner_amd.lattice import Lattice              # noqa: E402
+
+lat = Lattice.load(os.path.join(ROOT, "tests", "golden", "monteblanco_lattice.npz"))
+hip = _capi.HipBackend(lat)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+scen, batch, vel = bench.make_batch(lat, n, seed=1, workload=sys.argv[2] if len(sys.argv) > 2 else "c2")
+res = hip.new_paths_result(n)
+for i in range(2):
+    hip.plan_paths(batch, res)
