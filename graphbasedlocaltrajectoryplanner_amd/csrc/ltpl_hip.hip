@@ -96,6 +96,7 @@ struct DevPathsOut {
     int* action_id; int* valid; int* reduced; int* goal_layer; int* n_nodes; int* n_pts; int* n_ties;
     int* nodes; int* node_idx; double* coeff; double* path_param;
     float2* vke;                     // optional tiled plane (|kappa|, element length) as fp32 pairs for the batch velocity stage
+    double* vxy;                     // optional tiled plane (x, y) of the FOLLOW jobs' path points (tile = follow job index): k_follow_prep
     // job compaction of the batch velocity stage (all nullptr outside the pipeline): every valid path takes a job index
     // from a counter of its class (0 = generic forward-backward profile, 1 = follow); its planes are tiled by JOB, so
     // the lanes of a velocity wave (64 consecutive jobs of one class) are all busy and equally long
@@ -925,6 +926,7 @@ struct VelPlanes {              // tiled planes (doubles), tile index = job inde
     double* P1;                 // type 1 result: unconstrained profile of a follow job                n_scen_pad tiles
     double* P2;                 // ego brake profile (follow)                                           n_scen_pad tiles
     double* P3;                 // segment profile (follow), afterwards the generic profile of a reduced-horizon follow job
+    double* XY;                 // (x, y) pairs of the follow jobs' path points (written by the path kernel)   n_scen_pad tiles x 2
     int* flags;                 // per tile: VF_* bits
     int* fseg;                  // per follow job [2]: n_decel (-1: everything from the brake profile), stop_idx -- composition of
                                 // "vx_profile" (:289 / :294) from P2 / P3 / zeros, done by k_vel_final (VF_COMPOSE)
@@ -1532,79 +1534,101 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
     }
 }
 
-// follow preparation: the wave-parallel reductions of the follow mode (projection of the object and of the ego position on
-// the path, OTH.py:774-784; projection of the object on the global race line, calc_vel_profile_follow.py:172-176) so that
-// the lane kernel only runs recurrences. No LDS: the path rows are read straight from the path kernel's output (L2 resident) --
-// both projections share one pass over the points and one pass over the element lengths (the arc length is only needed at the
-// two foot points: a masked wave sum instead of a prefix array). Round 2: with 11 KB of LDS per job the kernel fitted 14 waves
-// per CU (2 next to a resident path kernel), which made it the slowest stage of the overlapped pipeline.
-__device__ __forceinline__ void follow_prep(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const DevTickVelIn& vin,
-                                            const DevVelPrep& prep, int n, const double* pp, int s, int slot, int lane,
-                                            long long* dbg = nullptr, int drow = -1)
+// follow preparation (projection of the object and of the ego position on the path, OTH.py:774-784; projection of the object
+// on the global race line, calc_vel_profile_follow.py:172-176), ONE LANE PER FOLLOW JOB like the lane kernel. Round 2 history: the
+// wave-per-job form spent ~1 900 instructions per job on cross-lane reductions and half-empty lanes (47 M instructions per
+// 32 768-scenario step, 8 % of the path kernel's -- 118 us of the overlapped step); a lane that scans its own job serially needs
+// ~190: the race line is read with scalar loads (uniform index), the path points come from a tiled (x, y) plane the path kernel
+// writes for follow jobs (coalesced rows), closest point, arc length at the foot point (a running prefix: np.cumsum's order) and
+// the element in front of it are picked up in ONE pass for both query points.
+#define PCH 8
+__global__ __launch_bounds__(64) void k_follow_prep(DevLat lat, DevPathsIn in, DevPathsOut out, DevTickVelIn vin,
+                                                    DevVelPrep prep, VelPlanes vp, int n_slots, long long* dbg)
 {
+    const int lane = threadIdx.x, cnt = out.job_cnt[1];
+    if ((int)blockIdx.x * 64 >= cnt) return;
+    const int drow = blockIdx.x < 64 ? 192 + (int)blockIdx.x : -1;      // LTPL_DEBUG_TIMING: rows 192 .. 255 of the stamp table
+    vl_stamp(dbg, drow, 0);
+    const int j0 = (int)blockIdx.x * 64 + lane;
+    const bool have_job = j0 < cnt;
+    const int j = have_job ? j0 : cnt - 1;                  // idle lanes repeat the last job (uniform control flow), nothing stored
+    const int slot = out.job_slot[out.n_slots_pad + j];
+    const int s = slot / LTPL_MAX_ACTIONS, n = out.n_pts[slot];
     const int ci = out.closest_obj_index[s], v0 = in.veh_off[s];
     const bool have = !(ci < 0 || ci >= in.veh_off[s + 1] - v0);
     const double ex = vin.pos_est_x[s], ey = vin.pos_est_y[s];
     double ox = ex, oy = ey, vobj = 0.0, odist = 0.0;
     if (have) { const int q = in.pos_off[v0 + ci]; ox = in.pos_x[q]; oy = in.pos_y[q]; vobj = vin.veh_vel[v0 + ci]; }
     vl_stamp(dbg, drow, 1);
-    const int idx = globrl_index_dev(lat, ox, oy, lane);
-    vl_stamp(dbg, drow, 2);
-    if (have) {
-        // closest path point of the object and of the ego position (first minimum, like np.argmin)
-        double bo = INFINITY, be = INFINITY, d0 = 0.0, d1 = 0.0; int no = 0x7fffffff, ne = 0x7fffffff;
-        for (int i = lane; i < n; i += 64) {
-            const double x = pp[(size_t)i * 5], y = pp[(size_t)i * 5 + 1];
-            const double ao = (x - ox) * (x - ox) + (y - oy) * (y - oy), ae = (x - ex) * (x - ex) + (y - ey) * (y - ey);
-            if (ao < bo) { bo = ao; no = i; }
-            if (ae < be) { be = ae; ne = i; }
+    // ---- closest race line point (first minimum, like np.argmin), then the neighbour test of get_s_coord (closed = True) ----
+    int idx;
+    {
+        const int G = lat.G - 1;
+        double bd = INFINITY; int nb = 0;
+#pragma unroll 8
+        for (int i = 0; i < G; ++i) {
+            const double dx = lat.grx[i] - ox, dy = lat.gry[i] - oy, d2 = dx * dx + dy * dy;
+            if (d2 < bd) { bd = d2; nb = i; }
         }
-        wave_min3(bo, d0, no); wave_min3(be, d1, ne);
+        int i1 = nb - 1; if (i1 < 0) i1 += G;
+        int i2 = nb + 1; if (i2 > G - 1) i2 = 0;
+        const int ord = angle_order_dev(at(lat.grx, nb), at(lat.gry, nb), ox, oy, at(lat.grx, i1), at(lat.gry, i1), at(lat.grx, i2), at(lat.gry, i2));
+        idx = ord >= 0 ? i1 : nb;
+    }
+    vl_stamp(dbg, drow, 2);
+    if (__ballot(have) != 0ull) {
+        const double* xy = vp.XY + 2 * tile_base(j, vp.cap_pts);           // pairs: row r of this lane's job at xy + r * 128
+        const float2* KE = vp.KE + tile_base(out.n_slots_pad + j, vp.cap_pts);
+        int nmax = n;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(nmax, m); nmax = o > nmax ? o : nmax; }
+        // one pass: closest path point of the object (o) and of the ego position (e), arc length in front of it and the element before
+        double bo = INFINITY, be = INFINITY, so = 0.0, se = 0.0, po = 0.0, pe = 0.0, run = 0.0, e_prev = 0.0;
+        int no = 0, ne = 0;
+        dbl2 pr[PCH], pn[PCH]; float2 kr[PCH], kn[PCH];
+        auto load_rows = [&](int base, dbl2 (&p)[PCH], float2 (&k)[PCH]) {
+#pragma unroll
+            for (int c = 0; c < PCH; ++c) {
+                const int r = base + c < n ? base + c : n - 1;
+                p[c] = *reinterpret_cast<const dbl2*>(xy + (size_t)r * 128); k[c] = KE[(size_t)r * 64];
+            }
+        };
+        load_rows(0, pr, kr);
+        for (int base = 0; base < nmax; base += PCH) {
+            load_rows(base + PCH, pn, kn);
+#pragma unroll
+            for (int c = 0; c < PCH; ++c) {
+                const int i = base + c;
+                const bool valid = i < n;
+                const double x = pr[c].x, y = pr[c].y, e = (double)kr[c].y;
+                const double ao = (x - ox) * (x - ox) + (y - oy) * (y - oy), ae = (x - ex) * (x - ex) + (y - ey) * (y - ey);
+                if (valid && ao < bo) { bo = ao; no = i; so = run; po = e_prev; }
+                if (valid && ae < be) { be = ae; ne = i; se = run; pe = e_prev; }
+                if (valid) { run += e; e_prev = e; }
+            }
+#pragma unroll
+            for (int c = 0; c < PCH; ++c) { pr[c] = pn[c]; kr[c] = kn[c]; }
+        }
         vl_stamp(dbg, drow, 3);
-        // get_s_coord.py:34-99 (closed = False) for one query: index whose arc length is needed and the distance to add
-        auto foot = [&](int nb, double px, double py, int* is, double* ds) {
+        // get_s_coord.py:34-99 (closed = False) for one query: arc length of the foot point
+        auto foot = [&](int nb, double s_nb, double e_before, double px, double py) {
             const int i1 = nb - 1 > 0 ? nb - 1 : 0, i2 = nb + 1 < n - 1 ? nb + 1 : n - 1;
-            const double nx = pp[(size_t)nb * 5], ny = pp[(size_t)nb * 5 + 1];
-            const double x1 = pp[(size_t)i1 * 5], y1 = pp[(size_t)i1 * 5 + 1], x2 = pp[(size_t)i2 * 5], y2 = pp[(size_t)i2 * 5 + 1];
-            const int ord = angle_order_dev(nx, ny, px, py, x1, y1, x2, y2);
+            const dbl2 pN = *reinterpret_cast<const dbl2*>(xy + (size_t)nb * 128), p1 = *reinterpret_cast<const dbl2*>(xy + (size_t)i1 * 128),
+                       p2 = *reinterpret_cast<const dbl2*>(xy + (size_t)i2 * 128);
+            const int ord = angle_order_dev(pN.x, pN.y, px, py, p1.x, p1.y, p2.x, p2.y);
             double ax, ay, bx, by;
-            if (ord > 0) { ax = x1; ay = y1; bx = nx; by = ny; } else { ax = nx; ay = ny; bx = x2; by = y2; }
+            if (ord > 0) { ax = p1.x; ay = p1.y; bx = pN.x; by = pN.y; } else { ax = pN.x; ay = pN.y; bx = p2.x; by = p2.y; }
             const double t = ((px - ax) * (bx - ax) + (py - ay) * (by - ay)) / ((bx - ax) * (bx - ax) + (by - ay) * (by - ay));
             const double fx = ax + t * (bx - ax), fy = ay + t * (by - ay);
-            *ds = sqrt((ax - fx) * (ax - fx) + (ay - fy) * (ay - fy));
-            *is = ord > 0 ? i1 : nb;
+            const double ds = sqrt((ax - fx) * (ax - fx) + (ay - fy) * (ay - fy));
+            return (ord > 0 ? (nb > 0 ? s_nb - e_before : 0.0) : s_nb) + ds;        // s[i1] = s[nb] - el[nb - 1]; s[0] = 0
         };
-        int io, ie; double dso, dse;
-        foot(no, ox, oy, &io, &dso); foot(ne, ex, ey, &ie, &dse);
+        const double s_obj = foot(no, so, po, ox, oy), s_sta = foot(ne, se, pe, ex, ey);
+        if (have) odist = s_obj - s_sta;
         vl_stamp(dbg, drow, 4);
-        // s[i] = sum of el[0 .. i-1] at the two indices (wave-parallel sum: the distance has a 1e-5 tolerance)
-        double so = 0.0, se = 0.0;
-        for (int i = lane; i < n; i += 64) {
-            const double e = pp[(size_t)i * 5 + 4];
-            so += i < io ? e : 0.0; se += i < ie ? e : 0.0;
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { so += __shfl_xor(so, m); se += __shfl_xor(se, m); }
-        odist = (so + dso) - (se + dse);
     }
-    if (lane == 0) { prep.obj_dist[slot] = odist; prep.v_obj[slot] = vobj; prep.obj_x[slot] = ox; prep.obj_y[slot] = oy; prep.idx_s_opp[slot] = idx; }
+    if (have_job) { prep.obj_dist[slot] = odist; prep.v_obj[slot] = vobj; prep.obj_x[slot] = ox; prep.obj_y[slot] = oy; prep.idx_s_opp[slot] = idx; }
     vl_stamp(dbg, drow, 5);
-}
-
-// follow preparation as its own small kernel between the path kernel and the lane kernel: one wave per FOLLOW JOB (job table
-// of the path kernel; the count is only known on the device, so the grid is the upper bound n_scen and the rest exits at once).
-// A job is a chain of dependent global round trips with little arithmetic: many short-lived blocks in flight hide that better
-// than a grid-stride loop (measured: 141 us vs 199 us per 32 768 scenarios).
-__global__ __launch_bounds__(64) void k_follow_prep(DevLat lat, DevPathsIn in, DevPathsOut out, DevTickVelIn vin,
-                                                    DevVelPrep prep, int n_slots, long long* dbg)
-{
-    const int lane = threadIdx.x;
-    const int drow = blockIdx.x < 64 ? 192 + (int)blockIdx.x : -1;      // LTPL_DEBUG_TIMING: rows 192 .. 255 of the stamp table
-    vl_stamp(dbg, drow, 0);
-    if ((int)blockIdx.x >= out.job_cnt[1]) return;
-    const int slot = out.job_slot[out.n_slots_pad + blockIdx.x];
-    follow_prep(lat, in, out, vin, prep, out.n_pts[slot], out.path_param + (size_t)slot * out.cap_pts * 5, slot / LTPL_MAX_ACTIONS, slot, lane,
-                dbg, drow);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1757,6 +1781,7 @@ struct ltpl_handle {
     // descriptor came without raceline / node_psi columns
     ltplp::HostLat hostlat; bool has_hostlat = false;
     int scratch_poison_on = 0; unsigned scratch_poison_word = 0;   // LTPL_SCRATCH_POISON (testing)
+    int exp_skip = 0;                                               // LTPL_EXP_SKIP (timing experiments only): 1 prep, 2 lanes, 4 final kernel not launched
     int force_fused = 0, no_overlap = 0;                            // LTPL_FORCE_FUSED, LTPL_NO_OVERLAP (measurement switches)
     int poll_sync_every = 4096, poll_query = 0;
     int poll = 0;                    // LTPL_POLL=1: small zero-copy calls complete through a polled word in page-locked memory instead of a stream
@@ -2189,6 +2214,7 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
     if (const char* e = getenv("LTPL_SCRATCH_POISON")) { h->scratch_poison_on = 1; h->scratch_poison_word = (unsigned)strtoul(e, nullptr, 0); }
     h->force_fused = getenv("LTPL_FORCE_FUSED") ? 1 : 0;
     h->no_overlap = getenv("LTPL_NO_OVERLAP") ? 1 : 0;
+    if (const char* e = getenv("LTPL_EXP_SKIP")) h->exp_skip = atoi(e);
     if (const char* e = getenv("LTPL_NW1_MIN_SCEN")) h->nw1_min_scen = atoi(e) > 0 ? atoi(e) : PIPELINE_MIN_SCEN;
     if (getenv("LTPL_DEBUG_TIMING")) {
         if (hipMalloc(reinterpret_cast<void**>(&h->d_dbg), sizeof(long long) * 256 * DBG_SLOTS) == hipSuccess) {
@@ -2380,7 +2406,7 @@ static void bind_out(unsigned char* db, const OutLayout& lo, int cap_nodes, int 
     d->n_ties = reinterpret_cast<int*>(db + lo.n_ties); d->nodes = reinterpret_cast<int*>(db + lo.nodes);
     d->node_idx = reinterpret_cast<int*>(db + lo.node_idx); d->coeff = reinterpret_cast<double*>(db + lo.coeff);
     d->path_param = reinterpret_cast<double*>(db + lo.path_param);
-    d->vke = nullptr; d->job_cnt = nullptr; d->job_slot = nullptr; d->n_slots_pad = 0;
+    d->vke = nullptr; d->vxy = nullptr; d->job_cnt = nullptr; d->job_slot = nullptr; d->n_slots_pad = 0;
     d->done.host_flag = nullptr; d->done.dev_count = nullptr; d->done.seq = 0u;
 }
 
@@ -2730,7 +2756,7 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
     // tiled planes by job: K, E, P0 for generic + follow jobs, P1, P2, P3 for follow jobs; flags, job table and counters behind
     {
         const size_t tiles = (size_t)t->n_slots_pad + (size_t)t->n_scen_pad;
-        t->planes_bytes = t->pipeline ? sizeof(double) * (size_t)cap_pts * (3 * tiles + 3 * (size_t)t->n_scen_pad)
+        t->planes_bytes = t->pipeline ? sizeof(double) * (size_t)cap_pts * (3 * tiles + 5 * (size_t)t->n_scen_pad)
                                             + sizeof(int) * (2 * tiles + 16 + 2 * (size_t)t->n_scen_pad) : 0;
     }
     t->prep_off = 0; t->prep_stride = 0;
@@ -2759,11 +2785,12 @@ static void tick_bind_outputs(TickLayout* t, unsigned char* dob, double* planes)
         const size_t per_all = (size_t)t->cap_pts * tiles, per_scen = (size_t)t->cap_pts * (size_t)t->n_scen_pad;
         t->vp.KE = reinterpret_cast<float2*>(planes); t->vp.P0 = planes + 2 * per_all;       // (the second plane-sized region is unused)
         t->vp.P1 = planes + 3 * per_all; t->vp.P2 = t->vp.P1 + per_scen; t->vp.P3 = t->vp.P2 + per_scen;
-        int* ints = reinterpret_cast<int*>(t->vp.P3 + per_scen);
+        t->vp.XY = t->vp.P3 + per_scen;
+        int* ints = reinterpret_cast<int*>(t->vp.XY + 2 * per_scen);
         t->vp.flags = ints; t->dout.job_slot = ints + tiles; t->dout.job_cnt = ints + 2 * tiles; t->vp.fseg = ints + 2 * tiles + 16;
         t->dout.n_slots_pad = t->n_slots_pad;
         t->vp.cap_pts = t->cap_pts;
-        t->dout.vke = t->vp.KE;
+        t->dout.vke = t->vp.KE; t->dout.vxy = t->vp.XY;
     }
 }
 
@@ -2808,15 +2835,18 @@ static int tick_launch_vel(ltpl_handle* h, const TickLayout& t, hipStream_t st, 
     // slots without a path: vel_bound = too_close = 0 (the job kernels only touch slots that own a job)
     HIP_TRY(h, hipMemsetAsync(t.dvout.vel_bound, 0, sizeof(int) * (size_t)t.n_scen * LTPL_MAX_ACTIONS, st));
     HIP_TRY(h, hipMemsetAsync(t.dvout.too_close, 0, sizeof(int) * (size_t)t.n_scen * LTPL_MAX_ACTIONS, st));
-    hipLaunchKernelGGL(k_follow_prep, dim3(t.n_scen), dim3(64), 0, st, h->lat, t.di, t.dout,
-                       t.dvin, t.dprep, t.n_scen, h->lp4.dbg);
+    if (!(h->exp_skip & 1))
+    hipLaunchKernelGGL(k_follow_prep, dim3((t.n_scen + 63) / 64), dim3(64), 0, st, h->lat, t.di, t.dout,
+                       t.dvin, t.dprep, t.vp, t.n_scen, h->lp4.dbg);
     HIP_TRY(h, hipGetLastError());
     if (ev_after_prep) HIP_TRY(h, hipEventRecord(ev_after_prep, st));
     const int n_slots = t.n_scen * LTPL_MAX_ACTIONS;
     const int nb0 = (n_slots + 63) / 64, nb1 = (t.n_scen + 63) / 64;
+    if (!(h->exp_skip & 2))
     hipLaunchKernelGGL(lanes_kernel_of(t.variant), dim3(nb0 + 2 * nb1), dim3(64), 0, st, h->lat, t.di, t.dout,
                        t.p, t.dvin, t.dprep, t.vp, n_slots, t.n_scen, nb0, h->lp4.dbg);
     HIP_TRY(h, hipGetLastError());
+    if (!(h->exp_skip & 4))
     hipLaunchKernelGGL(k_vel_final, dim3(nb0 + nb1, (t.cap_pts + FCH - 1) / FCH), dim3(64), 0, st, t.dout, t.dvin, t.dvout, t.vp, n_slots, t.n_scen);
     HIP_TRY(h, hipGetLastError());
     return LTPL_OK;
