@@ -515,6 +515,31 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
             mx[i] = dx; my[i] = dy; cpy[i] = 2.0 * (ai + ci);
         }
         wave_sync_lds();
+        if (N <= 63) {
+            // Parallel cyclic reduction (lane = row i of the system, i = 1 .. N-1 unknown slopes; rows 0 and N and every lane
+            // beyond are IDENTITY rows a = c = 0, b = 1, d = 0, which the update leaves unchanged -- no masks anywhere): log2(N)
+            // rounds in which every row eliminates its two neighbours at distance 1, 2, 4, ... The serial elimination (Thomas) ran
+            // ~30 instructions per ROW on two lanes. The system is strictly diagonally dominant (b = 2 (a + c)), so PCR is as
+            // stable as the elimination; the slopes agree to rounding.
+            const int i = lane;
+            const bool row = i >= 1 && i <= N - 1;
+            double ra = 0.0, rb = 1.0, rc = 0.0, rx = 0.0, ry = 0.0;
+            if (row) { ra = (i == 1) ? 0.0 : cpx[i - 1]; rc = (i == N - 1) ? 0.0 : cpx[i]; rb = cpy[i]; rx = mx[i]; ry = my[i]; }
+            wave_sync_lds();
+            for (int st = 1; st < N - 1; st <<= 1) {
+                if (i <= N) { cpx[i] = ra; cpy[i] = rb; mx[i] = rx; my[i] = ry; }
+                wave_sync_lds();
+                const int lo = i - st > 0 ? i - st : 0, hi = i + st < N ? i + st : N;
+                const double cm = __shfl(rc, lo), cp = __shfl(rc, hi);
+                const double al = -ra * fast_rcp(cpy[lo]), ga = -rc * fast_rcp(cpy[hi]);
+                rb = rb + al * cm + ga * cpx[hi];
+                rx = rx + al * mx[lo] + ga * mx[hi]; ry = ry + al * my[lo] + ga * my[hi];
+                ra = al * cpx[lo]; rc = ga * cp;
+                wave_sync_lds();
+            }
+            if (row) { const double ib = fast_rcp(rb); mx[i] = rx * ib; my[i] = ry * ib; }
+            if (lane == 0) { mx[0] = sx0; my[0] = sy0; mx[N] = sxN; my[N] = syN; }
+        } else {
         if (lane < 2) {
             double* m = lane == 0 ? mx : my;
             m[0] = lane == 0 ? sx0 : sy0; m[N] = lane == 0 ? sxN : syN;
@@ -534,6 +559,7 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
         if (lane < 2) {
             double* m = lane == 0 ? mx : my;
             for (int i = N - 2; i >= 1; --i) m[i] = m[i] - cpy[i] * m[i + 1];
+        }
         }
     }
     wave_sync_lds();
