@@ -955,8 +955,27 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             mref += (lat.sampled_resolution * lat.sampled_resolution) / 4;
             msq = sqrt(mref);
         }
-        if (__ballot(ol >= 0) == 0ull) continue;
+        unsigned long long gated = __ballot(ol >= 0);
+        if (gated == 0ull) continue;
+        // transitions of the planning range that any position's window touches (a handful of the H layers): bit j
+        const bool sparse = H <= 63;                                    // (long-horizon lattices: every transition is looked at)
+        unsigned long long jbits = 0ull;
+        if (sparse) {
+            int jj = ol - sc.sl; if (jj < 0) jj += L;                 // transition INTO layer ol; INTO ol + 1 is jj + 1 (never across the seam)
+            unsigned long long mine = 0ull;
+            if (ol >= 0) {
+                if (jj >= 1 && jj <= H) mine |= 1ull << jj;
+                if (ol + 1 < L && jj + 1 >= 1 && jj + 1 <= H) mine |= 1ull << (jj + 1);
+            }
+            const unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
+            while (gated) {
+                const int src_lane = __ffsll((long long)gated) - 1;
+                gated &= gated - 1;
+                jbits |= (unsigned long long)__builtin_amdgcn_readlane(lo, src_lane) | ((unsigned long long)__builtin_amdgcn_readlane(hi, src_lane) << 32);
+            }
+        }
         for (int j = 1; j <= H; ++j) {
+            if (sparse) { if (!jbits) break; j = __ffsll((long long)jbits) - 1; jbits &= jbits - 1; }
             int b = sc.sl + j; if (b >= L) b -= L;
             unsigned long long m = __ballot(ol >= 0 && (ol == b || ol + 1 == b));
             if (m == 0ull) continue;

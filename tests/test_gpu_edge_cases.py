@@ -126,3 +126,38 @@ def test_resident_batch_is_dropped_by_other_entry_points(monteblanco, hip_backen
     hip_backend.plan_paths(_capi.PathsBatch(scen[:3], w_last_edges=[0.0, 0.5, 0.8]))
     with pytest.raises(_capi.BackendError):
         hip_backend.batch_run(reps=1, timed=False)
+
+
+@pytest.mark.parametrize("env", [{"LTPL_POLL": "1"}, {"LTPL_ZC_OUT": "0"}, {"LTPL_ZC_IN": "1", "LTPL_POLL": "1"}])
+def test_latency_transport_variants_give_identical_results(monteblanco, hip_backend, monkeypatch, env):
+    """The transport of the single-tick path (zero-copy outputs in page-locked memory, optional polled completion word, optional
+    zero-copy inputs) must not change a bit of the results: a second handle created under the switches against the default one,
+    on seam (1), seam (2) jobs through the fused tick, one scenario per call."""
+    from scenarios import random_scenarios
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    other = _capi.HipBackend(monteblanco)
+    scen, vels = random_scenarios(monteblanco, 12, seed=77)
+    params = _capi.VelParamSet(len_veh=monteblanco.veh_length)
+    for i in range(12):
+        batch = _capi.PathsBatch(scen[i:i + 1], w_last_edges=W_LAST)
+        a, b = hip_backend.plan_paths(batch), other.plan_paths(batch)
+        assert int(a.n_actions[0]) == int(b.n_actions[0])
+        na = int(a.n_actions[0])
+        for name in ("action_id", "valid", "n_nodes", "n_pts"):
+            assert np.array_equal(getattr(a, name)[0, :na], getattr(b, name)[0, :na]), (i, name)
+        for k in range(na):
+            if a.valid[0, k]:
+                n, nn = int(a.n_pts[0, k]), int(a.n_nodes[0, k])
+                assert np.array_equal(a.nodes[0, k, :nn], b.nodes[0, k, :nn]) and np.array_equal(a.node_idx[0, k, :nn], b.node_idx[0, k, :nn])
+                assert np.array_equal(a.path_param[0, k, :n], b.path_param[0, k, :n]), (i, k)
+        sl, sn = scen[i]['start_node']
+        pos = monteblanco.node_pos[monteblanco.layer_off[sl] + sn][None, :]
+        vel = _capi.TickVelBatch(params, 1, np.full(1, 20.0), np.full(1, 20.0), pos, vels[i])
+        ra, va = hip_backend.tick_batch(batch, vel)
+        rb, vb = other.tick_batch(batch, vel)
+        for k in range(int(ra.n_actions[0])):
+            if ra.valid[0, k]:
+                n = int(ra.n_pts[0, k])
+                assert np.array_equal(va.vx[0, k, :n], vb.vx[0, k, :n]) and np.array_equal(va.ax[0, k, :n], vb.ax[0, k, :n]), (i, k)
+        assert np.array_equal(va.vel_bound, vb.vel_bound) and np.array_equal(va.too_close, vb.too_close)
