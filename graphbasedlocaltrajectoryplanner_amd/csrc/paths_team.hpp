@@ -824,6 +824,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     int4* lay = reinterpret_cast<int4*>(smem + P::off_lay(lp));
 
     dbg_stamp(lp.dbg, 0);
+    if (lp.ablate & 8) { WavePath w0; w0.valid = 0; w0.n_pts = 0; w0.n_nodes = 0; w0.name = LTPL_ACT_NONE; w0.reduced = 0; w0.goal_layer = -1; w0.end_node = -1; return w0; }   // timing experiment: launch cost only
     // ---- phase 0: scenario scalars (uniform; the planning range only depends on the start layer and is tabulated at
     //      ltpl_create: gen_local_node_template.py:101-147) -----------------------------------------------------------
     if (lp.poison_on) {
