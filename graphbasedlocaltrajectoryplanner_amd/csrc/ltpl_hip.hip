@@ -102,7 +102,7 @@ struct DevPathsOut {
     // the lanes of a velocity wave (64 consecutive jobs of one class) are all busy and equally long
     int* job_cnt;                    // [2]
     int* job_slot;                   // [n_slots_pad] generic jobs -> slot, then [n_scen_pad] follow jobs -> slot
-    int n_slots_pad;                 // tile index of follow job j = n_slots_pad + j
+    int n_slots_pad;                 // tile index of follow job j = n_slots_pad + j (rows of the blocked planes: cap_pts rounded up to 8)
     DoneSignal done;                 // latency path only (k_paths / k_tick launched for a few scenarios)
 };
 
@@ -931,6 +931,7 @@ struct VelPlanes {              // tiled planes (doubles), tile index = job inde
     int* fseg;                  // per follow job [2]: n_decel (-1: everything from the brake profile), stop_idx -- composition of
                                 // "vx_profile" (:289 / :294) from P2 / P3 / zeros, done by k_vel_final (VF_COMPOSE)
     int cap_pts;
+    int plane_rows;             // rows of the blocked planes KE / XY (kep_base / kep_row, paths_team.hpp)
 };
 
 __device__ __forceinline__ size_t tile_base(int idx, int cap_pts) { return ((size_t)(idx >> 6) * cap_pts) * 64 + (idx & 63); }
@@ -977,9 +978,10 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
     if (has_v_end && v_end < 0.0) v_end = 0.0;
     const double vmax2 = v_max * v_max, icay = 1.0 / cay, axm1 = axm_tab[1], dm = p.drag_m, axa = fabs(cax);
     const double vend2 = has_v_end ? v_end * v_end : INFINITY;
-    const float2* KEp = L.KE + (size_t)off * 64;
+    const float2* KEb = L.KE;                         // row r of this profile: KEb[kep_row(off + r)]
+#define KE_AT(r) KEb[kep_row(off + (r))]
     double* Dp = D + (size_t)off * 64;
-    const float2 rec0 = KEp[0];
+    const float2 rec0 = KE_AT(0);
     double kabs_i = (double)rec0.x, e_i = (double)rec0.y;
     double wi = fmin(cay * (double)__builtin_amdgcn_rcpf(rec0.x), vmax2);
     if (wi > v_start * v_start) wi = v_start * v_start;
@@ -999,7 +1001,7 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
         float2 kr[LCHA], kn[LCHA];
         const int nst = n - 1;
 #pragma unroll
-        for (int c = 0; c < LCHA; ++c) { const int r = 1 + c < n ? 1 + c : n - 1; kr[c] = KEp[(size_t)r * 64]; }
+        for (int c = 0; c < LCHA; ++c) { const int r = 1 + c < n ? 1 + c : n - 1; kr[c] = KE_AT(r); }
         auto step = [&](const float2& rec, int i, bool valid) {
             const double w0n = fmin(cay * (double)__builtin_amdgcn_rcpf(rec.x), vmax2);    // 1 / |kappa| in fp32 (1 ulp), inf on straights
             const bool acc = w0n > orig_p;
@@ -1019,7 +1021,7 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #pragma unroll
             for (int c = 0; c < LCHA; ++c) {                   // operands of the next chunk (clamped rows: harmless re-reads at the end)
                 const int r = base + LCHA + 1 + c < n ? base + LCHA + 1 + c : n - 1;
-                kn[c] = KEp[(size_t)r * 64];
+                kn[c] = KE_AT(r);
             }
 #pragma unroll
             for (int c = 0; c < LCHA; ++c) step(kr[c], base + c, true);
@@ -1031,13 +1033,13 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
             for (int c = 0; c < LCHA; ++c) step(kr[c], base + c, base + c < nst);
         }
         if (wi > vend2) { wi = vend2; Dp[(size_t)(n - 1) * 64] = wi; }            // the end-velocity clamp of the last step
-        kabs_i = (double)KEp[(size_t)(n - 1) * 64].x;                             // |kappa| of the last row (start of the backward sweep)
+        kabs_i = (double)KE_AT(n - 1).x;                             // |kappa| of the last row (start of the backward sweep)
     } else {
         double orig_i = wi;
         bool active = false, prev_acc = false;
         float2 kr[LCHF], kn[LCHF];
 #pragma unroll
-        for (int c = 0; c < LCHF; ++c) { const int r = 1 + c < n ? 1 + c : n - 1; kr[c] = KEp[(size_t)r * 64]; }
+        for (int c = 0; c < LCHF; ++c) { const int r = 1 + c < n ? 1 + c : n - 1; kr[c] = KE_AT(r); }
         for (int base = 0; base < n - 1; base += LCHF) {
 #pragma unroll
             for (int c = 0; c < LCHF; ++c) {                   // operands of the next chunk (clamped rows: harmless re-reads at the end)
@@ -1045,7 +1047,7 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #ifdef LTPL_EXP_NOLOAD
                 kn[c] = make_float2(0.01f + 1e-6f * (float)r, 2.0f);
 #else
-                kn[c] = KEp[(size_t)r * 64];
+                kn[c] = KE_AT(r);
 #endif
             }
 #pragma unroll
@@ -1093,7 +1095,7 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #pragma unroll
         for (int c = 0; c < LCHB; ++c) {
             const int r = n - 2 - c >= 0 ? n - 2 - c : 0;
-            kr[c] = KEp[(size_t)r * 64]; wr[c] = Dp[(size_t)r * 64];
+            kr[c] = KE_AT(r); wr[c] = Dp[(size_t)r * 64];
         }
         auto step = [&](const float2& rec, double wold, int i, bool valid) {
             const bool acc = wold > orig_p;
@@ -1117,7 +1119,7 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #pragma unroll
             for (int c = 0; c < LCHB; ++c) {
                 const int r = n - 2 - base - LCHB - c >= 0 ? n - 2 - base - LCHB - c : 0;
-                kn[c] = KEp[(size_t)r * 64]; wq[c] = Dp[(size_t)r * 64];
+                kn[c] = KE_AT(r); wq[c] = Dp[(size_t)r * 64];
             }
 #pragma unroll
             for (int c = 0; c < LCHB; ++c) step(kr[c], wr[c], base + c, true);
@@ -1135,14 +1137,14 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #pragma unroll
         for (int c = 0; c < LCHB; ++c) {
             const int r = n - 2 - c >= 0 ? n - 2 - c : 0;
-            kr[c] = KEp[(size_t)r * 64]; wr[c] = Dp[(size_t)r * 64];
+            kr[c] = KE_AT(r); wr[c] = Dp[(size_t)r * 64];
         }
         for (int base = 0; base < n - 1; base += LCHB) {
             // rows of the next chunk are not written by this chunk's steps (a step only rewrites its own row n - 2 - i)
 #pragma unroll
             for (int c = 0; c < LCHB; ++c) {
                 const int r = n - 2 - base - LCHB - c >= 0 ? n - 2 - base - LCHB - c : 0;
-                kn[c] = KEp[(size_t)r * 64]; wq[c] = Dp[(size_t)r * 64];
+                kn[c] = KE_AT(r); wq[c] = Dp[(size_t)r * 64];
             }
 #pragma unroll
             for (int c = 0; c < LCHB; ++c) {
@@ -1179,6 +1181,8 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
     }
 }
 
+#undef KE_AT
+
 #define VF_BOUND_FOLLOW 1
 #define VF_TOO_CLOSE    2
 #define VF_HAS_GENERIC  4
@@ -1199,9 +1203,9 @@ __device__ int lane_generic_profile(const DevLat& lat, const DevPathsOut& out, c
     if (reduced) {
         v_end = 0.0;
         double spl_len = 0.0;
-        for (int i = 0; i < n - 1; ++i) spl_len += (double)L.KE[(size_t)i * 64].y;
+        for (int i = 0; i < n - 1; ++i) spl_len += (double)L.KE[kep_row(i)].y;
         int first = -1; double c = 0.0;
-        for (int i = 0; i < n - 1; ++i) { c += (double)L.KE[(size_t)i * 64].y; if (first < 0 && !(c < (spl_len - 5.0))) first = i; }
+        for (int i = 0; i < n - 1; ++i) { c += (double)L.KE[kep_row(i)].y; if (first < 0 && !(c < (spl_len - 5.0))) first = i; }
         v_idx = (first < 0 ? 0 : first) + 1;
         if (v_idx == 1 && n > 1) v_idx = n;
     } else {
@@ -1240,7 +1244,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
         const int j = (b - nbG - nbF) * 64 + lane;
         if (j >= cntF) return;
         const int slot = out.job_slot[fbase + j];
-        LaneProf L; L.KE = vp.KE + tile_base(fbase + j, vp.cap_pts);
+        LaneProf L; L.KE = vp.KE + kep_base(fbase + j, vp.plane_rows);
         lane_fb_profile<EM, AXM1>(L, vp.P1 + tile_base(j, vp.cap_pts), 0, out.n_pts[slot], cax, cay, p, axm_tab, p.v_max,
                                   vin.vel_plan[slot / LTPL_MAX_ACTIONS], false, 0.0, dbg, drow);
         vl_stamp(dbg, drow, 6);
@@ -1253,7 +1257,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
     const int slot = out.job_slot[tile];
     const int s = slot / LTPL_MAX_ACTIONS;
     const int n = out.n_pts[slot];
-    LaneProf L; L.KE = vp.KE + tile_base(tile, vp.cap_pts);
+    LaneProf L; L.KE = vp.KE + kep_base(tile, vp.plane_rows);
     double* P0 = vp.P0 + tile_base(tile, vp.cap_pts);
     double* P2 = vp.P2 + tile_base(fjob ? j : 0, vp.cap_pts);
     double* P3 = vp.P3 + tile_base(fjob ? j : 0, vp.cap_pts);
@@ -1320,7 +1324,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
 #pragma unroll
                 for (int c = 0; c < LCH; ++c) {
                     const int r = base + c < n ? base + c : n - 1;
-                    const float2 ke = L.KE[(size_t)r * 64]; k[c] = (double)ke.x; e[c] = (double)ke.y;
+                    const float2 ke = L.KE[kep_row(r)]; k[c] = (double)ke.x; e[c] = (double)ke.y;
                 }
             };
             load_rows(0, kr, er);
@@ -1465,7 +1469,7 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
         const double* P1 = vp.P1 + tile_base(fjob ? j : 0, vp.cap_pts);
         const double* P2 = vp.P2 + tile_base(fjob ? j : 0, vp.cap_pts);
         const double* P3 = vp.P3 + tile_base(fjob ? j : 0, vp.cap_pts);
-        const float2* KE = vp.KE + tile_base(tile, vp.cap_pts);
+        const float2* KE = vp.KE + kep_base(tile, vp.plane_rows);
         const bool compose = follow && (flags & VF_COMPOSE);
         const int nd = compose ? vp.fseg[2 * j] : 0, stop_idx = compose ? vp.fseg[2 * j + 1] : 0;
         int vel_bound = follow ? ((flags & VF_BOUND_FOLLOW) ? 1 : 0) : ((flags & VF_BOUND_GENERIC) ? 1 : 0);
@@ -1490,7 +1494,7 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
 #pragma unroll
         for (int c = 0; c <= FCH; ++c) w[c] = value(base + c < n ? base + c : n - 1);
 #pragma unroll
-        for (int c = 0; c < FCH; ++c) er[c] = (double)KE[(size_t)(base + c < n ? base + c : n - 1) * 64].y;
+        for (int c = 0; c < FCH; ++c) er[c] = (double)KE[kep_row(base + c < n ? base + c : n - 1)].y;
 #pragma unroll
         for (int c = 0; c < FCH; ++c) {
             const int i = base + c;
@@ -1577,8 +1581,8 @@ __global__ __launch_bounds__(64) void k_follow_prep(DevLat lat, DevPathsIn in, D
     }
     vl_stamp(dbg, drow, 2);
     if (__ballot(have) != 0ull) {
-        const double* xy = vp.XY + 2 * tile_base(j, vp.cap_pts);           // pairs: row r of this lane's job at xy + r * 128
-        const float2* KE = vp.KE + tile_base(out.n_slots_pad + j, vp.cap_pts);
+        const double* xy = vp.XY + 2 * kep_base(j, vp.plane_rows);         // pairs: row r of this lane's job at xy + 2 * kep_row(r)
+        const float2* KE = vp.KE + kep_base(out.n_slots_pad + j, vp.plane_rows);
         int nmax = n;
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(nmax, m); nmax = o > nmax ? o : nmax; }
@@ -1590,7 +1594,7 @@ __global__ __launch_bounds__(64) void k_follow_prep(DevLat lat, DevPathsIn in, D
 #pragma unroll
             for (int c = 0; c < PCH; ++c) {
                 const int r = base + c < n ? base + c : n - 1;
-                p[c] = *reinterpret_cast<const dbl2*>(xy + (size_t)r * 128); k[c] = KE[(size_t)r * 64];
+                p[c] = *reinterpret_cast<const dbl2*>(xy + 2 * kep_row(r)); k[c] = KE[kep_row(r)];
             }
         };
         load_rows(0, pr, kr);
@@ -1613,8 +1617,8 @@ __global__ __launch_bounds__(64) void k_follow_prep(DevLat lat, DevPathsIn in, D
         // get_s_coord.py:34-99 (closed = False) for one query: arc length of the foot point
         auto foot = [&](int nb, double s_nb, double e_before, double px, double py) {
             const int i1 = nb - 1 > 0 ? nb - 1 : 0, i2 = nb + 1 < n - 1 ? nb + 1 : n - 1;
-            const dbl2 pN = *reinterpret_cast<const dbl2*>(xy + (size_t)nb * 128), p1 = *reinterpret_cast<const dbl2*>(xy + (size_t)i1 * 128),
-                       p2 = *reinterpret_cast<const dbl2*>(xy + (size_t)i2 * 128);
+            const dbl2 pN = *reinterpret_cast<const dbl2*>(xy + 2 * kep_row(nb)), p1 = *reinterpret_cast<const dbl2*>(xy + 2 * kep_row(i1)),
+                       p2 = *reinterpret_cast<const dbl2*>(xy + 2 * kep_row(i2));
             const int ord = angle_order_dev(pN.x, pN.y, px, py, p1.x, p1.y, p2.x, p2.y);
             double ax, ay, bx, by;
             if (ord > 0) { ax = p1.x; ay = p1.y; bx = pN.x; by = pN.y; } else { ax = pN.x; ay = pN.y; bx = p2.x; by = p2.y; }
@@ -2756,7 +2760,8 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
     // tiled planes by job: K, E, P0 for generic + follow jobs, P1, P2, P3 for follow jobs; flags, job table and counters behind
     {
         const size_t tiles = (size_t)t->n_slots_pad + (size_t)t->n_scen_pad;
-        t->planes_bytes = t->pipeline ? sizeof(double) * (size_t)cap_pts * (3 * tiles + 5 * (size_t)t->n_scen_pad)
+        const size_t plane_rows = align_up((size_t)cap_pts, 8);
+        t->planes_bytes = t->pipeline ? sizeof(double) * ((size_t)cap_pts * (3 * tiles + 3 * (size_t)t->n_scen_pad) + 2 * plane_rows * (size_t)t->n_scen_pad)
                                             + sizeof(int) * (2 * tiles + 16 + 2 * (size_t)t->n_scen_pad) : 0;
     }
     t->prep_off = 0; t->prep_stride = 0;
@@ -2786,10 +2791,11 @@ static void tick_bind_outputs(TickLayout* t, unsigned char* dob, double* planes)
         t->vp.KE = reinterpret_cast<float2*>(planes); t->vp.P0 = planes + 2 * per_all;       // (the second plane-sized region is unused)
         t->vp.P1 = planes + 3 * per_all; t->vp.P2 = t->vp.P1 + per_scen; t->vp.P3 = t->vp.P2 + per_scen;
         t->vp.XY = t->vp.P3 + per_scen;
-        int* ints = reinterpret_cast<int*>(t->vp.XY + 2 * per_scen);
+        const size_t plane_rows = align_up((size_t)t->cap_pts, 8);
+        int* ints = reinterpret_cast<int*>(t->vp.XY + 2 * plane_rows * (size_t)t->n_scen_pad);
         t->vp.flags = ints; t->dout.job_slot = ints + tiles; t->dout.job_cnt = ints + 2 * tiles; t->vp.fseg = ints + 2 * tiles + 16;
         t->dout.n_slots_pad = t->n_slots_pad;
-        t->vp.cap_pts = t->cap_pts;
+        t->vp.cap_pts = t->cap_pts; t->vp.plane_rows = (int)plane_rows;
         t->dout.vke = t->vp.KE; t->dout.vxy = t->vp.XY;
     }
 }

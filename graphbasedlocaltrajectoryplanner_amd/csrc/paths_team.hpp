@@ -37,6 +37,19 @@ __device__ __forceinline__ double fast_rcp(double b)
     return r;
 }
 
+// (|kappa|, e) / (x, y) planes of the batch velocity stage: tiled by job and BLOCKED by rows -- element (job, row) lives at
+//   ((job / 64 * plane_rows / 8 + row / 8) * 64 + job % 64) * 8 + row % 8
+// so that the path kernel (lane = row of ONE job) writes 8 rows = 64 contiguous bytes per block instead of one 8-byte element on
+// each of 64 cache lines (measured: the scattered plane stores were 45 us of the 1.1 ms launch), while the velocity kernels
+// (lane = job) still find the rows of a chunk in the lines they already touched.
+#define KE_RB 8
+// (32-bit element indices: a plane holds < 2^31 elements for any batch that fits the device)
+__device__ __forceinline__ unsigned kep_base(int job, int plane_rows)
+{
+    return ((unsigned)(job >> 6) * (unsigned)(plane_rows >> 3) * 64u + (unsigned)(job & 63)) * KE_RB;
+}
+__device__ __forceinline__ unsigned kep_row(int r) { return ((unsigned)(r >> 3) << 9) + (unsigned)(r & 7); }
+
 // element i of a lattice array (0 <= i, array < 4 GB): the byte offset is formed in 32 bits, which lets the compiler address the
 // element as scalar base + 32-bit lane offset instead of building a 64-bit address per lane
 template <class T>
@@ -606,13 +619,12 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
         const double len_r = at(lat.slen, pedge[i] + k);
         store2_u(row, x, y); store2_u(row + 2, psi_r, kap); row[4] = len_r;
         if (vel_kappa) { vel_kappa[r] = kap; vel_len[r] = len_r; }
-        if (out.vke) {                                    // tiled planes of the batch velocity stage
-            const size_t o = (((size_t)(vtile >> 6) * out.cap_pts) + r) * 64 + (vtile & 63);
-            out.vke[o] = make_float2((float)fabs(kap), (float)len_r);
-            if (vtile >= out.n_slots_pad) {               // follow job: (x, y) for the lane-per-job follow preparation
-                const int fj = vtile - out.n_slots_pad;
-                store2(out.vxy + 2 * ((((size_t)(fj >> 6) * out.cap_pts) + r) * 64 + (fj & 63)), x, y);
-            }
+        if (out.vke) {                                    // planes of the batch velocity stage
+            const unsigned ro = kep_row(r);
+            const int plane_rows = (out.cap_pts + 7) & ~7;
+            out.vke[kep_base(vtile, plane_rows) + ro] = make_float2((float)fabs(kap), (float)len_r);
+            if (vtile >= out.n_slots_pad)                 // follow job: (x, y) for the lane-per-job follow preparation
+                store2(out.vxy + 2 * (size_t)(kep_base(vtile - out.n_slots_pad, plane_rows) + ro), x, y);
         }
         if (vel_x) { vel_x[r] = x; vel_y[r] = y; }
     }
