@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? (P::fixed ? 4 : LTPL_RT_WAVES) 
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ TeamShared ts;
     (void)team_paths_body<NW, P>(lat, in, out, lp, smem, ts, nullptr, nullptr, nullptr, nullptr);
-    signal_done(out.done);
+    if constexpr (NW != 1) signal_done(out.done);          // (only the four-wave latency form is launched with a completion word)
 }
 typedef PlanFx<32, 32, 1> PlanA;      // <= 32 nodes per layer, <= 31 layers of planning range (Monteblanco, stock parameters)
 typedef PlanFx<32, 40, 1> PlanB;      // <= 32 nodes per layer, <= 39 layers (synthetic C3 oval)
@@ -2508,7 +2508,8 @@ static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_o
     // addressing): the kernel's stores cross PCIe as posted writes, no D2H copy is enqueued
     const bool zc = h->zc_out && in->n_scen <= 8;
     bind_out(static_cast<unsigned char*>(zc ? h->h_out : h->d_out), lo, out->cap_nodes, out->cap_pts, &dout);
-    const bool polled = zc && h->poll && !h->d_dbg;
+    const int nw = force_nw ? force_nw : ((in->n_scen >= h->nw1_min_scen && h->batch_nw == 1) ? 1 : NUM_WAVES);
+    const bool polled = zc && h->poll && !h->d_dbg && nw != 1;      // (the one-wave batch form carries no completion word)
     if (polled) dout.done = next_done_signal(h);
     prof_pack.stop();
     LTPL_PROF(prof_enq, "plan_paths.enqueue");
@@ -2517,7 +2518,6 @@ static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_o
         if (!zci) HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, li.total, hipMemcpyHostToDevice, h->stream));
     }
     scratch_poison(h);
-    const int nw = force_nw ? force_nw : ((in->n_scen >= h->nw1_min_scen && h->batch_nw == 1) ? 1 : NUM_WAVES);
     {
         LTPL_PROF(prof_l, "plan_paths.enqueue.launch");
         if ((rc = launch_paths(h, nw, in->n_scen, h->stream, di, dout))) return rc;

@@ -619,12 +619,15 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
         const double len_r = at(lat.slen, pedge[i] + k);
         store2_u(row, x, y); store2_u(row + 2, psi_r, kap); row[4] = len_r;
         if (vel_kappa) { vel_kappa[r] = kap; vel_len[r] = len_r; }
-        if (out.vke) {                                    // planes of the batch velocity stage
-            const unsigned ro = kep_row(r);
-            const int plane_rows = (out.cap_pts + 7) & ~7;
-            out.vke[kep_base(vtile, plane_rows) + ro] = make_float2((float)fabs(kap), (float)len_r);
-            if (vtile >= out.n_slots_pad)                 // follow job: (x, y) for the lane-per-job follow preparation
-                store2(out.vxy + 2 * (size_t)(kep_base(vtile - out.n_slots_pad, plane_rows) + ro), x, y);
+        if (out.vke) {                                    // planes of the batch velocity stage, blocked by 8 rows (kep_base / kep_row):
+            // r = lane + 64 k, so kep_row(r) = kep_row(lane) + 64 (r - lane)
+            const int nrb = (out.cap_pts + 7) >> 3;
+            const size_t ro = (size_t)(((lane >> 3) << 9) + (lane & 7)) + (size_t)(r - lane) * 64;
+            out.vke[((size_t)(vtile >> 6) * nrb * 64 + (vtile & 63)) * KE_RB + ro] = make_float2((float)fabs(kap), (float)len_r);
+            if (vtile >= out.n_slots_pad) {               // follow job: (x, y) for the lane-per-job follow preparation
+                const int fj = vtile - out.n_slots_pad;
+                store2(out.vxy + 2 * (((size_t)(fj >> 6) * nrb * 64 + (fj & 63)) * KE_RB + ro), x, y);
+            }
         }
         if (vel_x) { vel_x[r] = x; vel_y[r] = y; }
     }
@@ -1239,12 +1242,18 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     }
     dbg_stamp(lp.dbg, 5);
     // ---- phase 5: search loop with horizon back-off (main_online_path_gen.py:187-248); uniform, every thread ---------
-    int slot_valid[LTPL_MAX_ACTIONS], slot_j[LTPL_MAX_ACTIONS], slot_name[LTPL_MAX_ACTIONS], slot_red[LTPL_MAX_ACTIONS];
+    // per action slot, ONE packed word (valid | reduced << 1 | (name + 1) << 2 | layer distance << 8): these uniform values live across the
+    // whole assembly; as four int arrays they ended up as a VGPR tuple in scratch once the kernel was at its 128-register budget
+    int slot_pk[LTPL_MAX_ACTIONS];
+    auto slot_valid = [&](int a) { return slot_pk[a] & 1; };
+    auto slot_red = [&](int a) { return (slot_pk[a] >> 1) & 1; };
+    auto slot_name = [&](int a) { return ((slot_pk[a] >> 2) & 63) - 1; };
+    auto slot_j = [&](int a) { return slot_pk[a] >> 8; };
     {
         const bool in_const = sc.flags & LTPL_FLAG_OBJ_IN_CONST;
         int mod_j = H;
         for (int a = 0; a < LTPL_MAX_ACTIONS; ++a) {
-            slot_valid[a] = 0; slot_j[a] = 0; slot_name[a] = LTPL_ACT_NONE; slot_red[a] = 0;
+            slot_pk[a] = (LTPL_ACT_NONE + 1) << 2;
             if (a >= n_act) continue;
             const int f = filt[a]; int nm = nm0[a];
             bool found = false;
@@ -1267,7 +1276,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                     else found = false;
                 }
             }
-            slot_valid[a] = found ? 1 : 0; slot_j[a] = mod_j; slot_name[a] = nm; slot_red[a] = reduced ? 1 : 0;
+            slot_pk[a] = (found ? 1 : 0) | (reduced ? 2 : 0) | ((nm + 1) << 2) | (mod_j << 8);
         }
         if (tid == 0) {
             for (int a = 0; a < LTPL_MAX_ACTIONS; ++a) {
@@ -1277,10 +1286,10 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                     out.n_nodes[slot] = 0; out.n_pts[slot] = 0; out.n_ties[slot] = 0;
                     continue;
                 }
-                int goal = sc.sl + slot_j[a]; if (goal >= L) goal -= L;
-                out.action_id[slot] = slot_name[a]; out.reduced[slot] = slot_red[a]; out.goal_layer[slot] = goal;
-                out.valid[slot] = slot_valid[a];
-                if (!slot_valid[a]) { out.n_nodes[slot] = 0; out.n_pts[slot] = 0; out.n_ties[slot] = 0; }
+                int goal = sc.sl + slot_j(a); if (goal >= L) goal -= L;
+                out.action_id[slot] = slot_name(a); out.reduced[slot] = slot_red(a); out.goal_layer[slot] = goal;
+                out.valid[slot] = slot_valid(a);
+                if (!slot_valid(a)) { out.n_nodes[slot] = 0; out.n_pts[slot] = 0; out.n_ties[slot] = 0; }
             }
         }
     }
@@ -1290,7 +1299,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
         bool any_resweep = false;
         for (int f = 0; f < NFILT; ++f) {
             int Jf = -1;
-            for (int a = 0; a < n_act; ++a) if (slot_valid[a] && filt[a] == f && slot_j[a] != H) Jf = slot_j[a];
+            for (int a = 0; a < n_act; ++a) if (slot_valid(a) && filt[a] == f && slot_j(a) != H) Jf = slot_j(a);
             if (Jf < 0) continue;
             any_resweep = true;
             if (wave == f % NW) team_resweep<P>(lat, in, sc, lp, smem, ts, f, Jf, lane);
@@ -1306,12 +1315,12 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     WavePath wp; wp.valid = 0; wp.n_pts = 0; wp.n_nodes = 0; wp.name = LTPL_ACT_NONE; wp.reduced = 0; wp.goal_layer = -1;
     wp.end_node = -1;
     for (int a = wave; a < n_act; a += NW) {
-        wp.name = slot_name[a]; wp.reduced = slot_red[a]; wp.valid = 0;
-        if (!slot_valid[a] || (lp.ablate & 4)) continue;
+        wp.name = slot_name(a); wp.reduced = slot_red(a); wp.valid = 0;
+        if (!slot_valid(a) || (lp.ablate & 4)) continue;
         unsigned char* pw = smem + P::off_path(lp) + (size_t)(wave < P::n_path_bufs(lp) ? wave : P::n_path_bufs(lp) - 1) * P::path_stride(lp);
         // after a re-sweep the parents of every layer belong to filter f itself
-        const bool sp = share_prefix && (filt[a] == F_LEFT || filt[a] == F_RIGHT) && slot_j[a] == H;
-        wp = team_assemble<P>(lat, in, out, sc, lp, smem, a, filt[a], slot_j[a], slot_name[a], slot_red[a], jcl, sp, lane, pw,
+        const bool sp = share_prefix && (filt[a] == F_LEFT || filt[a] == F_RIGHT) && slot_j(a) == H;
+        wp = team_assemble<P>(lat, in, out, sc, lp, smem, a, filt[a], slot_j(a), slot_name(a), slot_red(a), jcl, sp, lane, pw,
                            vel_kappa, vel_len, vel_x, vel_y);
     }
     dbg_stamp(lp.dbg, 7);
