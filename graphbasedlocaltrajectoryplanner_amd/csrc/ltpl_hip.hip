@@ -55,9 +55,11 @@ struct DevLat {
     const unsigned* edge_meta;        // [E]     source node | destination node << 8 | in-edge rank << 16
     // track bounds per layer: bound1 = refline + normvec w_right, bound2 = refline - normvec w_left, centre = (b1 + b2) / 2
     const double* b1x; const double* b1y; const double* b2x; const double* b2y; const double* ctx; const double* cty;
-    const float4* edge_circ;          // [E] bounding circle of the edge's samples in fp32: (centre x, centre y, radius inflated by the
-                                      //     fp32 rounding of centre and query, first sample | #samples << 24 as bit pattern; #samples = 0: look
-                                      //     samp_ptr up) -- a conservative cull, the exact test is fp64
+    const float4* edge_cap;           // [2 E] capsule of the edge's samples in fp32: (Ax, Ay, ABx, ABy), (1 / |AB|^2, dev, hg2, first sample |
+                                      //     #samples << 24 as bit pattern; #samples = 0: look samp_ptr up): chord between the first and the last
+                                      //     sample, largest sample distance from it, squared half of the largest gap between consecutive sample
+                                      //     projections -- two-sided conservative cull of the obstacle mask, the exact test is fp64
+    float cull_slack;                 // bound on the fp32 rounding of the cull's distance (positions, chord, arithmetic)
 };
 
 struct DevPathsIn {
@@ -2098,32 +2100,49 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
             UP(b1x, b1x.data(), L.L); UP(b1y, b1y.data(), L.L); UP(b2x, b2x.data(), L.L); UP(b2y, b2y.data(), L.L);
             UP(ctx, cx.data(), L.L); UP(cty, cy.data(), L.L);
         }
-        // bounding circle per edge: centre of the samples' bounding box, radius = largest centre distance (inflated)
-        std::vector<float4> circ((size_t)L.E);
+        // capsule per edge (two-sided cull of the obstacle mask, paths_team.hpp phase 2): chord A -> B between the first and the last
+        // sample, dev = largest distance of a sample from the chord SEGMENT (rounded up), hg2 = (half the largest gap between
+        // consecutive sample projections on the chord)^2 (rounded up). fp32 effects (positions, chord, distance arithmetic) are
+        // covered by cull_slack, which the kernel adds to BOTH decisions.
+        std::vector<float4> cap((size_t)L.E * 2);
         double maxabs = 1.0;
         for (int k = 0; k < L.S; ++k) maxabs = std::fmax(maxabs, std::fmax(std::fabs(d->samp_x[k]), std::fabs(d->samp_y[k])));
-        // fp32 cull: centre and obstacle position are rounded to fp32 (relative 2^-24 each) and the squared distance is
-        // formed in fp32; the radius is inflated by a bound on all of that, so no edge that the exact test would hit is lost
-        const double slack = maxabs * 4.0 * 5.960464477539063e-08 + 1.0e-4;
+        L.cull_slack = (float)(maxabs * 16.0 * 5.960464477539063e-08 + 2.0e-4);
+        std::vector<double> along;
         for (int e = 0; e < L.E; ++e) {
-            double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
-            for (int k = d->samp_ptr[e]; k < d->samp_ptr[e + 1]; ++k) {
-                x0 = std::fmin(x0, d->samp_x[k]); x1 = std::fmax(x1, d->samp_x[k]);
-                y0 = std::fmin(y0, d->samp_y[k]); y1 = std::fmax(y1, d->samp_y[k]);
+            const int k0 = d->samp_ptr[e], k1 = d->samp_ptr[e + 1], ns = k1 - k0;
+            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ns > 0) {
+                const double ax = d->samp_x[k0], ay = d->samp_y[k0], bx = d->samp_x[k1 - 1], by = d->samp_y[k1 - 1];
+                // the kernel works with the fp32-rounded chord: measure dev / gaps against THAT chord
+                const float axf = (float)ax, ayf = (float)ay, abxf = (float)(bx - ax), abyf = (float)(by - ay);
+                const double cx = axf, cy = ayf, vx = abxf, vy = abyf, len2 = vx * vx + vy * vy, len = std::sqrt(len2);
+                double dev = 0.0;
+                along.clear();
+                for (int k = k0; k < k1; ++k) {
+                    const double ux = d->samp_x[k] - cx, uy = d->samp_y[k] - cy;
+                    double t = len2 > 0.0 ? (ux * vx + uy * vy) / len2 : 0.0;
+                    t = std::fmin(std::fmax(t, 0.0), 1.0);
+                    const double dx = ux - t * vx, dy = uy - t * vy;
+                    dev = std::fmax(dev, std::sqrt(dx * dx + dy * dy));
+                    along.push_back(t * len);
+                }
+                std::sort(along.begin(), along.end());
+                // the rounded chord ends are not samples: a_end = distance from a chord end to the nearest projection (~1e-5 m);
+                // it joins dev (foot of the query clamped at a chord end: nearest sample within d + a_end + dev) and the gaps
+                const double a_end = std::fmax(along.front(), len - along.back());
+                double g = 2.0 * a_end;
+                for (size_t i = 1; i < along.size(); ++i) g = std::fmax(g, along[i] - along[i - 1]);
+                const float invl2 = len2 > 0.0 ? (float)(1.0 / len2) : 0.0f;
+                const float devf = std::nextafter((float)((dev + a_end) * (1.0 + 1.0e-6)), INFINITY);
+                const float hg2f = std::nextafter((float)(0.25 * g * g * (1.0 + 1.0e-6)), INFINITY);
+                const unsigned packed = (k0 < (1 << 24) && ns <= 255) ? ((unsigned)k0 | ((unsigned)ns << 24)) : 0u;
+                float pf; memcpy(&pf, &packed, sizeof(pf));
+                r0 = make_float4(axf, ayf, abxf, abyf); r1 = make_float4(invl2, devf, hg2f, pf);
             }
-            const double mx = 0.5 * (x0 + x1), my = 0.5 * (y0 + y1);
-            double r2 = 0.0;
-            for (int k = d->samp_ptr[e]; k < d->samp_ptr[e + 1]; ++k) {
-                const double dx = d->samp_x[k] - mx, dy = d->samp_y[k] - my;
-                r2 = std::fmax(r2, dx * dx + dy * dy);
-            }
-            const float rf = std::nextafter((float)(std::sqrt(r2) * (1.0 + 1.0e-5) + slack), INFINITY);
-            const int k0 = d->samp_ptr[e], ns = d->samp_ptr[e + 1] - k0;
-            const unsigned packed = (k0 < (1 << 24) && ns <= 255) ? ((unsigned)k0 | ((unsigned)ns << 24)) : 0u;
-            float pf; memcpy(&pf, &packed, sizeof(pf));
-            circ[(size_t)e] = make_float4((float)mx, (float)my, rf, pf);
+            cap[(size_t)e * 2] = r0; cap[(size_t)e * 2 + 1] = r1;
         }
-        UP(edge_circ, circ.data(), L.E);
+        UP(edge_cap, cap.data(), (size_t)L.E * 2);
     }
 #undef UP
 

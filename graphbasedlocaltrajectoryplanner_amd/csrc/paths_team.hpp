@@ -375,7 +375,11 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
     if (out.job_cnt) {
         if (lane == 0) {
             const int cls = name == LTPL_ACT_FOLLOW ? 1 : 0;
+#ifdef LTPL_EXP_ABL
+            const int jb = (lp.ablate & 64) ? (cls ? s : slot) : atomicAdd(&out.job_cnt[cls], 1);
+#else
             const int jb = atomicAdd(&out.job_cnt[cls], 1);
+#endif
             vtile = cls ? out.n_slots_pad + jb : jb;
             out.job_slot[vtile] = slot;
         }
@@ -617,7 +621,10 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
         if (psi_r >= D_PI) psi_r -= 2.0 * D_PI;
         const double kap = (xd * ydd - yd * xdd) * fast_rcp(q * sqrt(q));
         const double len_r = at(lat.slen, pedge[i] + k);
-        store2_u(row, x, y); store2_u(row + 2, psi_r, kap); row[4] = len_r;
+#ifdef LTPL_EXP_ABL
+        if (!(lp.ablate & 16))
+#endif
+        { store2_u(row, x, y); store2_u(row + 2, psi_r, kap); row[4] = len_r; }
         if (vel_kappa) { vel_kappa[r] = kap; vel_len[r] = len_r; }
         if (out.vke) {                                    // planes of the batch velocity stage, blocked by 8 rows (kep_base / kep_row):
             // r = lane + 64 k, so kep_row(r) = kep_row(lane) + 64 (r - lane)
@@ -736,6 +743,9 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
     const bool has_tail = A.ne > CH * NT;
     if (has_tail) tail_edges(0);
     team_sync<NW>();
+#ifdef LTPL_EXP_ABL
+    if (!(lp.ablate & 256))
+#endif
 #pragma unroll
     for (int ci = 0; ci < CH; ++ci) {
         if ((ci * NW) * 64 >= A.ne) continue;
@@ -794,6 +804,9 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
         }
     }
     // lane = destination node
+#ifdef LTPL_EXP_ABL
+    if (!(lp.ablate & 512))
+#endif
 #pragma unroll
     for (int f = 0; f < NFILT; ++f) {
         if (!((ACT >> f) & 1u)) continue;
@@ -914,6 +927,9 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     // ---- phase 1: closest reference-line layer per obstacle position (get_intersec_edges.py:40-51) -----------------
     // lane = (layer segment, position): every lane scans its segment of the reference line for its position (strict '<'
     // keeps the first minimum), the segments of a position are then combined by log2(#segments) shuffle steps.
+#ifdef LTPL_EXP_ABL
+    if (lp.ablate & 128) { for (int q = tid; q < sc.n_pos; q += NT) pos_layer[q] = -1; } else
+#endif
     for (int pp0 = 0; pp0 < sc.n_pos; pp0 += 64) {
         const int cnt = min(64, sc.n_pos - pp0);
         const int cntw = (cnt - wave + NW - 1) / NW;                 // positions of this wave: q = wave + NW * i
@@ -1001,7 +1017,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                 // up to MQ matching positions per round, broadcast into uniform registers
                 constexpr int MQ = 2;
                 double qx[MQ], qy[MQ], qr[MQ];
-                float qxf[MQ], qyf[MQ], qsf[MQ];
+                float qxf[MQ], qyf[MQ], qlm[MQ], qlh[MQ];      // fp32 query, thresholds of the two-sided cull (without the edge's own terms)
 #pragma unroll
                 for (int q = 0; q < MQ; ++q) {
                     if (m) {
@@ -1010,24 +1026,41 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                         qx[q] = readlane_f64(mpx, src_lane); qy[q] = readlane_f64(mpy, src_lane);
                         qr[q] = readlane_f64(mref, src_lane);
                         qxf[q] = (float)qx[q]; qyf[q] = (float)qy[q];
-                        qsf[q] = (float)readlane_f64(msq, src_lane) * 1.00001f;      // rounded up: the cull stays conservative
-                    } else { qx[q] = 0.0; qy[q] = 0.0; qr[q] = -1.0; qxf[q] = 0.0f; qyf[q] = 0.0f; qsf[q] = -1.0e30f; }   // never near, never hit
+                        const float t = (float)readlane_f64(msq, src_lane);          // sqrt of the squared-distance threshold
+                        qlm[q] = t * 1.000001f + lat.cull_slack;                     // MISS  if dist(q, chord) > qlm + dev
+                        qlh[q] = t * 0.999999f - lat.cull_slack;                     // HIT   if dist^2 + (gap / 2)^2 <= (qlh - dev)^2
+                    } else { qx[q] = 0.0; qy[q] = 0.0; qr[q] = -1.0; qxf[q] = 0.0f; qyf[q] = 0.0f; qlm[q] = -1.0e30f; qlh[q] = -1.0e30f; }   // always MISS
                 }
                 for (int e0 = eb + wave * 64; e0 < ee; e0 += NT) {
                     const int e = e0 + lane;
                     if (e >= ee) continue;
                     int el_ = e - sc.e_base; if (el_ < 0) el_ += lat.E;
                     if ((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u) continue;       // already blocked by another object
-                    const float4 cc = at(lat.edge_circ, e);
-                    unsigned near = 0;
+                    // Two-sided cull on the edge's CAPSULE (chord A -> B between its first and last sample, `dev` = largest distance
+                    // of a sample from the chord, `hg2` = (half the largest gap between consecutive sample projections)^2, all
+                    // tabulated at ltpl_create, rounded so that both decisions are conservative): with d = dist(q, chord),
+                    //   every sample is at least d - dev away           -> MISS without touching the samples if d - dev > threshold
+                    //   some sample is at most sqrt(d^2 + hg2) + dev away -> HIT without touching the samples if that <= threshold
+                    // and only the thin shell in between runs the reference's exact fp64 sample test. (Round 2: with a bounding
+                    // CIRCLE nearly every edge of a window was "near" and loaded its samples -- 0.44 ms of a 1.05 ms launch.)
+                    const float4 c0 = at(lat.edge_cap, 2 * e), c1 = at(lat.edge_cap, 2 * e + 1);   // (Ax, Ay, ABx, ABy), (1 / |AB|^2, dev, hg2, samples)
+                    bool sure = false, unsure = false;
 #pragma unroll
                     for (int q = 0; q < MQ; ++q) {
-                        const float dx = cc.x - qxf[q], dy = cc.y - qyf[q], lim = qsf[q] + cc.z;
-                        if (dx * dx + dy * dy <= lim * lim * 1.00001f) near |= 1u << q;
+                        const float ux = qxf[q] - c0.x, uy = qyf[q] - c0.y;
+                        float t = (ux * c0.z + uy * c0.w) * c1.x;
+                        t = fminf(fmaxf(t, 0.0f), 1.0f);
+                        const float dx = ux - t * c0.z, dy = uy - t * c0.w, d2 = dx * dx + dy * dy;
+                        const float lm = qlm[q] + c1.y, lh = qlh[q] - c1.y;
+                        const bool miss = d2 > lm * lm * 1.000001f || lm < 0.0f;
+                        const bool hit_q = lh > 0.0f && (d2 + c1.z) * 1.000001f <= lh * lh;
+                        sure = sure || hit_q;
+                        unsure = unsure || (!miss && !hit_q);
                     }
-                    if (!near) continue;
-                    // sample range of the edge from the circle record (one dependent round trip less than via samp_ptr)
-                    const unsigned packed = __float_as_uint(cc.w);
+                    if (sure) { atomicOr(&blocked_bits[el_ >> 5], 1u << (el_ & 31)); continue; }
+                    if (!unsure) continue;
+                    // sample range of the edge from the record (one dependent round trip less than via samp_ptr)
+                    const unsigned packed = __float_as_uint(c1.w);
                     int k0 = (int)(packed & 0xffffffu), k1 = k0 + (int)(packed >> 24);
                     if (packed >> 24 == 0u) { k0 = at(lat.samp_ptr, e); k1 = at(lat.samp_ptr, e + 1); }
                     bool hit = false;
