@@ -355,7 +355,7 @@ template <class P>
 __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const Scen& sc,
                                   const TeamLds& lp, unsigned char* smem, int a, int f, int J, int name, int reduced,
                                   int jcl, bool share_prefix, int lane, unsigned char* pw,
-                                  double* vel_kappa, double* vel_len, double* vel_x, double* vel_y)
+                                  double* vel_kappa, double* vel_len, double* vel_x, double* vel_y, int vtile_in)
 {
     const int L = lat.L, hm = P::hmax(lp), N = J, s = sc.s;
     const int slot = s * LTPL_MAX_ACTIONS + a;
@@ -371,20 +371,18 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
     double* o_pp = out.path_param + (size_t)slot * out.cap_pts * 5;
     WavePath wp; wp.valid = 1; wp.name = name; wp.reduced = reduced;
     // batch pipeline: take a job of the velocity stage (class 0 = generic profile, 1 = follow); the planes are tiled by job
-    int vtile = -1;
-    if (out.job_cnt) {
+    // (one-wave batch form: the job indices of all paths of the scenario were reserved with ONE atomic in the decision phase --
+    //  vtile_in; the four-wave forms reserve per path here)
+    int vtile = vtile_in;
+    if (out.job_cnt && vtile_in < 0) {
         if (lane == 0) {
             const int cls = name == LTPL_ACT_FOLLOW ? 1 : 0;
-#ifdef LTPL_EXP_ABL
-            const int jb = (lp.ablate & 64) ? (cls ? s : slot) : atomicAdd(&out.job_cnt[cls], 1);
-#else
             const int jb = atomicAdd(&out.job_cnt[cls], 1);
-#endif
             vtile = cls ? out.n_slots_pad + jb : jb;
-            out.job_slot[vtile] = slot;
         }
         vtile = __builtin_amdgcn_readfirstlane(vtile);
     }
+    if (out.job_cnt && lane == 0) out.job_slot[vtile] = slot;
 
     // backtrack along the LDS parent table (lane 0), count exact ties on the way; rank of the in-edge -> pedge (as rank
     // first, resolved to edge ids by all lanes afterwards: the global in_ptr loads are then independent)
@@ -1278,6 +1276,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     // per action slot, ONE packed word (valid | reduced << 1 | (name + 1) << 2 | layer distance << 8): these uniform values live across the
     // whole assembly; as four int arrays they ended up as a VGPR tuple in scratch once the kernel was at its 128-register budget
     int slot_pk[LTPL_MAX_ACTIONS];
+    int job_base = 0;                                   // lanes 0 / 1: first reserved job index of the generic / follow class
     auto slot_valid = [&](int a) { return slot_pk[a] & 1; };
     auto slot_red = [&](int a) { return (slot_pk[a] >> 1) & 1; };
     auto slot_name = [&](int a) { return ((slot_pk[a] >> 2) & 63) - 1; };
@@ -1310,6 +1309,17 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                 }
             }
             slot_pk[a] = (found ? 1 : 0) | (reduced ? 2 : 0) | ((nm + 1) << 2) | (mod_j << 8);
+        }
+        // batch pipeline, one-wave form: reserve the velocity jobs of ALL valid paths of the scenario with one atomic per class
+        // (lane 0: generic profiles, lane 1: follow), issued here so that its round trip (it was 38 us of the launch as a
+        // per-path atomic in front of each assembly) passes behind the output stores and the backtrack
+        if constexpr (NW == 1) {
+            if (out.job_cnt) {
+                int n_gen = 0, n_fol = 0;
+                for (int a = 0; a < n_act; ++a) if (slot_valid(a)) { if (slot_name(a) == LTPL_ACT_FOLLOW) ++n_fol; else ++n_gen; }
+                const int mine = lane == 0 ? n_gen : n_fol;
+                if (lane < 2 && mine > 0) job_base = atomicAdd(&out.job_cnt[lane], mine);
+            }
         }
         if (tid == 0) {
             for (int a = 0; a < LTPL_MAX_ACTIONS; ++a) {
@@ -1353,8 +1363,17 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
         unsigned char* pw = smem + P::off_path(lp) + (size_t)(wave < P::n_path_bufs(lp) ? wave : P::n_path_bufs(lp) - 1) * P::path_stride(lp);
         // after a re-sweep the parents of every layer belong to filter f itself
         const bool sp = share_prefix && (filt[a] == F_LEFT || filt[a] == F_RIGHT) && slot_j(a) == H;
+        int vtile_in = -1;
+        if constexpr (NW == 1) {
+            if (out.job_cnt) {
+                const int cls = slot_name(a) == LTPL_ACT_FOLLOW ? 1 : 0;
+                int k = 0;                                  // valid paths of the same class in front of this one
+                for (int b = 0; b < a; ++b) if (slot_valid(b) && (slot_name(b) == LTPL_ACT_FOLLOW) == (cls == 1)) ++k;
+                vtile_in = __builtin_amdgcn_readlane(job_base, cls) + k + (cls ? out.n_slots_pad : 0);
+            }
+        }
         wp = team_assemble<P>(lat, in, out, sc, lp, smem, a, filt[a], slot_j(a), slot_name(a), slot_red(a), jcl, sp, lane, pw,
-                           vel_kappa, vel_len, vel_x, vel_y);
+                           vel_kappa, vel_len, vel_x, vel_y, vtile_in);
     }
     dbg_stamp(lp.dbg, 7);
     return wp;
