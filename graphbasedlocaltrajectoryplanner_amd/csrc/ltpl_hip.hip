@@ -102,8 +102,9 @@ struct DevPathsOut {
     // job compaction of the batch velocity stage (all nullptr outside the pipeline): every valid path takes a job index
     // from a counter of its class (0 = generic forward-backward profile, 1 = follow); its planes are tiled by JOB, so
     // the lanes of a velocity wave (64 consecutive jobs of one class) are all busy and equally long
-    int* job_cnt;                    // [2]
-    int* job_slot;                   // [n_slots_pad] generic jobs -> slot, then [n_scen_pad] follow jobs -> slot
+    int* job_cnt;                    // [0] generic jobs, [1] follow jobs, [2] largest n_pts of the launch (row chunks beyond it exit at once)
+    int2* job_slot;                  // [n_slots_pad] generic jobs -> (slot, n_pts), then [n_scen_pad] follow jobs: one load gives a velocity
+                                     // wave slot AND length of its job (two dependent round trips less per block)
     int n_slots_pad;                 // tile index of follow job j = n_slots_pad + j (rows of the blocked planes: cap_pts rounded up to 8)
     DoneSignal done;                 // latency path only (k_paths / k_tick launched for a few scenarios)
 };
@@ -1245,9 +1246,10 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
         // ---- follow jobs, unconstrained profile (calc_vel_profile_follow.py:297-307) -------------------------------------
         const int j = (b - nbG - nbF) * 64 + lane;
         if (j >= cntF) return;
-        const int slot = out.job_slot[fbase + j];
+        const int2 js = out.job_slot[fbase + j];
+        const int slot = js.x;
         LaneProf L; L.KE = vp.KE + kep_base(fbase + j, vp.plane_rows);
-        lane_fb_profile<EM, AXM1>(L, vp.P1 + tile_base(j, vp.cap_pts), 0, out.n_pts[slot], cax, cay, p, axm_tab, p.v_max,
+        lane_fb_profile<EM, AXM1>(L, vp.P1 + tile_base(j, vp.cap_pts), 0, js.y, cax, cay, p, axm_tab, p.v_max,
                                   vin.vel_plan[slot / LTPL_MAX_ACTIONS], false, 0.0, dbg, drow);
         vl_stamp(dbg, drow, 6);
         return;
@@ -1256,9 +1258,17 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
     const int j = (fjob ? b - nbG : b) * 64 + lane;
     if (j >= (fjob ? cntF : cntG)) return;
     const int tile = fjob ? fbase + j : j;
-    const int slot = out.job_slot[tile];
+    const int2 js = out.job_slot[tile];
+    const int slot = js.x;
+    {
+        // longest profile of the launch (k_vel_final skips row chunks beyond it): one atomic per wave
+        int nmax = js.y;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(nmax, m); nmax = o > nmax ? o : nmax; }
+        if (lane == 0) atomicMax(&out.job_cnt[2], nmax);
+    }
     const int s = slot / LTPL_MAX_ACTIONS;
-    const int n = out.n_pts[slot];
+    const int n = js.y;
     LaneProf L; L.KE = vp.KE + kep_base(tile, vp.plane_rows);
     double* P0 = vp.P0 + tile_base(tile, vp.cap_pts);
     double* P2 = vp.P2 + tile_base(fjob ? j : 0, vp.cap_pts);
@@ -1458,8 +1468,9 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
     if ((j - lane) >= cnt) return;                                      // whole tile without jobs (uniform)
     const bool have = j < cnt;
     const int tile = fjob ? out.n_slots_pad + j : j;
-    const int slot = have ? out.job_slot[tile] : 0;
-    const int n = have ? out.n_pts[slot] : 0;
+    if (base >= out.job_cnt[2]) return;                                 // no path of the launch is this long (uniform)
+    const int2 js = have ? out.job_slot[tile] : make_int2(0, 0);
+    const int slot = js.x, n = js.y;
     s_slot[lane] = slot; s_n[lane] = n;
     const bool act = have && base < n;
     if (__ballot(act) == 0ull) return;                                  // uniform
@@ -1495,8 +1506,13 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
         double w[FCH + 1], er[FCH];
 #pragma unroll
         for (int c = 0; c <= FCH; ++c) w[c] = value(base + c < n ? base + c : n - 1);
+        // element lengths: two rows per 16-byte load (rows 2m, 2m + 1 are adjacent in the blocked plane and `base` is a multiple of 16;
+        // rows beyond n - 1 are unused padding of the block -- never NaN-sensitive: their ax is discarded)
 #pragma unroll
-        for (int c = 0; c < FCH; ++c) er[c] = (double)KE[kep_row(base + c < n ? base + c : n - 1)].y;
+        for (int c = 0; c < FCH; c += 2) {
+            const float4 v = *reinterpret_cast<const float4*>(&KE[kep_row(base + c)]);
+            er[c] = (double)v.y; er[c + 1] = (double)v.w;
+        }
 #pragma unroll
         for (int c = 0; c < FCH; ++c) {
             const int i = base + c;
@@ -1558,8 +1574,8 @@ __global__ __launch_bounds__(64) void k_follow_prep(DevLat lat, DevPathsIn in, D
     const int j0 = (int)blockIdx.x * 64 + lane;
     const bool have_job = j0 < cnt;
     const int j = have_job ? j0 : cnt - 1;                  // idle lanes repeat the last job (uniform control flow), nothing stored
-    const int slot = out.job_slot[out.n_slots_pad + j];
-    const int s = slot / LTPL_MAX_ACTIONS, n = out.n_pts[slot];
+    const int2 js = out.job_slot[out.n_slots_pad + j];
+    const int slot = js.x, s = slot / LTPL_MAX_ACTIONS, n = js.y;
     const int ci = out.closest_obj_index[s], v0 = in.veh_off[s];
     const bool have = !(ci < 0 || ci >= in.veh_off[s + 1] - v0);
     const double ex = vin.pos_est_x[s], ey = vin.pos_est_y[s];
@@ -2263,7 +2279,9 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { h->err = "hipGetDeviceProperties failed"; return fail(LTPL_ERR_HIP); }
-    h->caps.max_path_nodes = hmax; h->caps.max_path_pts = ptsmax; h->caps.max_horizon_edges = ehmax;
+    // capacity in rows rounded up to 16: a slot's row block of the fp64 outputs (vx, ax: 8 B per row; path_param: 40 B) then starts on a
+    // 128-byte line, so the 128-byte chunks the final velocity kernel writes are whole sectors (measured write traffic was 1.8x the data)
+    h->caps.max_path_nodes = hmax; h->caps.max_path_pts = (int)align_up((size_t)ptsmax, 16); h->caps.max_horizon_edges = ehmax;
     h->caps.device = device; h->caps.num_cus = prop.multiProcessorCount; h->caps.lds_bytes_paths = h->lp1.total;
     if (d->raceline_x && d->raceline_y && d->node_psi) {
         std::string why;
@@ -2286,7 +2304,7 @@ extern "C" int ltpl_get_caps(const ltpl_handle* h, ltpl_caps* caps)
 // ---- staging arena ---------------------------------------------------------------------------------------------------
 struct Arena {
     size_t size = 0;
-    size_t add(size_t bytes) { size_t o = size; size = align_up(size + bytes, 16); return o; }
+    size_t add(size_t bytes) { size_t o = size; size = align_up(size + bytes, 256); return o; }   // arrays start on cache-line multiples
 };
 
 // The device-resident batch of ltpl_batch_upload points into the staging buffers (d_in / d_out / d_planes). Every other
@@ -2781,7 +2799,7 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
         const size_t tiles = (size_t)t->n_slots_pad + (size_t)t->n_scen_pad;
         const size_t plane_rows = align_up((size_t)cap_pts, 8);
         t->planes_bytes = t->pipeline ? sizeof(double) * ((size_t)cap_pts * (3 * tiles + 3 * (size_t)t->n_scen_pad) + 2 * plane_rows * (size_t)t->n_scen_pad)
-                                            + sizeof(int) * (2 * tiles + 16 + 2 * (size_t)t->n_scen_pad) : 0;
+                                            + sizeof(int) * (3 * tiles + 16 + 2 * (size_t)t->n_scen_pad) : 0;
     }
     t->prep_off = 0; t->prep_stride = 0;
     t->vel_cap = h->caps.max_path_pts;
@@ -2812,7 +2830,7 @@ static void tick_bind_outputs(TickLayout* t, unsigned char* dob, double* planes)
         t->vp.XY = t->vp.P3 + per_scen;
         const size_t plane_rows = align_up((size_t)t->cap_pts, 8);
         int* ints = reinterpret_cast<int*>(t->vp.XY + 2 * plane_rows * (size_t)t->n_scen_pad);
-        t->vp.flags = ints; t->dout.job_slot = ints + tiles; t->dout.job_cnt = ints + 2 * tiles; t->vp.fseg = ints + 2 * tiles + 16;
+        t->vp.flags = ints; t->dout.job_slot = reinterpret_cast<int2*>(ints + tiles); t->dout.job_cnt = ints + 3 * tiles; t->vp.fseg = ints + 3 * tiles + 16;
         t->dout.n_slots_pad = t->n_slots_pad;
         t->vp.cap_pts = t->cap_pts; t->vp.plane_rows = (int)plane_rows;
         t->dout.vke = t->vp.KE; t->dout.vxy = t->vp.XY;
@@ -2851,7 +2869,7 @@ static int tick_pack(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_ve
 
 static int tick_launch_paths(ltpl_handle* h, const TickLayout& t, hipStream_t st)
 {
-    if (t.dout.job_cnt) HIP_TRY(h, hipMemsetAsync(t.dout.job_cnt, 0, 2 * sizeof(int), st));
+    if (t.dout.job_cnt) HIP_TRY(h, hipMemsetAsync(t.dout.job_cnt, 0, 3 * sizeof(int), st));
     return launch_paths(h, (t.n_scen >= h->nw1_min_scen && h->batch_nw == 1) ? 1 : NUM_WAVES, t.n_scen, st, t.di, t.dout);
 }
 

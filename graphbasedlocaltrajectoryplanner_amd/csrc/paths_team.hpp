@@ -382,7 +382,6 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
         }
         vtile = __builtin_amdgcn_readfirstlane(vtile);
     }
-    if (out.job_cnt && lane == 0) out.job_slot[vtile] = slot;
 
     // backtrack along the LDS parent table (lane 0), count exact ties on the way; rank of the in-edge -> pedge (as rank
     // first, resolved to edge ids by all lanes afterwards: the global in_ptr loads are then independent)
@@ -636,6 +635,7 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
         }
         if (vel_x) { vel_x[r] = x; vel_y[r] = y; }
     }
+    if (out.job_cnt && lane == 0) out.job_slot[vtile] = make_int2(slot, n_pts);
     wp.n_pts = n_pts; wp.n_nodes = J + 1;
     { int gl = sc.sl + J; if (gl >= L) gl -= L; wp.goal_layer = gl; }
     wp.end_node = best[f * hm + J] & 0xffff;
