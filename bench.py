@@ -335,8 +335,11 @@ def worker(args):
                          "pipeline_ms": {"k_paths": prof_ms[0], "k_follow_prep": prof_ms[1], "k_vel_lanes": prof_ms[2],
                                          "all_kernels_back_to_back": kern_ms},
                          "whole_tick_achieved": ab["total"] / (kern_ms * 1e-3) / 1e9,
-                         "note": "achieved = algorithmic bytes / kernel time (contract); the lattice is cache resident, measured "
-                                 "HBM traffic is `traffic`: the kernel is instruction-issue / LDS-latency bound, not DRAM bound"},
+                         "note": "achieved = algorithmic bytes / kernel time (contract: SURVEY 8d counts, for every edge in an obstacle's "
+                                 "window, all its samples). The lattice is cache resident and since round 2 the capsule cull decides most "
+                                 "edges without reading their samples, so the kernel moves far fewer bytes than the model: measured HBM "
+                                 "traffic is `traffic`, and frac can exceed 1 -- the kernel is LDS-latency / instruction-issue bound, not "
+                                 "DRAM bound"},
             "latency_us": {"p50": float(np.percentile(lat_us, 50)) if lat_us.size else None,
                            "p99": float(np.percentile(lat_us, 99)) if lat_us.size else None,
                            "mean": float(lat_us.mean()) if lat_us.size else None, "ticks": int(lat_us.size),

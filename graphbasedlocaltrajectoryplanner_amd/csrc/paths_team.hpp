@@ -1200,6 +1200,20 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
         };
         team_sync<NW>();
         prefetch(1, er, bm);
+        // `planning_range` (every edge) and `default` (unblocked edges) only differ from the first transition on that holds a
+        // blocked edge: in front of it the planning_range sweep is not run, `default`'s frontier, parents and reachability are
+        // copied when the sweeps part (one-wave batch form; a transition with edges beyond the register image parts conservatively)
+        bool pr_shared = NW == 1 && !P::par_global && ((need >> F_PR) & 1u) && (((need >> F_DEF) & 1u) || share_prefix);
+        auto copy_def_to_pr = [&](int jn, int buf) {          // layers [0, jn) are complete, frontier of layer jn - 1 in buffer `buf`
+            for (int n = lane; n < kpad; n += 64) dist[(size_t)(F_PR * 2 + buf) * kpad + n] = dist[(size_t)(F_DEF * 2 + buf) * kpad + n];
+            const int roww = kpad * P::par_entry / 4;           // 4-byte words per layer row (kpad is a multiple of 4)
+            unsigned* p0 = reinterpret_cast<unsigned*>(par) + (size_t)par_tab(F_PR) * hm * roww;
+            const unsigned* p1 = reinterpret_cast<const unsigned*>(par) + (size_t)par_tab(F_DEF) * hm * roww;
+            for (int w = roww + lane; w < jn * roww; w += 64) p0[w] = p1[w];
+            for (int r = lane; r < jn; r += 64) best[F_PR * hm + r] = best[F_DEF * hm + r];
+            if (lane == 0) ts.start_ok[F_PR] = ts.start_ok[F_DEF];
+            team_sync<NW>();
+        };
         for (int j = 1; j <= H && !(lp.ablate & 2); ++j) {
             int b = sc.sl + j; if (b >= L) b -= L;
             const int4 ly = lay[j];
@@ -1218,6 +1232,13 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             if (((need >> F_LEFT) & 1u) && (!share_prefix || j >= jcl)) actm |= 1u << F_LEFT;
             if (((need >> F_RIGHT) & 1u) && (!share_prefix || j >= jcl)) actm |= 1u << F_RIGHT;
             A.from_def = share_prefix && j == jcl;
+            if (pr_shared) {
+                unsigned long long anyb = 0ull;
+#pragma unroll
+                for (int ci = 0; ci < CH; ++ci) anyb |= bm[ci];
+                if (anyb != 0ull || A.ne > CH * NT || (share_prefix && j == jcl)) { copy_def_to_pr(j, A.prv); pr_shared = false; }
+                else actm &= ~(1u << F_PR);
+            }
             if (j < H) prefetch(j + 1, en, bn);                    // global loads in flight during this layer's LDS work
             // the action templates only produce these filter sets (phase 3); anything else takes the serial form
             const bool known = actm == (1u << F_DEF) || actm == (1u << F_PR) || actm == ((1u << F_PR) | (1u << F_DEF)) ||
@@ -1253,6 +1274,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             for (int ci = 0; ci < CH; ++ci) { er[ci] = en[ci]; bm[ci] = bn[ci]; }
             team_sync<NW>();
         }
+        if (pr_shared && !(lp.ablate & 2)) copy_def_to_pr(H + 1, H & 1);        // no blocked edge in the whole range: identical sweeps
         // goal node of the last layer for every filter that reached it (virtual goal edges, GraphBase.py:188-194)
         if (!(lp.ablate & 2)) {
             const int4 lyH = lay[H];
