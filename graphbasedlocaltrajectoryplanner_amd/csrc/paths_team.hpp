@@ -762,21 +762,30 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
     }
     if (has_tail) tail_edges(1);
     team_sync<NW>();
+    // lane = destination node (this form is only entered with at most 64 nodes in the layer): counters, elected edges and the zone bit
+    // of every active filter are fetched in ONE LDS round trip and serve both the tie check and the node step (they used to be
+    // read twice with a wait each -- the sweep is a chain of LDS round trips, ~6 per layer)
+    const int n = lane;
+    const bool nv = n < A.Kb;
+    unsigned c_r[NA], w_r[NA];
+#pragma unroll
+    for (int f = 0; f < NFILT; ++f)
+        if ((ACT >> f) & 1u) { c_r[SL[f]] = nv ? cnt_all[f * kpad + n] : 0u; w_r[SL[f]] = nv ? widx_all[f * kpad + n] : 0xffffffffu; }
+    bool zone_rem = false;
+    if (nv) { int nl = A.v0 + n - sc.n_base; if (nl < 0) nl += lat.V; zone_rem = (zone_bits[nl >> 5] >> (nl & 31)) & 1u; }
     // exact tie-break (rare): a node whose minimum is attained by several edges takes, in the reference's order, the
     // predecessor with the smaller distance first, then CSC order. Every wave reads the same counters, so the branch is
     // uniform over the team.
     {
         bool tied = false;
-        for (int n = lane; n < A.Kb; n += 64) {
 #pragma unroll
-            for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) tied = tied || cnt_all[f * kpad + n] >= 2u;
-        }
+        for (int k = 0; k < NA; ++k) tied = tied || c_r[k] >= 2u;
         if (__ballot(tied) != 0ull) {
             double* dumin = reinterpret_cast<double*>(smem + P::off_dumin(lp));
-            for (int n = tid; n < A.Kb; n += NT) {
+            for (int m = tid; m < A.Kb; m += NT) {
 #pragma unroll
                 for (int f = 0; f < NFILT; ++f)
-                    if (((ACT >> f) & 1u) && cnt_all[f * kpad + n] >= 2u) { dumin[f * kpad + n] = INFINITY; widx_all[f * kpad + n] = 0xffffffffu; }
+                    if (((ACT >> f) & 1u) && cnt_all[f * kpad + m] >= 2u) { dumin[f * kpad + m] = INFINITY; widx_all[f * kpad + m] = 0xffffffffu; }
             }
             team_sync<NW>();
 #pragma unroll 1
@@ -799,28 +808,26 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
                 if (has_tail) tail_edges(2 + round);
                 team_sync<NW>();
             }
+#pragma unroll
+            for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) w_r[SL[f]] = nv ? widx_all[f * kpad + n] : 0xffffffffu;      // re-elected
         }
     }
-    // lane = destination node
-#ifdef LTPL_EXP_ABL
-    if (!(lp.ablate & 512))
-#endif
+    // node step: parents, node filters, reachability
 #pragma unroll
     for (int f = 0; f < NFILT; ++f) {
         if (!((ACT >> f) & 1u)) continue;
         if (NW > 1 && (f % NW) != wave) continue;
         bool any = false;
-        for (int n = lane; n < A.Kb; n += 64) {
-            const unsigned c = cnt_all[f * kpad + n], w = widx_all[f * kpad + n];
-            int nl = A.v0 + n - sc.n_base; if (nl < 0) nl += lat.V;
-            bool rem = (zone_bits[nl >> 5] >> (nl & 31)) & 1u;
+        if (nv) {
+            const unsigned c = c_r[SL[f]], w = w_r[SL[f]];
+            bool rem = zone_rem;
             if (f == F_LEFT) rem = rem || (A.cl_hit && n >= A.cn);
             if (f == F_RIGHT) rem = rem || (A.cl_hit && n < A.cn);
             const bool fin = c >= 1u && !rem;
             const int bsrc = fin ? (int)(w & 255u) : 0, bk = fin ? (int)((w >> 8) & 255u) : 0, tie = (fin && c >= 2u) ? 1 : 0;
             if (rem) dist[coff[f] + n] = INFINITY;
             par_store<P>(par, ((size_t)par_tab(f) * A.hm + A.j) * kpad + n, bsrc, bk, tie);
-            any = any || fin;
+            any = fin;
         }
         any = __ballot(any) != 0ull;
         if (lane == 0) best[f * A.hm + A.j] = any ? -2 : -1;           // the goal node of the last layer is evaluated after the sweep
