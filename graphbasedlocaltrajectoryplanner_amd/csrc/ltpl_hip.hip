@@ -17,6 +17,7 @@
 
 #include "../../include/ltpl_hip.h"
 #include "planner_api.hpp"
+#include "capsule.hpp"
 
 #define WG_THREADS 256
 #define PIPELINE_MIN_SCEN 64   // batches from this size on use the one-wave-per-scenario pipeline
@@ -2116,48 +2117,10 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
             UP(b1x, b1x.data(), L.L); UP(b1y, b1y.data(), L.L); UP(b2x, b2x.data(), L.L); UP(b2y, b2y.data(), L.L);
             UP(ctx, cx.data(), L.L); UP(cty, cy.data(), L.L);
         }
-        // capsule per edge (two-sided cull of the obstacle mask, paths_team.hpp phase 2): chord A -> B between the first and the last
-        // sample, dev = largest distance of a sample from the chord SEGMENT (rounded up), hg2 = (half the largest gap between
-        // consecutive sample projections on the chord)^2 (rounded up). fp32 effects (positions, chord, distance arithmetic) are
-        // covered by cull_slack, which the kernel adds to BOTH decisions.
+        // capsule per edge (two-sided cull of the obstacle mask, paths_team.hpp phase 2; construction and its conservativeness
+        // argument in capsule.hpp)
         std::vector<float4> cap((size_t)L.E * 2);
-        double maxabs = 1.0;
-        for (int k = 0; k < L.S; ++k) maxabs = std::fmax(maxabs, std::fmax(std::fabs(d->samp_x[k]), std::fabs(d->samp_y[k])));
-        L.cull_slack = (float)(maxabs * 16.0 * 5.960464477539063e-08 + 2.0e-4);
-        std::vector<double> along;
-        for (int e = 0; e < L.E; ++e) {
-            const int k0 = d->samp_ptr[e], k1 = d->samp_ptr[e + 1], ns = k1 - k0;
-            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ns > 0) {
-                const double ax = d->samp_x[k0], ay = d->samp_y[k0], bx = d->samp_x[k1 - 1], by = d->samp_y[k1 - 1];
-                // the kernel works with the fp32-rounded chord: measure dev / gaps against THAT chord
-                const float axf = (float)ax, ayf = (float)ay, abxf = (float)(bx - ax), abyf = (float)(by - ay);
-                const double cx = axf, cy = ayf, vx = abxf, vy = abyf, len2 = vx * vx + vy * vy, len = std::sqrt(len2);
-                double dev = 0.0;
-                along.clear();
-                for (int k = k0; k < k1; ++k) {
-                    const double ux = d->samp_x[k] - cx, uy = d->samp_y[k] - cy;
-                    double t = len2 > 0.0 ? (ux * vx + uy * vy) / len2 : 0.0;
-                    t = std::fmin(std::fmax(t, 0.0), 1.0);
-                    const double dx = ux - t * vx, dy = uy - t * vy;
-                    dev = std::fmax(dev, std::sqrt(dx * dx + dy * dy));
-                    along.push_back(t * len);
-                }
-                std::sort(along.begin(), along.end());
-                // the rounded chord ends are not samples: a_end = distance from a chord end to the nearest projection (~1e-5 m);
-                // it joins dev (foot of the query clamped at a chord end: nearest sample within d + a_end + dev) and the gaps
-                const double a_end = std::fmax(along.front(), len - along.back());
-                double g = 2.0 * a_end;
-                for (size_t i = 1; i < along.size(); ++i) g = std::fmax(g, along[i] - along[i - 1]);
-                const float invl2 = len2 > 0.0 ? (float)(1.0 / len2) : 0.0f;
-                const float devf = std::nextafter((float)((dev + a_end) * (1.0 + 1.0e-6)), INFINITY);
-                const float hg2f = std::nextafter((float)(0.25 * g * g * (1.0 + 1.0e-6)), INFINITY);
-                const unsigned packed = (k0 < (1 << 24) && ns <= 255) ? ((unsigned)k0 | ((unsigned)ns << 24)) : 0u;
-                float pf; memcpy(&pf, &packed, sizeof(pf));
-                r0 = make_float4(axf, ayf, abxf, abyf); r1 = make_float4(invl2, devf, hg2f, pf);
-            }
-            cap[(size_t)e * 2] = r0; cap[(size_t)e * 2 + 1] = r1;
-        }
+        L.cull_slack = ltplcap::build(L.E, d->samp_ptr, d->samp_x, d->samp_y, L.S, reinterpret_cast<float*>(cap.data()));
         UP(edge_cap, cap.data(), (size_t)L.E * 2);
     }
 #undef UP
@@ -3373,6 +3336,14 @@ extern "C" int ltpl_const_segment_test(const ltpl_handle* h, const double* seg, 
     ltplp::const_segment_test(h->hostlat, n_rows > 0 ? seg : nullptr, n_rows, pos_est, n_veh, veh_x, veh_y, veh_radius, &in_const, &besides, &closest);
     *flags_out = (in_const ? LTPL_FLAG_OBJ_IN_CONST : 0) | (besides ? LTPL_FLAG_OBJ_BESIDES : 0);
     *closest_out = closest;
+    return LTPL_OK;
+}
+
+extern "C" int ltpl_edge_capsules(int32_t n_edges, const int32_t* samp_ptr, const double* samp_x, const double* samp_y, int32_t n_samples,
+                                  float* capsules_out, float* slack_out)
+{
+    if (n_edges < 0 || !samp_ptr || !samp_x || !samp_y || !capsules_out || !slack_out) return LTPL_ERR_INVALID_ARG;
+    *slack_out = ltplcap::build(n_edges, samp_ptr, samp_x, samp_y, n_samples, capsules_out);
     return LTPL_OK;
 }
 

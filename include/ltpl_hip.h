@@ -290,6 +290,15 @@ int ltpl_const_segment_test(const ltpl_handle* handle, const double* seg, int32_
  *     (get_s_coord.py:8-99; call sites Graph_LTPL.py:436-440 for the log row, main_online_path_gen.py:86-101) ------------- */
 int ltpl_raceline_s(const ltpl_handle* handle, double x, double y, double* s_out);
 
+/* --- diagnostics (host only, no device needed): the per-edge capsule table ltpl_create derives for the obstacle mask
+ *     (GraphBase.get_intersec_edges_in_range, GraphBase.py:567-646). The path kernel decides "no sample of the edge is within
+ *     the obstacle's threshold" / "some sample is" from it without reading the samples whenever either is certain, and runs the
+ *     reference's exact sample test otherwise. capsules_out: 8 floats per edge (Ax, Ay, ABx, ABy, 1 / |AB|^2, dev, (gap / 2)^2,
+ *     packed sample range); slack_out: the fp32 rounding bound added to both decisions. tests/test_capsule_cull.py checks the
+ *     conservativeness of the decisions against the exact test on the real lattices. ------------------------------------- */
+int ltpl_edge_capsules(int32_t n_edges, const int32_t* samp_ptr, const double* samp_x, const double* samp_y, int32_t n_samples,
+                       float* capsules_out, float* slack_out);
+
 /* --- object ingestion: ObjectListInterface.py:75-153, check_inside_bounds.py:7-59 --------------------------------- */
 int ltpl_process_objects(ltpl_handle* handle, const ltpl_objects_in* in, ltpl_objects_out* out);
 

@@ -1,0 +1,79 @@
+"""CPU: the two-sided capsule cull of the obstacle mask (paths_team.hpp phase 2) never contradicts the reference's exact test.
+
+The kernel decides per (edge, obstacle position) from the edge's capsule -- chord, deviation, sample gap, tabulated by
+``ltpl_edge_capsules`` (the routine ``ltpl_create`` uses) -- whether NO sample (MISS) or SOME sample (HIT) lies within the threshold
+``(r + w/2)^2 + step^2/4`` of GraphBase.get_intersec_edges_in_range (GraphBase.py:626-643), and only runs the exact sample test
+when neither is certain. Here the kernel's fp32 decision arithmetic is restated in NumPy and compared with the exact fp64 test on
+every edge of the recorded lattices for query points concentrated around the decision boundary."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def capsules(lat):
+    import __graft_entry__ as ge
+    lib = C.CDLL(ge.build_hip())
+    sp = np.ascontiguousarray(lat.samp_ptr, dtype=np.int32)
+    sx = np.ascontiguousarray(lat.samples[:, 0], dtype=np.float64)
+    sy = np.ascontiguousarray(lat.samples[:, 1], dtype=np.float64)
+    n_e = len(sp) - 1
+    out = np.zeros((n_e, 8), np.float32)
+    slack = C.c_float(0.0)
+    rc = lib.ltpl_edge_capsules(C.c_int32(n_e), sp.ctypes.data_as(C.c_void_p), sx.ctypes.data_as(C.c_void_p),
+                                sy.ctypes.data_as(C.c_void_p), C.c_int32(len(sx)), out.ctypes.data_as(C.c_void_p), C.byref(slack))
+    assert rc == 0
+    return out, np.float32(slack.value), sp, sx, sy
+
+
+def kernel_decisions(cap, slack, qx, qy, thr):
+    """fp32 restatement of the kernel's cull for edges `cap` (n, 8), one query (qx, qy) and threshold distance `thr` per edge."""
+    f = np.float32
+    qxf, qyf, t = qx.astype(f), qy.astype(f), thr.astype(f)
+    qlm = t * f(1.000001) + slack
+    qlh = t * f(0.999999) - slack
+    ux, uy = qxf - cap[:, 0], qyf - cap[:, 1]
+    tt = (ux * cap[:, 2] + uy * cap[:, 3]) * cap[:, 4]
+    tt = np.minimum(np.maximum(tt, f(0.0)), f(1.0))
+    dx, dy = ux - tt * cap[:, 2], uy - tt * cap[:, 3]
+    d2 = dx * dx + dy * dy
+    lm, lh = qlm + cap[:, 5], qlh - cap[:, 5]
+    miss = (d2 > lm * lm * f(1.000001)) | (lm < 0)
+    hit = (lh > 0) & ((d2 + cap[:, 6]) * f(1.000001) <= lh * lh)
+    return miss, hit
+
+
+@pytest.mark.parametrize("name", ["monteblanco_lattice.npz", "open_lattice.npz"])
+def test_cull_decisions_are_conservative(name):
+    from graphbasedlocaltrajectoryplanner_amd.lattice import Lattice
+    lat = Lattice.load(os.path.join(ROOT, "tests", "golden", name))
+    cap, slack, sp, sx, sy = capsules(lat)
+    n_e = len(sp) - 1
+    assert np.all(cap[:, 5] >= 0) and np.all(cap[:, 6] >= 0)
+    rng = np.random.default_rng(3)
+    res = float(lat.sampled_resolution)
+    decided = total = 0
+    for rep in range(12):
+        # one query per edge: a random sample of the edge, pushed away by a distance around the threshold (the decision boundary)
+        rr = rng.uniform(0.5, 4.0, n_e) + float(lat.veh_width) / 2.0
+        thr2 = rr * rr + res * res / 4.0
+        thr = np.sqrt(thr2)
+        k = sp[:-1] + (rng.random(n_e) * (sp[1:] - sp[:-1])).astype(np.int64)
+        ang = rng.uniform(0.0, 2.0 * np.pi, n_e)
+        dist = thr + rng.normal(0.0, [0.02, 0.3, 1.5][rep % 3], n_e)
+        qx, qy = sx[k] + dist * np.cos(ang), sy[k] + dist * np.sin(ang)
+        miss, hit = kernel_decisions(cap, slack, qx, qy, thr)
+        assert not np.any(miss & hit)
+        # exact test of the reference on every edge (fp64)
+        exact = np.zeros(n_e, bool)
+        for e in range(n_e):
+            dx, dy = sx[sp[e]:sp[e + 1]] - qx[e], sy[sp[e]:sp[e + 1]] - qy[e]
+            exact[e] = bool(np.any(dx * dx + dy * dy <= thr2[e]))
+        assert not np.any(miss & exact), "cull says MISS where the exact test hits: edges %s" % np.nonzero(miss & exact)[0][:5]
+        assert not np.any(hit & ~exact), "cull says HIT where the exact test misses: edges %s" % np.nonzero(hit & ~exact)[0][:5]
+        decided += int(np.count_nonzero(miss | hit)); total += n_e
+    # even with every query placed near the boundary most decisions need no samples
+    assert decided > 0.5 * total
