@@ -618,7 +618,7 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
         if (psi_r >= D_PI) psi_r -= 2.0 * D_PI;
         const double kap = (xd * ydd - yd * xdd) * fast_rcp(q * sqrt(q));
         const double len_r = at(lat.slen, pedge[i] + k);
-#ifdef LTPL_EXP_ABL
+#ifdef LTPL_EXP_ABL        // experiment build (-DLTPL_EXP_ABL, tools/README.md): LTPL_ABLATE bit 16 drops the path_param stores (timing only)
         if (!(lp.ablate & 16))
 #endif
         { store2_u(row, x, y); store2_u(row + 2, psi_r, kap); row[4] = len_r; }
@@ -741,9 +741,6 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
     const bool has_tail = A.ne > CH * NT;
     if (has_tail) tail_edges(0);
     team_sync<NW>();
-#ifdef LTPL_EXP_ABL
-    if (!(lp.ablate & 256))
-#endif
 #pragma unroll
     for (int ci = 0; ci < CH; ++ci) {
         if ((ci * NW) * 64 >= A.ne) continue;
@@ -932,9 +929,6 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     // ---- phase 1: closest reference-line layer per obstacle position (get_intersec_edges.py:40-51) -----------------
     // lane = (layer segment, position): every lane scans its segment of the reference line for its position (strict '<'
     // keeps the first minimum), the segments of a position are then combined by log2(#segments) shuffle steps.
-#ifdef LTPL_EXP_ABL
-    if (lp.ablate & 128) { for (int q = tid; q < sc.n_pos; q += NT) pos_layer[q] = -1; } else
-#endif
     for (int pp0 = 0; pp0 < sc.n_pos; pp0 += 64) {
         const int cnt = min(64, sc.n_pos - pp0);
         const int cntw = (cnt - wave + NW - 1) / NW;                 // positions of this wave: q = wave + NW * i
