@@ -334,7 +334,8 @@ __device__ __forceinline__ void fb_sweep(int n, const VelScratch& vs, double cax
         const double C0 = te * dm, C1 = C0 - te * (ax_n * kq_n), D1 = te * ax_n;
         double w_in = wi, wnext = wold;
         int act_in = active, act_out = 0;
-        for (int it = 0; it < cnt; ++it) {
+        // four steps per loop iteration: steps beyond cnt recompute final values from final inputs (idempotent), nothing is stored for them
+        auto sys_step = [&]() {
             const bool act = (act_in | st) != 0;
             double wn;
             if constexpr (AFFINE) {
@@ -363,7 +364,8 @@ __device__ __forceinline__ void fb_sweep(int n, const VelScratch& vs, double cax
             // hand the state to the next lane; lane 0 keeps the state entering the chunk
             w_in = wave_shr1_f64(wnext, wi);
             act_in = wave_shr1_i32(act_out, active);
-        }
+                };
+        for (int it = 0; it < cnt; it += 4) { sys_step(); sys_step(); sys_step(); sys_step(); }
         if (lane < cnt) vs.w[Pb] = wnext;
         wi = readlane_f64(wnext, cnt - 1);
         active = __builtin_amdgcn_readlane(act_out, cnt - 1);
@@ -413,14 +415,15 @@ __device__ __forceinline__ void brake_profile(int n, double* out, const VelScrat
         const double A0 = 1.0 - te * p.drag_m, A1 = A0 + te * (axa * kq_i), B1 = te * axa;
         double w_in = w, w_out = w; int st_in = stopped, st_out = 0;
         double r = 0.0;
-        for (int it = 0; it < cnt; ++it) {
+        auto sys_step = [&]() {
             if constexpr (EM == 1) r = fmin(fma(A1, w_in, -B1), A0 * w_in);
             else r = w_in + 2.0 * ax_poss_w<EM, true, VMODE_DECEL_FORW>(w_in, kq_i, ax_i, p, vs.axm, 0.0) * e_i;
             st_out = (st_in || (r < 0.0)) ? 1 : 0;
             w_out = st_out ? w_in : r;
             w_in = wave_shr1_f64(w_out, w);
             st_in = wave_shr1_i32(st_out, stopped);
-        }
+                };
+        for (int it = 0; it < cnt; it += 4) { sys_step(); sys_step(); sys_step(); sys_step(); }      // (idempotent beyond cnt)
         if (lane < cnt) out[base + lane + 1] = st_out ? 0.0 : r;
         w = readlane_f64(w_out, cnt - 1);
         stopped = __builtin_amdgcn_readlane(st_out, cnt - 1);
@@ -438,7 +441,10 @@ __device__ __forceinline__ void wave_cumsum_seq(const double* src, double* out, 
         const int cnt = (m - 1 - base) < 64 ? (m - 1 - base) : 64;
         const double e = src[(lane < cnt) ? base + lane : base + cnt - 1];
         double s_in = carry, s_out = 0.0;
-        for (int it = 0; it < cnt; ++it) { s_out = s_in + e; s_in = wave_shr1_f64(s_out, carry); }
+        for (int it = 0; it < cnt; it += 4) {                        // (idempotent beyond cnt)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s_out = s_in + e; s_in = wave_shr1_f64(s_out, carry); }
+        }
         if (lane < cnt) out[base + lane + 1] = s_out;
         carry = readlane_f64(s_out, cnt - 1);
     }
