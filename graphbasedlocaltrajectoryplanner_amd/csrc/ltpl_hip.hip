@@ -1471,16 +1471,18 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
     const int lane = threadIdx.x;
     const int j = (fjob ? blockIdx.x - nbG : blockIdx.x) * 64 + lane;
     const int cnt = out.job_cnt[fjob ? 1 : 0];
-    const int base = (int)blockIdx.y * FCH;
     if ((j - lane) >= cnt) return;                                      // whole tile without jobs (uniform)
     const bool have = j < cnt;
     const int tile = fjob ? out.n_slots_pad + j : j;
-    if (base >= out.job_cnt[2]) return;                                 // no path of the launch is this long (uniform)
+    const int nmax_all = out.job_cnt[2];                                // longest profile of the launch (lane kernel)
     const int2 js = have ? out.job_slot[tile] : make_int2(0, 0);
     const int slot = js.x, n = js.y;
     s_slot[lane] = slot; s_n[lane] = n;
+    // blockIdx.y strides over the row chunks: a few long-lived blocks per tile instead of one block per (tile, chunk), most of
+    // which used to find nothing to do
+    for (int base = (int)blockIdx.y * FCH; base < nmax_all; base += (int)gridDim.y * FCH) {
     const bool act = have && base < n;
-    if (__ballot(act) == 0ull) return;                                  // uniform
+    if (__ballot(act) == 0ull) continue;                                // uniform
     double vv[FCH], aa[FCH];
     if (act) {
         const int flags = vp.flags[tile];
@@ -1533,7 +1535,7 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
             }
             vv[c] = v; aa[c] = a;
         }
-        if (blockIdx.y == 0) { vout.vel_bound[slot] = vel_bound; vout.too_close[slot] = (flags & VF_TOO_CLOSE) ? 1 : 0; }
+        if (base == 0) { vout.vel_bound[slot] = vel_bound; vout.too_close[slot] = (flags & VF_TOO_CLOSE) ? 1 : 0; }
     } else {
 #pragma unroll
         for (int c = 0; c < FCH; ++c) { vv[c] = 0.0; aa[c] = 0.0; }
@@ -1560,6 +1562,7 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
             if (i + 1 < nn) store2_u(o, v.x, v.y); else o[0] = v.x;
         }
         wave_sync_lds();
+    }
     }
 }
 
@@ -1810,6 +1813,7 @@ struct ltpl_handle {
     // descriptor came without raceline / node_psi columns
     ltplp::HostLat hostlat; bool has_hostlat = false;
     int scratch_poison_on = 0; unsigned scratch_poison_word = 0;   // LTPL_SCRATCH_POISON (testing)
+    int final_y = 8;                                                // row-chunk blocks per tile of k_vel_final (LTPL_FINAL_Y; A/B on one box: 2: 1.09, 4: 1.07, 8 / 22: 1.06 ms per step)
     int exp_skip = 0;                                               // LTPL_EXP_SKIP (timing experiments only): 1 prep, 2 lanes, 4 final kernel not launched
     int force_fused = 0, no_overlap = 0;                            // LTPL_FORCE_FUSED, LTPL_NO_OVERLAP (measurement switches)
     int poll_sync_every = 4096, poll_query = 0;
@@ -2223,6 +2227,7 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
     h->force_fused = getenv("LTPL_FORCE_FUSED") ? 1 : 0;
     h->no_overlap = getenv("LTPL_NO_OVERLAP") ? 1 : 0;
     if (const char* e = getenv("LTPL_EXP_SKIP")) h->exp_skip = atoi(e);
+    if (const char* e = getenv("LTPL_FINAL_Y")) h->final_y = atoi(e) > 0 ? atoi(e) : 8;
     if (const char* e = getenv("LTPL_NW1_MIN_SCEN")) h->nw1_min_scen = atoi(e) > 0 ? atoi(e) : PIPELINE_MIN_SCEN;
     if (getenv("LTPL_DEBUG_TIMING")) {
         if (hipMalloc(reinterpret_cast<void**>(&h->d_dbg), sizeof(long long) * 256 * DBG_SLOTS) == hipSuccess) {
@@ -2859,7 +2864,7 @@ static int tick_launch_vel(ltpl_handle* h, const TickLayout& t, hipStream_t st, 
                        t.p, t.dvin, t.dprep, t.vp, n_slots, t.n_scen, nb0, h->lp4.dbg);
     HIP_TRY(h, hipGetLastError());
     if (!(h->exp_skip & 4))
-    hipLaunchKernelGGL(k_vel_final, dim3(nb0 + nb1, (t.cap_pts + FCH - 1) / FCH), dim3(64), 0, st, t.dout, t.dvin, t.dvout, t.vp, n_slots, t.n_scen);
+    hipLaunchKernelGGL(k_vel_final, dim3(nb0 + nb1, h->final_y), dim3(64), 0, st, t.dout, t.dvin, t.dvout, t.vp, n_slots, t.n_scen);
     HIP_TRY(h, hipGetLastError());
     return LTPL_OK;
 }
