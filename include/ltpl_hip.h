@@ -167,7 +167,8 @@ typedef struct {
     int32_t* valid;                 /* 1 = key present in the reference's dicts                                   */
     int32_t* reduced;               /* action_set_red_len                                                         */
     int32_t* goal_layer;            /* layer the path ends in                                                     */
-    int32_t* n_nodes;
+    int32_t* n_nodes;               /* entries of nodes / node_idx / coeff behind n_nodes and rows of path_param (and of vx / ax of the
+                                     * tick outputs) behind n_pts are UNSPECIFIED padding, as are slots a >= n_actions and invalid slots */
     int32_t* n_pts;
     int32_t* n_ties;                /* exact cost ties met while picking predecessors along this sweep            */
     int32_t* nodes;                 /* [.. * cap_nodes]      node index per layer, layer i = (start + i) mod L    */
