@@ -267,22 +267,21 @@ class PathsBatch(object):
     """
 
     def __init__(self, scenarios, w_last_edges=()):
+        # Everything is collected in plain Python lists and converted ONCE per element type; the public attributes are views
+        # into those two arrays and the struct's pointer members are base address + offset. (A NumPy operation per field and
+        # vehicle plus an address lookup per column made the packing of ONE scenario cost as much as its planning kernel.)
         n = len(scenarios)
         self.n_scen = n
-        self.w_last = _f64(list(w_last_edges) if len(w_last_edges) else [0.0])
         self.n_w_last = len(w_last_edges)
-        self.start_layer = np.zeros(n, np.int32)
-        self.start_node = np.zeros(n, np.int32)
-        self.flags = np.zeros(n, np.int32)
-        self.last_action = np.full(n, ACT_NONE, np.int32)
-        self.const_closest = np.full(n, -1, np.int32)
-        self.psi_s = np.zeros(n)
-        self.n_last = np.zeros(n, np.int32)
-        self.last_layer = np.full((n, MAX_LAST_NODES), -1, np.int32)
-        self.last_node = np.full((n, MAX_LAST_NODES), -1, np.int32)
+        if self.n_w_last > MAX_LAST_NODES - 1:
+            raise ValueError("w_last_edges longer than %d entries is not supported" % (MAX_LAST_NODES - 1))
+        M = MAX_LAST_NODES
+        start_layer, start_node, flags, last_action, const_closest, psi_s, n_last = [], [], [], [], [], [], []
+        last_layer, last_node = [], []
         veh_off, pos_off, radius, px, py, zone_off, zone = [0], [0], [], [], [], [0], []
-        for i, sc in enumerate(scenarios):
-            self.start_layer[i], self.start_node[i] = int(sc["start_node"][0]), int(sc["start_node"][1])
+        for sc in scenarios:
+            sn = sc["start_node"]
+            start_layer.append(int(sn[0])); start_node.append(int(sn[1]))
             f = 0
             if sc.get("action_sets", True):
                 f |= FLAG_ACTION_SETS
@@ -290,46 +289,70 @@ class PathsBatch(object):
                 f |= FLAG_OBJ_IN_CONST
             if sc.get("obj_besides", False):
                 f |= FLAG_OBJ_BESIDES
-            if sc.get("psi_s") is not None:
+            ps = sc.get("psi_s")
+            if ps is not None:
                 f |= FLAG_HAS_PSI_S
-                self.psi_s[i] = float(sc["psi_s"])
-            self.flags[i] = f
+            psi_s.append(0.0 if ps is None else float(ps))
+            flags.append(f)
             la = sc.get("last_action")
-            self.last_action[i] = ACTION_IDS.get(la, ACT_NONE) if isinstance(la, str) else ACT_NONE
+            last_action.append(ACTION_IDS.get(la, ACT_NONE) if isinstance(la, str) else ACT_NONE)
             cc = sc.get("const_closest")
-            self.const_closest[i] = -1 if cc is None else int(cc)
+            const_closest.append(-1 if cc is None else int(cc))
             for radius_k, positions in sc.get("vehicles", ()):
-                positions = np.asarray(positions, dtype=np.float64).reshape(-1, 2)
                 radius.append(float(radius_k))
-                px.extend(positions[:, 0].tolist())
-                py.extend(positions[:, 1].tolist())
+                if isinstance(positions, np.ndarray):
+                    positions = positions.reshape(-1, 2).tolist()
+                elif len(positions) and not isinstance(positions[0], (list, tuple, np.ndarray)):
+                    positions = [positions]                     # a single (x, y)
+                for xy in positions:
+                    px.append(float(xy[0])); py.append(float(xy[1]))
                 pos_off.append(len(px))
             veh_off.append(len(radius))
-            zone.extend(int(g) for g in sc.get("zone_gids", ()))
+            zg = sc.get("zone_gids", ())
+            zone.extend(zg.tolist() if isinstance(zg, np.ndarray) else [int(g) for g in zg])
             zone_off.append(len(zone))
+            ll, lnn = [-1] * M, [-1] * M
+            k = 0
             ln = sc.get("last_nodes")
             if ln:
                 # only nodes that can take part in a cost discount are shipped (w_last_edges has <= MAX-1 entries)
-                k = 0
-                for node in ln[:MAX_LAST_NODES]:
+                for node in ln[:M]:
                     if node is None or node[0] is None or node[1] is None:
                         break
-                    self.last_layer[i, k], self.last_node[i, k] = int(node[0]), int(node[1])
+                    ll[k], lnn[k] = int(node[0]), int(node[1])
                     k += 1
-                self.n_last[i] = k
-        self.veh_off, self.pos_off = _i32(veh_off), _i32(pos_off)
-        self.veh_radius = _f64(radius if radius else [0.0])
-        self.pos_x, self.pos_y = _f64(px if px else [0.0]), _f64(py if py else [0.0])
-        self.zone_off, self.zone_gid = _i32(zone_off), _i32(zone if zone else [0])
+            n_last.append(k)
+            last_layer += ll; last_node += lnn
         self.n_veh_total = len(radius)
-        if self.n_w_last > MAX_LAST_NODES - 1:
-            raise ValueError("w_last_edges longer than %d entries is not supported" % (MAX_LAST_NODES - 1))
-        s = self.struct = PathsIn()
-        s.n_scen, s.n_w_last = n, self.n_w_last
-        s.w_last_edges = self.w_last.ctypes.data
-        for name in ("start_layer", "start_node", "flags", "last_action", "const_closest", "veh_off", "pos_off",
-                     "zone_off", "zone_gid", "n_last", "last_layer", "last_node", "psi_s", "veh_radius", "pos_x", "pos_y"):
-            setattr(s, name, getattr(self, name).ctypes.data)
+        if not radius:
+            radius = [0.0]
+        if not px:
+            px, py = [0.0], [0.0]
+        if not zone:
+            zone = [0]
+        wl = [float(w) for w in w_last_edges] if self.n_w_last else [0.0]
+        ints = np.array(start_layer + start_node + flags + last_action + const_closest + n_last + last_layer + last_node +
+                        veh_off + pos_off + zone_off + zone, np.int32)
+        dbls = np.array(wl + psi_s + radius + px + py, np.float64)
+        self._ints, self._dbls = ints, dbls
+        bi, bd = ints.ctypes.data, dbls.ctypes.data
+        st = self.struct = PathsIn()
+        st.n_scen, st.n_w_last = n, self.n_w_last
+        o = 0
+        for name, cnt, shape in (("start_layer", n, None), ("start_node", n, None), ("flags", n, None), ("last_action", n, None),
+                                 ("const_closest", n, None), ("n_last", n, None), ("last_layer", n * M, (n, M)),
+                                 ("last_node", n * M, (n, M)), ("veh_off", len(veh_off), None), ("pos_off", len(pos_off), None),
+                                 ("zone_off", len(zone_off), None), ("zone_gid", len(zone), None)):
+            v = ints[o:o + cnt]
+            setattr(self, name, v if shape is None else v.reshape(shape))
+            setattr(st, name, bi + 4 * o)
+            o += cnt
+        o = 0
+        for name, sname, cnt in (("w_last", "w_last_edges", len(wl)), ("psi_s", "psi_s", n), ("veh_radius", "veh_radius", len(radius)),
+                                 ("pos_x", "pos_x", len(px)), ("pos_y", "pos_y", len(px))):
+            setattr(self, name, dbls[o:o + cnt])
+            setattr(st, sname, bd + 8 * o)
+            o += cnt
 
 
 class PathsResult(object):
