@@ -401,18 +401,28 @@ class PathsResult(object):
 class TickVelBatch(object):
     def __init__(self, params: VelParamSet, n_scen, vel_plan, vel_est, pos_est, veh_vel, gg=(5.0, 5.0),
                  gg_brake_scale=1.0, safety_d=30.0, v_max_offset=0.1):
+        # one array, views and pointer arithmetic (see PathsBatch)
         self.params = params
-        self.vel_plan, self.vel_est = _f64(vel_plan), _f64(vel_est)
-        pos_est = np.asarray(pos_est, dtype=np.float64).reshape(n_scen, 2)
-        self.pos_x, self.pos_y = _f64(pos_est[:, 0]), _f64(pos_est[:, 1])
-        self.veh_vel = _f64(veh_vel if len(veh_vel) else [0.0])
+        n = int(n_scen)
+        pos = np.asarray(pos_est, dtype=np.float64).reshape(n, 2)
+        vv = np.asarray(veh_vel, dtype=np.float64).reshape(-1)
+        nv = max(len(vv), 1)
+        buf = np.zeros(4 * n + nv)
+        buf[0:n] = vel_plan
+        buf[n:2 * n] = vel_est
+        buf[2 * n:3 * n] = pos[:, 0]
+        buf[3 * n:4 * n] = pos[:, 1]
+        if len(vv):
+            buf[4 * n:] = vv
+        self._buf = buf
+        self.vel_plan, self.vel_est = buf[0:n], buf[n:2 * n]
+        self.pos_x, self.pos_y, self.veh_vel = buf[2 * n:3 * n], buf[3 * n:4 * n], buf[4 * n:]
         s = self.struct = TickVelIn()
         s.params = C.pointer(params.struct)
         s.gg_ax, s.gg_ay, s.gg_brake_scale = float(gg[0]), float(gg[1]), float(gg_brake_scale)
         s.safety_d, s.v_max_offset = float(safety_d), float(v_max_offset)
-        s.vel_plan, s.vel_est = self.vel_plan.ctypes.data, self.vel_est.ctypes.data
-        s.pos_est_x, s.pos_est_y = self.pos_x.ctypes.data, self.pos_y.ctypes.data
-        s.veh_vel = self.veh_vel.ctypes.data
+        b = buf.ctypes.data
+        s.vel_plan, s.vel_est, s.pos_est_x, s.pos_est_y, s.veh_vel = b, b + 8 * n, b + 16 * n, b + 24 * n, b + 32 * n
 
 
 class TickVelResult(object):
