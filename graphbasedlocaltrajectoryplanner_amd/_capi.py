@@ -384,13 +384,15 @@ class PathsResult(object):
         name in insertion order, each value a one-element list; absent keys = no solution.
         """
         nodes, node_idx, coeff, path_param, red_len = {}, {}, {}, {}, {}
+        start_layer = int(start_layer)
         for a in range(int(self.n_actions[s])):
             if not self.valid[s, a]:
                 continue
             name = ACTION_NAMES[int(self.action_id[s, a])]
             nn, npts = int(self.n_nodes[s, a]), int(self.n_pts[s, a])
-            nodes[name] = [[[int((start_layer + i) % num_layers), int(self.nodes[s, a, i])] for i in range(nn)]]
-            node_idx[name] = [[int(v) for v in self.node_idx[s, a, :nn]]]
+            nl = self.nodes[s, a, :nn].tolist()                 # (one conversion instead of a NumPy scalar access per node)
+            nodes[name] = [[[(start_layer + i) % num_layers, nl[i]] for i in range(nn)]]
+            node_idx[name] = [self.node_idx[s, a, :nn].tolist()]
             coeff[name] = [self.coeff[s, a, :nn - 1, :].copy()]
             path_param[name] = [self.path_param[s, a, :npts, :].copy()]
             red_len[name] = [bool(self.reduced[s, a])]
