@@ -320,12 +320,14 @@ class Planner(object):
         """State after calc_paths of planner ``scen``: dict with the reference's structures (OTH.py:509-516)."""
         v = self._pv
         self._check(self._fn("get_paths")(self.handle, int(scen), C.byref(v)))
+        nk = v.n_keys
+        key_id, n_rows, n_nodes, red = v.key_id[:nk], v.n_rows[:nk], v.n_nodes[:nk], v.red_len[:nk]     # ctypes arrays -> lists, once
+        coi = v.closest_obj_index
         out = {"keys": [], "path_param": {}, "coeff": {}, "nodes": {}, "node_idx": {}, "red_len": {},
-               "start_node": [int(v.start_node[0]), int(v.start_node[1])], "const_rows": int(v.const_rows),
-               "closest_obj_index": None if v.closest_obj_index < 0 else int(v.closest_obj_index)}
-        for k in range(v.n_keys):
-            name = KEY_NAMES[int(v.key_id[k])]
-            nr, nn = int(v.n_rows[k]), int(v.n_nodes[k])
+               "start_node": v.start_node[:2], "const_rows": v.const_rows, "closest_obj_index": None if coi < 0 else coi}
+        for k in range(nk):
+            name = KEY_NAMES[key_id[k]]
+            nr, nn = n_rows[k], n_nodes[k]
             out["keys"].append(name)
             out["path_param"][name] = self._pp[k][:nr].copy()
             out["coeff"][name] = self._co[k][:max(nn - 1, 0)].copy()
@@ -334,7 +336,7 @@ class Planner(object):
                 nodes = [[None if a < 0 else a, None if b < 0 else b] for a, b in nodes]
             out["nodes"][name] = nodes
             out["node_idx"][name] = self._ni[k][:nn].tolist()
-            out["red_len"][name] = bool(v.red_len[k])
+            out["red_len"][name] = bool(red[k])
         return out
 
     def trajectories(self, scen=0):
@@ -342,11 +344,13 @@ class Planner(object):
         v = self._tv
         self._check(self._fn("get_trajectories")(self.handle, int(scen), C.byref(v)))
         action_set, ids = {}, {}
-        for k in range(v.n_keys):
-            name = KEY_NAMES[int(v.key_id[k])]
-            action_set[name] = [self._tr[k][:int(v.n_rows[k])].copy()]
-        for k in range(v.n_ids):
-            ids[KEY_NAMES[int(v.id_key[k])]] = int(v.id_val[k])
-        ref = {"cut_index_pos": int(v.cut_index_pos), "cut_layer": int(v.cut_layer), "vel_plan": float(v.vel_plan),
-               "acc_plan": float(v.acc_plan), "vel_course": self._vc[:int(v.n_vel_course)].copy()}
+        nk, ni = v.n_keys, v.n_ids
+        key_id, n_rows = v.key_id[:nk], v.n_rows[:nk]
+        for k in range(nk):
+            action_set[KEY_NAMES[key_id[k]]] = [self._tr[k][:n_rows[k]].copy()]
+        id_key, id_val = v.id_key[:ni], v.id_val[:ni]
+        for k in range(ni):
+            ids[KEY_NAMES[id_key[k]]] = id_val[k]
+        ref = {"cut_index_pos": v.cut_index_pos, "cut_layer": v.cut_layer, "vel_plan": v.vel_plan,
+               "acc_plan": v.acc_plan, "vel_course": self._vc[:v.n_vel_course].copy()}
         return action_set, ids, ref
