@@ -100,29 +100,34 @@ class TickVelIn(C.Structure):
                 ("veh_vel", _vp)]
 
 
-class ObjectsIn(C.Structure):
+class ObjectsIn(C.Structure):              # pointer members as plain addresses (see planner.py: a typed pointer costs ~4 us to build)
     _fields_ = [("n_obj", C.c_int32), ("reserved0", C.c_int32), ("dt", C.c_double),
-                ("x", _pf64), ("y", _pf64), ("theta", _pf64), ("v", _pf64), ("length", _pf64)]
+                ("x", C.c_void_p), ("y", C.c_void_p), ("theta", C.c_void_p), ("v", C.c_void_p), ("length", C.c_void_p)]
 
 
 class ObjectsOut(C.Structure):
-    _fields_ = [("on_track", _pi32), ("pred_x", _pf64), ("pred_y", _pf64), ("radius", _pf64)]
+    _fields_ = [("on_track", C.c_void_p), ("pred_x", C.c_void_p), ("pred_y", C.c_void_p), ("radius", C.c_void_p)]
 
 
 def make_objects(x, y, theta, v, length, dt=0.2):
-    """(ObjectsIn, ObjectsOut, output arrays dict, keep-alive list) for n flat objects."""
-    arrs = [_f64(a).reshape(-1) for a in (x, y, theta, v, length)]
-    n = arrs[0].size
-    if n == 0:
-        arrs = [np.zeros(1) for _ in arrs]
-    o = {"on_track": np.zeros(max(n, 1), np.int32), "pred_x": np.zeros(max(n, 1)), "pred_y": np.zeros(max(n, 1)),
-         "radius": np.zeros(max(n, 1))}
+    """(ObjectsIn, ObjectsOut, output arrays dict, keep-alive list) for n flat objects: one float64 array [inputs | outputs], one
+    int32 array, views and pointer arithmetic."""
+    cols = [np.asarray(a, dtype=np.float64).reshape(-1) for a in (x, y, theta, v, length)]
+    n = cols[0].size
+    m = max(n, 1)
+    buf = np.zeros(8 * m)
+    for k, c in enumerate(cols):
+        if n:
+            buf[k * m:k * m + n] = c
+    flags = np.zeros(m, np.int32)
     i, out = ObjectsIn(), ObjectsOut()
     i.n_obj, i.dt = n, float(dt)
-    i.x, i.y, i.theta, i.v, i.length = (_p(a, _pf64) for a in arrs)
-    out.on_track = _p(o["on_track"], _pi32)
-    out.pred_x, out.pred_y, out.radius = _p(o["pred_x"], _pf64), _p(o["pred_y"], _pf64), _p(o["radius"], _pf64)
-    return i, out, {k: a[:n] for k, a in o.items()}, arrs
+    b = buf.ctypes.data
+    i.x, i.y, i.theta, i.v, i.length = b, b + 8 * m, b + 16 * m, b + 24 * m, b + 32 * m
+    out.pred_x, out.pred_y, out.radius = b + 40 * m, b + 48 * m, b + 56 * m
+    out.on_track = flags.ctypes.data
+    o = {"on_track": flags[:n], "pred_x": buf[5 * m:5 * m + n], "pred_y": buf[6 * m:6 * m + n], "radius": buf[7 * m:7 * m + n]}
+    return i, out, o, [buf, flags]
 
 
 class TrajOut(C.Structure):
