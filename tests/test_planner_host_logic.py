@@ -65,3 +65,34 @@ def test_closed_loop_replay_on_an_open_track(open_lattice):
     seen = pr.replay(HostPlannerBackend(open_lattice).planner(1), open_lattice, ticks)
     assert {"straight", "follow", "right"} <= seen['keys'] and seen['full'] >= 15
     assert sum(1 for t in ticks if any(t['paths']['red_len'].values())) > 100
+
+
+def test_input_staging_grows_and_keeps_the_layout(host_backend):
+    """The per-tick input staging of the planner binding (one packed double / int32 array, pointers by offset) beyond its initial
+    capacity: 150 vehicles with 3 positions each, read back through the pointers the C side receives."""
+    import ctypes as C
+    import numpy as np
+    planner = host_backend.planner(2)
+    rng = np.random.default_rng(5)
+    veh = [[(float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.0, 50.0)), rng.uniform(-100.0, 100.0, (3, 2))) for _ in range(150)],
+           [(1.0, 2.0, [[3.0, 4.0]])]]
+    zones = [list(range(700)), np.arange(5, dtype=np.int32)]
+    i, _keep = planner._pack_paths_in(["straight", None], [0.25, 0.5], veh, zones)
+
+    def dbl(addr, k):
+        return np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_double)), (k,)).copy()
+
+    def i32(addr, k):
+        return np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_int32)), (k,)).copy()
+    assert dbl(i.t_now, 2).tolist() == [0.25, 0.5]
+    assert i32(i.veh_off, 3).tolist() == [0, 150, 151]
+    pos_off = i32(i.pos_off, 152)
+    assert pos_off[150] == 450 and pos_off[151] == 451
+    assert np.array_equal(dbl(i.veh_radius, 151), np.array([v[0] for v in veh[0]] + [1.0]))
+    assert np.array_equal(dbl(i.veh_vel, 151), np.array([v[1] for v in veh[0]] + [2.0]))
+    px = np.concatenate([v[2][:, 0] for v in veh[0]] + [[3.0]]); py = np.concatenate([v[2][:, 1] for v in veh[0]] + [[4.0]])
+    assert np.array_equal(dbl(i.pos_x, 451), px) and np.array_equal(dbl(i.pos_y, 451), py)
+    assert i32(i.zone_off, 3).tolist() == [0, 700, 705]
+    assert i32(i.zone_gid, 705).tolist() == list(range(700)) + list(range(5))
+    acts = i32(i.prev_action, 2)
+    assert acts[1] == -1 and acts[0] != -1
