@@ -343,21 +343,34 @@ class PathsBatch(object):
         bi, bd = ints.ctypes.data, dbls.ctypes.data
         st = self.struct = PathsIn()
         st.n_scen, st.n_w_last = n, self.n_w_last
+        # the array attributes (start_layer, veh_off, pos_x, ...) are views created on first access (__getattr__)
+        views = self._views = {}
         o = 0
         for name, cnt, shape in (("start_layer", n, None), ("start_node", n, None), ("flags", n, None), ("last_action", n, None),
                                  ("const_closest", n, None), ("n_last", n, None), ("last_layer", n * M, (n, M)),
                                  ("last_node", n * M, (n, M)), ("veh_off", len(veh_off), None), ("pos_off", len(pos_off), None),
                                  ("zone_off", len(zone_off), None), ("zone_gid", len(zone), None)):
-            v = ints[o:o + cnt]
-            setattr(self, name, v if shape is None else v.reshape(shape))
+            views[name] = (0, o, cnt, shape)
             setattr(st, name, bi + 4 * o)
             o += cnt
         o = 0
         for name, sname, cnt in (("w_last", "w_last_edges", len(wl)), ("psi_s", "psi_s", n), ("veh_radius", "veh_radius", len(radius)),
                                  ("pos_x", "pos_x", len(px)), ("pos_y", "pos_y", len(px))):
-            setattr(self, name, dbls[o:o + cnt])
+            views[name] = (1, o, cnt, None)
             setattr(st, sname, bd + 8 * o)
             o += cnt
+
+    def __getattr__(self, name):
+        # only reached for names that are not instance attributes yet: materialise the view once
+        views = self.__dict__.get("_views")
+        if views is None or name not in views:
+            raise AttributeError(name)
+        kind, o, cnt, shape = views[name]
+        v = (self._dbls if kind else self._ints)[o:o + cnt]
+        if shape is not None:
+            v = v.reshape(shape)
+        self.__dict__[name] = v
+        return v
 
 
 class PathsResult(object):
