@@ -2687,8 +2687,15 @@ extern "C" int ltpl_vel_profile(ltpl_handle* h, const ltpl_vel_params* vp, int n
         memcpy(pool + d.off_gg, jb.loc_gg, sizeof(double) * 2 * (size_t)jb.n);
     }
     vel_kernel_t kern = vel_kernel_of(vel_variant(vp));
-    if (lds > 48 * 1024)
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        // the dynamic-LDS limit of a kernel is process-wide state: raised when a call needs more, never lowered, not re-set per tick
+        static size_t g_set[16][8];
+        size_t& cur = g_set[h->device & 15][vel_variant(vp) & 7];
+        if (lds > 48 * 1024 && lds > cur) {
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            cur = lds;
+        }
+    }
     prof_pack.stop();
     LTPL_PROF(prof_enq, "vel_profile.enqueue");
     if (!zci) HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, ain.size, hipMemcpyHostToDevice, h->stream));
@@ -2903,8 +2910,12 @@ static void tick_scatter(const unsigned char* hb, const TickLayout& t, ltpl_path
 static int tick_set_lds_limit(ltpl_handle* h, size_t lds, int variant)
 {
     if (h->long_horizon) return LTPL_OK;                  // the fused kernel is not used
-    if (lds > 48 * 1024)
+    static size_t g_set[16][8][2];                        // (process-wide limit: raised on demand, never lowered, not re-set per tick)
+    size_t& cur = g_set[h->device & 15][variant & 7][h->plan_class4 == 1 ? 1 : 0];
+    if (lds > 48 * 1024 && lds > cur) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(tick_kernel_of(variant, h->plan_class4 == 1)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        cur = lds;
+    }
     return LTPL_OK;
 }
 
