@@ -311,6 +311,7 @@ def worker(args):
                                        "what": "ltpl_tick_batch_compact: host buffers in, trajectories [s,x,y,psi,kappa,vx,ax] "
                                                "(115 export rows, Graph_LTPL.py:401-406) packed on the device and DMA-written into "
                                                "page-locked host memory; capacity_slab_* = ltpl_tick_batch with full capacity slabs"}
+        traffic = read_traffic(args.batch, args.workload)            # measured HBM bytes per launch of the dominant kernel (PMC), or None
         out = {
             "metric": "planning ticks/s (all action primitives), " + ("Monteblanco lattice" if args.workload == "c2" else "synthetic C3 lattice"),
             "value": world * args.batch * timed_steps / elapsed,
@@ -326,7 +327,8 @@ def worker(args):
                                    + "; %d independent scenarios per GPU per step, tick pipeline (paths + velocity)" % args.batch,
                        "batch_per_gpu": args.batch, "parallelism": "scenario-sharded x%d (no collective)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": read_traffic(args.batch, args.workload),
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          "kernel": "k_paths<1>", "kernel_ms": dom_ms,
                          "kernel_ms_not_overlapped": prof_ms[0],
                          "algorithmic_bytes_per_launch": ab_paths,
