@@ -1,0 +1,181 @@
+"""CPU: dry run of bench.py's rank-0 line assembly (the driver's contract) with a stand-in backend.
+
+The build container has no GPU, so ``bench.worker`` cannot run here as shipped -- and a Python-level slip in the ~150 lines that
+put the JSON line together would only show at round end on the GPU box. This test swaps the device backend for a stand-in that
+answers every call bench.py makes with the ORACLE's results and made-up durations, and lets the planner entry points of the
+drop-in leg run on the host-logic harness (oracle/planner_host.py). It checks the shape of the line, not any number in it:
+the numbers are the GPU box's business (tests -m gpu, bench.py itself). Nothing here is product code.
+"""
+import argparse
+import json
+import types
+
+import numpy as np
+import pytest
+
+import bench
+from graphbasedlocaltrajectoryplanner_amd import _capi
+from oracle.oracle_lib import OracleBackend
+from oracle.planner_host import HostPlannerBackend       # bound to the real Planner class before the test patches the name
+
+
+class StandInBackend(object):
+    """HipBackend's surface as bench.py uses it; results from the oracle, durations invented."""
+
+    def __init__(self, lattice, device=-1):
+        self.orc = OracleBackend(lattice)
+        self.host = HostPlannerBackend(lattice)
+        self.caps = self.orc.caps
+        self.calls = []
+        self._resident = None
+
+    def new_paths_result(self, n_scen):
+        return self.orc.new_paths_result(n_scen)
+
+    def tick_batch(self, batch, vel, result=None, vresult=None):
+        self.calls.append("tick_batch")
+        return self.orc.tick_batch(batch, vel, result, vresult)
+
+    def new_compact_trajectories(self, n_scen, max_rows=115, capacity_rows=None):
+        return types.SimpleNamespace(struct=types.SimpleNamespace(total_rows=0), n_scen=n_scen, max_rows=max_rows)
+
+    def tick_batch_compact(self, batch, vel, out):
+        self.calls.append("tick_batch_compact")
+        res, _ = self.orc.tick_batch(batch, vel)
+        out.struct.total_rows = int(res.valid.sum()) * out.max_rows
+        return out
+
+    def batch_upload(self, batch, vel):
+        self.calls.append("batch_upload")
+        self._resident = (batch, vel)
+
+    def batch_run(self, reps=1, timed=True):
+        self.calls.append("batch_run")
+        assert self._resident is not None
+        return 0.9 * reps if timed else 0.0
+
+    def batch_last_paths_ms(self):
+        return 0.8
+
+    def batch_run_profile(self, reps=10):
+        return [0.8, 0.07, 0.15]
+
+    def batch_download(self):
+        return self.orc.tick_batch(*self._resident)
+
+
+def run_worker(monkeypatch, capsys, **over):
+    import torch
+    from graphbasedlocaltrajectoryplanner_amd import planner as planner_mod
+    made = []
+
+    def backend(lattice, device=-1):
+        made.append(StandInBackend(lattice, device))
+        return made[-1]
+
+    monkeypatch.setattr(_capi, "HipBackend", backend)
+    monkeypatch.setattr(planner_mod, "Planner", lambda hip, n_scen=1, **cfg: hip.host.planner(n_scen, **cfg))
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    args = dict(gpus=1, steps=3, warmup=1, batch=64, cpu_sample=8, latency_ticks=4, dropin_ticks=40, no_cpu=False,
+                no_extra=False, exact_steps=True, workload="c2")
+    args.update(over)
+    bench.worker(argparse.Namespace(**args))
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly ONE JSON line"
+    return json.loads(lines[0]), made[0]
+
+
+def test_the_line_carries_the_drivers_contract(monkeypatch, capsys):
+    out, hip = run_worker(monkeypatch, capsys)
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                     ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(out[key], typ), key
+    assert out["vs_baseline"] is None and out["unit"] == "ticks/s" and out["scaling"] == "weak" and out["dtype"] == "f64"
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["timed_steps"] == 3
+    assert "workload" in out["config"] and "model" not in out["config"]
+    assert "ticks/s" in out["metric"] and out["value"] > 0 and np.isfinite(out["value"])
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 64.0) < 1e-6          # value = units of all ranks / timed region
+
+    r = out["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == bench.HBM_PEAK_GBPS
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["kernel_ms"] == pytest.approx(0.8)                                # the live, in-region duration wins over the profile's
+    assert r["traffic"] is None and r["traffic_frac"] is None                  # PMC summary is for the 32768-scenario grid only
+
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "ticks/s" and c["value"] > 0 and "8 scenarios" in c["sample"]
+    assert out["parity_checked"] is True and out["parity_detail"]["scenarios"] == 8 and not out["parity_detail"]["mismatches"]
+
+    l = out["latency_us"]
+    assert l["ticks"] == 4 and l["p50"] > 0 and l["device_us"] == pytest.approx(900.0)
+    assert l["dropin_ticks"] == 40 and l["dropin_keys_match_recording"] is True
+    assert out["extra"]["pcie_inclusive"]["scenarios_per_call"] == 64 and out["extra"]["three_slot_paths_per_tick"] >= 1.0
+    assert 1.0 <= out["paths_per_tick"] <= 4.0
+    # order of the device calls: resident inputs before any run, and the sample re-uploaded for the device-only latency
+    assert hip.calls[0] == "batch_upload" and hip.calls.count("batch_upload") == 3
+
+
+def test_traffic_is_reported_for_the_grid_it_was_measured_on(monkeypatch, capsys):
+    import os
+    with open(os.path.join(bench.ROOT, "profiles", "pmc_traffic.json")) as fh:
+        pmc = json.load(fh)
+    n = int(pmc["grid_size"]) // 64
+    assert bench.read_traffic(n, pmc.get("workload", "c2")) == pmc["hbm_bytes_per_launch"]
+    assert bench.read_traffic(n // 2, "c2") is None and bench.read_traffic(n, "c3") is None
+
+
+def test_flags_that_drop_legs(monkeypatch, capsys):
+    out, hip = run_worker(monkeypatch, capsys, no_cpu=True, no_extra=True, latency_ticks=0)
+    assert "cpu_baseline" not in out and "parity_checked" not in out and out["extra"] == {}
+    assert out["latency_us"]["p50"] is None and out["latency_us"]["dropin_p50"] is None and out["latency_us"]["ticks"] == 0
+    assert "tick_batch" not in hip.calls
+
+
+def test_refuses_to_run_without_a_gpu(monkeypatch):
+    import torch
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    with pytest.raises(SystemExit, match="no CPU fallback"):
+        bench.worker(argparse.Namespace(gpus=1, steps=1, warmup=0, batch=8, workload="c2"))
+
+
+def _rank_main(rank, port, out_dir):
+    """One rank of the two-rank rehearsal (spawned process: patches by hand, no pytest fixtures here)."""
+    import contextlib
+    import os
+    import torch
+    from graphbasedlocaltrajectoryplanner_amd import planner as planner_mod
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port), "LTPL_BENCH_SHARE_GPU": "1"})       # share: gloo + CPU tensors for the max
+    _capi.HipBackend = lambda lattice, device=-1: StandInBackend(lattice, device)
+    planner_mod.Planner = lambda hip, n_scen=1, **cfg: hip.host.planner(n_scen, **cfg)
+    torch.cuda.is_available = lambda: True
+    torch.cuda.set_device = lambda d: None
+    torch.cuda.synchronize = lambda *a: None
+    args = argparse.Namespace(gpus=2, steps=2, warmup=1, batch=64, cpu_sample=8, latency_ticks=0, dropin_ticks=0, no_cpu=False,
+                              no_extra=True, exact_steps=True, workload="c2")
+    with open(os.path.join(out_dir, "rank%d.out" % rank), "w") as fh, contextlib.redirect_stdout(fh):
+        bench.worker(args)
+
+
+def test_two_ranks_print_one_line_with_the_whole_job_rate(tmp_path):
+    """N > 1 as the driver launches it (one process per rank, env rendezvous on 127.0.0.1), rehearsed over gloo: only rank 0
+    prints, n_gpus is the world size, and value counts the scenarios of BOTH shards over the max-over-ranks region."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_rank_main, args=(port, str(tmp_path)), nprocs=2, join=True)
+    out0 = [l for l in (tmp_path / "rank0.out").read_text().splitlines() if l.startswith("{")]
+    assert len(out0) == 1 and (tmp_path / "rank1.out").read_text().strip() == ""
+    out = json.loads(out0[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and "x2" in out["config"]["parallelism"]
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 128.0) < 1e-6
+    assert out["cpu_baseline"]["cores"] == 1 and out["parity_checked"] is True
