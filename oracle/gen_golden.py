@@ -24,6 +24,10 @@ reference (imported from /root/reference over oracle/shims, see oracle/ref_env.p
                                        requested: overtakes dropped for broken velocity bounds (OTH.py:945,1007-1015),
                                        calc_brake_emergency (OTH.py:1028-1034)
 
+  <track>_*.npz             (python -m oracle.gen_golden track zalazone|millbrook|lvms) further tracks of the reference's
+                            inputs/traj_ltpl_cl: race line columns, the lattice of the reference's offline build, and a 900-tick
+                            closed loop with race-line followers recorded at both seams and at tick level (main_track)
+
 The reference ships no golden vectors of its own, so these recordings are the parity anchor; parity of
 the shimmed third-party arithmetic (igraph / tph) itself stays UNPINNED.
 """
@@ -202,6 +206,82 @@ def main_open():
     seam.uninstall()
 
 
+class RaceLineFollower(object):
+    """Vehicle at constant speed on the race line of the planner's OWN track (the reference's ObjectlistDummy always follows the
+    track named in params/driving_task.ini, i.e. Monteblanco). Object-list dicts in the format of objectlist_dummy.py:171-181."""
+
+    def __init__(self, gb, s0, v, ident, dt=0.05):
+        self.g, self.s, self.v, self.id, self.dt = gb.glob_rl, float(s0), float(v), ident, dt
+        self.closed = bool(gb.closed)
+
+    def get_objectlist(self):
+        g = self.g
+        s_end = float(g[-1, 0])
+        self.s += self.v * self.dt
+        if self.closed:
+            self.s = self.s % s_end
+        else:
+            self.s = min(self.s, float(g[-2, 0]))
+        i = max(0, min(int(np.searchsorted(g[:, 0], self.s, side="right")) - 1, g.shape[0] - 2))
+        t = (self.s - g[i, 0]) / (g[i + 1, 0] - g[i, 0])
+        x, y = g[i, 1] + t * (g[i + 1, 1] - g[i, 1]), g[i, 2] + t * (g[i + 1, 2] - g[i, 2])
+        psi = np.arctan2(g[i + 1, 2] - g[i, 2], g[i + 1, 1] - g[i, 1]) - np.pi / 2
+        return [{'X': float(x), 'Y': float(y), 'theta': float(psi), 'type': 'physical', 'id': self.id, 'length': 5.0,
+                 'v': float(self.v)}]
+
+
+# (fraction of the lap where the follower starts, speed in m/s): short tracks get one follower, otherwise an object is always in range
+TRACK_OPPONENTS = {"lvms": ((0.06, 12.0), (0.14, 16.0), (0.3, 10.0)), "zalazone": ((0.5, 8.0),), "millbrook": ((0.5, 8.0),)}
+
+
+def main_track(track, n_ticks=900):
+    """A second (third ...) track of the reference's inputs/traj_ltpl_cl: the reference's offline build + a closed loop with three
+    slow race-line followers ahead of the ego, recorded at both seams and at tick level.
+      <track>_track.npz (columns of the race line file), <track>_lattice.npz, <track>_path_calls.npz, <track>_vel_calls.npz,
+      <track>_ticks.npz"""
+    warnings.simplefilter("ignore")
+    from oracle import ref_env
+    from graphbasedlocaltrajectoryplanner_amd.offline_build import import_track_csv
+    os.makedirs(GOLDEN, exist_ok=True)
+    gl, clock, ltpl_obj, gb, path_dict = rs.make_planner(CACHE, track=track)
+    np.savez_compressed(os.path.join(GOLDEN, track + "_track.npz"), **import_track_csv(path_dict['globtraj_input_path']))
+    lat = Lattice.from_graph_base(gb)
+    lat.save(os.path.join(GOLDEN, track + "_lattice.npz"))
+    print("%s lattice: L=%d V=%d E=%d S=%d closed=%s, nodes per layer %d..%d" % (
+        track, lat.num_layers, lat.num_nodes, lat.num_edges, lat.num_samples, lat.closed,
+        int(lat.nodes_in_layer.min()), int(lat.nodes_in_layer.max())))
+    seam = rs.SeamRecorder(gl, gb)
+    rec = rs.TickRecorder(gl, clock, seam)
+    s_end = float(gb.glob_rl[-1, 0])
+    opp = [RaceLineFollower(gb, s0=s_end * f, v=v, ident=10 + k) for k, (f, v) in enumerate(TRACK_OPPONENTS.get(track, ((0.5, 14.0),)))]
+    n_done = [0]
+    try:
+        rs.run_loop(gl, clock, ltpl_obj, path_dict, n_ticks=n_ticks, dt=0.05, dummies=opp, zones=None,
+                    on_tick=lambda i, e: n_done.__setitem__(0, i + 1))
+    except Exception as e:
+        print("%s loop stopped after %d ticks: %s: %s" % (track, n_done[0], type(e).__name__, e))
+    ticks = rec.export(full_every=50)
+    n = len(ticks)
+    sel = select_path_ticks(seam.path_calls[:n], every=25)
+    if len(sel) > 70:                                         # many changes of the offered set: thin out evenly
+        sel = [sel[int(round(k))] for k in np.linspace(0, len(sel) - 1, 70)]
+    save_records(os.path.join(GOLDEN, track + "_path_calls.npz"), [dict(seam.path_calls[i], tick=i) for i in sel])
+    vsel = select_vel_calls(seam.vel_calls, every=23)
+    if len(vsel) > 90:
+        vsel = [vsel[int(round(k))] for k in np.linspace(0, len(vsel) - 1, 90)]
+    save_records(os.path.join(GOLDEN, track + "_vel_calls.npz"), [seam.vel_calls[i] for i in vsel])
+    save_records(os.path.join(GOLDEN, track + "_ticks.npz"), ticks, packed=True)
+    import collections
+    print("%s: %d ticks, %d path calls kept, %d vel calls kept; offered sets %s; reduced %s" % (
+        track, n, len(sel), len(vsel), dict(collections.Counter(tuple(t['vel']['keys']) for t in ticks)),
+        dict(collections.Counter(tuple(sorted(t['paths']['red_len'].items())) for t in ticks))))
+    rec.uninstall()
+    seam.uninstall()
+    for f in sorted(os.listdir(GOLDEN)):
+        if f.startswith(track):
+            print("%-32s %8.2f MB" % (f, os.path.getsize(os.path.join(GOLDEN, f)) / 1e6))
+
+
 def main():
     warnings.simplefilter("ignore")
     os.makedirs(GOLDEN, exist_ok=True)
@@ -268,6 +348,8 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "open":
         main_open()
+    elif len(sys.argv) > 2 and sys.argv[1] == "track":
+        main_track(sys.argv[2])
     elif len(sys.argv) > 1 and sys.argv[1] == "ticks":
         main_ticks(sys.argv[2:])
     else:
