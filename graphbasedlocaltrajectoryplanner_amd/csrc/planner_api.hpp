@@ -76,6 +76,14 @@ inline int api_calc_vel_profile(ltpl_planner* p, const ltpl_planner_vel_in* in)
     return p->P.calc_vel_profile(req.data(), in->ax_max_machines, in->n_ax_max_machines, nullptr);
 }
 
+// copy-out of one accessor array: nothing to do without a destination or for an empty source (whose data() may be null --
+// memcpy must not be handed a null pointer, not even for zero bytes)
+template <class T>
+inline void copy_out(T* dst, const std::vector<T>& src, size_t n)
+{
+    if (dst && n > 0) std::memcpy(dst, src.data(), sizeof(T) * n);
+}
+
 inline int api_get_paths(const ltpl_planner* p, int scen, ltpl_planner_paths_view* v)
 {
     if (!p || !v || scen < 0 || scen >= (int)p->P.sc.size()) return LTPL_ERR_INVALID_ARG;
@@ -89,10 +97,10 @@ inline int api_get_paths(const ltpl_planner* p, int scen, ltpl_planner_paths_vie
         const int k = v->n_keys++;
         v->key_id[k] = T.id; v->n_rows[k] = T.rows(); v->n_nodes[k] = T.n_nodes(); v->red_len[k] = T.red_len ? 1 : 0;
         if (T.rows() > caps.cap_rows || T.n_nodes() > caps.cap_nodes) return LTPL_ERR_CAPACITY;
-        if (v->path_param[k]) std::memcpy(v->path_param[k], T.pp.data(), sizeof(double) * T.pp.size());
-        if (v->coeff[k]) std::memcpy(v->coeff[k], T.coeff.data(), sizeof(double) * std::min(T.coeff.size(), (size_t)caps.cap_nodes * 8));
-        if (v->nodes[k]) std::memcpy(v->nodes[k], T.nodes.data(), sizeof(int) * T.nodes.size());
-        if (v->node_idx[k]) std::memcpy(v->node_idx[k], T.node_idx.data(), sizeof(int) * std::min(T.node_idx.size(), (size_t)caps.cap_nodes));
+        copy_out(v->path_param[k], T.pp, T.pp.size());
+        copy_out(v->coeff[k], T.coeff, std::min(T.coeff.size(), (size_t)caps.cap_nodes * 8));
+        copy_out(v->nodes[k], T.nodes, T.nodes.size());
+        copy_out(v->node_idx[k], T.node_idx, std::min(T.node_idx.size(), (size_t)caps.cap_nodes));
     }
     return LTPL_OK;
 }
@@ -107,13 +115,13 @@ inline int api_get_trajectories(const ltpl_planner* p, int scen, ltpl_planner_tr
     v->n_vel_course = (int)S.vel_course.size();
     v->n_ids = 0;
     for (const auto& e : S.path_ids) if (v->n_ids < LTPL_PLANNER_MAX_KEYS) { v->id_key[v->n_ids] = e.first; v->id_val[v->n_ids] = e.second; ++v->n_ids; }
-    if (v->vel_course) std::memcpy(v->vel_course, S.vel_course.data(), sizeof(double) * std::min(S.vel_course.size(), (size_t)caps.cap_rows));
+    copy_out(v->vel_course, S.vel_course, std::min(S.vel_course.size(), (size_t)caps.cap_rows));
     for (const BpTraj& B : S.last_bp) {
         if (v->n_keys >= LTPL_PLANNER_MAX_KEYS) break;
         const int k = v->n_keys++;
         v->key_id[k] = B.id; v->traj_id[k] = B.traj_id; v->n_rows[k] = B.rows();
         if (B.rows() > caps.cap_rows) return LTPL_ERR_CAPACITY;
-        if (v->traj[k]) std::memcpy(v->traj[k], B.bp.data(), sizeof(double) * B.bp.size());
+        copy_out(v->traj[k], B.bp, B.bp.size());
     }
     return LTPL_OK;
 }

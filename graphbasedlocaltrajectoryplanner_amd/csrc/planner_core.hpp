@@ -981,8 +981,9 @@ struct Planner {
                     r[5] = v[(size_t)i];
                     if (i + 1 < m) r[6] = (std::pow(v[(size_t)i + 1], 2) - std::pow(v[(size_t)i], 2)) / (2 * (base.bp[(size_t)(i + 1) * 7] - base.bp[(size_t)i * 7]));
                 }
+                const int base_traj_id = base.traj_id;          // (`base` refers into last_bp: the push_back below may reallocate it)
                 S.last_bp.push_back(std::move(em));
-                S.path_ids.push_back({LTPL_ACT_EMERGENCY, base.traj_id});
+                S.path_ids.push_back({LTPL_ACT_EMERGENCY, base_traj_id});
             }
         }
         return LTPL_OK;
