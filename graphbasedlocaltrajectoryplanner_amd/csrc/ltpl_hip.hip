@@ -7,6 +7,7 @@
 // bit-identical to the NumPy arithmetic of the reference.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -2689,9 +2690,9 @@ extern "C" int ltpl_vel_profile(ltpl_handle* h, const ltpl_vel_params* vp, int n
     vel_kernel_t kern = vel_kernel_of(vel_variant(vp));
     {
         // the dynamic-LDS limit of a kernel is process-wide state: raised when a call needs more, never lowered, not re-set per tick
-        static size_t g_set[16][8];
-        size_t& cur = g_set[h->device & 15][vel_variant(vp) & 7];
-        if (lds > 48 * 1024 && lds > cur) {
+        static std::atomic<size_t> g_set[16][8];
+        std::atomic<size_t>& cur = g_set[h->device & 15][vel_variant(vp) & 7];
+        if (lds > 48 * 1024 && lds > cur.load(std::memory_order_relaxed)) {
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             cur = lds;
         }
@@ -2910,9 +2911,9 @@ static void tick_scatter(const unsigned char* hb, const TickLayout& t, ltpl_path
 static int tick_set_lds_limit(ltpl_handle* h, size_t lds, int variant)
 {
     if (h->long_horizon) return LTPL_OK;                  // the fused kernel is not used
-    static size_t g_set[16][8][2];                        // (process-wide limit: raised on demand, never lowered, not re-set per tick)
-    size_t& cur = g_set[h->device & 15][variant & 7][h->plan_class4 == 1 ? 1 : 0];
-    if (lds > 48 * 1024 && lds > cur) {
+    static std::atomic<size_t> g_set[16][8][2];           // (process-wide limit: raised on demand, never lowered, not re-set per tick)
+    std::atomic<size_t>& cur = g_set[h->device & 15][variant & 7][h->plan_class4 == 1 ? 1 : 0];
+    if (lds > 48 * 1024 && lds > cur.load(std::memory_order_relaxed)) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(tick_kernel_of(variant, h->plan_class4 == 1)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         cur = lds;
     }

@@ -5,7 +5,7 @@ set -eu
 cd "$(dirname "$0")"
 ROOT=$(cd ../.. && pwd)
 mkdir -p build
-SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g -O1"
+SAN="-fsanitize=${FAKEHIP_SAN:-address,undefined} -fno-omit-frame-pointer -g -O1"      # FAKEHIP_SAN=thread: ThreadSanitizer build
 CLANG=/opt/rocm/lib/llvm/bin/clang++          # one toolchain for all objects: the sanitizer run-time is clang's (see run.sh)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 --offload-host-only -c $SAN -std=c++17 -ffp-contract=off -fPIC -D_GLIBCXX_ASSERTIONS \
     -Wno-unused-function -o build/ltpl_host.o "$ROOT/graphbasedlocaltrajectoryplanner_amd/csrc/ltpl_hip.hip"

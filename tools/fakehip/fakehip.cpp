@@ -12,11 +12,12 @@
 #include <cstring>
 #include <set>
 #include <mutex>
+#include <atomic>
 
 namespace {
 std::mutex g_mu;
 std::set<void*> g_host;          // page-locked allocations (hipPointerGetAttributes)
-long g_launches = 0;
+std::atomic<long> g_launches{0};
 struct CallCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
 thread_local CallCfg g_cfg[8];
 thread_local int g_ncfg = 0;
