@@ -5,6 +5,7 @@ There is deliberately NO CPU fallback: if the shared library is missing or no HI
 ``HipBackend`` raises. The struct layouts below mirror include/ltpl_hip.h field by field.
 """
 
+import array
 import ctypes as C
 import os
 import numpy as np
@@ -336,39 +337,55 @@ class PathsBatch(object):
         if not zone:
             zone = [0]
         wl = [float(w) for w in w_last_edges] if self.n_w_last else [0.0]
-        ints = np.array(start_layer + start_node + flags + last_action + const_closest + n_last + last_layer + last_node +
-                        veh_off + pos_off + zone_off + zone, np.int32)
-        dbls = np.array(wl + psi_s + radius + px + py, np.float64)
+        # (array.array: list -> C buffer and its address in 1.5 us; np.array + ndarray.ctypes.data take 3 us per array)
+        ints = array.array("i", start_layer + start_node + flags + last_action + const_closest + n_last + last_layer + last_node +
+                           veh_off + pos_off + zone_off + zone)
+        dbls = array.array("d", wl + psi_s + radius + px + py)
         self._ints, self._dbls = ints, dbls
-        bi, bd = ints.ctypes.data, dbls.ctypes.data
+        bi, bd = ints.buffer_info()[0], dbls.buffer_info()[0]
         st = self.struct = PathsIn()
         st.n_scen, st.n_w_last = n, self.n_w_last
-        # the array attributes (start_layer, veh_off, pos_x, ...) are views created on first access (__getattr__)
-        views = self._views = {}
-        o = 0
-        for name, cnt, shape in (("start_layer", n, None), ("start_node", n, None), ("flags", n, None), ("last_action", n, None),
-                                 ("const_closest", n, None), ("n_last", n, None), ("last_layer", n * M, (n, M)),
-                                 ("last_node", n * M, (n, M)), ("veh_off", len(veh_off), None), ("pos_off", len(pos_off), None),
-                                 ("zone_off", len(zone_off), None), ("zone_gid", len(zone), None)):
-            views[name] = (0, o, cnt, shape)
-            setattr(st, name, bi + 4 * o)
-            o += cnt
-        o = 0
-        for name, sname, cnt in (("w_last", "w_last_edges", len(wl)), ("psi_s", "psi_s", n), ("veh_radius", "veh_radius", len(radius)),
-                                 ("pos_x", "pos_x", len(px)), ("pos_y", "pos_y", len(px))):
-            views[name] = (1, o, cnt, None)
-            setattr(st, sname, bd + 8 * o)
-            o += cnt
+        # pointer members = base address + offset, in the order the lists were concatenated; the array attributes of the same names
+        # (start_layer, veh_off, pos_x, ...) are views created on first access (__getattr__) from the element counts kept here
+        nvo, npo, nzo, nz, nw, nr, npx = len(veh_off), len(pos_off), len(zone_off), len(zone), len(wl), len(radius), len(px)
+        self._counts = (n, n, n, n, n, n, n * M, n * M, nvo, npo, nzo, nz), (nw, n, nr, npx, npx)
+        st.start_layer = bi; bi += 4 * n
+        st.start_node = bi; bi += 4 * n
+        st.flags = bi; bi += 4 * n
+        st.last_action = bi; bi += 4 * n
+        st.const_closest = bi; bi += 4 * n
+        st.n_last = bi; bi += 4 * n
+        st.last_layer = bi; bi += 4 * n * M
+        st.last_node = bi; bi += 4 * n * M
+        st.veh_off = bi; bi += 4 * nvo
+        st.pos_off = bi; bi += 4 * npo
+        st.zone_off = bi; bi += 4 * nzo
+        st.zone_gid = bi
+        st.w_last_edges = bd; bd += 8 * nw
+        st.psi_s = bd; bd += 8 * n
+        st.veh_radius = bd; bd += 8 * nr
+        st.pos_x = bd; bd += 8 * npx
+        st.pos_y = bd
+
+    _INT_VIEWS = ("start_layer", "start_node", "flags", "last_action", "const_closest", "n_last", "last_layer", "last_node",
+                  "veh_off", "pos_off", "zone_off", "zone_gid")
+    _DBL_VIEWS = ("w_last", "psi_s", "veh_radius", "pos_x", "pos_y")
 
     def __getattr__(self, name):
         # only reached for names that are not instance attributes yet: materialise the view once
-        views = self.__dict__.get("_views")
-        if views is None or name not in views:
+        counts = self.__dict__.get("_counts")
+        if counts is None:
             raise AttributeError(name)
-        kind, o, cnt, shape = views[name]
-        v = (self._dbls if kind else self._ints)[o:o + cnt]
-        if shape is not None:
-            v = v.reshape(shape)
+        if name in self._INT_VIEWS:
+            k, cnt, arr = self._INT_VIEWS.index(name), counts[0], np.frombuffer(self._ints, np.int32)
+        elif name in self._DBL_VIEWS:
+            k, cnt, arr = self._DBL_VIEWS.index(name), counts[1], np.frombuffer(self._dbls, np.float64)
+        else:
+            raise AttributeError(name)
+        o = sum(cnt[:k])
+        v = arr[o:o + cnt[k]]
+        if name in ("last_layer", "last_node"):
+            v = v.reshape(self.n_scen, MAX_LAST_NODES)
         self.__dict__[name] = v
         return v
 
