@@ -54,6 +54,27 @@ def test_host_logic_reproduces_the_reference_lattice(name):
     check_against_reference_export(lat, name)
 
 
+@pytest.mark.parametrize("name", ["berlin", "modena"])
+def test_host_logic_reproduces_the_reference_lattice_fingerprint(name):
+    """Tracks whose reference-built lattice is not committed in full (5 MB each): sizes, SHA-256 of every topology column and the
+    moments of the float columns of the lattice the REFERENCE built (tests/golden/lattice_digests.json, oracle/gen_golden.py digests)."""
+    import json
+    from oracle import offline_edges_ref
+    from oracle.gen_golden import lattice_digest
+    with open(os.path.join(ROOT, "tests", "golden", "lattice_digests.json")) as fh:
+        ref = json.load(fh)[name]
+    got = lattice_digest(ob.build_lattice(track(name), ob.OFFLINE_DEFAULTS, offline_edges_ref.evaluate))
+    assert got["sizes"] == ref["sizes"]
+    for k in ref:
+        if k.startswith("sha_"):
+            assert got[k] == ref[k], k                                                   # bit-exact topology
+        elif k.startswith("mom_"):
+            scale = max(abs(ref[k][1]), 1e-9)                                            # sum of magnitudes
+            assert abs(got[k][0] - ref[k][0]) <= 1e-9 * scale and abs(got[k][1] - ref[k][1]) <= 1e-9 * scale, k
+            assert abs(got[k][2] - ref[k][2]) <= 1e-9 * max(ref[k][2], 1e-9), k
+            assert abs(got[k][3] - ref[k][3]) <= 1e-7 * max(abs(ref[k][3]), 1e-3) and abs(got[k][4] - ref[k][4]) <= 1e-7 * max(abs(ref[k][4]), 1e-3), k
+
+
 def test_vehicle_too_wide_is_rejected():
     from oracle import offline_edges_ref
     cfg = dict(ob.OFFLINE_DEFAULTS, veh_width=9.0)
