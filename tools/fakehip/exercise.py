@@ -31,6 +31,20 @@ def expect_error(fn, what):
     raise AssertionError("no error for " + what)
 
 
+GARBAGE = os.environ.get("FAKEHIP_GARBAGE") is not None
+
+
+def tolerant(fn):
+    """FAKEHIP_GARBAGE mode: launches leave random words behind, so anything that INTERPRETS results may fail with a Python error or a
+    status code -- that is fine; what must not happen is a sanitizer report from the library's host code."""
+    if not GARBAGE:
+        return fn()
+    try:
+        return fn()
+    except (KeyError, ValueError, IndexError, OverflowError, MemoryError, _capi.BackendError) as e:
+        return None
+
+
 def exercise(name, lat):
     hip = _capi.HipBackend(lat, lib_path=FAKE)
     print("%s: L=%d V=%d E=%d, caps nodes %d pts %d" % (name, lat.num_layers, lat.num_nodes, lat.num_edges,
@@ -46,7 +60,7 @@ def exercise(name, lat):
                 sc['last_nodes'] = None
         batch = _capi.PathsBatch(scen, w_last_edges=W)
         res = hip.plan_paths(batch)
-        res.action_sets(0, scen[0]['start_node'][0], lat.num_layers)
+        tolerant(lambda: res.action_sets(0, scen[0]['start_node'][0], lat.num_layers))
         vplan = rng.uniform(0.0, 60.0, n)
         pos = np.array([lat.node_pos[lat.layer_off[sc['start_node'][0]] + sc['start_node'][1]] for sc in scen])
         vt = _capi.TickVelBatch(_capi.VelParamSet(len_veh=lat.veh_length), n, vplan, vplan + 0.5, pos,
@@ -54,8 +68,7 @@ def exercise(name, lat):
         bt = batch
         r, v = hip.tick_batch(bt, vt)
         comp = hip.new_compact_trajectories(n, max_rows=115 if n % 2 else 0)
-        hip.tick_batch_compact(bt, vt, comp)
-        comp.trajectories(n - 1)
+        tolerant(lambda: (hip.tick_batch_compact(bt, vt, comp), comp.trajectories(n - 1)))
         hip.batch_upload(bt, vt)
         hip.batch_run(reps=2, timed=True)
         hip.batch_last_paths_ms()
@@ -78,17 +91,17 @@ def exercise(name, lat):
         params = _capi.VelParamSet(dyn_model_exp=exp, len_veh=lat.veh_length) if axm is None else \
             _capi.VelParamSet(dyn_model_exp=exp, len_veh=lat.veh_length, ax_max_machines=axm)
         for nj in (1, 16, 17, 250):
-            hip.vel_profile(params, random_jobs(lat, rng, nj, varying))
+            tolerant(lambda: hip.vel_profile(params, random_jobs(lat, rng, nj, varying)))
             calls[0] += 1
     # object ingestion, race-line projection, constant-segment test
     n = 5000
     l = rng.integers(0, lat.num_layers, n)
     p = lat.refline[l] + lat.normvec[l] * rng.uniform(-8.0, 8.0, n)[:, None]
-    hip.process_objects(p[:, 0], p[:, 1], rng.uniform(-3, 3, n), rng.uniform(0, 80, n), rng.uniform(3, 6, n))
+    tolerant(lambda: hip.process_objects(p[:, 0], p[:, 1], rng.uniform(-3, 3, n), rng.uniform(0, 80, n), rng.uniform(3, 6, n)))
     hip.process_objects(np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0))
-    hip.raceline_s(p[3])
+    tolerant(lambda: hip.raceline_s(p[3]))
     seg = np.column_stack((lat.refline[:30], np.zeros(30), np.zeros(30), np.ones(30)))
-    hip.const_segment_test(seg, p[0], [(2.5, p[:3])])
+    tolerant(lambda: hip.const_segment_test(seg, p[0], [(2.5, p[:3])]))
     calls[0] += 4
     # the planner entry points: start pose, one tick (no path comes back from a kernel that does nothing -> the state machine must say so)
     from graphbasedlocaltrajectoryplanner_amd.planner import Planner
@@ -104,8 +117,8 @@ def exercise(name, lat):
             pl.paths(0)
             pl.calc_vel_profile([pos] * n_scen, 0.0)
             pl.trajectories(n_scen - 1)
-        except _capi.BackendError as e:
-            print("    (planner with empty kernel results: %s)" % str(e)[:100])
+        except (_capi.BackendError, KeyError, ValueError, IndexError) as e:
+            print("    (planner with empty / garbage kernel results: %s)" % str(e)[:100])
         pl.close()
         calls[0] += 4
     hip.close()

@@ -11,12 +11,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <set>
+#include <map>
+#include <random>
 #include <mutex>
 #include <atomic>
 
 namespace {
 std::mutex g_mu;
-std::set<void*> g_host;          // page-locked allocations (hipPointerGetAttributes)
+std::map<void*, size_t> g_host; // page-locked allocations (hipPointerGetAttributes; zero-copy outputs live here)
+std::map<void*, size_t> g_dev;   // "device" allocations (FAKEHIP_GARBAGE: what a launch scribbles over)
 std::atomic<long> g_launches{0};
 struct CallCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
 thread_local CallCfg g_cfg[8];
@@ -46,14 +49,26 @@ hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_tR0600* p, int)
     return hipSuccess;
 }
 
-hipError_t hipMalloc(void** p, size_t n) { *p = std::calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+hipError_t hipMalloc(void** p, size_t n)
+{
+    *p = std::calloc(n ? n : 1, 1);
+    if (!*p) return hipErrorOutOfMemory;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_dev[*p] = n;
+    return hipSuccess;
+}
+hipError_t hipFree(void* p)
+{
+    { std::lock_guard<std::mutex> lk(g_mu); g_dev.erase(p); }
+    std::free(p);
+    return hipSuccess;
+}
 hipError_t hipHostMalloc(void** p, size_t n, unsigned)
 {
     *p = std::calloc(n ? n : 1, 1);
     if (!*p) return hipErrorOutOfMemory;
     std::lock_guard<std::mutex> lk(g_mu);
-    g_host.insert(*p);
+    g_host[*p] = n;
     return hipSuccess;
 }
 hipError_t hipHostFree(void* p)
@@ -114,6 +129,23 @@ hipError_t hipLaunchKernel(const void*, dim3 grid, dim3 block, void**, size_t sh
         return hipErrorInvalidConfiguration;
     }
     ++g_launches;
+    // FAKEHIP_GARBAGE=<seed>: a launch overwrites every "device" allocation and every page-locked buffer with random words whose
+    // magnitude is small often enough to pass for counts -- the host side must never turn a wrong device result into an out-of-bounds
+    // access of its own (it may return nonsense or an error, not corrupt memory)
+    static const char* garbage = std::getenv("FAKEHIP_GARBAGE");
+    if (garbage) {
+        static std::mt19937 rng((unsigned)std::atoi(garbage));
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto scribble = [&](void* p, size_t n) {
+            int* w = static_cast<int*>(p);
+            for (size_t i = 0; i + 4 <= n; i += 4) {
+                const unsigned r = rng();
+                w[i / 4] = (r & 3u) == 0 ? (int)r : (r & 3u) == 1 ? (int)(r >> 8) % 5000 : (r & 3u) == 2 ? -(int)((r >> 8) % 100) : (int)(r >> 8) % 8;
+            }
+        };
+        for (auto& a : g_dev) if (a.second <= ((size_t)64 << 20)) scribble(a.first, a.second);
+        for (auto& a : g_host) if (a.second <= ((size_t)64 << 20)) scribble(a.first, a.second);
+    }
     return hipSuccess;
 }
 void** __hipRegisterFatBinary(const void*) { static void* dummy = nullptr; return &dummy; }
