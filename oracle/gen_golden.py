@@ -24,7 +24,7 @@ reference (imported from /root/reference over oracle/shims, see oracle/ref_env.p
                                        requested: overtakes dropped for broken velocity bounds (OTH.py:945,1007-1015),
                                        calc_brake_emergency (OTH.py:1028-1034)
 
-  <track>_*.npz             (python -m oracle.gen_golden track zalazone|millbrook|lvms) further tracks of the reference's
+  <track>_*.npz             (python -m oracle.gen_golden track zalazone|millbrook|lvms|berlin|modena) further tracks of the reference's
                             inputs/traj_ltpl_cl: race line columns, the lattice of the reference's offline build, and a 900-tick
                             closed loop with race-line followers recorded at both seams and at tick level (main_track)
   lattice_digests.json      (python -m oracle.gen_golden digests) berlin, modena: fingerprint (sizes, SHA-256 of the topology columns,
@@ -233,7 +233,10 @@ class RaceLineFollower(object):
 
 
 # (fraction of the lap where the follower starts, speed in m/s): short tracks get one follower, otherwise an object is always in range
-TRACK_OPPONENTS = {"lvms": ((0.06, 12.0), (0.14, 16.0), (0.3, 10.0)), "zalazone": ((0.5, 8.0),), "millbrook": ((0.5, 8.0),)}
+# tracks whose 5 MB lattice export is not committed: the tests rebuild it with the product's offline build, which reproduces the reference's
+# lattice (tests/test_offline_build.py: fingerprint in lattice_digests.json)
+NO_LATTICE_EXPORT = ("berlin", "modena")
+TRACK_OPPONENTS = {"berlin": ((0.05, 12.0), (0.12, 16.0), (0.3, 10.0)), "modena": ((0.05, 12.0), (0.12, 16.0), (0.3, 10.0)), "lvms": ((0.06, 12.0), (0.14, 16.0), (0.3, 10.0)), "zalazone": ((0.5, 8.0),), "millbrook": ((0.5, 8.0),)}
 
 
 def main_track(track, n_ticks=900):
@@ -248,7 +251,8 @@ def main_track(track, n_ticks=900):
     gl, clock, ltpl_obj, gb, path_dict = rs.make_planner(CACHE, track=track)
     np.savez_compressed(os.path.join(GOLDEN, track + "_track.npz"), **import_track_csv(path_dict['globtraj_input_path']))
     lat = Lattice.from_graph_base(gb)
-    lat.save(os.path.join(GOLDEN, track + "_lattice.npz"))
+    if track not in NO_LATTICE_EXPORT:
+        lat.save(os.path.join(GOLDEN, track + "_lattice.npz"))
     print("%s lattice: L=%d V=%d E=%d S=%d closed=%s, nodes per layer %d..%d" % (
         track, lat.num_layers, lat.num_nodes, lat.num_edges, lat.num_samples, lat.closed,
         int(lat.nodes_in_layer.min()), int(lat.nodes_in_layer.max())))

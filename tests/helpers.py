@@ -61,7 +61,9 @@ def replay_path_call(gen, rec):
     return sc
 
 
-def check_path_output(out6, rec, what=""):
+def check_path_output(out6, rec, what="", exact_el=True):
+    """``exact_el=False``: the lattice under test was rebuilt (offline build, floats ~1e-13 from the reference's lattice) instead of
+    exported from the reference's GraphBase, so the element-length column is a copy of slightly different numbers."""
     nodes, node_idx, coeff, path_param, red_len, closest = out6
     exp = rec['out']
     assert list(nodes.keys()) == exp['keys'], "%s: keys %s vs %s" % (what, list(nodes.keys()), exp['keys'])
@@ -77,4 +79,7 @@ def check_path_output(out6, rec, what=""):
         dpsi = np.abs(np.mod(pp[:, 2] - epp[:, 2] + np.pi, 2 * np.pi) - np.pi)
         assert float(dpsi.max()) <= REL_TOL * np.pi, "%s/%s psi" % (what, k)
         assert_close_rel(pp[:, 3], epp[:, 3], what="%s/%s kappa" % (what, k), floor=KAPPA_FLOOR)
-        assert np.array_equal(pp[:, 4], epp[:, 4]), "%s/%s el_length column must be copied bit-exact" % (what, k)
+        if exact_el:
+            assert np.array_equal(pp[:, 4], epp[:, 4]), "%s/%s el_length column must be copied bit-exact" % (what, k)
+        else:
+            assert_close_rel(pp[:, 4], epp[:, 4], rel=1e-9, what="%s/%s el" % (what, k))

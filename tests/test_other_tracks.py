@@ -6,6 +6,8 @@ Further tracks of the reference's inputs/traj_ltpl_cl (all other fixtures are Mo
   millbrook  429 m lap, 37 layers, 1..14 nodes per layer (layers with ONE node); the 300 m planning range covers 31 of the 37
              layers, so the single opponent is in range on every tick
   lvms      1844 m lap, 159 layers, 9..23 nodes per layer: oval, three race-line followers, all four primitives
+  berlin    132 layers, 8..40 nodes per layer (street circuit: the widest layers of all tracks); modena  150 layers, 17..21 nodes per layer.
+            Their lattices are not committed (5 MB each): the tests rebuild them with the product's offline build (see lattice_of)
 
 CPU: the oracle at both seams, the planner's host state machine in closed loop, and the offline lattice build against the
 lattice exported from the reference's GraphBase. GPU: the same through libltpl_hip.so.
@@ -22,7 +24,8 @@ from graphbasedlocaltrajectoryplanner_amd import _capi
 from graphbasedlocaltrajectoryplanner_amd.lattice import Lattice
 from graphbasedlocaltrajectoryplanner_amd.path_gen import OnlinePathGenerator
 
-TRACKS = ["zalazone", "millbrook", "lvms"]
+TRACKS = ["zalazone", "millbrook", "lvms", "berlin", "modena"]
+BUILT_HERE = ("berlin", "modena")       # no lattice export committed (5 MB each): rebuilt by the product's offline build, see lattice_of
 _lattices = {}
 
 # The GPU legs were written at the end of round 2, after the round's GPU budget was spent: they have not run on an MI355X yet.
@@ -32,8 +35,18 @@ gpu_pending = pytest.mark.skipif(os.environ.get("LTPL_GPU_OTHER_TRACKS") != "1",
 
 
 def lattice_of(track):
+    """Lattice of ``track``: the export of the reference's GraphBase where it is committed; for berlin / modena the lattice the product's
+    offline build makes from the race line file -- it reproduces the reference's lattice (topology bit-exact, floats ~1e-13:
+    tests/test_offline_build.py against the fingerprints in lattice_digests.json), and the recordings replayed on it below were made by
+    the reference on ITS lattice."""
     if track not in _lattices:
-        _lattices[track] = Lattice.load(os.path.join(ROOT, "tests", "golden", track + "_lattice.npz"))
+        if track in BUILT_HERE:
+            from oracle import offline_edges_ref
+            from test_offline_build import track as track_arrays
+            from graphbasedlocaltrajectoryplanner_amd import offline_build as ob
+            _lattices[track] = ob.build_lattice(track_arrays(track), ob.OFFLINE_DEFAULTS, offline_edges_ref.evaluate)
+        else:
+            _lattices[track] = Lattice.load(os.path.join(ROOT, "tests", "golden", track + "_lattice.npz"))
     return _lattices[track]
 
 
@@ -44,7 +57,8 @@ def check_paths_against_recordings(lat, backend, track):
     for rec in recs:
         sc = replay_path_call(gen, rec)
         res = backend.plan_paths(_capi.PathsBatch([sc], w_last_edges=rec['w_last_edges']))
-        check_path_output(res.action_sets(0, rec['start_node'][0], lat.num_layers), rec, what="%s tick %d" % (track, rec['tick']))
+        check_path_output(res.action_sets(0, rec['start_node'][0], lat.num_layers), rec, what="%s tick %d" % (track, rec['tick']),
+                          exact_el=track not in BUILT_HERE)
     return recs
 
 
@@ -60,7 +74,7 @@ def check_vel_against_recordings(lat, backend, track):
 
 # ---- CPU ----------------------------------------------------------------------------------------------------------------------
 def test_fixtures_differ_from_monteblanco_where_it_matters(monteblanco):
-    mz, mm, ml = (lattice_of(t) for t in TRACKS)
+    mz, mm, ml = (lattice_of(t) for t in TRACKS[:3])
     assert int(mm.nodes_in_layer.min()) == 1 and mm.num_layers < monteblanco.max_horizon()[0] + 8      # one-node layers; range ~ lap
     assert ml.num_layers > monteblanco.num_layers and mz.num_layers < monteblanco.num_layers
     assert all(lat.closed for lat in (mz, mm, ml))
@@ -73,7 +87,7 @@ def test_oracle_matches_reference_path_recordings(track):
     recs = check_paths_against_recordings(lat, OracleBackend(lat), track)
     keys = set(k for r in recs for k in r['out']['keys'])
     assert keys >= {"zalazone": {"straight", "follow", "left", "right"}, "millbrook": {"follow"},
-                    "lvms": {"straight", "follow", "left", "right"}}[track]
+                    "lvms": {"straight", "follow", "left", "right"}}.get(track, {"follow", "left", "right"})
     if track == "zalazone":
         assert any(any(r['out']['red_len'].values()) for r in recs)
 
@@ -87,7 +101,8 @@ def test_oracle_matches_reference_vel_recordings(track):
 
 
 @pytest.mark.parametrize("track,must_see", [("zalazone", {"straight", "follow", "left", "right"}), ("millbrook", {"follow"}),
-                                            ("lvms", {"straight", "follow", "left", "right"})])
+                                            ("lvms", {"straight", "follow", "left", "right"}),
+                                            ("berlin", {"follow", "left", "right"}), ("modena", {"follow", "left", "right"})])
 def test_host_state_machine_in_closed_loop(track, must_see):
     from oracle.planner_host import HostPlannerBackend
     lat = lattice_of(track)
@@ -96,7 +111,7 @@ def test_host_state_machine_in_closed_loop(track, must_see):
     assert len(ticks) == 900 and must_see <= seen['keys'] and seen['full'] >= 15, seen
 
 
-@pytest.mark.parametrize("track", TRACKS)
+@pytest.mark.parametrize("track", TRACKS[:3])
 def test_offline_build_reproduces_the_reference_lattice(track):
     from oracle import offline_edges_ref
     from test_offline_build import track as track_arrays, check_against_reference_export
@@ -146,7 +161,7 @@ def test_planner_closed_loop_on_the_device(hip_of, track):
 
 @pytest.mark.gpu
 @gpu_pending
-@pytest.mark.parametrize("track", TRACKS)
+@pytest.mark.parametrize("track", TRACKS[:3])
 def test_device_build_reproduces_the_reference_lattice(hip_of, track):
     from test_offline_build import track as track_arrays, check_against_reference_export
     from graphbasedlocaltrajectoryplanner_amd import offline_build as ob
