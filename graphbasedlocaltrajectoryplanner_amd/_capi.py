@@ -22,7 +22,7 @@ FLAG_ACTION_SETS, FLAG_OBJ_IN_CONST, FLAG_OBJ_BESIDES, FLAG_HAS_PSI_S = 1, 2, 4,
 VEL_FB, VEL_BRAKE, VEL_FOLLOW = 0, 1, 2
 
 _STATUS = {0: "OK", 1: "invalid argument", 2: "no HIP device", 3: "HIP runtime error", 4: "capacity exceeded",
-           5: "unsupported configuration"}
+           5: "unsupported configuration", 6: "internal error (C++ exception caught at the ABI)"}
 
 _pi32 = C.POINTER(C.c_int32)
 _pf64 = C.POINTER(C.c_double)

@@ -2019,6 +2019,20 @@ static int horizon_stats(const ltpl_lattice_desc* d, int* hmax, int* ehmax, int*
     return LTPL_OK;
 }
 
+// "No C++ exception crosses the ABI" (include/ltpl_hip.h): every entry point that allocates is a function-try-block; an exception
+// (std::bad_alloc / std::length_error of a host container in practice) becomes LTPL_ERR_EXCEPTION with the message in the handle's
+// (or the thread's create-time) error string.
+static int abi_caught(std::string* err, const char* what) noexcept
+{
+    try { (err ? *err : g_create_error) = std::string("C++ exception caught at the ABI: ") + what; } catch (...) {}
+    return LTPL_ERR_EXCEPTION;
+}
+static std::string* abi_err_of(const ltpl_handle* h) { return h ? const_cast<std::string*>(&h->err) : nullptr; }
+static std::string* abi_err_of(const ltpl_planner* p) { return p ? const_cast<std::string*>(&p->P.err) : nullptr; }
+#define LTPL_ABI_CATCH(errptr) \
+    catch (const std::exception& e) { return abi_caught(errptr, e.what()); } \
+    catch (...) { return abi_caught(errptr, "unknown exception"); }
+
 extern "C" int ltpl_version(void) { return LTPL_ABI_VERSION; }
 
 extern "C" const char* ltpl_last_error(const ltpl_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -2050,7 +2064,7 @@ extern "C" int ltpl_destroy(ltpl_handle* h)
 }
 
 extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle** out_handle)
-{
+try {
     g_create_error.clear();
     if (!d || !out_handle) { g_create_error = "null argument"; return LTPL_ERR_INVALID_ARG; }
     if (d->num_layers < 4 || d->num_nodes < 1 || d->num_edges < 1) { g_create_error = "empty lattice"; return LTPL_ERR_INVALID_ARG; }
@@ -2267,7 +2281,7 @@ extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle**
     }
     *out_handle = h;
     return LTPL_OK;
-}
+} LTPL_ABI_CATCH(nullptr)
 
 extern "C" int ltpl_get_caps(const ltpl_handle* h, ltpl_caps* caps)
 {
@@ -2491,9 +2505,9 @@ static int wait_done(ltpl_handle* h, unsigned seq)
 static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_out* out, int force_nw);
 
 extern "C" int ltpl_plan_paths(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_out* out)
-{
+try {
     return plan_paths_impl(h, in, out, 0);
-}
+} LTPL_ABI_CATCH(abi_err_of(h))
 
 // force_nw: 0 = choose by batch size, 1 / NUM_WAVES = one-wave batch kernel / four-wave latency kernel (self-test)
 static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_out* out, int force_nw)
@@ -2547,7 +2561,7 @@ static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_o
 }
 
 extern "C" int ltpl_process_objects(ltpl_handle* h, const ltpl_objects_in* in, ltpl_objects_out* out)
-{
+try {
     if (!h) return LTPL_ERR_INVALID_ARG;
     if (!in || !out || in->n_obj < 1 || !in->x || !in->y || !in->theta || !in->v || !in->length ||
         !out->on_track || !out->pred_x || !out->pred_y || !out->radius) { h->err = "null argument or n_obj < 1"; return LTPL_ERR_INVALID_ARG; }
@@ -2578,7 +2592,7 @@ extern "C" int ltpl_process_objects(ltpl_handle* h, const ltpl_objects_in* in, l
     memcpy(out->pred_x, ho + o_px, 8 * n); memcpy(out->pred_y, ho + o_py, 8 * n); memcpy(out->radius, ho + o_r, 8 * n);
     memcpy(out->on_track, ho + o_on, 4 * n);
     return LTPL_OK;
-}
+} LTPL_ABI_CATCH(abi_err_of(h))
 
 // --- velocity seam / fused tick ---------------------------------------------------------------------------------------
 // kernel variant = (exponent mode, single-row machine table): compile-time specialisations of the recurrences
@@ -2634,7 +2648,7 @@ static int make_vel_params(ltpl_handle* h, const ltpl_vel_params* vp, const doub
 
 extern "C" int ltpl_vel_profile(ltpl_handle* h, const ltpl_vel_params* vp, int n_jobs, const ltpl_vel_job* jobs,
                                 ltpl_vel_result* results)
-{
+try {
     if (!h) return LTPL_ERR_INVALID_ARG;
     if (n_jobs < 1 || !jobs || !results) { h->err = "no jobs"; return LTPL_ERR_INVALID_ARG; }
     LTPL_PROF(prof_pack, "vel_profile.validate+pack");
@@ -2725,7 +2739,7 @@ extern "C" int ltpl_vel_profile(ltpl_handle* h, const ltpl_vel_params* vp, int n
         results[j].too_close = flags[2 * j]; results[j].vel_bound = flags[2 * j + 1];
     }
     return LTPL_OK;
-}
+} LTPL_ABI_CATCH(abi_err_of(h))
 
 // ---- fused tick ------------------------------------------------------------------------------------------------------
 struct TickLayout {
@@ -2922,7 +2936,7 @@ static int tick_set_lds_limit(ltpl_handle* h, size_t lds, int variant)
 
 extern "C" int ltpl_tick_batch(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin, ltpl_paths_out* out,
                                ltpl_tick_vel_out* vout)
-{
+try {
     if (!h) return LTPL_ERR_INVALID_ARG;
     if (!out || !vout) { h->err = "null output"; return LTPL_ERR_INVALID_ARG; }
     HIP_TRY(h, hipSetDevice(h->device));
@@ -2947,7 +2961,7 @@ extern "C" int ltpl_tick_batch(ltpl_handle* h, const ltpl_paths_in* in, const lt
     if (t.pipeline) dbg_report_lanes(h); else dbg_report(h, "k_tick", in->n_scen);
     tick_scatter(static_cast<const unsigned char*>(h->h_out), t, out, vout);
     return LTPL_OK;
-}
+} LTPL_ABI_CATCH(abi_err_of(h))
 
 extern "C" void* ltpl_host_alloc(size_t bytes)
 {
@@ -2958,7 +2972,7 @@ extern "C" void* ltpl_host_alloc(size_t bytes)
 extern "C" void ltpl_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 extern "C" int ltpl_tick_batch_compact(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin, ltpl_traj_out* out)
-{
+try {
     if (!h) return LTPL_ERR_INVALID_ARG;
     if (!out || !out->rows || !out->action_id || !out->n_rows || !out->vel_bound || !out->reduced || !out->row_off || out->capacity_rows < 0) {
         h->err = "null output"; return LTPL_ERR_INVALID_ARG;
@@ -3016,12 +3030,12 @@ extern "C" int ltpl_tick_batch_compact(ltpl_handle* h, const ltpl_paths_in* in, 
     memcpy(out->vel_bound, h_vb, sizeof(int) * n_slots); memcpy(out->reduced, h_red, sizeof(int) * n_slots);
     memcpy(out->row_off, h_off, sizeof(long long) * n_slots);
     return LTPL_OK;
-}
+} LTPL_ABI_CATCH(abi_err_of(h))
 
 // device-resident batch (benchmarks): inputs stay in HBM, the fused kernel is replayed on the handle's stream
 extern "C" int ltpl_batch_upload(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin, int32_t cap_nodes,
                                  int32_t cap_pts)
-{
+try {
     if (!h) return LTPL_ERR_INVALID_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     drop_resident(h);
@@ -3059,10 +3073,10 @@ extern "C" int ltpl_batch_upload(ltpl_handle* h, const ltpl_paths_in* in, const 
         h->resident2 = t2;
     }
     return LTPL_OK;
-}
+} LTPL_ABI_CATCH(abi_err_of(h))
 
 extern "C" int ltpl_batch_run(ltpl_handle* h, int reps, float* ms_total)
-{
+try {
     if (!h) return LTPL_ERR_INVALID_ARG;
     if (!h->resident) { h->err = "no resident batch: call ltpl_batch_upload first"; return LTPL_ERR_INVALID_ARG; }
     if (reps < 1) { h->err = "reps < 1"; return LTPL_ERR_INVALID_ARG; }
@@ -3116,7 +3130,7 @@ extern "C" int ltpl_batch_run(ltpl_handle* h, int reps, float* ms_total)
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     return LTPL_OK;
-}
+} LTPL_ABI_CATCH(abi_err_of(h))
 
 extern "C" int ltpl_batch_last_paths_ms(ltpl_handle* h, float* ms_avg)
 {
@@ -3126,7 +3140,7 @@ extern "C" int ltpl_batch_last_paths_ms(ltpl_handle* h, float* ms_avg)
 }
 
 extern "C" int ltpl_batch_run_profile(ltpl_handle* h, int reps, float* ms_kernels)
-{
+try {
     if (!h) return LTPL_ERR_INVALID_ARG;
     if (!h->resident) { h->err = "no resident batch: call ltpl_batch_upload first"; return LTPL_ERR_INVALID_ARG; }
     if (reps < 1 || !ms_kernels) { h->err = "reps < 1 or null output"; return LTPL_ERR_INVALID_ARG; }
@@ -3142,10 +3156,10 @@ extern "C" int ltpl_batch_run_profile(ltpl_handle* h, int reps, float* ms_kernel
     }
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
     return LTPL_OK;
-}
+} LTPL_ABI_CATCH(abi_err_of(h))
 
 extern "C" int ltpl_batch_download(ltpl_handle* h, ltpl_paths_out* out, ltpl_tick_vel_out* vout)
-{
+try {
     if (!h) return LTPL_ERR_INVALID_ARG;
     if (!h->resident) { h->err = "no resident batch"; return LTPL_ERR_INVALID_ARG; }
     if (!out || !vout || out->cap_nodes != h->resident->cap_nodes || out->cap_pts != h->resident->cap_pts) {
@@ -3157,7 +3171,7 @@ extern "C" int ltpl_batch_download(ltpl_handle* h, ltpl_paths_out* out, ltpl_tic
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     tick_scatter(static_cast<const unsigned char*>(h->h_out), *h->resident, out, vout);
     return LTPL_OK;
-}
+} LTPL_ABI_CATCH(abi_err_of(h))
 
 static void free_resident(TickLayout* t) { delete t; }
 
@@ -3234,7 +3248,7 @@ __global__ __launch_bounds__(64) void k_offline_edges(DevOfflineIn in, DevOfflin
 }
 
 extern "C" int ltpl_offline_edges(int device, const ltpl_offline_edges_in* in, ltpl_offline_edges_out* out)
-{
+try {
     g_create_error.clear();
     if (!in || !out || in->n_edges < 1 || in->cap_samples < 2 || !(in->stepsize_approx > 0.0)) { g_create_error = "offline edges: invalid argument"; return LTPL_ERR_INVALID_ARG; }
     int ndev = 0;
@@ -3269,7 +3283,7 @@ extern "C" int ltpl_offline_edges(int device, const ltpl_offline_edges_in* in, l
         !down(out->kappa_avg, q_ka, 8 * n) || !down(out->kappa_range, q_kr, 8 * n) || !down(out->samples, q_sa, 8 * 5 * cap * n)) return fail("offline edges: download failed");
     (void)hipFree(di); (void)hipFree(dobuf);
     return LTPL_OK;
-}
+} LTPL_ABI_CATCH(nullptr)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // self-test at ltpl_create: the one-wave batch kernel and the four-wave latency kernel are two differently scheduled builds
@@ -3352,7 +3366,7 @@ struct HipCompute : ltplp::Compute {
 extern "C" int ltpl_const_segment_test(const ltpl_handle* h, const double* seg, int32_t n_rows, const double* pos_est, int32_t n_veh,
                                        const double* veh_x, const double* veh_y, const double* veh_radius, int32_t* flags_out,
                                        int32_t* closest_out)
-{
+try {
     if (!h || !flags_out || !closest_out || n_veh < 0 || n_rows < 0) return LTPL_ERR_INVALID_ARG;
     if (!h->has_hostlat) return LTPL_ERR_UNSUPPORTED;
     int in_const, besides, closest;
@@ -3360,44 +3374,44 @@ extern "C" int ltpl_const_segment_test(const ltpl_handle* h, const double* seg, 
     *flags_out = (in_const ? LTPL_FLAG_OBJ_IN_CONST : 0) | (besides ? LTPL_FLAG_OBJ_BESIDES : 0);
     *closest_out = closest;
     return LTPL_OK;
-}
+} LTPL_ABI_CATCH(abi_err_of(h))
 
 extern "C" int ltpl_edge_capsules(int32_t n_edges, const int32_t* samp_ptr, const double* samp_x, const double* samp_y, int32_t n_samples,
                                   float* capsules_out, float* slack_out)
-{
+try {
     if (n_edges < 0 || !samp_ptr || !samp_x || !samp_y || !capsules_out || !slack_out) return LTPL_ERR_INVALID_ARG;
     *slack_out = ltplcap::build(n_edges, samp_ptr, samp_x, samp_y, n_samples, capsules_out);
     return LTPL_OK;
-}
+} LTPL_ABI_CATCH(nullptr)
 
 extern "C" int ltpl_raceline_s(const ltpl_handle* h, double x, double y, double* s_out)
-{
+try {
     if (!h || !s_out) return LTPL_ERR_INVALID_ARG;
     if (!h->has_hostlat) return LTPL_ERR_UNSUPPORTED;
     *s_out = ltplp::raceline_s(h->hostlat, x, y);
     return LTPL_OK;
-}
+} LTPL_ABI_CATCH(abi_err_of(h))
 
 extern "C" int ltpl_planner_create(ltpl_handle* h, const ltpl_planner_config* cfg, ltpl_planner** out)
-{
+try {
     g_create_error.clear();
     if (!h) { g_create_error = "planner: null handle"; return LTPL_ERR_INVALID_ARG; }
     if (!h->has_hostlat) { g_create_error = "planner: the lattice was created without raceline_x / raceline_y / node_psi"; return LTPL_ERR_UNSUPPORTED; }
     return ltplp::api_create(new HipCompute(h), h->hostlat, cfg, out, &g_create_error);
-}
+} LTPL_ABI_CATCH(nullptr)
 extern "C" int ltpl_planner_destroy(ltpl_planner* p) { delete p; return LTPL_OK; }
-extern "C" int ltpl_planner_get_caps(const ltpl_planner* p, ltpl_planner_caps* c) { return ltplp::api_get_caps(p, c); }
+extern "C" int ltpl_planner_get_caps(const ltpl_planner* p, ltpl_planner_caps* c) try { return ltplp::api_get_caps(p, c); } LTPL_ABI_CATCH(abi_err_of(p))
 extern "C" const char* ltpl_planner_last_error(const ltpl_planner* p) { return p ? p->P.err.c_str() : g_create_error.c_str(); }
 extern "C" int ltpl_planner_set_start(ltpl_planner* p, int32_t scen, double x, double y, double heading, double vel,
                                       double max_heading_offset, int32_t* in_track, int32_t* cor_heading)
-{
+try {
     if (!p || !in_track || !cor_heading) return LTPL_ERR_INVALID_ARG;
     return p->P.set_start(scen, x, y, heading, vel, max_heading_offset, in_track, cor_heading);
-}
-extern "C" int ltpl_planner_calc_paths(ltpl_planner* p, const ltpl_planner_paths_in* in) { return ltplp::api_calc_paths(p, in); }
-extern "C" int ltpl_planner_calc_paths_begin(ltpl_planner* p, const ltpl_planner_paths_in* in) { return ltplp::api_calc_paths_begin(p, in); }
-extern "C" int ltpl_planner_calc_paths_finish(ltpl_planner* p, const int32_t* zo, const int32_t* zg) { return ltplp::api_calc_paths_finish(p, zo, zg); }
-extern "C" int ltpl_planner_get_ref_idx(ltpl_planner* p, const double* px, const double* py) { return (p && px && py) ? p->P.get_ref_idx(px, py) : LTPL_ERR_INVALID_ARG; }
-extern "C" int ltpl_planner_calc_vel_profile(ltpl_planner* p, const ltpl_planner_vel_in* in) { return ltplp::api_calc_vel_profile(p, in); }
-extern "C" int ltpl_planner_get_paths(const ltpl_planner* p, int32_t scen, ltpl_planner_paths_view* v) { return ltplp::api_get_paths(p, scen, v); }
-extern "C" int ltpl_planner_get_trajectories(const ltpl_planner* p, int32_t scen, ltpl_planner_traj_view* v) { return ltplp::api_get_trajectories(p, scen, v); }
+} LTPL_ABI_CATCH(abi_err_of(p))
+extern "C" int ltpl_planner_calc_paths(ltpl_planner* p, const ltpl_planner_paths_in* in) try { return ltplp::api_calc_paths(p, in); } LTPL_ABI_CATCH(abi_err_of(p))
+extern "C" int ltpl_planner_calc_paths_begin(ltpl_planner* p, const ltpl_planner_paths_in* in) try { return ltplp::api_calc_paths_begin(p, in); } LTPL_ABI_CATCH(abi_err_of(p))
+extern "C" int ltpl_planner_calc_paths_finish(ltpl_planner* p, const int32_t* zo, const int32_t* zg) try { return ltplp::api_calc_paths_finish(p, zo, zg); } LTPL_ABI_CATCH(abi_err_of(p))
+extern "C" int ltpl_planner_get_ref_idx(ltpl_planner* p, const double* px, const double* py) try { return (p && px && py) ? p->P.get_ref_idx(px, py) : LTPL_ERR_INVALID_ARG; } LTPL_ABI_CATCH(abi_err_of(p))
+extern "C" int ltpl_planner_calc_vel_profile(ltpl_planner* p, const ltpl_planner_vel_in* in) try { return ltplp::api_calc_vel_profile(p, in); } LTPL_ABI_CATCH(abi_err_of(p))
+extern "C" int ltpl_planner_get_paths(const ltpl_planner* p, int32_t scen, ltpl_planner_paths_view* v) try { return ltplp::api_get_paths(p, scen, v); } LTPL_ABI_CATCH(abi_err_of(p))
+extern "C" int ltpl_planner_get_trajectories(const ltpl_planner* p, int32_t scen, ltpl_planner_traj_view* v) try { return ltplp::api_get_trajectories(p, scen, v); } LTPL_ABI_CATCH(abi_err_of(p))

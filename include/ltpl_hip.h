@@ -33,6 +33,7 @@ extern "C" {
 #define LTPL_ERR_HIP          3
 #define LTPL_ERR_CAPACITY     4
 #define LTPL_ERR_UNSUPPORTED  5
+#define LTPL_ERR_EXCEPTION    6    /* a C++ exception (out of host memory, ...) was caught at the ABI; message in ltpl_last_error */
 
 /* action primitives: ACTION_ID_MAP, OnlineTrajectoryHandler.py:14-17 */
 #define LTPL_ACT_STRAIGHT 0

@@ -20,3 +20,15 @@ def test_library_host_code_is_clean_under_asan_and_ubsan():
     p = subprocess.run([os.path.join(ROOT, "tools", "fakehip", "run.sh"), "--quick"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        universal_newlines=True, timeout=1200)
     assert p.returncode == 0 and "sanitizer reports: 0" in p.stdout and "entry-point calls" in p.stdout, p.stdout[-3000:]
+
+
+def test_allocation_failures_come_back_as_status_codes():
+    """include/ltpl_hip.h: "No C++ exception crosses the ABI". With the address space capped (RLIMIT_AS) the host containers of the entry
+    points fail to allocate: std::bad_alloc must surface as LTPL_ERR_EXCEPTION + message, not as an abort (tools/fakehip/alloc_failure.py,
+    library host code on the stand-in runtime, no sanitizers: they do not get along with an address-space limit)."""
+    import sys
+    env = dict(os.environ, FAKEHIP_SAN="none", LTPL_NO_SELFTEST="1")
+    subprocess.run([os.path.join(ROOT, "tools", "fakehip", "build.sh")], check=True, env=env, stdout=subprocess.DEVNULL, timeout=900)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fakehip", "alloc_failure.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert p.returncode == 0 and "alloc-failure check OK" in p.stdout and "C++ exception caught at the ABI" in p.stdout, p.stdout[-3000:]
