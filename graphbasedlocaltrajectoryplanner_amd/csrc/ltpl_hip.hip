@@ -2084,7 +2084,8 @@ try {
     ltpl_handle* h = new ltpl_handle();
     h->device = device;
     h->rng_end_host = rng_end;
-    auto fail = [&](int code) { g_create_error = h->err; ltpl_destroy(h); return code; };
+    struct Guard { ltpl_handle* h; ~Guard() { if (h) ltpl_destroy(h); } } guard{h};     // error returns and exceptions release the handle
+    auto fail = [&](int code) { g_create_error = h->err; return code; };
     if (hipSetDevice(device) != hipSuccess) { h->err = "hipSetDevice failed"; return fail(LTPL_ERR_HIP); }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return fail(LTPL_ERR_HIP); }
 
@@ -2279,6 +2280,7 @@ try {
     if (!getenv("LTPL_NO_SELFTEST")) {
         if ((rc = self_test(h, d)) != LTPL_OK) return fail(rc);
     }
+    guard.h = nullptr;
     *out_handle = h;
     return LTPL_OK;
 } LTPL_ABI_CATCH(nullptr)

@@ -124,8 +124,29 @@ def exercise(name, lat):
     hip.close()
 
 
+def create_failures(lat):
+    """ltpl_create with the n-th device allocation failing: every error return releases what was acquired so far (no leak / double free
+    under the sanitizers), the error is reported, and a later create works."""
+    import ctypes as C
+    lib = C.CDLL(FAKE)
+    lib.fakehip_fail_malloc_after.argtypes = [C.c_long]
+    refused = 0
+    for n in (1, 2, 3, 7, 15, 25, 33, 40, 45, 60):
+        lib.fakehip_fail_malloc_after(n)
+        try:
+            _capi.HipBackend(lat, lib_path=FAKE).close()
+        except _capi.BackendError:
+            refused += 1
+        lib.fakehip_fail_malloc_after(0)
+    _capi.HipBackend(lat, lib_path=FAKE).close()
+    print("create with injected allocation failures: %d of 10 refused, create works afterwards" % refused)
+    assert refused >= 5
+    calls[0] += 11
+
+
 def main():
     g = os.path.join(ROOT, "tests", "golden")
+    create_failures(Lattice.load(os.path.join(g, "millbrook_lattice.npz")))
     quick = "--quick" in sys.argv                              # (the CPU test suite's leg: two lattices)
     for name in ("monteblanco", "millbrook") if quick else ("monteblanco", "open", "zalazone", "millbrook", "lvms"):
         exercise(name, Lattice.load(os.path.join(g, name + "_lattice.npz")))

@@ -29,6 +29,10 @@ thread_local int g_ncfg = 0;
 extern "C" {
 
 long fakehip_launch_count() { return g_launches; }
+// failure injection: the n-th "device" allocation from now on fails (n <= 0: off). Error paths of ltpl_create and of the growing
+// staging buffers run under the sanitizers this way.
+static std::atomic<long> g_fail_malloc_in{0};
+void fakehip_fail_malloc_after(long n) { g_fail_malloc_in = n; }
 
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
@@ -51,6 +55,7 @@ hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_tR0600* p, int)
 
 hipError_t hipMalloc(void** p, size_t n)
 {
+    if (g_fail_malloc_in > 0 && --g_fail_malloc_in == 0) { *p = nullptr; return hipErrorOutOfMemory; }
     *p = std::calloc(n ? n : 1, 1);
     if (!*p) return hipErrorOutOfMemory;
     std::lock_guard<std::mutex> lk(g_mu);
