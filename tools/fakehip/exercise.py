@@ -141,7 +141,26 @@ def create_failures(lat):
     _capi.HipBackend(lat, lib_path=FAKE).close()
     print("create with injected allocation failures: %d of 10 refused, create works afterwards" % refused)
     assert refused >= 5
-    calls[0] += 11
+    # growth of the staging buffers fails in the middle of a call: error now, and the handle works on the next call
+    hip = _capi.HipBackend(lat, lib_path=FAKE)
+    grown = 0
+    for n in (10, 200, 3000):
+        scen, vels = random_scenarios(lat, n, seed=n)
+        batch = _capi.PathsBatch(scen, w_last_edges=W)
+        vt = _capi.TickVelBatch(_capi.VelParamSet(len_veh=lat.veh_length), n, np.full(n, 20.0), np.full(n, 20.0),
+                                np.array([lat.node_pos[lat.layer_off[sc['start_node'][0]] + sc['start_node'][1]] for sc in scen]), np.concatenate(vels))
+        for entry in (lambda: hip.plan_paths(batch), lambda: hip.tick_batch(batch, vt), lambda: hip.batch_upload(batch, vt)):
+            lib.fakehip_fail_malloc_after(1)
+            try:
+                entry()
+            except _capi.BackendError:
+                grown += 1
+            lib.fakehip_fail_malloc_after(0)
+            entry()
+    hip.close()
+    print("staging growth with injected allocation failures: %d calls refused, every retry worked" % grown)
+    assert grown >= 3
+    calls[0] += 30
 
 
 def main():
