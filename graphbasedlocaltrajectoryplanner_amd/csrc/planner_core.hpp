@@ -15,11 +15,20 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <functional>
 #include <limits>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ltpl_hip.h"
@@ -233,6 +242,81 @@ struct Config {
 // arguments of Graph_LTPL.calc_vel_profile (Graph_LTPL.py:344-408), per scenario
 struct VelReq { double pos_x, pos_y, vel_est, vel_max, gg_scale, gg_ax, gg_ay, safety_d; int incl_emerg; };
 
+// Persistent worker threads for the per-planner loops of a BATCH of planners (the state machines of different planners share nothing
+// but the read-only lattice): run(f) calls f(t) for t = 0 .. size() - 1, f(0) on the calling thread, and returns when all are done. An
+// exception thrown by any f is re-thrown on the calling thread after the others have finished (the ABI's try blocks sit there).
+class WorkerPool {
+public:
+    explicit WorkerPool(int workers, int spin_us = 300) : spin_us_(spin_us) { for (int i = 0; i < workers; ++i) th.emplace_back([this, i] { loop(i + 1); }); }
+    ~WorkerPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; gen.fetch_add(1, std::memory_order_release); }
+        cv_go.notify_all();
+        for (std::thread& t : th) t.join();
+    }
+    int size() const { return (int)th.size() + 1; }
+    void run(const std::function<void(int)>& f)
+    {
+        { std::lock_guard<std::mutex> lk(mu); job = &f; pending.store((int)th.size(), std::memory_order_relaxed); eptr = nullptr; gen.fetch_add(1, std::memory_order_release); }
+        if (sleepers.load(std::memory_order_acquire) > 0) cv_go.notify_all();
+        std::exception_ptr mine;
+        try { f(0); } catch (...) { mine = std::current_exception(); }
+        // the regions are short: wait for the stragglers by polling first
+        const auto t0 = std::chrono::steady_clock::now();
+        while (pending.load(std::memory_order_acquire) != 0) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_done.wait(lk, [this] { return pending.load(std::memory_order_acquire) == 0; });
+                break;
+            }
+        }
+        std::exception_ptr theirs;
+        { std::lock_guard<std::mutex> lk(mu); job = nullptr; theirs = eptr; }
+        if (mine) std::rethrow_exception(mine);
+        if (theirs) std::rethrow_exception(theirs);
+    }
+private:
+    void loop(int id)
+    {
+        long seen = 0;
+        for (;;) {
+            // A sleeping thread woken through the condition variable starts on the waker's core and only runs once the waker blocks
+            // (measured: short regions then execute one after the other), so a worker polls the generation counter for spin_us_ after its
+            // last job -- the regions of one tick follow each other within that window -- and only then goes to sleep.
+            const auto t0 = std::chrono::steady_clock::now();
+            bool got = false;
+            while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us_)) {
+                if (gen.load(std::memory_order_acquire) != seen) { got = true; break; }
+            }
+            const std::function<void(int)>* f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                if (!got) {
+                    sleepers.fetch_add(1, std::memory_order_release);
+                    cv_go.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen; });
+                    sleepers.fetch_sub(1, std::memory_order_release);
+                }
+                seen = gen.load(std::memory_order_acquire);
+                if (stop) return;
+                f = job;
+            }
+            std::exception_ptr e;
+            try { (*f)(id); } catch (...) { e = std::current_exception(); }
+            if (e) { std::lock_guard<std::mutex> lk(mu); if (!eptr) eptr = e; }
+            if (pending.fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> lk(mu); cv_done.notify_one(); }
+        }
+    }
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    const std::function<void(int)>* job = nullptr;
+    std::exception_ptr eptr;
+    std::atomic<long> gen{0};
+    std::atomic<int> pending{0}, sleepers{0};
+    int spin_us_;
+    bool stop = false;
+};
+
 struct Planner {
     HostLat lat;
     Config cfg;
@@ -248,8 +332,48 @@ struct Planner {
         o_n_ties, o_nodes, o_node_idx;
     std::vector<double> o_coeff, o_pp;
 
-    ~Planner() { delete cmp; }
-    int fail(int code, const std::string& why) { err = why; return code; }
+    // Batches (OPT-IN, LTPL_PLANNER_THREADS=<n>; default 1 = serial): the per-planner loops (objects + paths_pre, paths_post, stage A of the
+    // velocity step: ~85 % of the host time of a tick, ~30 us per planner) run on n threads once a call carries at least kParMin
+    // planners. The compute calls (kernel launches) always stay on the calling thread. Build container, 64 planners, 8 threads: the three
+    // regions take 115 / 78 / 389 instead of 357 / 260 / 861 us -- but only while the workers are still polling (LTPL_PLANNER_SPIN_US,
+    // default 300 us after their last job): woken from sleep they start on the caller's core and the regions serialise. Results are
+    // identical to the serial run (ranges are contiguous and merged in order); not yet measured on the GPU box, hence opt-in.
+    static constexpr int kParMin = 32, kParGrain = 8;
+    int n_threads = default_threads();
+    int spin_us = std::getenv("LTPL_PLANNER_SPIN_US") ? std::atoi(std::getenv("LTPL_PLANNER_SPIN_US")) : 300;
+    std::unique_ptr<WorkerPool> pool;
+    static int default_threads()
+    {
+        int t = 1;
+        if (const char* e = std::getenv("LTPL_PLANNER_THREADS")) t = std::atoi(e);
+        return std::min(std::max(t, 1), 64);
+    }
+    static std::string*& tl_err() { static thread_local std::string* p = nullptr; return p; }     // error sink of a worker's range
+
+    ~Planner() { pool.reset(); delete cmp; }
+    int fail(int code, const std::string& why) { (tl_err() ? *tl_err() : err) = why; return code; }
+    // body(s0, s1, t) -> status for the planners [s0, s1) of part t; parts are contiguous and ordered, so "the first error" is the
+    // error of the first failing part. Returns the number of parts through *parts (1 = ran serially on the calling thread).
+    template <class F>
+    int for_planner_ranges(int n, int* parts, F&& body)
+    {
+        const int T = (n >= kParMin && n_threads > 1) ? std::min(n_threads, n / kParGrain) : 1;
+        if (parts) *parts = T;
+        if (T <= 1) return body(0, n, 0);
+        if (!pool || pool->size() != n_threads) pool.reset(new WorkerPool(n_threads - 1, spin_us));
+        std::vector<int> rc((size_t)T, LTPL_OK);
+        std::vector<std::string> errs((size_t)T);
+        const int chunk = (n + T - 1) / T;
+        pool->run([&](int t) {
+            if (t >= T) return;
+            const int s0 = t * chunk, s1 = std::min(n, s0 + chunk);
+            if (s0 >= s1) return;
+            struct Sink { std::string*& p; Sink(std::string*& q, std::string* to) : p(q) { p = to; } ~Sink() { p = nullptr; } } sink(tl_err(), &errs[(size_t)t]);
+            rc[(size_t)t] = body(s0, s1, t);
+        });
+        for (int t = 0; t < T; ++t) if (rc[(size_t)t]) { err = errs[(size_t)t]; return rc[(size_t)t]; }
+        return LTPL_OK;
+    }
     int fail_cmp(int code) { err = cmp->last_error() ? cmp->last_error() : "compute backend failed"; return code; }
 
     // -----------------------------------------------------------------------------------------------------------------
@@ -470,7 +594,8 @@ struct Planner {
         Scn& S = sc[(size_t)s];
         const int A = LTPL_MAX_ACTIONS, cn = lat.max_path_nodes, cp = lat.max_path_pts;
         Traj* lsel = S.const_exists ? S.find_last(S.sel_action) : nullptr;
-        const Traj old = lsel ? *lsel : Traj();            // the dicts are replaced below; the old entry is still read
+        Traj old;                                          // the dicts are replaced below; the old entry is still read (moved out: S.last is
+        if (lsel) old = std::move(*lsel);                  // not looked at again before it is replaced at the end of this function)
         const int loc = S.loc_path_start_idx, sni = S.start_node_idx;
         std::vector<Traj> fresh;
         S.closest_obj_index = o_coi[(size_t)s];
@@ -537,22 +662,26 @@ struct Planner {
         b_veh_off.assign(veh_off, veh_off + n + 1); b_pos_off.assign(pos_off, pos_off + nv + 1);
         b_radius.assign(veh_radius, veh_radius + nv); b_px.assign(pos_x, pos_x + np_); b_py.assign(pos_y, pos_y + np_);
         b_radius.push_back(0.0); b_px.push_back(0.0); b_py.push_back(0.0);          // never empty
-        // OTH.update_objects (OTH.py:272-287)
-        for (int s = 0; s < n; ++s) {
-            Scn& S = sc[(size_t)s];
-            S.veh.clear();
-            for (int v = veh_off[s]; v < veh_off[s + 1]; ++v) {
-                ObjVeh o; o.radius = veh_radius[v]; o.vel = veh_vel ? veh_vel[v] : 0.0;
-                if (pos_off[v + 1] - pos_off[v] < 1) return fail(LTPL_ERR_INVALID_ARG, "vehicle without position");
-                o.x = pos_x[pos_off[v]]; o.y = pos_y[pos_off[v]];
-                for (int p = pos_off[v]; p < pos_off[v + 1]; ++p) { o.pos.push_back(pos_x[p]); o.pos.push_back(pos_y[p]); }
-                S.veh.push_back(std::move(o));
+        // OTH.update_objects (OTH.py:272-287), then the part of OTH.calc_paths in front of seam (1); planner by planner, in parallel for batches
+        LTPL_PROF(prof_pre, "planner.paths_pre");
+        const int rc_all = for_planner_ranges(n, nullptr, [&](int s0, int s1, int) {
+            for (int s = s0; s < s1; ++s) {
+                Scn& S = sc[(size_t)s];
+                S.veh.clear();
+                for (int v = veh_off[s]; v < veh_off[s + 1]; ++v) {
+                    ObjVeh o; o.radius = veh_radius[v]; o.vel = veh_vel ? veh_vel[v] : 0.0;
+                    if (pos_off[v + 1] - pos_off[v] < 1) return fail(LTPL_ERR_INVALID_ARG, "vehicle without position");
+                    o.x = pos_x[pos_off[v]]; o.y = pos_y[pos_off[v]];
+                    for (int p = pos_off[v]; p < pos_off[v + 1]; ++p) { o.pos.push_back(pos_x[p]); o.pos.push_back(pos_y[p]); }
+                    S.veh.push_back(std::move(o));
+                }
+                S.closest_obj_index = -1;
+                const int rc = paths_pre(s, prev_action[s], t_now[s]);
+                if (rc) return rc;
             }
-            S.closest_obj_index = -1;
-            LTPL_PROF(prof_pre, "planner.paths_pre");
-            int rc = paths_pre(s, prev_action[s], t_now[s]);
-            if (rc) return rc;
-        }
+            return (int)LTPL_OK;
+        });
+        if (rc_all) return rc_all;
         began = true;
         return LTPL_OK;
     }
@@ -585,8 +714,10 @@ struct Planner {
         int rc = cmp->plan_paths(&in, &out);
         if (rc) return fail_cmp(rc);
         LTPL_PROF(prof_post, "planner.paths_post");
-        for (int s = 0; s < n; ++s) if ((rc = paths_post(s))) return rc;
-        return LTPL_OK;
+        return for_planner_ranges(n, nullptr, [&](int s0, int s1, int) {
+            for (int s = s0; s < s1; ++s) { const int r = paths_post(s); if (r) return r; }
+            return (int)LTPL_OK;
+        });
     }
 
     int calc_paths(const int* prev_action, const double* t_now, const int* veh_off, const int* pos_off, const double* veh_radius,
@@ -710,7 +841,9 @@ struct Planner {
         std::vector<Work> work;
         std::vector<ltpl_vel_job> jobs; std::vector<JobBuf> bufs; std::vector<ltpl_vel_result> res;
         // ---- stage A: get_ref_idx, slicing (:700-731), job construction (:736-903) ---------------------------------------
-        for (int s = 0; s < n; ++s) {
+        // (planners [s0, s1) into the given lists: a batch is cut into ranges that fill their own lists in parallel, merged in order below)
+        auto stage_a = [&](int s0, int s1, std::vector<Work>& work, std::vector<ltpl_vel_job>& jobs, std::vector<JobBuf>& bufs) -> int {
+        for (int s = s0; s < s1; ++s) {
             Scn& S = sc[(size_t)s];
             const VelReq& R = req[s];
             if (!S.ref_done) ref_idx(S, R.pos_x, R.pos_y);
@@ -762,6 +895,7 @@ struct Planner {
                     JobBuf B;
                     jb.mode = mode; jb.n = i1 - i0; jb.n_el = n_el; jb.has_v_end = has_end ? 1 : 0;
                     jb.v_start = v_start; jb.v_end = v_end;
+                    B.kappa.reserve((size_t)(i1 - i0)); B.gg.reserve((size_t)(i1 - i0) * 2); B.el.reserve((size_t)std::max(n_el, 1));
                     for (int i = i0; i < i1; ++i) {
                         B.kappa.push_back(W.pv[(size_t)i * 5 + 3]);
                         B.gg.push_back(W.gv[(size_t)i * 2] * R.gg_scale); B.gg.push_back(W.gv[(size_t)i * 2 + 1] * R.gg_scale);
@@ -819,6 +953,31 @@ struct Planner {
                 }
                 work.push_back(std::move(W));
             }
+        }
+        return LTPL_OK;
+        };
+        {
+            struct Part { std::vector<Work> work; std::vector<ltpl_vel_job> jobs; std::vector<JobBuf> bufs; };
+            std::vector<Part> part((size_t)std::max(n_threads, 1));
+            int parts = 1;
+            const int rc_a = for_planner_ranges(n, &parts, [&](int s0, int s1, int t) {
+                return parts == 1 ? stage_a(s0, s1, work, jobs, bufs) : stage_a(s0, s1, part[(size_t)t].work, part[(size_t)t].jobs, part[(size_t)t].bufs);
+            });
+            if (rc_a) return rc_a;
+            if (parts > 1)
+                for (int t = 0; t < parts; ++t) {                 // ranges are ordered by planner: same order as the serial loop
+                    Part& P = part[(size_t)t];
+                    const int off = (int)jobs.size();
+                    for (Work& W : P.work) {
+                        if (W.job_follow >= 0) W.job_follow += off;
+                        if (W.job_free >= 0) W.job_free += off;
+                        if (W.job_fb >= 0) W.job_fb += off;
+                        if (W.job_backup >= 0) W.job_backup += off;
+                        work.push_back(std::move(W));
+                    }
+                    jobs.insert(jobs.end(), P.jobs.begin(), P.jobs.end());
+                    for (JobBuf& B : P.bufs) bufs.push_back(std::move(B));
+                }
         }
         prof_a.stop();
         int rc = run_jobs(vp, jobs, bufs, res);
