@@ -28,6 +28,7 @@ def test_allocation_failures_come_back_as_status_codes():
     library host code on the stand-in runtime, no sanitizers: they do not get along with an address-space limit)."""
     import sys
     env = dict(os.environ, FAKEHIP_SAN="none", LTPL_NO_SELFTEST="1")
+    env.pop("LD_PRELOAD", None)                    # (when the suite itself runs under tools/sanitize_host.sh)
     subprocess.run([os.path.join(ROOT, "tools", "fakehip", "build.sh")], check=True, env=env, stdout=subprocess.DEVNULL, timeout=900)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fakehip", "alloc_failure.py")], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
