@@ -334,10 +334,10 @@ struct Planner {
 
     // Batches (OPT-IN, LTPL_PLANNER_THREADS=<n>; default 1 = serial): the per-planner loops (objects + paths_pre, paths_post, stage A of the
     // velocity step: ~85 % of the host time of a tick, ~30 us per planner) run on n threads once a call carries at least kParMin
-    // planners. The compute calls (kernel launches) always stay on the calling thread. Build container, 64 planners, 8 threads: the three
-    // regions take 115 / 78 / 389 instead of 357 / 260 / 861 us -- but only while the workers are still polling (LTPL_PLANNER_SPIN_US,
-    // default 300 us after their last job): woken from sleep they start on the caller's core and the regions serialise. Results are
-    // identical to the serial run (ranges are contiguous and merged in order); not yet measured on the GPU box, hence opt-in.
+    // planners. The compute calls (kernel launches) always stay on the calling thread. Results are identical to the serial run (ranges
+    // are contiguous and merged in order). EXPERIMENTAL: in the build container the regions only get faster while the workers are still
+    // polling (LTPL_PLANNER_SPIN_US after their last job; 8 threads: 115 / 78 / 389 instead of 357 / 260 / 861 us) -- workers that went to
+    // sleep take milliseconds to come back there and the tick gets SLOWER. Not measured on the GPU box yet.
     static constexpr int kParMin = 32, kParGrain = 8;
     int n_threads = default_threads();
     int spin_us = std::getenv("LTPL_PLANNER_SPIN_US") ? std::atoi(std::getenv("LTPL_PLANNER_SPIN_US")) : 300;

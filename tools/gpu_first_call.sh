@@ -6,6 +6,7 @@
 #    own timeout so that a hang cannot take the box down with it
 # 3. the planner / edge-case GPU tests through a build of the library with libstdc++ assertions in its host code
 #    (-D_GLIBCXX_ASSERTIONS: vector bounds on REAL kernel results; the sanitizer runs of tools/fakehip only see empty results)
+# 4. closed-loop rate of 256 planners with 1 / 4 / 8 host threads
 # Logs under gpurun_out/first_call/.
 set -u
 cd "$(dirname "$0")/.."
@@ -25,3 +26,5 @@ if /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -f
 else
   echo "host assertions build: compile failed (see assert_build.log)" | tee -a $OUT/summary.txt
 fi
+# 4. batches of planners: serial host loops vs the opt-in worker threads
+for T in 1 4 8; do LTPL_PLANNER_THREADS=$T timeout 300 python tools/planner_batch_rate.py --planners 256 --ticks 200 2>&1 | tail -1 | tee -a $OUT/summary.txt; done
