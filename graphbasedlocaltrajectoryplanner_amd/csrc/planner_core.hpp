@@ -840,6 +840,7 @@ struct Planner {
 
         std::vector<Work> work;
         std::vector<ltpl_vel_job> jobs; std::vector<JobBuf> bufs; std::vector<ltpl_vel_result> res;
+        work.reserve((size_t)n * 3); jobs.reserve((size_t)n * 4); bufs.reserve((size_t)n * 4);     // (<= 3 keys and <= 4 jobs per planner, typically)
         // ---- stage A: get_ref_idx, slicing (:700-731), job construction (:736-903) ---------------------------------------
         // (planners [s0, s1) into the given lists: a batch is cut into ranges that fill their own lists in parallel, merged in order below)
         auto stage_a = [&](int s0, int s1, std::vector<Work>& work, std::vector<ltpl_vel_job>& jobs, std::vector<JobBuf>& bufs) -> int {
