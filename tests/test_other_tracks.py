@@ -10,7 +10,8 @@ Further tracks of the reference's inputs/traj_ltpl_cl (all other fixtures are Mo
             Their lattices are not committed (5 MB each): the tests rebuild them with the product's offline build (see lattice_of)
 
 CPU: the oracle at both seams, the planner's host state machine in closed loop, and the offline lattice build against the
-lattice exported from the reference's GraphBase. GPU: the same through libltpl_hip.so.
+lattice exported from the reference's GraphBase. GPU: the same through libltpl_hip.so (first run on an MI355X: round 3, all 13 legs
+green, gpurun_out/r03a -> profiles/r03a_other_tracks.txt).
 """
 import os
 
@@ -27,11 +28,6 @@ from graphbasedlocaltrajectoryplanner_amd.path_gen import OnlinePathGenerator
 TRACKS = ["zalazone", "millbrook", "lvms", "berlin", "modena"]
 BUILT_HERE = ("berlin", "modena")       # no lattice export committed (5 MB each): rebuilt by the product's offline build, see lattice_of
 _lattices = {}
-
-# The GPU legs were written at the end of round 2, after the round's GPU budget was spent: they have not run on an MI355X yet.
-# Until they have, they only run on request (LTPL_GPU_OTHER_TRACKS=1) so that an unverified test cannot colour the suite.
-gpu_pending = pytest.mark.skipif(os.environ.get("LTPL_GPU_OTHER_TRACKS") != "1",
-                                 reason="GPU legs of the additional tracks: not yet verified on an MI355X (set LTPL_GPU_OTHER_TRACKS=1)")
 
 
 def lattice_of(track):
@@ -132,7 +128,6 @@ def hip_of():
 
 
 @pytest.mark.gpu
-@gpu_pending
 @pytest.mark.parametrize("track", TRACKS)
 def test_hip_matches_reference_recordings_and_the_oracle(hip_of, track):
     from oracle.oracle_lib import OracleBackend
@@ -148,7 +143,6 @@ def test_hip_matches_reference_recordings_and_the_oracle(hip_of, track):
 
 
 @pytest.mark.gpu
-@gpu_pending
 @pytest.mark.parametrize("track", TRACKS)
 def test_planner_closed_loop_on_the_device(hip_of, track):
     from graphbasedlocaltrajectoryplanner_amd.planner import Planner
@@ -160,7 +154,6 @@ def test_planner_closed_loop_on_the_device(hip_of, track):
 
 
 @pytest.mark.gpu
-@gpu_pending
 @pytest.mark.parametrize("track", TRACKS[:3])
 def test_device_build_reproduces_the_reference_lattice(hip_of, track):
     from test_offline_build import track as track_arrays, check_against_reference_export
