@@ -525,6 +525,11 @@ def default_library_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libltpl_hip.so")
 
 
+def experiment_library_path():
+    """The -DLTPL_EXPERIMENT build (timing / fault-injection switches, include/ltpl_hip.h): tools/ and one fault-injection test."""
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libltpl_hip_exp.so")
+
+
 class BackendError(RuntimeError):
     pass
 
@@ -558,6 +563,7 @@ class HipBackend(object):
         L.ltpl_last_error.argtypes = [C.c_void_p]
         L.ltpl_last_error.restype = C.c_char_p
         L.ltpl_plan_paths.argtypes = [C.c_void_p, C.POINTER(PathsIn), C.POINTER(PathsOut)]
+        L.ltpl_plan_paths_mask.argtypes = [C.c_void_p, C.POINTER(PathsIn), C.POINTER(PathsOut), C.c_int32, C.c_void_p]
         L.ltpl_vel_profile.argtypes = [C.c_void_p, C.POINTER(VelParams), C.c_int, C.POINTER(VelJob),
                                        C.POINTER(VelResult)]
         L.ltpl_tick_batch.argtypes = [C.c_void_p, C.POINTER(PathsIn), C.POINTER(TickVelIn), C.POINTER(PathsOut),
@@ -598,6 +604,15 @@ class HipBackend(object):
             result = self.new_paths_result(batch.n_scen)
         self._check(self.lib.ltpl_plan_paths(self.handle, C.byref(batch.struct), C.byref(result.struct)))
         return result
+
+    def plan_paths_mask(self, batch: PathsBatch, team_waves: int = 0):
+        """Diagnostics (ltpl_plan_paths_mask): seam (1) plus the obstacle x edge mask as the path kernel computed it,
+        uint8 [n_scen, num_edges] by global edge id. ``team_waves``: 0 = automatic, 1 = one-wave batch kernel, 4 = latency kernel."""
+        result = self.new_paths_result(batch.n_scen)
+        blocked = np.zeros((batch.n_scen, self.lattice.num_edges), np.uint8)
+        self._check(self.lib.ltpl_plan_paths_mask(self.handle, C.byref(batch.struct), C.byref(result.struct), int(team_waves),
+                                                  blocked.ctypes.data))
+        return result, blocked
 
     def const_segment_test(self, const_path_seg, pos_est, vehicles):
         """(obj_in_const_path, object_besides_const_path, closest object index | None) of main_online_path_gen.py:76-122;

@@ -112,17 +112,28 @@ struct DevPathsOut {
 };
 
 
+// Timing / fault-injection switches (LTPL_ABLATE, LTPL_EXP_SKIP, LTPL_LDS_POISON, LTPL_SCRATCH_POISON, LTPL_DEBUG_TIMING, LTPL_DEBUG_OCC)
+// only exist in the EXPERIMENT build (-DLTPL_EXPERIMENT -> libltpl_hip_exp.so, tools/ and the stale-LDS test): the release library has
+// no code path that skips work, alters memory or instruments kernels on an environment variable's say-so.
 #define DBG_SLOTS 64
+#ifdef LTPL_EXPERIMENT
 __device__ __forceinline__ void dbg_stamp(long long* dbg, int k)
 {
     if (dbg && (threadIdx.x & 63) == 0 && blockIdx.x < 256) dbg[(size_t)blockIdx.x * DBG_SLOTS + (threadIdx.x >> 6) * 16 + k] = clock64();
 }
+#else
+__device__ __forceinline__ void dbg_stamp(long long*, int) {}
+#endif
 
 // LTPL_DEBUG_TIMING for the lane kernel: `row` selects one of 256 sample rows (generic / follow / unconstrained blocks)
+#ifdef LTPL_EXPERIMENT
 __device__ __forceinline__ void vl_stamp(long long* dbg, int row, int k)
 {
     if (dbg && (threadIdx.x & 63) == 0 && row >= 0 && row < 256) dbg[(size_t)row * DBG_SLOTS + k] = clock64();
 }
+#else
+__device__ __forceinline__ void vl_stamp(long long*, int, int) {}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // wave helpers (wave64)
@@ -1852,9 +1863,11 @@ static const void* paths_kernel_of(const ltpl_handle* h, int nw)
 }
 
 // the path kernel with `nw` waves per scenario in the LDS plan class chosen for the lattice at ltpl_create
-static int launch_paths(ltpl_handle* h, int nw, int n_scen, hipStream_t st, const DevPathsIn& di, const DevPathsOut& dout)
+static int launch_paths(ltpl_handle* h, int nw, int n_scen, hipStream_t st, const DevPathsIn& di, const DevPathsOut& dout,
+                        unsigned* mask_out = nullptr)
 {
     TeamLds lp = nw == 1 ? h->lp1 : h->lp4;
+    lp.mask_out = mask_out;
     if (h->long_horizon) {
         const size_t need = (size_t)lp.par_glob_stride * (size_t)n_scen;
         if (need > h->d_par_cap) {
@@ -2182,10 +2195,13 @@ try {
         lp->off_pos_layer = (int)off; off += sizeof(short) * MAX_POS; off = align_up(off, 16);
         lp->off_pos_veh = (int)off; off += MAX_POS; off = align_up(off, 16);
         lp->total = (int)off;
+        lp->mask_out = nullptr;
+        lp->ablate = 0; lp->poison_on = 0; lp->poison = 0u; lp->dbg = nullptr;
+#ifdef LTPL_EXPERIMENT
         lp->ablate = getenv("LTPL_ABLATE") ? atoi(getenv("LTPL_ABLATE")) : 0;
         lp->poison_on = getenv("LTPL_LDS_POISON") ? 1 : 0;
         lp->poison = lp->poison_on ? (unsigned)strtoul(getenv("LTPL_LDS_POISON"), nullptr, 0) : 0u;
-        lp->dbg = nullptr;
+#endif
     };
     make_plan(1, &h->lp1, false); make_plan(NUM_WAVES, &h->lp4, false);
     const int lds_limit = 150 * 1024;
@@ -2239,18 +2255,22 @@ try {
         *h->h_flag = 0u;
     }
     // environment switches are read ONCE here: getenv() in a per-tick entry point costs microseconds in a process with a large environment
+#ifdef LTPL_EXPERIMENT
     if (const char* e = getenv("LTPL_SCRATCH_POISON")) { h->scratch_poison_on = 1; h->scratch_poison_word = (unsigned)strtoul(e, nullptr, 0); }
+    if (const char* e = getenv("LTPL_EXP_SKIP")) h->exp_skip = atoi(e);
+#endif
     h->force_fused = getenv("LTPL_FORCE_FUSED") ? 1 : 0;
     h->no_overlap = getenv("LTPL_NO_OVERLAP") ? 1 : 0;
-    if (const char* e = getenv("LTPL_EXP_SKIP")) h->exp_skip = atoi(e);
     if (const char* e = getenv("LTPL_FINAL_Y")) h->final_y = atoi(e) > 0 ? atoi(e) : 8;
     if (const char* e = getenv("LTPL_NW1_MIN_SCEN")) h->nw1_min_scen = atoi(e) > 0 ? atoi(e) : PIPELINE_MIN_SCEN;
+#ifdef LTPL_EXPERIMENT
     if (getenv("LTPL_DEBUG_TIMING")) {
         if (hipMalloc(reinterpret_cast<void**>(&h->d_dbg), sizeof(long long) * 256 * DBG_SLOTS) == hipSuccess) {
             (void)hipMemset(h->d_dbg, 0, sizeof(long long) * 256 * DBG_SLOTS);
             h->lp1.dbg = h->d_dbg; h->lp4.dbg = h->d_dbg;
         }
     }
+#endif
     if (h->lp4.total > lds_limit || h->lp1.total > lds_limit) {
         h->err = "planning horizon too large: the path scratch of the sweep does not fit in LDS (" + std::to_string(h->lp4.total) + " B > 150 KiB)";
         return fail(LTPL_ERR_CAPACITY);
@@ -2261,7 +2281,12 @@ try {
             hipFuncSetAttribute(paths_kernel_of(h, NUM_WAVES), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 h->lp4.total) != hipSuccess) { h->err = "cannot raise dynamic LDS limit"; return fail(LTPL_ERR_HIP); }
     }
-    if (getenv("LTPL_DEBUG_OCC")) {
+#ifdef LTPL_EXPERIMENT
+    if (getenv("LTPL_DEBUG_OCC"))
+#else
+    if (false)
+#endif
+    {
         int nb1 = -1, nb4 = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, paths_kernel_of(h, 1), 64, (size_t)h->lp1.total);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb4, paths_kernel_of(h, NUM_WAVES), WG_THREADS, (size_t)h->lp4.total);
@@ -2464,6 +2489,7 @@ static void scatter_out(const unsigned char* hb, const OutLayout& lo, int n, ltp
 
 // testing only (LTPL_SCRATCH_POISON=<hex word>): fills the private-segment arena of the stream with a pattern before the
 // path kernel runs, so that a reload of a register spill slot the lane never stored shows up as a parity failure
+#ifdef LTPL_EXPERIMENT
 __global__ __launch_bounds__(64) void k_scratch_poison(unsigned pattern, unsigned* sink)
 {
     volatile unsigned a[256];
@@ -2472,11 +2498,16 @@ __global__ __launch_bounds__(64) void k_scratch_poison(unsigned pattern, unsigne
     for (int i = 0; i < 256; i += 37) acc += a[i];
     if (acc == 0x12345u && sink) *sink = acc;
 }
+#endif
 
 static void scratch_poison(ltpl_handle* h)
 {
+#ifdef LTPL_EXPERIMENT
     if (h->scratch_poison_on)
         hipLaunchKernelGGL(k_scratch_poison, dim3(256 * 64), dim3(64), 0, h->stream, h->scratch_poison_word, (unsigned*)nullptr);
+#else
+    (void)h;
+#endif
 }
 
 // completion of a small zero-copy call. The polled word is written by the kernel's last block (signal_done); a launch that
@@ -2504,15 +2535,23 @@ static int wait_done(ltpl_handle* h, unsigned seq)
     return LTPL_OK;
 }
 
-static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_out* out, int force_nw);
+static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_out* out, int force_nw, uint8_t* blocked = nullptr);
 
 extern "C" int ltpl_plan_paths(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_out* out)
 try {
     return plan_paths_impl(h, in, out, 0);
 } LTPL_ABI_CATCH(abi_err_of(h))
 
-// force_nw: 0 = choose by batch size, 1 / NUM_WAVES = one-wave batch kernel / four-wave latency kernel (self-test)
-static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_out* out, int force_nw)
+extern "C" int ltpl_plan_paths_mask(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_out* out, int32_t team_waves, uint8_t* blocked)
+try {
+    if (!h) return LTPL_ERR_INVALID_ARG;
+    if (!blocked || !(team_waves == 0 || team_waves == 1 || team_waves == NUM_WAVES)) { h->err = "ltpl_plan_paths_mask: bad argument"; return LTPL_ERR_INVALID_ARG; }
+    return plan_paths_impl(h, in, out, team_waves, blocked);
+} LTPL_ABI_CATCH(abi_err_of(h))
+
+// force_nw: 0 = choose by batch size, 1 / NUM_WAVES = one-wave batch kernel / four-wave latency kernel (self-test, diagnostics);
+// blocked: [n_scen * E] bytes or nullptr -- the obstacle x edge mask as the kernel computed it (ltpl_plan_paths_mask)
+static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_out* out, int force_nw, uint8_t* blocked)
 {
     if (!h) return LTPL_ERR_INVALID_ARG;
     if (!out) { h->err = "null output"; return LTPL_ERR_INVALID_ARG; }
@@ -2546,9 +2585,16 @@ static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_o
         if (!zci) HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, li.total, hipMemcpyHostToDevice, h->stream));
     }
     scratch_poison(h);
+    unsigned* d_mask = nullptr;
+    const size_t mask_words = (size_t)((nw == 1 ? h->lp1 : h->lp4).words_blocked + 2);
+    struct MaskGuard { unsigned* p = nullptr; ~MaskGuard() { if (p) (void)hipFree(p); } } mask_guard;
+    if (blocked) {
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&d_mask), sizeof(unsigned) * mask_words * (size_t)in->n_scen));
+        mask_guard.p = d_mask;
+    }
     {
         LTPL_PROF(prof_l, "plan_paths.enqueue.launch");
-        if ((rc = launch_paths(h, nw, in->n_scen, h->stream, di, dout))) return rc;
+        if ((rc = launch_paths(h, nw, in->n_scen, h->stream, di, dout, d_mask))) return rc;
     }
     if (!zc) HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, lo.total, hipMemcpyDeviceToHost, h->stream));
     prof_enq.stop();
@@ -2557,6 +2603,19 @@ static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_o
     else HIP_TRY(h, hipStreamSynchronize(h->stream));
     prof_sync.stop();
     dbg_report(h, "k_paths", in->n_scen);
+    if (blocked) {
+        // per scenario: first edge of the planning range, its layer count, one bit per edge of the range in edge-id order (wraps at E)
+        std::vector<unsigned> hm(mask_words * (size_t)in->n_scen);
+        HIP_TRY(h, hipMemcpy(hm.data(), d_mask, sizeof(unsigned) * hm.size(), hipMemcpyDeviceToHost));
+        const size_t E = (size_t)h->lat.E;
+        memset(blocked, 0, E * (size_t)in->n_scen);
+        for (int s = 0; s < in->n_scen; ++s) {
+            const unsigned* w = hm.data() + mask_words * (size_t)s;
+            const size_t e_base = w[0];
+            for (size_t i = 0; i < (mask_words - 2) * 32 && i < E; ++i)
+                if ((w[2 + (i >> 5)] >> (i & 31)) & 1u) blocked[(size_t)s * E + (e_base + i) % E] = 1;
+        }
+    }
     LTPL_PROF(prof_sc, "plan_paths.scatter");
     scatter_out(static_cast<const unsigned char*>(h->h_out), lo, in->n_scen, out);
     return LTPL_OK;
@@ -2876,18 +2935,24 @@ static int tick_launch_vel(ltpl_handle* h, const TickLayout& t, hipStream_t st, 
     // slots without a path: vel_bound = too_close = 0 (the job kernels only touch slots that own a job)
     HIP_TRY(h, hipMemsetAsync(t.dvout.vel_bound, 0, sizeof(int) * (size_t)t.n_scen * LTPL_MAX_ACTIONS, st));
     HIP_TRY(h, hipMemsetAsync(t.dvout.too_close, 0, sizeof(int) * (size_t)t.n_scen * LTPL_MAX_ACTIONS, st));
+#ifdef LTPL_EXPERIMENT
     if (!(h->exp_skip & 1))
+#endif
     hipLaunchKernelGGL(k_follow_prep, dim3((t.n_scen + 63) / 64), dim3(64), 0, st, h->lat, t.di, t.dout,
                        t.dvin, t.dprep, t.vp, t.n_scen, h->lp4.dbg);
     HIP_TRY(h, hipGetLastError());
     if (ev_after_prep) HIP_TRY(h, hipEventRecord(ev_after_prep, st));
     const int n_slots = t.n_scen * LTPL_MAX_ACTIONS;
     const int nb0 = (n_slots + 63) / 64, nb1 = (t.n_scen + 63) / 64;
+#ifdef LTPL_EXPERIMENT
     if (!(h->exp_skip & 2))
+#endif
     hipLaunchKernelGGL(lanes_kernel_of(t.variant), dim3(nb0 + 2 * nb1), dim3(64), 0, st, h->lat, t.di, t.dout,
                        t.p, t.dvin, t.dprep, t.vp, n_slots, t.n_scen, nb0, h->lp4.dbg);
     HIP_TRY(h, hipGetLastError());
+#ifdef LTPL_EXPERIMENT
     if (!(h->exp_skip & 4))
+#endif
     hipLaunchKernelGGL(k_vel_final, dim3(nb0 + nb1, h->final_y), dim3(64), 0, st, t.dout, t.dvin, t.dvout, t.vp, n_slots, t.n_scen);
     HIP_TRY(h, hipGetLastError());
     return LTPL_OK;

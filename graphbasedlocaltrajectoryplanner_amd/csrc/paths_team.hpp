@@ -79,11 +79,25 @@ struct TeamLds {                 // dynamic-LDS plan (byte offsets), computed on
     int total;
     // long planning horizons (PlanRtG): the parent tables live in global memory, `par_glob_stride` bytes per scenario
     unsigned char* par_glob; long long par_glob_stride;
-    int ablate;                  // profiling only (LTPL_ABLATE): 1 = skip the mask, 2 = skip the sweeps, 4 = skip path assembly
-    int poison_on; unsigned poison;   // testing only (LTPL_LDS_POISON=<hex word>): fill the team's LDS before phase 0, so that a read of
-                                 // LDS the scenario has not written itself shows up as a parity failure instead of depending on stale data
-    long long* dbg;
+    // diagnostics (ltpl_plan_paths_mask; nullptr otherwise): the obstacle x edge mask of phase 2 as the kernel computed it, per scenario
+    // `words_blocked + 2` words: first edge of the planning range (global edge id), layers of the planning range, then one bit per
+    // edge of the planning range in edge-id order
+    unsigned* mask_out;
+    // EXPERIMENT BUILD ONLY (-DLTPL_EXPERIMENT, libltpl_hip_exp.so; never read by the release library):
+    int ablate;                  // LTPL_ABLATE, timing only: 1 = skip the mask, 2 = skip the sweeps, 4 = skip path assembly, 8 = launch cost only
+    int poison_on; unsigned poison;   // LTPL_LDS_POISON=<hex word>: fill the team's LDS before phase 0, so that a read of LDS the
+                                 // scenario has not written itself shows up as a parity failure instead of depending on stale data
+    long long* dbg;              // LTPL_DEBUG_TIMING: cycle stamps per phase
 };
+// The timing / fault-injection switches exist in the experiment build only: the release library contains no code path that skips
+// work or alters LDS on an environment variable's say-so.
+#ifdef LTPL_EXPERIMENT
+#define LTPL_ABLATED(lp, bits) (((lp).ablate & (bits)) != 0)
+#define LTPL_POISON_ON(lp) ((lp).poison_on != 0)
+#else
+#define LTPL_ABLATED(lp, bits) false
+#define LTPL_POISON_ON(lp) false
+#endif
 
 __device__ __forceinline__ double readlane_f64(double v, int src_lane)
 {
@@ -618,9 +632,7 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
         if (psi_r >= D_PI) psi_r -= 2.0 * D_PI;
         const double kap = (xd * ydd - yd * xdd) * fast_rcp(q * sqrt(q));
         const double len_r = at(lat.slen, pedge[i] + k);
-#ifdef LTPL_EXP_ABL        // experiment build (-DLTPL_EXP_ABL, tools/README.md): LTPL_ABLATE bit 16 drops the path_param stores (timing only)
-        if (!(lp.ablate & 16))
-#endif
+        if (!LTPL_ABLATED(lp, 16))           // (experiment build: LTPL_ABLATE bit 16 drops the path_param stores, timing only)
         { store2_u(row, x, y); store2_u(row + 2, psi_r, kap); row[4] = len_r; }
         if (vel_kappa) { vel_kappa[r] = kap; vel_len[r] = len_r; }
         if (out.vke) {                                    // planes of the batch velocity stage, blocked by 8 rows (kep_base / kep_row):
@@ -854,10 +866,10 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     int4* lay = reinterpret_cast<int4*>(smem + P::off_lay(lp));
 
     dbg_stamp(lp.dbg, 0);
-    if (lp.ablate & 8) { WavePath w0; w0.valid = 0; w0.n_pts = 0; w0.n_nodes = 0; w0.name = LTPL_ACT_NONE; w0.reduced = 0; w0.goal_layer = -1; w0.end_node = -1; return w0; }   // timing experiment: launch cost only
+    if (LTPL_ABLATED(lp, 8)) { WavePath w0; w0.valid = 0; w0.n_pts = 0; w0.n_nodes = 0; w0.name = LTPL_ACT_NONE; w0.reduced = 0; w0.goal_layer = -1; w0.end_node = -1; return w0; }   // timing experiment: launch cost only
     // ---- phase 0: scenario scalars (uniform; the planning range only depends on the start layer and is tabulated at
     //      ltpl_create: gen_local_node_template.py:101-147) -----------------------------------------------------------
-    if (lp.poison_on) {
+    if (LTPL_POISON_ON(lp)) {
         unsigned* w = reinterpret_cast<unsigned*>(smem);
         for (int i = tid; i < lp.total / 4; i += NT) w[i] = lp.poison;
         unsigned* tw = reinterpret_cast<unsigned*>(&ts);
@@ -975,7 +987,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     // whose window contains transition j; lane = edge of the transition; an edge whose bounding circle (centre + radius
     // over its samples, tabulated at ltpl_create) cannot reach the obstacle disc is rejected without touching its
     // samples, the others test their samples exactly like the reference (d^2 <= (r + w/2)^2 + step^2 / 4).
-    for (int pp0 = 0; pp0 < sc.n_pos && !(lp.ablate & 1); pp0 += 64) {
+    for (int pp0 = 0; pp0 < sc.n_pos && !LTPL_ABLATED(lp, 1); pp0 += 64) {
         const int p = pp0 + lane;
         int ol = -1; double mpx = 0.0, mpy = 0.0, mref = 0.0, msq = 0.0;
         if (p < sc.n_pos) {
@@ -1121,6 +1133,12 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
         if (lane == 0) { ts.closest_idx = ci; ts.cl = cl; ts.cn = cn; ts.have_cn = have; }
     }
     team_sync<NW>();
+    if (lp.mask_out) {
+        // diagnostics: phase 2's result as it stands (every atomicOr of every wave lies in front of the barrier above)
+        unsigned* mo = lp.mask_out + (size_t)sc.s * (size_t)(lp.words_blocked + 2);
+        if (tid == 0) { mo[0] = (unsigned)sc.e_base; mo[1] = (unsigned)H; }
+        for (int i = tid; i < lp.words_blocked; i += NT) mo[2 + i] = blocked_bits[i];
+    }
     const int t_cl = ts.cl, t_cn = ts.cn, t_have = ts.have_cn, fac_jmax = ts.fac_jmax;
     // action template (uniform, every thread)
     int n_act = 0, filt[LTPL_MAX_ACTIONS], nm0[LTPL_MAX_ACTIONS];
@@ -1215,7 +1233,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             if (lane == 0) ts.start_ok[F_PR] = ts.start_ok[F_DEF];
             team_sync<NW>();
         };
-        for (int j = 1; j <= H && !(lp.ablate & 2); ++j) {
+        for (int j = 1; j <= H && !LTPL_ABLATED(lp, 2); ++j) {
             int b = sc.sl + j; if (b >= L) b -= L;
             const int4 ly = lay[j];
             LayerArgs A;
@@ -1275,9 +1293,9 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             for (int ci = 0; ci < CH; ++ci) { er[ci] = en[ci]; bm[ci] = bn[ci]; }
             team_sync<NW>();
         }
-        if (pr_shared && !(lp.ablate & 2)) copy_def_to_pr(H + 1, H & 1);        // no blocked edge in the whole range: identical sweeps
+        if (pr_shared && !LTPL_ABLATED(lp, 2)) copy_def_to_pr(H + 1, H & 1);        // no blocked edge in the whole range: identical sweeps
         // goal node of the last layer for every filter that reached it (virtual goal edges, GraphBase.py:188-194)
-        if (!(lp.ablate & 2)) {
+        if (!LTPL_ABLATED(lp, 2)) {
             const int4 lyH = lay[H];
             for (int f = wave; f < NFILT; f += NW)
                 if (((need >> f) & 1u) && best[f * hm + H] == -2) {
@@ -1382,7 +1400,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     wp.end_node = -1;
     for (int a = wave; a < n_act; a += NW) {
         wp.name = slot_name(a); wp.reduced = slot_red(a); wp.valid = 0;
-        if (!slot_valid(a) || (lp.ablate & 4)) continue;
+        if (!slot_valid(a) || LTPL_ABLATED(lp, 4)) continue;
         unsigned char* pw = smem + P::off_path(lp) + (size_t)(wave < P::n_path_bufs(lp) ? wave : P::n_path_bufs(lp) - 1) * P::path_stride(lp);
         // after a re-sweep the parents of every layer belong to filter f itself
         const bool sp = share_prefix && (filt[a] == F_LEFT || filt[a] == F_RIGHT) && slot_j(a) == H;

@@ -58,11 +58,36 @@ class TickLogWriter(object):
         with open(self.path, "a") as fh:
             fh.write("\n" + ";".join(cells))
 
-    def write_planner_tick(self, planner, backend, time, pos_est, action_id_prev, vehicles, zone_layers=(), zone_nodes=(),
-                           scen=0, export_rows=None):
-        """One row from the state of planner ``scen`` after calc_vel_profile. ``vehicles`` = [(radius, vel, positions)]."""
+    @staticmethod
+    def snapshot_paths(planner, scen=0):
+        """What the row needs from ``calc_paths``: call this BETWEEN calc_paths and calc_vel_profile. The reference logs the start node,
+        the node lists and the constant path segment as calc_paths returned them (Graph_LTPL.py:336-340, :445-447); the velocity stage
+        trims the planner's stored paths and node lists by the cut layer afterwards (OTH.py:714-731)."""
         p = planner.paths(scen)
+        const = None
+        if p["const_rows"] >= 0 and p["keys"]:
+            const = p["path_param"][p["keys"][0]][:max(p["const_rows"], 0), :].copy()
+        return {"start_node": list(p["start_node"]), "nodes": {k: [p["nodes"][k]] for k in p["keys"]}, "const_path_seg": const}
+
+    def write_planner_tick(self, planner, backend, time, pos_est, action_id_prev, vehicles, zone_layers=(), zone_nodes=(),
+                           scen=0, export_rows=None, paths_snapshot=None):
+        """One row from the state of planner ``scen`` after calc_vel_profile. ``vehicles`` = [(radius, vel, positions)].
+        ``paths_snapshot``: result of ``snapshot_paths`` taken right after calc_paths (recommended: without it the node lists and the
+        constant segment are read from the state the velocity stage has already trimmed, which is only the same while cut_layer = 0)."""
         traj, ids, ref = planner.trajectories(scen)
+        if paths_snapshot is not None:
+            const = paths_snapshot["const_path_seg"]
+            if const is not None:
+                const = const[ref["cut_index_pos"]:, :]               # Graph_LTPL.py:445-447
+            if export_rows is not None:
+                traj = {k: [t[:export_rows] for t in v] for k, v in traj.items()}
+            obj_veh = [[k, list(map(float, pos[0])), 0.0, float(r), float(v), np.asarray(pos[1:]).reshape(-1, 2)]
+                       for k, (r, v, pos) in enumerate(vehicles)]
+            zones = [[[list(map(int, zone_layers)), list(map(int, zone_nodes))], [[0.0, 0.0], [0.0, 0.0]]]] if len(zone_layers) else []
+            self.write(time, backend.raceline_s(pos_est), paths_snapshot["start_node"], obj_veh, zones, paths_snapshot["nodes"],
+                       traj, ids, list(map(float, pos_est)), action_id_prev, 0, const)
+            return
+        p = planner.paths(scen)
         if export_rows is not None:
             traj = {k: [t[:export_rows] for t in v] for k, v in traj.items()}
         obj_veh = [[k, list(map(float, pos[0])), 0.0, float(r), float(v), np.asarray(pos[1:]).reshape(-1, 2)]
@@ -101,11 +126,18 @@ def read_log(log_path: str):
     return graph_id, rows
 
 
-def revalidate(backend, lattice, rows, w_last_edges=()):
+def revalidate(backend, lattice, rows, w_last_edges=(), context=False):
     """Re-plan every logged tick (start node, objects, zones, previous action; no constant segment, like the stock viewer's
     re-run) as ONE batch through seam (1) and compare node lists. A logged list may carry nodes of the constant segment in
-    front (visualize_graph_log.py:226-230), so the re-planned list has to match its tail. Returns the list of mismatches."""
+    front (visualize_graph_log.py:226-230), so the re-planned list has to match its tail. Returns the list of mismatches.
+
+    ``context=True`` goes beyond the stock viewer: a row's PREDECESSOR in the log holds what seam (1) was additionally given on that
+    tick -- the previous solution's nodes from the start node on (cost discount ``w_last_edges``, OTH.py:386-393), the position
+    estimate (``clip_pos`` of the row before, OTH.py:585) -- and the row itself the constant segment (x, y from the current position
+    on: decides the [follow, left / right] template of main_online_path_gen.py:76-122). With them the re-run reproduces the logged
+    node lists tick for tick, which turns a log into a strict regression vector (tests/test_tick_log.py)."""
     scen = []
+    prev = None
     for r in rows:
         vehicles = []
         for o in r["obj_veh"]:
@@ -117,9 +149,23 @@ def revalidate(backend, lattice, rows, w_last_edges=()):
             for l, n in zip(z[0][0], z[0][1]):
                 if 0 <= l < lattice.num_layers and 0 <= n < lattice.nodes_in_layer[l]:
                     gids.append(int(lattice.layer_off[l]) + int(n))
-        scen.append({"start_node": tuple(r["start_node"]), "action_sets": True, "vehicles": vehicles,
-                     "zone_gids": sorted(set(gids)), "last_action": r["action_id_prev"], "last_nodes": None,
-                     "obj_in_const": False, "obj_besides": False, "const_closest": None, "psi_s": None})
+        sc = {"start_node": tuple(r["start_node"]), "action_sets": True, "vehicles": vehicles,
+              "zone_gids": sorted(set(gids)), "last_action": r["action_id_prev"], "last_nodes": None,
+              "obj_in_const": False, "obj_besides": False, "const_closest": None, "psi_s": None}
+        if context and prev is not None:
+            last = prev["nodes_list"].get(r["action_id_prev"])
+            if last is not None:
+                nl = [list(v) for v in last[0]]
+                if list(r["start_node"]) in nl:
+                    sc["last_nodes"] = nl[nl.index(list(r["start_node"])):]
+            seg = r.get("const_path_seg")
+            if seg is not None and len(seg) >= 2:
+                seg5 = np.zeros((len(seg), 5))                       # rows [x, y, psi, kappa, el]: the test only reads x, y
+                seg5[:, 0:2] = np.asarray(seg, dtype=float).reshape(-1, 2)
+                ic, bs, cc = backend.const_segment_test(seg5, prev["clip_pos"], vehicles)
+                sc.update(obj_in_const=ic, obj_besides=bs, const_closest=cc)
+        scen.append(sc)
+        prev = r
     if not scen:
         return []
     res = backend.plan_paths(_capi.PathsBatch(scen, w_last_edges=w_last_edges))

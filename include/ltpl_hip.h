@@ -14,6 +14,22 @@
  * (LTPL_OK == 0). "No path found" is NOT an error (valid == 0). No C++ exception crosses the ABI. A handle owns its
  * device memory, pinned staging and one HIP stream; calls on one handle are synchronous on return and must not be
  * issued concurrently; different handles may be used from different threads / processes.
+ *
+ * Environment switches (all read ONCE, at ltpl_create / ltpl_planner_create). Every switch of the RELEASE library selects among
+ * code paths that produce identical results (the GPU test-suite runs them); none skips work:
+ *   LTPL_NO_FIXED_PLAN=1        batch kernel with the runtime LDS plan instead of a compile-time plan class (any lattice)
+ *   LTPL_FORCE_LONG_HORIZON=1   parent tables in global memory (the mode lattices with very long planning ranges get automatically)
+ *   LTPL_BATCH_NW=4             four-wave teams also for batches; LTPL_NW1_MIN_SCEN=<n>: smallest batch that uses one-wave teams (64)
+ *   LTPL_FORCE_FUSED=1          fused k_tick also for batches; LTPL_NO_OVERLAP=1: resident batches on one stream (no pipelining)
+ *   LTPL_FINAL_Y=<n>            row-chunk blocks per tile of the final velocity kernel (8)
+ *   LTPL_ZC_OUT=0 / LTPL_ZC_IN=1   zero-copy outputs (default on) / inputs (default off) of calls with <= 8 scenarios
+ *   LTPL_POLL=1 (+ LTPL_POLL_SYNC_EVERY, LTPL_POLL_QUERY)   completion of small calls through a polled word instead of a stream sync
+ *   LTPL_NO_SELFTEST=1          skip the create-time self-test (one-wave vs four-wave kernel on probe scenarios)
+ *   LTPL_HOST_PROF=1            host-side timing table of the entry points on stderr at exit
+ *   LTPL_PLANNER_THREADS=<n>, LTPL_PLANNER_SPIN_US=<us>   worker threads of the planner's per-planner host loops (default: serial)
+ * Timing / fault-injection switches (LTPL_ABLATE, LTPL_EXP_SKIP, LTPL_LDS_POISON, LTPL_SCRATCH_POISON, LTPL_DEBUG_TIMING,
+ * LTPL_DEBUG_OCC) skip work, overwrite memory or instrument kernels; they are compiled into the EXPERIMENT build only
+ * (-DLTPL_EXPERIMENT -> libltpl_hip_exp.so, used by tools/ and one fault-injection test) and do not exist in libltpl_hip.so.
  */
 #ifndef LTPL_HIP_H
 #define LTPL_HIP_H
@@ -280,6 +296,15 @@ int ltpl_version(void);
 
 /* --- seam (1): main_online_path_gen.py:11 ------------------------------------------------------------------------- */
 int ltpl_plan_paths(ltpl_handle* handle, const ltpl_paths_in* in, ltpl_paths_out* out);
+
+/* --- diagnostics of seam (1): the same call with the obstacle x edge mask exported (GraphBase.get_intersec_edges_in_range,
+ *     GraphBase.py:567-646; the set of edges gen_local_node_template.py:164-203 deletes from the "default" filter) exactly as the
+ *     path kernel computed it in its LDS bitmap: blocked[s * num_edges + e] = 1 if edge e (global id) is blocked in scenario s.
+ *     The kernel tests every edge of an obstacle's 3-layer window that lies in the planning range, whether or not its end nodes
+ *     are removed by the zone filter (the reference only tests edges of the active "planning_range" filter; edges at removed
+ *     nodes cannot be used either way). team_waves: 0 = the form ltpl_plan_paths would choose for n_scen, 1 = one-wave batch
+ *     kernel, 4 = four-wave latency kernel. tests/test_edge_mask.py compares the bitmap with the oracle's bit for bit. ------- */
+int ltpl_plan_paths_mask(ltpl_handle* handle, const ltpl_paths_in* in, ltpl_paths_out* out, int32_t team_waves, uint8_t* blocked);
 
 /* --- constant-segment test in front of seam (1): main_online_path_gen.py:76-122 (host side, O(#objects) projections on the
  *     race line). seg = rows [x, y, psi, kappa, el] of const_path_seg (n_rows may be 0), pos_est = 2 doubles or NULL;

@@ -12,7 +12,6 @@ reference (imported from /root/reference over oracle/shims, see oracle/ref_env.p
   c1_vel_calls.npz          "wall" of static obstacles that forces the reduced-horizon / blocked-track branches
   zonewall_*.npz            a full-width blocked zone plus one slow opponent (horizon back-off / reduced horizon /
                             blocked-track branches, main_online_path_gen.py:203-243, OTH.py:474-506)
-  c2_exported.npz           trajectories returned by Graph_LTPL.calc_vel_profile at selected ticks
   *_ticks.npz               (python -m oracle.gen_golden ticks) one record per planning tick at the level of
                             OnlineTrajectoryHandler (oracle/ref_scenarios.TickRecorder): inputs of calc_paths / get_ref_idx /
                             calc_vel_profile for EVERY tick (so that a stateful re-implementation can be driven in closed
@@ -332,14 +331,12 @@ def main():
     # ---- C2: std example with 8 dynamic opponents ------------------------------------------------------------------
     rec = rs.SeamRecorder(gl, gb)
     dummies = rs.opponents_c2(gl, 8)
-    exported = rs.run_loop(gl, clock, ltpl_obj, path_dict, n_ticks=2500, dt=0.05, dummies=dummies,
+    rs.run_loop(gl, clock, ltpl_obj, path_dict, n_ticks=2500, dt=0.05, dummies=dummies,
                            zones=rs.ZONE_EXAMPLE)
     sel = select_path_ticks(rec.path_calls, every=40)
     save_records(os.path.join(GOLDEN, "c2_path_calls.npz"), [dict(rec.path_calls[i], tick=i) for i in sel])
     vsel = select_vel_calls(rec.vel_calls, every=29)
     save_records(os.path.join(GOLDEN, "c2_vel_calls.npz"), [rec.vel_calls[i] for i in vsel])
-    esel = list(range(0, len(exported), 125))
-    save_records(os.path.join(GOLDEN, "c2_exported.npz"), [dict(exported[i], tick=i) for i in esel])
     print("C2: %d/%d path calls, %d/%d vel calls kept" % (len(sel), len(rec.path_calls), len(vsel),
                                                           len(rec.vel_calls)))
     rec.uninstall()

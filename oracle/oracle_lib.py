@@ -63,6 +63,17 @@ class OracleBackend(object):
                                                C.byref(result.struct)))
         return result
 
+    def plan_paths_mask(self, batch, team_waves=0):
+        """Checker of HipBackend.plan_paths_mask: blocked edges of every scenario (uint8 [n_scen, num_edges])."""
+        import numpy as np
+        self.lib.oracle_plan_paths_mask.argtypes = [C.POINTER(_capi.LatticeDesc), C.POINTER(_capi.PathsIn),
+                                                    C.POINTER(_capi.PathsOut), C.c_void_p]
+        result = self.new_paths_result(batch.n_scen)
+        blocked = np.zeros((batch.n_scen, self.lattice.num_edges), np.uint8)
+        self._check(self.lib.oracle_plan_paths_mask(C.byref(self.binding.desc), C.byref(batch.struct), C.byref(result.struct),
+                                                    blocked.ctypes.data))
+        return result, blocked
+
     def vel_profile(self, params, jobs):
         jarr, rarr, outs, keep = _capi.make_vel_jobs(jobs)
         self._check(self.lib.oracle_vel_profile(C.byref(self.binding.desc), C.byref(params.struct), len(jobs), jarr,

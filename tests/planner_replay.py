@@ -14,7 +14,7 @@ state machine shows up and compounds.
 """
 import numpy as np
 
-from helpers import assert_close_rel, REL_TOL, KAPPA_FLOOR, load_golden
+from helpers import assert_close_rel, assert_xy_close, assert_coeff_close, REL_TOL, KAPPA_FLOOR, load_golden
 
 
 def vehicles_of_tick(t):
@@ -49,6 +49,8 @@ def check_traj(got, exp, what):
                 what, float(np.max(np.abs(got[:, col] - exp[:, col]))))
         elif name == "kappa":
             assert_close_rel(got[:, col], exp[:, col], what="%s kappa" % what, floor=KAPPA_FLOOR)
+        elif name in ("x", "y"):
+            assert_xy_close(got[:, col:col + 1], exp[:, col:col + 1], what="%s %s" % (what, name))
         else:
             assert_close_rel(got[:, col], exp[:, col], what="%s %s" % (what, name))
 
@@ -63,9 +65,9 @@ def replay(planner, lat, ticks, scen=0, n_ticks=None, others=None):
         assert (in_track, cor) == (st['in_track'], st['cor_heading'])
     p0 = planner.paths(scen)
     assert p0['start_node'] == st['start_node']
-    assert_close_rel(p0['path_param']['straight'][:, 0:2], st['path_param'][:, 0:2], what="start spline xy")
+    assert_xy_close(p0['path_param']['straight'][:, 0:2], st['path_param'][:, 0:2], what="start spline xy")
     assert_close_rel(p0['path_param']['straight'][:, 4], st['path_param'][:, 4], what="start spline el")
-    assert_close_rel(p0['coeff']['straight'], st['coeff'], what="start spline coeff") if p0['coeff']['straight'].size else None
+    assert_coeff_close(p0['coeff']['straight'], st['coeff'], what="start spline coeff") if p0['coeff']['straight'].size else None
     seen = {'full': 0, 'keys': set(), 'backup': 0, 'dropped': 0, 'emergency': 0}
     for t in ticks[:n_ticks]:
         what = "tick %d" % t['tick']
@@ -88,12 +90,12 @@ def replay(planner, lat, ticks, scen=0, n_ticks=None, others=None):
         if full is not None:
             for k in exp['keys']:
                 pp, epp = got['path_param'][k], full['path_param'][k]
-                assert_close_rel(pp[:, 0:2], epp[:, 0:2], what="%s/%s xy" % (what, k))
+                assert_xy_close(pp[:, 0:2], epp[:, 0:2], what="%s/%s xy" % (what, k))
                 d = np.abs(np.mod(pp[:, 2] - epp[:, 2] + np.pi, 2 * np.pi) - np.pi)
                 assert float(d.max()) <= REL_TOL * np.pi, "%s/%s psi" % (what, k)
                 assert_close_rel(pp[:, 3], epp[:, 3], what="%s/%s kappa" % (what, k), floor=KAPPA_FLOOR)
                 assert_close_rel(pp[:, 4], epp[:, 4], what="%s/%s el" % (what, k))
-                assert_close_rel(got['coeff'][k], full['coeff'][k], what="%s/%s coeff" % (what, k))
+                assert_coeff_close(got['coeff'][k], full['coeff'][k], what="%s/%s coeff" % (what, k))
         va = t['vel_args']
         planner.calc_vel_profile([t['pos_est']] * n, va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'],
                                  local_gg=tuple(va['local_gg']), ax_max_machines=va['ax_max_machines'],

@@ -79,7 +79,8 @@ def test_batch_kernel_plan_classes_and_stale_lds(env, monteblanco, oracle_backen
     lat3 = c3_lattice()
     for lat, orc, scen in ((monteblanco, oracle_backend, random_scenarios(monteblanco, 192, seed=7, n_veh=8)[0]),
                            (lat3, OracleBackend(lat3), scattered_obstacle_scenarios(lat3, 128, n_obj=32, seed=3)[0])):
-        hip = _capi.HipBackend(lat)                       # environment is read at ltpl_create
+        # environment is read at ltpl_create; LTPL_LDS_POISON only exists in the experiment build of the library
+        hip = _capi.HipBackend(lat, lib_path=_capi.experiment_library_path() if "LTPL_LDS_POISON" in env else None)
         batch = _capi.PathsBatch(scen, w_last_edges=[0.0, 0.5, 0.8])
         compare_results(hip.plan_paths(batch), orc.plan_paths(batch), lat)
 

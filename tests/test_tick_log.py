@@ -25,11 +25,12 @@ def write_planner_log(path, backend, planner, lat, ticks, n):
     for t in ticks[:n]:
         veh = pr.vehicles_of_tick(t)
         planner.calc_paths([t['action_id_sel']], [t['t']], [veh], [pr.zone_gids_of_tick(lat, t)])
+        snap = w.snapshot_paths(planner)
         va = t['vel_args']
         planner.calc_vel_profile([t['pos_est']], va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'],
                                  local_gg=tuple(va['local_gg']), ax_max_machines=va['ax_max_machines'], safety_d=va['safety_d'])
         w.write_planner_tick(planner, backend, t['t'], t['pos_est'], t['action_id_sel'], veh,
-                             t.get('zone_layers', ()), t.get('zone_nodes', ()), export_rows=115)
+                             t.get('zone_layers', ()), t.get('zone_nodes', ()), export_rows=115, paths_snapshot=snap)
         trajs.append(planner.trajectories(0)[0])
     return trajs
 
@@ -56,6 +57,32 @@ def test_planner_log_round_trip_and_revalidation(tmp_path, monteblanco, oracle_b
     # re-planning without the constant segment and without the previous-solution discount (like the stock viewer) restores the
     # logged node lists on (nearly) every tick
     assert len(bad) <= len(rows) // 10, bad
+    # with the context the neighbouring rows hold (previous solution, position estimate, constant segment): EVERY tick, every key
+    assert tick_log.revalidate(oracle_backend, monteblanco, rows, w_last_edges=(0.0, 0.5, 0.8), context=True) == []
+    # the constant segment is logged from the current position on (Graph_LTPL.py:445-447): its last point is the start node
+    for r in rows[1:]:
+        if r["const_path_seg"]:
+            l, n = r["start_node"]
+            assert np.allclose(r["const_path_seg"][-1], monteblanco.node_pos[monteblanco.layer_off[l] + n], atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_revalidation_on_the_device(tmp_path, monteblanco, hip_backend, oracle_backend):
+    """SURVEY.md section 8f rank 4 on the MI355X: a closed loop of the HIP planner writes the log, the batched re-validation runs on the
+    HIP backend (one launch for all rows). Strict: with the rows' context every logged node list is reproduced; in the stock
+    viewer's context-free form the device finds exactly the mismatches the oracle finds."""
+    from graphbasedlocaltrajectoryplanner_amd.planner import Planner
+    ticks = pr.load_ticks("c2")
+    planner = Planner(hip_backend, 1)
+    path = str(tmp_path / "ticks_data.csv")
+    write_planner_log(path, hip_backend, planner, monteblanco, ticks, 400)
+    planner.close()
+    _, rows = tick_log.read_log(path)
+    assert len(rows) == 400
+    for r, t in zip(rows, ticks):
+        assert {k: v[0] for k, v in r["nodes_list"].items()} == t["paths"]["nodes"]
+    assert tick_log.revalidate(hip_backend, monteblanco, rows, w_last_edges=(0.0, 0.5, 0.8), context=True) == []
+    assert tick_log.revalidate(hip_backend, monteblanco, rows) == tick_log.revalidate(oracle_backend, monteblanco, rows)
 
 
 @pytest.mark.reference

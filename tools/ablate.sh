@@ -1,4 +1,6 @@
 #!/bin/bash
+# the switches used here only exist in the experiment build of the library (include/ltpl_hip.h)
+export LTPL_HIP_LIB="$(cd "$(dirname "$0")/.." && pwd)/graphbasedlocaltrajectoryplanner_amd/csrc/libltpl_hip_exp.so"
 # per-phase cost attribution of the path kernel by ablation (results are wrong with LTPL_ABLATE != 0; timing only)
 export TMPDIR=/tmp
 for A in 0 1 4 5 6 7; do

@@ -4,6 +4,9 @@ Stamps: 0 start | 1 scenario set-up | 2 closest layer per position | 3 edge mask
 import os
 import sys
 os.environ["LTPL_DEBUG_TIMING"] = "1"
+# the switch only exists in the experiment build of the library (include/ltpl_hip.h)
+os.environ.setdefault("LTPL_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                   "graphbasedlocaltrajectoryplanner_amd", "csrc", "libltpl_hip_exp.so"))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench                                                                  # noqa: E402
