@@ -20,6 +20,7 @@ import pytest
 from helpers import load_golden, replay_path_call
 from scenarios import random_scenarios
 from test_fresh_tick_golden import records, scenario_of
+from test_gpu_paths import compare_results
 from graphbasedlocaltrajectoryplanner_amd import _capi
 from graphbasedlocaltrajectoryplanner_amd.path_gen import OnlinePathGenerator
 
@@ -71,7 +72,7 @@ def hip_vs_oracle(lat, hip, orc, batch, forms=(1, 4), min_blocked=1):
         diff = (mask != omask) & act
         assert not diff.any(), "team of %d waves: %d edges differ (first: scenario %d edge %d, hip %d oracle %d)" % (
             nw, int(diff.sum()), *[int(x[0]) for x in np.nonzero(diff)], int(mask[diff][0]), int(omask[diff][0]))
-        assert np.array_equal(res.nodes * (res.valid[..., None] > 0), ores.nodes * (ores.valid[..., None] > 0))
+        compare_results(res, ores, lat)                         # the diagnostic call plans like ltpl_plan_paths
     return omask
 
 
