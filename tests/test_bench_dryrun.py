@@ -96,7 +96,9 @@ def test_the_line_carries_the_drivers_contract(monkeypatch, capsys):
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
         assert isinstance(out[key], typ), key
-    assert out["vs_baseline"] is None and out["unit"] == "ticks/s" and out["scaling"] == "weak" and out["dtype"] == "f64"
+    # no published reference number exists: the ratio is against BASELINE.json's stated target and says so
+    assert out["vs_baseline"] == pytest.approx(out["value"] / 10000.0) and "target" in out["vs_baseline_basis"]
+    assert out["unit"] == "ticks/s" and out["scaling"] == "weak" and out["dtype"] == "f64"
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["timed_steps"] == 3
     assert "workload" in out["config"] and "model" not in out["config"]
     assert "ticks/s" in out["metric"] and out["value"] > 0 and np.isfinite(out["value"])
@@ -108,6 +110,10 @@ def test_the_line_carries_the_drivers_contract(monkeypatch, capsys):
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert r["kernel_ms"] == pytest.approx(0.8)                                # the live, in-region duration wins over the profile's
     assert r["traffic"] is None and r["traffic_frac"] is None                  # PMC summary is for the 32768-scenario grid only
+    assert r["issue"] is None and "issue" in r["limiter"]
+    # the re-based byte model never exceeds the survey's (which charged every window edge all its samples, every sweep its own edges)
+    assert r["split_per_tick"]["mask"] <= r["survey_model_per_tick"]["mask"] and r["split_per_tick"]["sweep"] <= r["survey_model_per_tick"]["sweep"]
+    assert r["mask_counts_per_tick"]["shell_edges"] <= r["mask_counts_per_tick"]["window_edges"]
 
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "ticks/s" and c["value"] > 0 and "8 scenarios" in c["sample"]
