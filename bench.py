@@ -162,7 +162,7 @@ def read_issue(batch, workload):
     return None
 
 
-N_SIMD, CLOCK_HZ, VALU_CYCLES_PER_INST = 1024, 2.4e9, 4      # MI355X_MICROARCH.md: 256 CUs x 4 SIMD16, 2.4 GHz, a wave64 VALU op issues over 4 cycles
+N_SIMD, CLOCK_HZ, VALU_CYCLES_PER_INST = 1024, 2.4e9, 4      # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz max clock; SQ counters tick in quad-cycles
 
 
 def single_tick_latency(hip, lat, scen, vel, batch, n_ticks):
@@ -342,8 +342,11 @@ def worker(args):
         issue = None
         if issue_pmc:
             issue = {"valu_insts": issue_pmc["valu_insts_per_launch"], "lanes_active": issue_pmc["lanes_active_per_valu_inst"],
-                     # wave-level VALU instructions x 4 issue cycles over the SIMD-cycles of the launch (live kernel duration)
-                     "valu_util": issue_pmc["valu_insts_per_launch"] * VALU_CYCLES_PER_INST / (N_SIMD * dom_ms * 1e-3 * CLOCK_HZ),
+                     # SQ_ACTIVE_INST_VALU (quad-cycles with a VALU instruction in flight, summed over the SIMDs) over the SIMD-cycles of the
+                     # launch at its live duration; without that counter: instructions x 4 cycles (fp64 / transcendental rate; fp32 and
+                     # integer wave64 instructions issue in 2 on CDNA4's SIMD-32, so this is an upper bound then)
+                     "valu_util": (issue_pmc.get("valu_active_quad_cycles_per_launch") or issue_pmc["valu_insts_per_launch"])
+                     * VALU_CYCLES_PER_INST / (N_SIMD * dom_ms * 1e-3 * CLOCK_HZ),
                      "salu_insts": issue_pmc.get("salu_insts_per_launch"), "lds_insts": issue_pmc.get("lds_insts_per_launch"),
                      "valu_insts_per_scenario": issue_pmc["valu_insts_per_launch"] / args.batch,
                      "source": "profiles/pmc_issue.json (tag %s)" % issue_pmc.get("tag")}

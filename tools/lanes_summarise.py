@@ -60,6 +60,8 @@ def main():
             json.dump({"kernel": dom[0], "tag": tag, "workload": workload, "grid_size": e["grid_size"],
                        "valu_insts_per_launch": e.get("SQ_INSTS_VALU"), "salu_insts_per_launch": e.get("SQ_INSTS_SALU"),
                        "lds_insts_per_launch": e.get("SQ_INSTS_LDS"),
+                       "valu_active_quad_cycles_per_launch": e.get("SQ_ACTIVE_INST_VALU"),    # quad-cycles a VALU instruction is in flight
+                       "wave_quad_cycles_per_launch": e.get("SQ_WAVE_CYCLES"), "busy_quad_cycles_per_launch": e.get("SQ_BUSY_CYCLES"),
                        "lanes_active_per_valu_inst": e.get("lanes_active_per_valu_instruction"),
                        "waves_per_launch": e.get("SQ_WAVES")}, fh, indent=1)
     print(json.dumps(out, indent=1))
