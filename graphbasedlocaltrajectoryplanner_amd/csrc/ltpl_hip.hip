@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/ltpl_hip.h"
@@ -54,10 +55,19 @@ struct DevLat {
     const unsigned char* edge_dst8;   // [E]     destination node index inside its layer
     const unsigned char* edge_rank8;  // [E]     rank of the edge among the in-edges of its destination
     const int* layer_degmax;          // [L]     largest in-degree of a node of layer l
-    const unsigned* edge_meta;        // [E]     source node | destination node << 8 | in-edge rank << 16
+    // SWEEP ORDER. Inside every layer transition the sweep, the obstacle mask and the LDS edge bitmap address the edges in a second order:
+    // sorted by (in-edge rank, destination node) instead of CSC (destination, source). The lanes of a wave then hold edges into DIFFERENT
+    // nodes, so the LDS atomics of the sweep (ds_min_u64 on the destination's frontier slot) meet at most two lanes per address; in CSC
+    // order the ~5 (up to 21) in-edges of a node sit in consecutive lanes and every atomic serialises that many times. A transition's
+    // edges occupy the same index range [layer_ebase[l], layer_ebase[l + 1]) in both orders.
+    const double* sw_cost;            // [E + 1] edge cost in sweep order; [E] = +inf (sentinel for the lanes beyond a transition)
+    const unsigned* sw_meta;          // [E + 1] in-edge rank | source node << 8 | destination node << 16, sweep order; [E] = 0 (the low half
+                                      //         is the election key among equal candidates: the reference settles them by source node)
+    const int* sw2csc;                // [E]     CSC edge id of sweep position p
+    const int* csc2sw;                // [E]     sweep position of CSC edge e
     // track bounds per layer: bound1 = refline + normvec w_right, bound2 = refline - normvec w_left, centre = (b1 + b2) / 2
     const double* b1x; const double* b1y; const double* b2x; const double* b2y; const double* ctx; const double* cty;
-    const float4* edge_cap;           // [2 E] capsule of the edge's samples in fp32: (Ax, Ay, ABx, ABy), (1 / |AB|^2, dev, hg2, first sample |
+    const float4* edge_cap;           // [2 E] IN SWEEP ORDER: capsule of the edge's samples in fp32: (Ax, Ay, ABx, ABy), (1 / |AB|^2, dev, hg2, first sample |
                                       //     #samples << 24 as bit pattern; #samples = 0: look samp_ptr up): chord between the first and the last
                                       //     sample, largest sample distance from it, squared half of the largest gap between consecutive sample
                                       //     projections -- two-sided conservative cull of the obstacle mask, the exact test is fp64
@@ -1836,6 +1846,7 @@ struct ltpl_handle {
     int zc_in = 0;                   // small calls: kernels read their inputs straight from the page-locked staging buffer (no H2D copy)
     int zc_out = 0;                  // small calls: kernels write their outputs straight into the page-locked host buffer (no D2H copy)
     std::vector<int> rng_end_host;   // planning range end per start layer, -1 = no planning range (end of an open track)
+    std::vector<int> sw2csc_host;    // CSC edge id of every sweep position (DevLat::sw2csc)
 };
 
 #define HIP_TRY(h, call)                                                                                              \
@@ -2112,7 +2123,8 @@ try {
     UP(s_rl, d->s_raceline, L.L); UP(ref_x, d->refline_x, L.L); UP(ref_y, d->refline_y, L.L);
     UP(vel_rl, d->vel_raceline, L.L);
     UP(node_x, d->node_x, L.V); UP(node_y, d->node_y, L.V); UP(vgoal, d->vgoal_cost, L.V);
-    UP(in_ptr, d->in_ptr, L.V + 1); UP(edge_src, d->edge_src, L.E); UP(edge_cost, d->edge_cost, L.E);
+    UP(in_ptr, d->in_ptr, L.V + 1); UP(edge_src, d->edge_src, L.E);
+    UP(edge_cost, d->edge_cost, L.E);
     UP(edge_len, d->edge_len, L.E); UP(samp_ptr, d->samp_ptr, L.E + 1);
     UP(sx, d->samp_x, L.S); UP(sy, d->samp_y, L.S); UP(spsi, d->samp_psi, L.S); UP(slen, d->samp_len, L.S);
     UP(glob_rl, d->glob_rl, (size_t)L.G * 5);
@@ -2142,9 +2154,27 @@ try {
             for (int v = d->layer_node_off[l]; v < d->layer_node_off[l + 1]; ++v)
                 ldeg[(size_t)l] = std::max(ldeg[(size_t)l], d->in_ptr[v + 1] - d->in_ptr[v]);
         UP(layer_degmax, ldeg.data(), L.L);
-        std::vector<unsigned> meta((size_t)L.E);
-        for (int e = 0; e < L.E; ++e) meta[(size_t)e] = (unsigned)src8[(size_t)e] | ((unsigned)dst8[(size_t)e] << 8) | ((unsigned)rank8[(size_t)e] << 16);
-        UP(edge_meta, meta.data(), L.E);
+        // sweep order (see DevLat): per transition sorted by (rank, destination); cost / meta with the sentinel at index E
+        h->sw2csc_host.resize((size_t)L.E);
+        std::vector<int> csc2sw((size_t)L.E);
+        for (int l = 0; l < L.L; ++l) {
+            const int e0 = ebase[(size_t)l], e1 = ebase[(size_t)l + 1];
+            for (int e = e0; e < e1; ++e) h->sw2csc_host[(size_t)e] = e;
+            std::stable_sort(h->sw2csc_host.begin() + e0, h->sw2csc_host.begin() + e1, [&](int a, int b) {
+                if (rank8[(size_t)a] != rank8[(size_t)b]) return rank8[(size_t)a] < rank8[(size_t)b];
+                return dst8[(size_t)a] < dst8[(size_t)b];
+            });
+        }
+        std::vector<double> swc((size_t)L.E + 1);
+        std::vector<unsigned> swm((size_t)L.E + 1, 0u);
+        for (int p = 0; p < L.E; ++p) {
+            const int e = h->sw2csc_host[(size_t)p];
+            csc2sw[(size_t)e] = p; swc[(size_t)p] = d->edge_cost[e];
+            swm[(size_t)p] = (unsigned)rank8[(size_t)e] | ((unsigned)src8[(size_t)e] << 8) | ((unsigned)dst8[(size_t)e] << 16);
+        }
+        swc[(size_t)L.E] = INFINITY;
+        UP(sw_cost, swc.data(), L.E + 1); UP(sw_meta, swm.data(), L.E + 1);
+        UP(sw2csc, h->sw2csc_host.data(), L.E); UP(csc2sw, csc2sw.data(), L.E);
         if (d->normvec_x && d->normvec_y && d->width_right && d->width_left) {
             // ObjectListInterface.py:71-72 and check_inside_bounds.py:27 (same operations, no contraction)
             std::vector<double> b1x((size_t)L.L), b1y((size_t)L.L), b2x((size_t)L.L), b2y((size_t)L.L), cx((size_t)L.L), cy((size_t)L.L);
@@ -2158,9 +2188,13 @@ try {
         }
         // capsule per edge (two-sided cull of the obstacle mask, paths_team.hpp phase 2; construction and its conservativeness
         // argument in capsule.hpp)
-        std::vector<float4> cap((size_t)L.E * 2);
+        std::vector<float4> cap((size_t)L.E * 2), cap_sw((size_t)L.E * 2);
         L.cull_slack = ltplcap::build(L.E, d->samp_ptr, d->samp_x, d->samp_y, L.S, reinterpret_cast<float*>(cap.data()));
-        UP(edge_cap, cap.data(), (size_t)L.E * 2);
+        for (int p = 0; p < L.E; ++p) {                         // the mask phase walks a transition in sweep order
+            const size_t e = (size_t)h->sw2csc_host[(size_t)p];
+            cap_sw[2 * (size_t)p] = cap[2 * e]; cap_sw[2 * (size_t)p + 1] = cap[2 * e + 1];
+        }
+        UP(edge_cap, cap_sw.data(), (size_t)L.E * 2);
     }
 #undef UP
 
@@ -2194,6 +2228,8 @@ try {
         lp->off_lay = (int)off; off += sizeof(int) * 4 * (size_t)lp->hmax;
         lp->off_pos_layer = (int)off; off += sizeof(short) * MAX_POS; off = align_up(off, 16);
         lp->off_pos_veh = (int)off; off += MAX_POS; off = align_up(off, 16);
+        // shell list of the obstacle mask (phase 2): 128 entries of 8 bytes per wave (runtime plans: own storage)
+        lp->shell_cap = 128; lp->off_shell = (int)off; off += (size_t)8 * 128 * nw; off = align_up(off, 16);
         lp->total = (int)off;
         lp->mask_out = nullptr;
         lp->ablate = 0; lp->poison_on = 0; lp->poison = 0u; lp->dbg = nullptr;
@@ -2217,6 +2253,9 @@ try {
         lp->off_dist = PL::c_off_dist; lp->off_cnt = PL::c_off_cnt; lp->off_widx = PL::c_off_widx; lp->off_dumin = PL::c_off_dumin;
         lp->path_stride = PL::c_path_stride; lp->off_path = PL::c_off_path; lp->off_best = PL::c_off_best;
         lp->off_par = PL::c_off_par; lp->off_lay = PL::c_off_lay;
+        // the shell list of phase 2 lives in the frontier / election arrays (not written before phase 4)
+        lp->off_shell = PL::c_off_dist;
+        lp->shell_cap = (PL::c_end_elect - PL::c_off_dist) / 8 / (PL::c_n_path_bufs == 1 ? 1 : NUM_WAVES);
         size_t off = (size_t)PL::c_fixed_end;
         lp->off_blocked = (int)off; off += sizeof(unsigned) * lp->words_blocked; off = align_up(off, 16);
         lp->off_zone = (int)off; off += sizeof(unsigned) * lp->words_zone; off = align_up(off, 16);
@@ -2613,7 +2652,7 @@ static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_o
             const unsigned* w = hm.data() + mask_words * (size_t)s;
             const size_t e_base = w[0];
             for (size_t i = 0; i < (mask_words - 2) * 32 && i < E; ++i)
-                if ((w[2 + (i >> 5)] >> (i & 31)) & 1u) blocked[(size_t)s * E + (e_base + i) % E] = 1;
+                if ((w[2 + (i >> 5)] >> (i & 31)) & 1u) blocked[(size_t)s * E + (size_t)h->sw2csc_host[(e_base + i) % E]] = 1;   // bitmap in sweep order
         }
     }
     LTPL_PROF(prof_sc, "plan_paths.scatter");

@@ -58,6 +58,18 @@ __device__ __forceinline__ const T& at(const T* p, int i)
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + (unsigned)((unsigned)i * (unsigned)sizeof(T)));
 }
 
+// c, or +inf where bit `lane` of `mask` is set: two v_cndmask_b32 that take the 64-bit lane mask (a ballot kept in an SGPR pair) as their
+// select operand. Written as (mask >> lane) & 1 the compiler materialises the bit per lane first (two v_and, a 64-bit compare, then the
+// two selects): 7 instructions per edge chunk and filter in the sweep's inner loop.
+__device__ __forceinline__ double sel_inf(double c, unsigned long long mask)
+{
+    int lo = __double2loint(c), hi = __double2hiint(c);
+    const int inf_hi = 0x7ff00000;
+    asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(lo) : "v"(lo), "s"(mask));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(hi), "v"(inf_hi), "s"(mask));
+    return __hiloint2double(hi, lo);
+}
+
 struct TeamLds {                 // dynamic-LDS plan (byte offsets), computed once per lattice on the host
     int kpad, hmax, etmax;
     int words_blocked, words_zone;
@@ -70,7 +82,7 @@ struct TeamLds {                 // dynamic-LDS plan (byte offsets), computed on
                                  // tie bit 0x80), PlanFx: 1 byte (source node | tie bit 0x80; the in-edge is looked up at path assembly)
     int off_best;                // int[NFILT][hmax]  -1 unreachable, -2 reachable (goal not evaluated), >= 0 goal node | tie << 30
     int off_cnt;                 // u32[NFILT][kpad]  number of in-edges that attain the minimum
-    int off_widx;                // u32[NFILT][kpad]  (edge index in the transition << 16 | in-edge rank << 8 | source node) of the first
+    int off_widx;                // u32[NFILT][kpad]  election key (source node << 8 | in-edge rank, elect_key) of the first
     int off_dumin;               // double[NFILT][kpad]  smallest predecessor distance among tying edges (exact tie-break, rare)
     int off_lay;                 // int4[hmax]  per horizon layer j: first node id, #nodes, first / past-last edge INTO it
     int ref_lds;                 // 1: the reference line (x, y interleaved) is staged in the `par` region during phase 1
@@ -83,6 +95,7 @@ struct TeamLds {                 // dynamic-LDS plan (byte offsets), computed on
     // `words_blocked + 2` words: first edge of the planning range (global edge id), layers of the planning range, then one bit per
     // edge of the planning range in edge-id order
     unsigned* mask_out;
+    int off_shell, shell_cap;    // uint2[shell_cap] per wave: shell list of the obstacle mask (phase 2); fixed plans: in the frontier / election arrays
     // EXPERIMENT BUILD ONLY (-DLTPL_EXPERIMENT, libltpl_hip_exp.so; never read by the release library):
     int ablate;                  // LTPL_ABLATE, timing only: 1 = skip the mask, 2 = skip the sweeps, 4 = skip path assembly, 8 = launch cost only
     int poison_on; unsigned poison;   // LTPL_LDS_POISON=<hex word>: fill the team's LDS before phase 0, so that a read of LDS the
@@ -227,8 +240,16 @@ __device__ __forceinline__ void team_sync()
     }
 }
 
+// Election key of an edge among the edges that attain a node's minimum: the reference settles equal candidates in CSC order, i.e. by
+// source node (the in-edges of a node are sorted by source); key = source << 8 | in-edge rank, the smallest key wins. (The lanes hold the
+// edges in SWEEP order -- see DevLat -- so a lane or edge index says nothing about that order.)
+// Sweep-order edge word (DevLat::sw_meta): in-edge rank | source node << 8 | destination node << 16 -- the low half IS the election key.
+__device__ __forceinline__ unsigned elect_key(unsigned meta) { return meta & 0xffffu; }
+__device__ __forceinline__ int sw_src(unsigned meta) { return (int)((meta >> 8) & 255u); }
+__device__ __forceinline__ int sw_dst(unsigned meta) { return (int)(meta >> 16); }
+
 // register image of one edge of the NEXT layer transition (raw prefetched values, consumed one layer later)
-struct EdgeRegs { double c; unsigned meta; };     // meta = source node | destination node << 8 | in-edge rank << 16
+struct EdgeRegs { double c; unsigned meta; };     // meta: sweep-order edge word (elect_key / sw_src / sw_dst)
 
 // goal node of layer j for filter f from the frontier distances in `dcur` (virtual goal edges, GraphBase.py:188-194):
 // lexicographic min over (dist + vgoal, dist, node); returns node | (tie << 30) or -1
@@ -263,7 +284,7 @@ __device__ __forceinline__ void team_serial_node(const DevLat& lat, const Scen& 
         const int src = at(lat.edge_src8, e);
         double c = at(lat.edge_cost, e);
         if (f != F_PR) {
-            int el_ = e - sc.e_base; if (el_ < 0) el_ += lat.E;
+            int el_ = at(lat.csc2sw, e) - sc.e_base; if (el_ < 0) el_ += lat.E;       // the edge bitmap is indexed in sweep order
             if ((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u) continue;
         }
         const double du = dprev[src];
@@ -702,20 +723,29 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
     // An edge that must not be used (beyond the transition, blocked, unreachable source) simply carries the candidate
     // +inf: inf + cost = inf never wins the atomic min and never matches a finite minimum, so the rounds need no
     // per-lane bookkeeping and no divergent control flow.
+    // Lanes beyond the transition hold the SENTINEL edge (cost +inf, lattice edge id E: prefetch), so every lane of a loaded chunk runs
+    // the same code: all LDS reads of a round are issued before the first wait and no lane needs an "is this an edge" select. Only chunks
+    // from the third on are skipped when empty (uniform; 111 edges per transition on average).
     double cand[CH][NA];
 #pragma unroll
     for (int ci = 0; ci < CH; ++ci) {
-        if ((ci * NW) * 64 >= A.ne) continue;                       // uniform: no edges in this chunk
-        const int ei = (ci * NW + wave) * 64 + lane;
-        const int src = er[ci].meta & 255u, dst = (er[ci].meta >> 8) & 255u;
-        const double c_pr = (ei < A.ne) ? er[ci].c : INFINITY;                        // planning_range: every edge
-        const double c_np = ((blkm[ci] >> lane) & 1ull) ? INFINITY : c_pr;            // other filters: unblocked edges
+        if (ci >= 2 && (ci * NW) * 64 >= A.ne) continue;            // uniform: no edges in this chunk
+        const int src = sw_src(er[ci].meta);
 #pragma unroll
         for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) cand[ci][SL[f]] = dist[poff[f] + src];
+    }
+#pragma unroll
+    for (int ci = 0; ci < CH; ++ci) {
+        if (ci >= 2 && (ci * NW) * 64 >= A.ne) continue;
+        const int dst = sw_dst(er[ci].meta);
+        const double c_pr = er[ci].c;                                                  // planning_range: every edge
+        const double c_np = (ACT & ~(1u << F_PR)) ? sel_inf(c_pr, blkm[ci]) : c_pr;   // other filters: unblocked edges
 #pragma unroll
         for (int f = 0; f < NFILT; ++f) {
             if (!((ACT >> f) & 1u)) continue;
             cand[ci][SL[f]] = cand[ci][SL[f]] + (f == F_PR ? c_pr : c_np);
+            // (conditional: unused lanes would all hit one address -- the sentinel's destination -- and serialise in the LDS; measured
+            //  +18 % on the whole kernel with unconditional atomics)
             if (cand[ci][SL[f]] < INFINITY)
                 atomicMin(reinterpret_cast<unsigned long long*>(&dist[coff[f] + dst]), (unsigned long long)__double_as_longlong(cand[ci][SL[f]]));
         }
@@ -726,13 +756,13 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
         double* dumin = reinterpret_cast<double*>(smem + P::off_dumin(lp));
         for (int ei = CH * NT + tid; ei < A.ne; ei += NT) {
             const int e = A.eb + ei;
-            double c = at(lat.edge_cost, e);
-            const unsigned meta = at(lat.edge_meta, e);
-            const int src = meta & 255u, dst = (meta >> 8) & 255u;
+            double c = at(lat.sw_cost, e);
+            const unsigned meta = at(lat.sw_meta, e);
+            const int src = sw_src(meta), dst = sw_dst(meta);
             int el_ = e - sc.e_base; if (el_ < 0) el_ += lat.E;
             const bool unbl = !((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u);
             if (A.fs >= 0 && src == A.fs && dst == A.fd) c *= A.fac;
-            const unsigned key = ((unsigned)ei << 16) | ((meta >> 8) & 0xff00u) | (meta & 255u);
+            const unsigned key = elect_key(meta);
 #pragma unroll
             for (int f = 0; f < NFILT; ++f) {
                 if (!((ACT >> f) & 1u)) continue;
@@ -753,21 +783,27 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
     const bool has_tail = A.ne > CH * NT;
     if (has_tail) tail_edges(0);
     team_sync<NW>();
+    {
+        double got[CH][NA];
 #pragma unroll
-    for (int ci = 0; ci < CH; ++ci) {
-        if ((ci * NW) * 64 >= A.ne) continue;
-        const int ei = (ci * NW + wave) * 64 + lane;
-        const int dst = (er[ci].meta >> 8) & 255u;
-        const unsigned key = ((unsigned)ei << 16) | ((er[ci].meta >> 8) & 0xff00u) | (er[ci].meta & 255u);
-        double got[NFILT];
+        for (int ci = 0; ci < CH; ++ci) {
+            if (ci >= 2 && (ci * NW) * 64 >= A.ne) continue;
+            const int dst = sw_dst(er[ci].meta);
 #pragma unroll
-        for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) got[f] = dist[coff[f] + dst];
+            for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) got[ci][SL[f]] = dist[coff[f] + dst];
+        }
 #pragma unroll
-        for (int f = 0; f < NFILT; ++f)
-            if (((ACT >> f) & 1u) && got[f] == cand[ci][SL[f]] && cand[ci][SL[f]] < INFINITY) {
-                atomicAdd(&cnt_all[f * kpad + dst], 1u);
-                atomicMin(&widx_all[f * kpad + dst], key);
-            }
+        for (int ci = 0; ci < CH; ++ci) {
+            if (ci >= 2 && (ci * NW) * 64 >= A.ne) continue;
+            const int dst = sw_dst(er[ci].meta);
+            const unsigned key = elect_key(er[ci].meta);
+#pragma unroll
+            for (int f = 0; f < NFILT; ++f)
+                if (((ACT >> f) & 1u) && got[ci][SL[f]] == cand[ci][SL[f]] && cand[ci][SL[f]] < INFINITY) {
+                    atomicAdd(&cnt_all[f * kpad + dst], 1u);
+                    atomicMin(&widx_all[f * kpad + dst], key);
+                }
+        }
     }
     if (has_tail) tail_edges(1);
     team_sync<NW>();
@@ -801,10 +837,9 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
             for (int round = 0; round < 2; ++round) {
 #pragma unroll
                 for (int ci = 0; ci < CH; ++ci) {
-                    if ((ci * NW) * 64 >= A.ne) continue;
-                    const int ei = (ci * NW + wave) * 64 + lane;
-                    const int src = er[ci].meta & 255u, dst = (er[ci].meta >> 8) & 255u;
-                    const unsigned key = ((unsigned)ei << 16) | ((er[ci].meta >> 8) & 0xff00u) | (er[ci].meta & 255u);
+                    if (ci >= 2 && (ci * NW) * 64 >= A.ne) continue;
+                    const int src = sw_src(er[ci].meta), dst = sw_dst(er[ci].meta);
+                    const unsigned key = elect_key(er[ci].meta);
 #pragma unroll
                     for (int f = 0; f < NFILT; ++f) {
                         if (!((ACT >> f) & 1u) || !(cand[ci][SL[f]] < INFINITY)) continue;
@@ -833,7 +868,7 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
             if (f == F_LEFT) rem = rem || (A.cl_hit && n >= A.cn);
             if (f == F_RIGHT) rem = rem || (A.cl_hit && n < A.cn);
             const bool fin = c >= 1u && !rem;
-            const int bsrc = fin ? (int)(w & 255u) : 0, bk = fin ? (int)((w >> 8) & 255u) : 0, tie = (fin && c >= 2u) ? 1 : 0;
+            const int bsrc = fin ? (int)((w >> 8) & 255u) : 0, bk = fin ? (int)(w & 255u) : 0, tie = (fin && c >= 2u) ? 1 : 0;   // elect_key layout
             if (rem) dist[coff[f] + n] = INFINITY;
             par_store<P>(par, ((size_t)par_tab(f) * A.hm + A.j) * kpad + n, bsrc, bk, tie);
             any = fin;
@@ -987,6 +1022,44 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     // whose window contains transition j; lane = edge of the transition; an edge whose bounding circle (centre + radius
     // over its samples, tabulated at ltpl_create) cannot reach the obstacle disc is rejected without touching its
     // samples, the others test their samples exactly like the reference (d^2 <= (r + w/2)^2 + step^2 / 4).
+    // transitions of the planning range inside SOME obstacle window (bit j; every other transition cannot hold a blocked edge, so the
+    // sweep's prefetch skips the bitmap look-up there); planning ranges beyond 63 layers: every transition is looked up
+    unsigned long long touched = H <= 63 ? 0ull : ~0ull;
+    // shell list of this wave: entries (edge in sweep order | query lane << 24, packed sample range of the capsule record)
+    uint2* shell = reinterpret_cast<uint2*>(smem + lp.off_shell) + (size_t)(NW == 1 ? 0 : wave) * lp.shell_cap;
+    int n_shell = 0;                                               // uniform
+    auto shell_push = [&](bool mine, int e, float packed_f, int ql) {
+        const unsigned long long mk = __ballot(mine);
+        if (mine) shell[n_shell + __popcll(mk & ((1ull << lane) - 1ull))] = make_uint2((unsigned)e | ((unsigned)ql << 24), __float_as_uint(packed_f));
+        n_shell += __popcll(mk);
+    };
+    // exact test of the listed (edge, position) pairs, GraphBase.py:626-643: lane = (entry, sample slot), four entries x 16 samples per
+    // pass; positions come from the lanes of the current position batch (mx, my, mr = its x, y and squared threshold)
+    auto flush_shell = [&](double mx, double my, double mr) {
+        if (n_shell == 0) return;
+        wave_sync_lds();
+        for (int t0 = 0; t0 < n_shell; t0 += 4) {
+            const int t = t0 + (lane >> 4), slot = lane & 15;
+            const bool tv = t < n_shell;
+            const uint2 en_ = shell[tv ? t : t0];
+            const int e = (int)(en_.x & 0xffffffu), ql = (int)(en_.x >> 24);
+            int k0 = (int)(en_.y & 0xffffffu), ns = (int)(en_.y >> 24);
+            if (ns == 0) { const int ec_ = at(lat.sw2csc, e); k0 = at(lat.samp_ptr, ec_); ns = at(lat.samp_ptr, ec_ + 1) - k0; }   // (range too large for the packing)
+            const double px = __shfl(mx, ql), py = __shfl(my, ql), pr = __shfl(mr, ql);
+            bool hit = false;
+            for (int k = slot; k < ns; k += 16) {
+                const double dx = at(lat.sx, k0 + k) - px, dy = at(lat.sy, k0 + k) - py;
+                hit = hit || (dx * dx + dy * dy <= pr);
+            }
+            const unsigned long long hm = __ballot(tv && hit);
+            if (tv && slot == 0 && ((hm >> (lane & 48)) & 0xffffull)) {
+                int el_ = e - sc.e_base; if (el_ < 0) el_ += lat.E;
+                atomicOr(&blocked_bits[el_ >> 5], 1u << (el_ & 31));
+            }
+        }
+        n_shell = 0;
+        wave_sync_lds();
+    };
     for (int pp0 = 0; pp0 < sc.n_pos && !LTPL_ABLATED(lp, 1); pp0 += 64) {
         const int p = pp0 + lane;
         int ol = -1; double mpx = 0.0, mpy = 0.0, mref = 0.0, msq = 0.0;
@@ -1017,6 +1090,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                 jbits |= (unsigned long long)__builtin_amdgcn_readlane(lo, src_lane) | ((unsigned long long)__builtin_amdgcn_readlane(hi, src_lane) << 32);
             }
         }
+        touched |= jbits;
         for (int j = 1; j <= H; ++j) {
             if (sparse) { if (!jbits) break; j = __ffsll((long long)jbits) - 1; jbits &= jbits - 1; }
             int b = sc.sl + j; if (b >= L) b -= L;
@@ -1028,25 +1102,28 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                 // up to MQ matching positions per round, broadcast into uniform registers
                 constexpr int MQ = 2;
                 double qx[MQ], qy[MQ], qr[MQ];
+                int qlane[MQ];                                 // lane that holds the query's position (exact test: flush_shell)
                 float qxf[MQ], qyf[MQ], qlm[MQ], qlh[MQ];      // fp32 query, thresholds of the two-sided cull (without the edge's own terms)
 #pragma unroll
                 for (int q = 0; q < MQ; ++q) {
                     if (m) {
                         const int src_lane = __ffsll((long long)m) - 1;
                         m &= m - 1;
+                        qlane[q] = src_lane;
                         qx[q] = readlane_f64(mpx, src_lane); qy[q] = readlane_f64(mpy, src_lane);
                         qr[q] = readlane_f64(mref, src_lane);
                         qxf[q] = (float)qx[q]; qyf[q] = (float)qy[q];
                         const float t = (float)readlane_f64(msq, src_lane);          // sqrt of the squared-distance threshold
                         qlm[q] = t * 1.000001f + lat.cull_slack;                     // MISS  if dist(q, chord) > qlm + dev
                         qlh[q] = t * 0.999999f - lat.cull_slack;                     // HIT   if dist^2 + (gap / 2)^2 <= (qlh - dev)^2
-                    } else { qx[q] = 0.0; qy[q] = 0.0; qr[q] = -1.0; qxf[q] = 0.0f; qyf[q] = 0.0f; qlm[q] = -1.0e30f; qlh[q] = -1.0e30f; }   // always MISS
+                    } else { qlane[q] = 0; qx[q] = 0.0; qy[q] = 0.0; qr[q] = -1.0; qxf[q] = 0.0f; qyf[q] = 0.0f; qlm[q] = -1.0e30f; qlh[q] = -1.0e30f; }   // always MISS
                 }
                 for (int e0 = eb + wave * 64; e0 < ee; e0 += NT) {
-                    const int e = e0 + lane;
-                    if (e >= ee) continue;
+                    // (predicated, not branched: the list bookkeeping below is wave-uniform)
+                    const int e = min(e0 + lane, ee - 1);
                     int el_ = e - sc.e_base; if (el_ < 0) el_ += lat.E;
-                    if ((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u) continue;       // already blocked by another object
+                    // lanes beyond the transition and edges already blocked by another object take no part
+                    const bool live = e0 + lane < ee && !((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u);
                     // Two-sided cull on the edge's CAPSULE (chord A -> B between its first and last sample, `dev` = largest distance
                     // of a sample from the chord, `hg2` = (half the largest gap between consecutive sample projections)^2, all
                     // tabulated at ltpl_create, rounded so that both decisions are conservative): with d = dist(q, chord),
@@ -1055,7 +1132,8 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                     // and only the thin shell in between runs the reference's exact fp64 sample test. (Round 2: with a bounding
                     // CIRCLE nearly every edge of a window was "near" and loaded its samples -- 0.44 ms of a 1.05 ms launch.)
                     const float4 c0 = at(lat.edge_cap, 2 * e), c1 = at(lat.edge_cap, 2 * e + 1);   // (Ax, Ay, ABx, ABy), (1 / |AB|^2, dev, hg2, samples)
-                    bool sure = false, unsure = false;
+                    bool sure = false;
+                    bool unsure_q[MQ];
 #pragma unroll
                     for (int q = 0; q < MQ; ++q) {
                         const float ux = qxf[q] - c0.x, uy = qyf[q] - c0.y;
@@ -1066,32 +1144,22 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                         const bool miss = d2 > lm * lm * 1.000001f || lm < 0.0f;
                         const bool hit_q = lh > 0.0f && (d2 + c1.z) * 1.000001f <= lh * lh;
                         sure = sure || hit_q;
-                        unsure = unsure || (!miss && !hit_q);
+                        unsure_q[q] = !miss && !hit_q;
                     }
-                    if (sure) { atomicOr(&blocked_bits[el_ >> 5], 1u << (el_ & 31)); continue; }
-                    if (!unsure) continue;
-                    // sample range of the edge from the record (one dependent round trip less than via samp_ptr)
-                    const unsigned packed = __float_as_uint(c1.w);
-                    int k0 = (int)(packed & 0xffffffu), k1 = k0 + (int)(packed >> 24);
-                    if (packed >> 24 == 0u) { k0 = at(lat.samp_ptr, e); k1 = at(lat.samp_ptr, e + 1); }
-                    bool hit = false;
-                    constexpr int SG = 8;                             // samples per round trip
-                    for (int k = k0; k < k1 && !hit; k += SG) {
-                        double xs[SG], ys[SG];
+                    if (live && sure) atomicOr(&blocked_bits[el_ >> 5], 1u << (el_ & 31));
+                    // SHELL edges (neither certain MISS nor certain HIT for some query) need the reference's exact fp64 sample test. They
+                    // are few (7 % of the window edges) and scattered over the lanes, so running the sample loop here would drag the whole
+                    // wave through ~250 instructions per chunk for a handful of busy lanes: they are APPENDED to a list instead (edge,
+                    // query lane, sample range) and tested with lane = (entry, sample) in flush_shell.
+                    const bool sh = live && !sure && !LTPL_ABLATED(lp, 32);   // (experiment build: bit 32 treats shell edges as MISS, timing only)
 #pragma unroll
-                        for (int u = 0; u < SG; ++u) { const int kk = min(k + u, k1 - 1); xs[u] = at(lat.sx, kk); ys[u] = at(lat.sy, kk); }
-#pragma unroll
-                        for (int u = 0; u < SG; ++u)
-#pragma unroll
-                            for (int q = 0; q < MQ; ++q) {
-                                const double dx = xs[u] - qx[q], dy = ys[u] - qy[q];
-                                hit = hit || (dx * dx + dy * dy <= qr[q]);
-                            }
-                    }
-                    if (hit) atomicOr(&blocked_bits[el_ >> 5], 1u << (el_ & 31));
+                    for (int q = 0; q < MQ; ++q) shell_push(sh && unsure_q[q], e, c1.w, qlane[q]);
+                    (void)qx; (void)qy; (void)qr;
+                    if (n_shell + MQ * 64 > lp.shell_cap) flush_shell(mpx, mpy, mref);
                 }
             }
         }
+        flush_shell(mpx, mpy, mref);                                 // (the query lanes change with the next batch of positions)
     }
 
     dbg_stamp(lp.dbg, 3);
@@ -1203,19 +1271,23 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
         auto prefetch = [&](int j, EdgeRegs (&dr)[CH], unsigned long long (&db)[CH]) {
             const int4 ly = lay[j];
             unsigned bw[CH]; int sh[CH];
+            const bool look = j > 63 || ((touched >> j) & 1ull);  // uniform: can this transition hold a blocked edge at all?
 #pragma unroll
             for (int ci = 0; ci < CH; ++ci) {
                 bw[ci] = 0u; sh[ci] = 32;
                 if (ci >= 2 && ly.z + ci * NT >= ly.w) continue;   // uniform: chunks 0 and 1 are always loaded, the rest on demand
                 const int e = ly.z + (ci * NW + wave) * 64 + lane;
-                // clamped address: a fixed number of loads in flight lets the compiler wait precisely
-                const int ec = e < ly.w ? e : ly.w - 1;
-                dr[ci].c = at(lat.edge_cost, ec); dr[ci].meta = at(lat.edge_meta, ec);
-                int el_ = ec - sc.e_base; if (el_ < 0) el_ += lat.E;
-                bw[ci] = blocked_bits[el_ >> 5]; sh[ci] = (e < ly.w) ? (el_ & 31) : 32;
+                // lanes beyond the transition load the SENTINEL edge (index E: cost +inf, source = destination = node 0): a fixed
+                // number of loads in flight lets the compiler wait precisely, and the sweep needs no "is this lane an edge" select
+                const int ec = e < ly.w ? e : lat.E;
+                dr[ci].c = at(lat.sw_cost, ec); dr[ci].meta = at(lat.sw_meta, ec);
+                if (look) {
+                    int el_ = (e < ly.w ? e : ly.w - 1) - sc.e_base; if (el_ < 0) el_ += lat.E;
+                    bw[ci] = blocked_bits[el_ >> 5]; sh[ci] = (e < ly.w) ? (el_ & 31) : 32;
+                }
             }
 #pragma unroll
-            for (int ci = 0; ci < CH; ++ci) db[ci] = __ballot(sh[ci] < 32 && ((bw[ci] >> (sh[ci] & 31)) & 1u));
+            for (int ci = 0; ci < CH; ++ci) db[ci] = look ? __ballot(sh[ci] < 32 && ((bw[ci] >> (sh[ci] & 31)) & 1u)) : 0ull;
         };
         team_sync<NW>();
         prefetch(1, er, bm);
@@ -1233,10 +1305,14 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             if (lane == 0) ts.start_ok[F_PR] = ts.start_ok[F_DEF];
             team_sync<NW>();
         };
-        for (int j = 1; j <= H && !LTPL_ABLATED(lp, 2); ++j) {
-            int b = sc.sl + j; if (b >= L) b -= L;
-            const int4 ly = lay[j];
+        // The layer loop is split into RUNS of layers that share one configuration (set of advancing filters, `planning_range` still
+        // riding on `default` or not): the per-layer decisions (which filters advance, first own layer of left / right, ...) are taken
+        // once per run by the driver below, the loop of a run is specialised for its filter set at compile time and carries no template
+        // logic. (As one loop with the decisions inside, the uniform booleans lived in scalar register PAIRS across the whole sweep and
+        // were spilled: ~20 v_readlane reloads per layer.)
+        auto layer_args = [&](int j, const int4& ly, bool from_def) {
             LayerArgs A;
+            int b = sc.sl + j; if (b >= L) b -= L;
             A.j = j; A.b = b; A.v0 = ly.x; A.Kb = ly.y & 0xffff; A.ne = ly.w - ly.z; A.eb = ly.z; A.kpad = kpad; A.hm = hm; A.cur = j & 1; A.prv = (j - 1) & 1;
             A.H = H; A.cl_hit = (b == t_cl) ? 1 : 0; A.cn = t_cn;
             A.fs = -1; A.fd = -1; A.fac = 1.0;
@@ -1244,54 +1320,93 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                 for (int i = 0; i < sc.n_fac; ++i)
                     if (ts.fac_j[i] == j) { A.fs = ts.fac_src[i]; A.fd = ts.fac_dst[i]; A.fac = ts.fac[i]; break; }
             }
-            // filters that advance through this layer; left / right read `default`'s frontier in their first own layer
-            unsigned actm = 0;
-            if ((need >> F_PR) & 1u) actm |= 1u << F_PR;
-            if (((need >> F_DEF) & 1u) || (share_prefix && j < jcl)) actm |= 1u << F_DEF;
-            if (((need >> F_LEFT) & 1u) && (!share_prefix || j >= jcl)) actm |= 1u << F_LEFT;
-            if (((need >> F_RIGHT) & 1u) && (!share_prefix || j >= jcl)) actm |= 1u << F_RIGHT;
-            A.from_def = share_prefix && j == jcl;
-            if (pr_shared) {
-                unsigned long long anyb = 0ull;
-#pragma unroll
-                for (int ci = 0; ci < CH; ++ci) anyb |= bm[ci];
-                if (anyb != 0ull || A.ne > CH * NT || (share_prefix && j == jcl)) { copy_def_to_pr(j, A.prv); pr_shared = false; }
-                else actm &= ~(1u << F_PR);
-            }
-            if (j < H) prefetch(j + 1, en, bn);                    // global loads in flight during this layer's LDS work
-            // the action templates only produce these filter sets (phase 3); anything else takes the serial form
-            const bool known = actm == (1u << F_DEF) || actm == (1u << F_PR) || actm == ((1u << F_PR) | (1u << F_DEF)) ||
-                               actm == ((1u << F_PR) | (1u << F_LEFT) | (1u << F_RIGHT));
+            A.from_def = from_def;
             if (A.fs >= 0) {
                 // previous-solution discount (first layers only): patch the one edge in the register image
 #pragma unroll
-                for (int ci = 0; ci < CH; ++ci)
-                    if ((int)(er[ci].meta & 255u) == A.fs && (int)((er[ci].meta >> 8) & 255u) == A.fd) er[ci].c *= A.fac;
+                for (int ci = 0; ci < CH; ++ci)         // (the sentinel lanes carry +inf: +inf * 0 would be NaN)
+                    if (sw_src(er[ci].meta) == A.fs && sw_dst(er[ci].meta) == A.fd && er[ci].c < INFINITY) er[ci].c *= A.fac;
             }
-            if (A.Kb <= 64 && known) {
-                // compile-time specialisations per filter set
-                switch (actm) {
-                    case (1u << F_DEF): team_layer<P, NW, CH, (1u << F_DEF)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
-                    case (1u << F_PR): team_layer<P, NW, CH, (1u << F_PR)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
-                    case (1u << F_PR) | (1u << F_DEF): team_layer<P, NW, CH, (1u << F_PR) | (1u << F_DEF)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
-                    default:
-                        team_layer<P, NW, CH, (1u << F_PR) | (1u << F_LEFT) | (1u << F_RIGHT)>(lat, sc, lp, smem, A, er, bm, wave, lane); break;
-                }
-            } else {
-                // more than 64 nodes in the layer (or an unknown filter set): serial form (lane = node)
-                for (int f = wave; f < NFILT; f += NW) {
-                    if (!((actm >> f) & 1u)) continue;
-                    const int fprev = (A.from_def && (f == F_LEFT || f == F_RIGHT)) ? F_DEF : f;
-                    double* dcur = dist + (size_t)(f * 2 + A.cur) * kpad;
-                    const bool any = team_relax_layer<P>(lat, in, sc, lp, smem, t_cl, t_cn, f, j, b, A.v0, A.Kb,
-                                                      dist + (size_t)(fprev * 2 + A.prv) * kpad, dcur,
-                                                      par, ((size_t)par_tab(f) * hm + j) * kpad, lane, A.fs, A.fd, A.fac);
-                    if (lane == 0) best[f * hm + j] = any ? -2 : -1;
-                }
-            }
+            return A;
+        };
+        auto rotate = [&]() {
 #pragma unroll
             for (int ci = 0; ci < CH; ++ci) { er[ci] = en[ci]; bm[ci] = bn[ci]; }
             team_sync<NW>();
+        };
+        // layers j0 .. j1 for the compile-time filter set of `act_tag`; stops in front of the first layer that needs something else:
+        // why = 1: `planning_range` has to part from `default` here (a blocked edge, or edges beyond the register image),
+        // why = 2: more than 64 nodes in the layer (serial form; runtime LDS plans only). Returns the first layer NOT done.
+        auto run = [&](auto act_tag, int j0, int j1, bool riding, bool from_def, int& why) -> int {
+            constexpr unsigned ACT = decltype(act_tag)::value;
+            why = 0;
+            int j = j0;
+            for (; j <= j1; ++j) {
+                const int4 ly = lay[j];
+                if (riding) {
+                    unsigned long long anyb = 0ull;
+#pragma unroll
+                    for (int ci = 0; ci < CH; ++ci) anyb |= bm[ci];
+                    if (anyb != 0ull || ly.w - ly.z > CH * NT) { why = 1; break; }
+                }
+                if constexpr (!P::fixed) { if ((ly.y & 0xffff) > 64) { why = 2; break; } }
+                const LayerArgs A = layer_args(j, ly, from_def && j == j0);
+                if (j < H) prefetch(j + 1, en, bn);                // global loads in flight during this layer's LDS work
+                team_layer<P, NW, CH, ACT>(lat, sc, lp, smem, A, er, bm, wave, lane);
+                rotate();
+            }
+            return j;
+        };
+        // one layer in the serial form (lane = node): more than 64 nodes in the layer, or a filter set without a specialisation
+        auto serial_layer = [&](int j, unsigned actm, bool from_def) {
+            const LayerArgs A = layer_args(j, lay[j], from_def);
+            if (j < H) prefetch(j + 1, en, bn);
+            for (int f = wave; f < NFILT; f += NW) {
+                if (!((actm >> f) & 1u)) continue;
+                const int fprev = (A.from_def && (f == F_LEFT || f == F_RIGHT)) ? F_DEF : f;
+                double* dcur = dist + (size_t)(f * 2 + A.cur) * kpad;
+                const bool any = team_relax_layer<P>(lat, in, sc, lp, smem, t_cl, t_cn, f, j, A.b, A.v0, A.Kb,
+                                                  dist + (size_t)(fprev * 2 + A.prv) * kpad, dcur,
+                                                  par, ((size_t)par_tab(f) * hm + j) * kpad, lane, A.fs, A.fd, A.fac);
+                if (lane == 0) best[f * hm + j] = any ? -2 : -1;
+            }
+            rotate();
+        };
+        for (int j = 1; j <= H && !LTPL_ABLATED(lp, 2);) {
+            // filters that advance through layer j; left / right read `default`'s frontier in their first own layer (j == jcl)
+            const bool from_def = share_prefix && j == jcl;
+            if (pr_shared && from_def) { copy_def_to_pr(j, (j - 1) & 1); pr_shared = false; }
+            unsigned actm = 0;
+            if (((need >> F_PR) & 1u) && !pr_shared) actm |= 1u << F_PR;
+            if (((need >> F_DEF) & 1u) || (share_prefix && j < jcl)) actm |= 1u << F_DEF;
+            if (((need >> F_LEFT) & 1u) && (!share_prefix || j >= jcl)) actm |= 1u << F_LEFT;
+            if (((need >> F_RIGHT) & 1u) && (!share_prefix || j >= jcl)) actm |= 1u << F_RIGHT;
+            const int j1 = (share_prefix && j < jcl) ? jcl - 1 : (from_def ? j : H);       // last layer of this configuration
+            int why = 0, jn;
+            switch (actm) {          // the action templates only produce these filter sets (phase 3); anything else takes the serial form
+                case (1u << F_DEF):
+                    jn = run(std::integral_constant<unsigned, (1u << F_DEF)>(), j, j1, pr_shared, from_def, why); break;
+                case (1u << F_PR):
+                    jn = run(std::integral_constant<unsigned, (1u << F_PR)>(), j, j1, false, from_def, why); break;
+                case (1u << F_PR) | (1u << F_DEF):
+                    jn = run(std::integral_constant<unsigned, (1u << F_PR) | (1u << F_DEF)>(), j, j1, false, from_def, why); break;
+                case (1u << F_PR) | (1u << F_LEFT) | (1u << F_RIGHT):
+                    jn = run(std::integral_constant<unsigned, (1u << F_PR) | (1u << F_LEFT) | (1u << F_RIGHT)>(), j, j1, false, from_def, why); break;
+                default:
+                    // riding `planning_range` parts in front of a layer that holds blocked edges here as well
+                    if (pr_shared) {
+                        unsigned long long anyb = 0ull;
+#pragma unroll
+                        for (int ci = 0; ci < CH; ++ci) anyb |= bm[ci];
+                        const int4 ly = lay[j];
+                        if (anyb != 0ull || ly.w - ly.z > CH * NT) { jn = j; why = 1; break; }
+                    }
+                    serial_layer(j, actm, from_def); jn = j + 1; break;
+            }
+            if (why == 1) { copy_def_to_pr(jn, (jn - 1) & 1); pr_shared = false; }
+            else if (why == 2) { serial_layer(jn, actm, from_def && jn == j); jn = jn + 1; }   // (the run has already checked that a riding
+                                                                                               //  `planning_range` need not part here)
+            j = jn;
         }
         if (pr_shared && !LTPL_ABLATED(lp, 2)) copy_def_to_pr(H + 1, H & 1);        // no blocked edge in the whole range: identical sweeps
         // goal node of the last layer for every filter that reached it (virtual goal edges, GraphBase.py:188-194)
