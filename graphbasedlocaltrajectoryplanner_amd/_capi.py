@@ -163,13 +163,18 @@ class CompactTrajectories(object):
         s.row_off = self.row_off.ctypes.data_as(C.POINTER(C.c_int64))
         s.rows = C.cast(self._ptr, _pf64)
 
-    def trajectories(self, scen):
+    def trajectories(self, scen, copy=True):
+        """The trajectory set of scenario ``scen`` as Graph_LTPL.calc_vel_profile returns it ({action id: [ndarray (rows, 7)]}).
+        ``copy=True`` (default): independent arrays -- the reference's callers keep the dict (Graph_LTPL stores it as its action set),
+        while the packed buffer is overwritten by the next ltpl_tick_batch_compact and released with this object. ``copy=False``:
+        zero-copy VIEWS into the page-locked buffer, only valid until the next call on, or the release of, this object."""
         out = {}
         for a in range(MAX_ACTIONS):
             k = scen * MAX_ACTIONS + a
             if self.n_rows[k] > 0:
                 o = int(self.row_off[k])
-                out[ACTION_NAMES[int(self.action_id[k])]] = [self.rows[o:o + int(self.n_rows[k])]]
+                rows = self.rows[o:o + int(self.n_rows[k])]
+                out[ACTION_NAMES[int(self.action_id[k])]] = [rows.copy() if copy else rows]
         return out
 
     def __del__(self):

@@ -1847,6 +1847,7 @@ struct ltpl_handle {
     int zc_out = 0;                  // small calls: kernels write their outputs straight into the page-locked host buffer (no D2H copy)
     std::vector<int> rng_end_host;   // planning range end per start layer, -1 = no planning range (end of an open track)
     std::vector<int> sw2csc_host;    // CSC edge id of every sweep position (DevLat::sw2csc)
+    int n_planners = 0;              // live ltpl_planner objects that compute through this handle (ltpl_destroy refuses while > 0)
 };
 
 #define HIP_TRY(h, call)                                                                                              \
@@ -2064,6 +2065,7 @@ extern "C" const char* ltpl_last_error(const ltpl_handle* h) { return h ? h->err
 extern "C" int ltpl_destroy(ltpl_handle* h)
 {
     if (!h) return LTPL_ERR_INVALID_ARG;
+    if (h->n_planners > 0) { h->err = "ltpl_destroy: planners created on this handle are still alive (destroy them first)"; return LTPL_ERR_INVALID_ARG; }
     (void)hipSetDevice(h->device);
     for (void* p : h->dev_allocs) (void)hipFree(p);
     if (h->d_in) (void)hipFree(h->d_in);
@@ -3459,7 +3461,9 @@ static int self_test(ltpl_handle* h, const ltpl_lattice_desc* d)
 namespace {
 struct HipCompute : ltplp::Compute {
     ltpl_handle* h;
-    explicit HipCompute(ltpl_handle* handle) : h(handle) {}
+    // a planner holds on to its lattice handle: the handle counts its planners and ltpl_destroy refuses while one is alive
+    explicit HipCompute(ltpl_handle* handle) : h(handle) { ++h->n_planners; }
+    ~HipCompute() override { --h->n_planners; }
     int plan_paths(const ltpl_paths_in* in, ltpl_paths_out* out) override { return ltpl_plan_paths(h, in, out); }
     int vel_profile(const ltpl_vel_params* p, int n, const ltpl_vel_job* jobs, ltpl_vel_result* res) override
     {

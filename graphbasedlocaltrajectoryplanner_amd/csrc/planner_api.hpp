@@ -12,7 +12,6 @@ inline int api_create(Compute* cmp, const HostLat& lat, const ltpl_planner_confi
 {
     if (!cfg || !out || cfg->n_scen < 1) { *why = "planner: null argument or n_scen < 1"; delete cmp; return LTPL_ERR_INVALID_ARG; }
     if (cfg->n_w_last < 0 || cfg->n_w_last > LTPL_MAX_LAST_NODES - 1) { *why = "planner: n_w_last out of range"; delete cmp; return LTPL_ERR_INVALID_ARG; }
-    if (cfg->filt_window_width != 1) { *why = "planner: SMOOTHING.filt_window_width != 1 is not supported"; delete cmp; return LTPL_ERR_UNSUPPORTED; }
     ltpl_planner* p = new ltpl_planner();
     p->P.lat = lat; p->P.cmp = cmp;
     Config& c = p->P.cfg;
@@ -72,6 +71,14 @@ inline int api_calc_vel_profile(ltpl_planner* p, const ltpl_planner_vel_in* in)
         r.pos_x = in->pos_est_x[s]; r.pos_y = in->pos_est_y[s]; r.vel_est = in->vel_est[s]; r.vel_max = in->vel_max[s];
         r.gg_scale = in->gg_scale[s]; r.gg_ax = in->gg_ax[s]; r.gg_ay = in->gg_ay[s]; r.safety_d = in->safety_d[s];
         r.incl_emerg = in->incl_emerg_traj ? in->incl_emerg_traj[s] : 0;
+        for (int k = 0; k < LTPL_PLANNER_MAX_KEYS; ++k) {
+            r.gg_rows[k] = nullptr; r.gg_n[k] = 0;
+            if (in->gg_row_off && in->gg_rows) {
+                const int o0 = in->gg_row_off[s * LTPL_PLANNER_MAX_KEYS + k], o1 = in->gg_row_off[s * LTPL_PLANNER_MAX_KEYS + k + 1];
+                if (o0 < 0 || o1 < o0) return p->P.fail(LTPL_ERR_INVALID_ARG, "planner: gg_row_off must be non-decreasing");
+                r.gg_rows[k] = in->gg_rows + (size_t)o0 * 2; r.gg_n[k] = o1 - o0;
+            }
+        }
     }
     return p->P.calc_vel_profile(req.data(), in->ax_max_machines, in->n_ax_max_machines, nullptr);
 }

@@ -240,7 +240,11 @@ struct Config {
 };
 
 // arguments of Graph_LTPL.calc_vel_profile (Graph_LTPL.py:344-408), per scenario
-struct VelReq { double pos_x, pos_y, vel_est, vel_max, gg_scale, gg_ax, gg_ay, safety_d; int incl_emerg; };
+struct VelReq {
+    double pos_x, pos_y, vel_est, vel_max, gg_scale, gg_ax, gg_ay, safety_d; int incl_emerg;
+    // location dependent friction (local_gg as a dict, OTH.py:649-666): per path key (dict order) rows [ax, ay], or nullptr / 0 rows
+    const double* gg_rows[LTPL_PLANNER_MAX_KEYS] = {}; int gg_n[LTPL_PLANNER_MAX_KEYS] = {};
+};
 
 // Persistent worker threads for the per-planner loops of a BATCH of planners (the state machines of different planners share nothing
 // but the read-only lattice): run(f) calls f(t) for t = 0 .. size() - 1, f(0) on the calling thread, and returns when all are done. An
@@ -808,9 +812,26 @@ struct Planner {
         return rc ? fail_cmp(rc) : LTPL_OK;
     }
 
-    static void finalize_bp(const double* s_arr, const double* pv, const double* vx, int n, std::vector<double>* bp)
+    // tph.conv_filt(signal, filt_window, closed=False) (OTH.py:928-930, :988-990): centred moving average of odd width; the first and
+    // the last half window keep their values (np.convolve(..., "same") only replaces [half, n - half))
+    static void conv_filt_open(const double* vx, int n, int width, std::vector<double>* out)
     {
-        // :925-941 with filt_window_width = 1 (conv_filt is the identity): ax from neighbours, -5 at standstill
+        out->assign(vx, vx + n);
+        const int half = (width - 1) / 2;
+        if (half < 1 || n < width) return;              // width 1: identity (the stock value, ltpl_config_online.ini:60)
+        for (int i = half; i < n - half; ++i) {
+            double acc = 0.0;
+            for (int k = i - half; k <= i + half; ++k) acc += vx[k] * (1.0 / (double)width);
+            (*out)[(size_t)i] = acc;
+        }
+    }
+
+    void finalize_bp(const double* s_arr, const double* pv, const double* vx_in, int n, std::vector<double>* bp) const
+    {
+        // :925-941: vx filtered (conv_filt), ax from neighbours (tph.calc_ax_profile over np.diff(s)), -5 at standstill
+        std::vector<double> vxf;
+        conv_filt_open(vx_in, n, cfg.filt_window_width, &vxf);
+        const double* vx = vxf.data();
         bp->assign((size_t)n * 7, 0.0);
         for (int i = 0; i < n; ++i) {
             double* r = &(*bp)[(size_t)i * 7];
@@ -828,7 +849,8 @@ struct Planner {
     {
         const int n = (int)sc.size();
         LTPL_PROF(prof_a, "planner.vel_stage_A");
-        if (cfg.filt_window_width != 1) return fail(LTPL_ERR_UNSUPPORTED, "planner: SMOOTHING.filt_window_width != 1 is not supported");
+        if (cfg.filt_window_width < 1 || cfg.filt_window_width % 2 != 1)
+            return fail(LTPL_ERR_INVALID_ARG, "planner: Window width of moving average filter must be odd! (tph.conv_filt)");
         ltpl_vel_params vp; std::memset(&vp, 0, sizeof(vp));
         vp.dyn_model_exp = cfg.dyn_model_exp; vp.drag_coeff = cfg.drag_coeff; vp.m_veh = cfg.m_veh; vp.len_veh = lat.veh_length;
         vp.n_ax_max_machines = n_axm; vp.ax_max_machines = ax_max_machines; vp.follow_control_type = cfg.follow_control_type;
@@ -838,6 +860,21 @@ struct Planner {
         vp.v_max = req[0].vel_max;
         for (int s = 1; s < n; ++s) if (req[s].vel_max != req[0].vel_max) return fail(LTPL_ERR_UNSUPPORTED, "planner: vel_max must be the same for all scenarios of a call");
 
+        // Everything that can make the call fail is checked for ALL planners before any planner's memory is touched: an error of one
+        // planner of a batch (the reference's ValueError / IndexError for that vehicle) must not leave the others half-trimmed.
+        for (int s = 0; s < n; ++s) {
+            Scn& S = sc[(size_t)s];
+            if (!S.ref_done) { ref_idx(S, req[s].pos_x, req[s].pos_y); S.ref_done = true; }      // (OTH.get_ref_idx: no iterative memory is cut here)
+            for (const Traj& T : S.last) {
+                const int rows = T.rows(), m = rows - std::min(std::max(S.cut_index_pos, 0), rows);
+                if (S.cut_layer >= (int)T.node_idx.size())
+                    return fail(LTPL_ERR_INVALID_ARG, "planner " + std::to_string(s) + ": cut_layer beyond the node list (the reference raises IndexError, OTH.py:712)");
+                if (m > 0 && S.vel_plan > req[s].vel_max + 0.1)
+                    return fail(LTPL_ERR_UNSUPPORTED, "planner " + std::to_string(s) + ": vel_plan > vel_max + 0.1 (brake prefix): the reference raises ValueError at OTH.py:919");
+                if (m > 0 && T.id == LTPL_ACT_FOLLOW && m - (int)S.vel_course.size() < 1)
+                    return fail(LTPL_ERR_INVALID_ARG, "planner " + std::to_string(s) + ": follow profile without points");
+            }
+        }
         std::vector<Work> work;
         std::vector<ltpl_vel_job> jobs; std::vector<JobBuf> bufs; std::vector<ltpl_vel_result> res;
         work.reserve((size_t)n * 3); jobs.reserve((size_t)n * 4); bufs.reserve((size_t)n * 4);     // (<= 3 keys and <= 4 jobs per planner, typically)
@@ -859,9 +896,14 @@ struct Planner {
                 Work W; W.s = s; W.key = k; W.vel_idx = vel_idx;
                 S.path_ids.push_back({T.id, S.traj_base_id + (T.id >= 0 && T.id <= 3 ? T.id : 9)});
                 const int rows = T.rows();
-                // local gg rows of the stitched path (constant friction, :651-666)
+                // local gg rows of the stitched path: constant friction expanded to one row per path coordinate (:651-666), or the
+                // caller's rows for this key (location dependent friction, :641-646: "each path coordinate must be represented by a row")
                 std::vector<double> gg_full((size_t)rows * 2);
-                for (int i = 0; i < rows; ++i) { gg_full[(size_t)i * 2] = R.gg_ax; gg_full[(size_t)i * 2 + 1] = R.gg_ay; }
+                if (k < (size_t)LTPL_PLANNER_MAX_KEYS && R.gg_rows[k] && R.gg_n[k] > 0) {
+                    if (R.gg_n[k] != rows) return fail(LTPL_ERR_INVALID_ARG, "planner: local_gg rows of a path do not match its coordinates (OTH.py:641-646)");
+                    std::memcpy(gg_full.data(), R.gg_rows[k], sizeof(double) * 2 * (size_t)rows);
+                } else
+                    for (int i = 0; i < rows; ++i) { gg_full[(size_t)i * 2] = R.gg_ax; gg_full[(size_t)i * 2 + 1] = R.gg_ay; }
                 const int c0 = std::min(std::max(S.cut_index_pos, 0), rows);
                 W.pv.assign(T.pp.begin() + (size_t)c0 * 5, T.pp.end());
                 W.gv.assign(gg_full.begin() + (size_t)c0 * 2, gg_full.end());
@@ -1080,9 +1122,10 @@ struct Planner {
                     if (W.job_backup >= 0) {
                         const Traj& B = S.backup;
                         const int c0 = S.cut_index_pos, br = B.rows(), m = br - c0;
-                        std::vector<double> vx = S.vel_course;
-                        vx.insert(vx.end(), bufs2[(size_t)W.job_backup].out.begin(), bufs2[(size_t)W.job_backup].out.end());
-                        if ((int)vx.size() != m) return fail(LTPL_ERR_INVALID_ARG, "planner: backup brake profile length mismatch");
+                        std::vector<double> vx_raw = S.vel_course, vx;
+                        vx_raw.insert(vx_raw.end(), bufs2[(size_t)W.job_backup].out.begin(), bufs2[(size_t)W.job_backup].out.end());
+                        if ((int)vx_raw.size() != m) return fail(LTPL_ERR_INVALID_ARG, "planner: backup brake profile length mismatch");
+                        conv_filt_open(vx_raw.data(), m, cfg.filt_window_width, &vx);             // :986-990
                         std::vector<double> s_arr((size_t)m, 0.0);
                         for (int i = 1; i < m; ++i) s_arr[(size_t)i] = s_arr[(size_t)i - 1] + B.pp[(size_t)(c0 + i - 1) * 5 + 4];
                         // :996-1004: ax over the element lengths themselves, not over np.diff(s)

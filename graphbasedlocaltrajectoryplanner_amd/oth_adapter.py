@@ -99,9 +99,7 @@ class PlannerOnlineTrajectoryHandler(object):
                          vel_course: np.ndarray, vel_est: float, vel_max: float, ax_max_machines: np.ndarray,
                          safety_d: float, gg_scale: float, local_gg: dict = (5.0, 5.0),
                          incl_emerg_traj: bool = False) -> tuple:
-        if isinstance(local_gg, dict):
-            raise ValueError("location dependent friction (local_gg as dict) is not supported by this backend")
-        if type(local_gg) is not tuple or len(local_gg) != 2:
+        if not isinstance(local_gg, dict) and (type(local_gg) is not tuple or len(local_gg) != 2):
             raise ValueError("Provided local_gg does not satisfy requested format! Read parameter documentation.")
         stamp = self._clock.time()
         # the reference index of this tick already lives in the planner (get_ref_idx above); the pose is only re-sent

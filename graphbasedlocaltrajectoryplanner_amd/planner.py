@@ -1,5 +1,5 @@
 """
-ctypes binding of the planner entry points (``ltpl_planner_*``, include/ltpl_hip.h ABI v3): the iterative memory of the
+ctypes binding of the planner entry points (``ltpl_planner_*``, include/ltpl_hip.h ABI v3+): the iterative memory of the
 reference's ``OnlineTrajectoryHandler`` (graph_ltpl/online_graph/src/OnlineTrajectoryHandler.py:24-1040) lives in C++ behind
 the ABI, batched over ``n_scen`` independent planners on one lattice handle. One tick is two C calls:
 
@@ -46,7 +46,7 @@ class PlannerVelIn(C.Structure):
     _fields_ = [("pos_est_x", _vp), ("pos_est_y", _vp), ("vel_est", _vp), ("vel_max", _vp),
                 ("gg_scale", _vp), ("gg_ax", _vp), ("gg_ay", _vp), ("safety_d", _vp),
                 ("incl_emerg_traj", _vp), ("n_ax_max_machines", C.c_int32), ("reserved0", C.c_int32),
-                ("ax_max_machines", _vp)]
+                ("ax_max_machines", _vp), ("gg_row_off", _vp), ("gg_rows", _vp)]
 
 
 class _Staging(object):
@@ -267,6 +267,11 @@ class Planner(object):
         zone_off, zone = self._pack_zones(zone_gids)
         self._check(self._fn("calc_paths_finish")(self.handle, zone_off.ctypes.data, zone.ctypes.data))
 
+    def _path_keys(self, scen):
+        v = PathsView()                                    # counts only: no buffers attached
+        self._check(self._fn("get_paths")(self.handle, int(scen), C.byref(v)))
+        return [KEY_NAMES[v.key_id[k]] for k in range(v.n_keys)]
+
     def start_node(self, scen=0):
         v = PathsView()                                    # counts only: no buffers attached
         self._check(self._fn("get_paths")(self.handle, int(scen), C.byref(v)))
@@ -283,9 +288,35 @@ class Planner(object):
     # ---- Graph_LTPL.calc_vel_profile --------------------------------------------------------------------------------------
     def calc_vel_profile(self, pos_est, vel_est, vel_max=100.0, gg_scale=1.0, local_gg=(5.0, 5.0),
                          ax_max_machines=((100.0, 5.0),), safety_d=30.0, incl_emerg_traj=False):
+        """``local_gg``: the constant form (ax, ay) -- or, location dependent friction (OTH.py:649-666), a dict {action id: [ndarray
+        (rows, 2)]} with one row [ax, ay] per coordinate of that action's path (``paths(scen)['path_param'][key]``); for a batch a
+        list with one such dict (or tuple) per planner. ``incl_emerg_traj``: bool or one per planner."""
         n = self.n_scen
-        if isinstance(local_gg, dict) or len(local_gg) != 2:
-            raise ValueError("only the constant-friction form of local_gg (tuple (ax, ay)) is supported")
+        per = list(local_gg) if isinstance(local_gg, list) else [local_gg] * n
+        if len(per) != n:
+            raise ValueError("local_gg: one entry per planner expected")
+        gg_off, gg_rows, const = None, None, []
+        if any(isinstance(g, dict) for g in per):
+            gg_off, chunks = [0], []
+            for s_, g in enumerate(per):
+                keys = self._path_keys(s_) if isinstance(g, dict) else []
+                for k in range(K):
+                    if k < len(keys) and keys[k] in g:
+                        a = np.asarray(g[keys[k]][0] if isinstance(g[keys[k]], (list, tuple)) else g[keys[k]], dtype=np.float64)
+                        if a.ndim != 2 or a.shape[1] != 2:
+                            raise ValueError("local_gg['%s']: rows of (ax, ay) expected" % keys[k])
+                        chunks.append(a)
+                        gg_off.append(gg_off[-1] + a.shape[0])
+                    else:
+                        gg_off.append(gg_off[-1])
+                const.append((5.0, 5.0) if isinstance(g, dict) else g)
+            gg_rows = np.ascontiguousarray(np.concatenate(chunks + [np.zeros((1, 2))]))
+            gg_off = np.array(gg_off, np.int32)
+        else:
+            const = per
+        if any(type(g) not in (tuple, list) or len(g) != 2 for g in const):
+            raise ValueError("Provided local_gg does not satisfy requested format! Read parameter documentation.")
+        local_gg = ([float(g[0]) for g in const], [float(g[1]) for g in const])
         flat = np.asarray(pos_est, dtype=np.float64).reshape(-1).tolist()
         if len(flat) != 2 * n:
             raise ValueError("pos_est: one (x, y) per planner expected")
@@ -302,6 +333,8 @@ class Planner(object):
         if len(axm) < 2 or len(axm) % 2:
             raise ValueError("ax_max_machines: rows [v, ax] expected")
         emerg = [int(bool(incl_emerg_traj))] * n if isinstance(incl_emerg_traj, (bool, int)) else [int(bool(e)) for e in incl_emerg_traj]
+        if len(emerg) != n:
+            raise ValueError("incl_emerg_traj: a bool or one value per planner expected")
         st, i = self._stage_vel, self._vin
         dbl = []
         for c in cols:
@@ -313,6 +346,8 @@ class Planner(object):
         i.ax_max_machines = o + 64 * n
         i.n_ax_max_machines = len(axm) // 2
         i.incl_emerg_traj = st.ai
+        i.gg_row_off = None if gg_off is None else gg_off.ctypes.data
+        i.gg_rows = None if gg_rows is None else gg_rows.ctypes.data
         self._check(self._fn("calc_vel_profile")(self.handle, C.byref(i)))
 
     # ---- accessors ----------------------------------------------------------------------------------------------------------

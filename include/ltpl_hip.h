@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LTPL_ABI_VERSION 3
+#define LTPL_ABI_VERSION 4
 
 /* status codes */
 #define LTPL_OK               0
@@ -467,6 +467,13 @@ typedef struct {                    /* arguments of Graph_LTPL.calc_vel_profile 
     int32_t n_ax_max_machines;
     int32_t reserved0;
     const double*  ax_max_machines; /* [n_ax_max_machines * 2] rows [v, ax]                                       */
+    /* ABI v4 -- LOCATION DEPENDENT FRICTION, local_gg as a dict {action id: [rows x (ax, ay)]} (OnlineTrajectoryHandler.py:649-666;
+     * Graph_LTPL.py:360-365). Both NULL: constant friction (gg_ax / gg_ay). Otherwise rows gg_row_off[s * LTPL_PLANNER_MAX_KEYS + k]
+     * .. gg_row_off[s * LTPL_PLANNER_MAX_KEYS + k + 1] of gg_rows belong to planner s and its k-th path key (key order of
+     * ltpl_planner_paths_view); a key's row count must equal n_rows of that path (every path coordinate is represented by a row),
+     * a key with zero rows falls back to (gg_ax, gg_ay)                                                            */
+    const int32_t* gg_row_off;      /* [n_scen * LTPL_PLANNER_MAX_KEYS + 1]                                       */
+    const double*  gg_rows;         /* [total rows * 2] rows [ax, ay]                                             */
 } ltpl_planner_vel_in;
 
 /* Sizes a caller needs for the query buffers below: rows per (stitched) path / trajectory, nodes per path. */

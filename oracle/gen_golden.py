@@ -98,8 +98,10 @@ class StaticObjects(object):
 
 
 def record_ticks(name, n_ticks, dummies_f, zones, vel_kwargs=None, action_pref=("right", "left", "straight", "follow"),
-                 full_every=25):
-    gl, clock, ltpl_obj, gb, path_dict = rs.make_planner(CACHE)
+                 full_every=25, online_overrides=None):
+    """``online_overrides``: {(section, key): value} applied to a COPY of params/ltpl_config_online.ini (the reference reads the file
+    named in path_dict; the reference tree itself is read-only)."""
+    gl, clock, ltpl_obj, gb, path_dict = rs.make_planner(CACHE, online_overrides=online_overrides)
     seam = rs.SeamRecorder(gl, gb)
     rec = rs.TickRecorder(gl, clock, seam)
     rs.run_loop(gl, clock, ltpl_obj, path_dict, n_ticks=n_ticks, dt=0.05, dummies=dummies_f(gl), zones=zones,
@@ -136,6 +138,19 @@ def main_ticks(only=None):
     record_ticks("overtake", 600, lambda gl: [Dummy(gl)(dynamic=True, vel_scale=0.5, s0=120.0)], rs.ZONE_EXAMPLE,
                  vel_kwargs=lambda t: {'gg_scale': 1.0 if t < 200 else 0.5, 'incl_emerg_traj': (t % 3 == 0)},
                  action_pref=("left", "right", "straight", "follow"))
+    # location dependent friction: local_gg as a dict of per-path rows (OTH.py:649-666), rows = friction_map(path coordinates); an
+    # opponent ahead so that follow / overtake profiles and (with incl_emerg_traj) the emergency profile run on varying friction too
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from planner_replay import friction_map
+    record_ticks("ggmap", 500, lambda gl: [Dummy(gl)(dynamic=True, vel_scale=0.45, s0=150.0)], rs.ZONE_EXAMPLE,
+                 vel_kwargs=lambda t, paths: {'local_gg': {k: [friction_map(v[0][:, 0:2])] for k, v in paths.items()},
+                                              'gg_scale': 1.0 if t < 350 else 0.8, 'incl_emerg_traj': (t % 4 == 0)},
+                 action_pref=("left", "right", "straight", "follow"))
+    # SMOOTHING.filt_window_width = 5 (stock: 1): tph.conv_filt on every exported velocity profile (OTH.py:928-930) and on the backup
+    # profile (:988-990; the friction drop at tick 200 triggers the backup branch)
+    record_ticks("filt5", 320, lambda gl: [Dummy(gl)(dynamic=True, vel_scale=0.4, s0=200.0)], None,
+                 vel_kwargs=lambda t: {'local_gg': (5.0, 5.0) if t < 200 else (1.8, 1.8)},
+                 online_overrides={('SMOOTHING', 'filt_window_width'): '5'})
     for f in sorted(os.listdir(GOLDEN)):
         print("%-32s %8.2f MB" % (f, os.path.getsize(os.path.join(GOLDEN, f)) / 1e6))
 

@@ -14,6 +14,7 @@ The records are what oracle/gen_golden.py writes to tests/golden/*.npz.
 """
 
 import copy
+import os
 import numpy as np
 
 from . import ref_env
@@ -126,10 +127,22 @@ class SeamRecorder(object):
         self._orig = {}
 
 
-def make_planner(cache_dir, clock=None, track="monteblanco"):
-    """Graph_LTPL instance (reference facade) initialised like the example scripts, visualisation / logging off."""
+def make_planner(cache_dir, clock=None, track="monteblanco", online_overrides=None):
+    """Graph_LTPL instance (reference facade) initialised like the example scripts, visualisation / logging off.
+    ``online_overrides``: {(section, key): value} written into a copy of the reference's online parameter file."""
     graph_ltpl, clock = ref_env.load_reference(clock)
     path_dict = ref_env.default_path_dict(cache_dir, track)
+    if online_overrides:
+        import configparser
+        cp = configparser.ConfigParser()
+        cp.optionxform = str
+        cp.read(path_dict['ltpl_online_param_path'])
+        for (sec, key), val in online_overrides.items():
+            cp.set(sec, key, str(val))
+        mod = os.path.join(cache_dir, "ltpl_config_online_mod.ini")
+        with open(mod, "w") as fh:
+            cp.write(fh)
+        path_dict['ltpl_online_param_path'] = mod
     ltpl_obj = graph_ltpl.Graph_LTPL.Graph_LTPL(path_dict=path_dict, visual_mode=False, log_to_file=False)
     ltpl_obj.graph_init()
     graph_base = ltpl_obj._Graph_LTPL__graph_base
@@ -178,7 +191,7 @@ def run_loop(graph_ltpl, clock, ltpl_obj, path_dict, n_ticks, dt=0.05, dummies=N
         obj_list = get_objects(dummies) if dummies is not None else []
         if extra_objects is not None:
             obj_list = obj_list + list(extra_objects(tick))
-        ltpl_obj.calc_paths(prev_action_id=sel_action, object_list=obj_list, blocked_zones=zones)
+        tick_paths = ltpl_obj.calc_paths(prev_action_id=sel_action, object_list=obj_list, blocked_zones=zones)
         if traj_set[sel_action] is not None:
             pos_est, vel_est = graph_ltpl.testing_tools.src.vdc_dummy.vdc_dummy(
                 pos_est=pos_est,
@@ -186,7 +199,12 @@ def run_loop(graph_ltpl, clock, ltpl_obj, path_dict, n_ticks, dt=0.05, dummies=N
                 last_path=(traj_set[sel_action][0][:, 1:3]),
                 last_vel_course=(traj_set[sel_action][0][:, 5]),
                 iter_time=dt)
-        kw = vel_kwargs(tick) if vel_kwargs is not None else {}
+        kw = {}
+        if vel_kwargs is not None:
+            # ``vel_kwargs(tick)`` or ``vel_kwargs(tick, path_dict)`` -- the latter sees the paths of this tick (Graph_LTPL.calc_paths's
+            # first return value), which a location dependent ``local_gg`` dict has to match row for row (OTH.py:641-646)
+            import inspect
+            kw = vel_kwargs(tick, tick_paths) if len(inspect.signature(vel_kwargs).parameters) >= 2 else vel_kwargs(tick)
         traj_set, traj_id, _ = ltpl_obj.calc_vel_profile(pos_est=pos_est, vel_est=vel_est, **kw)
         exported.append({'sel_action': sel_action, 'pos_est': np.array(pos_est, dtype=float),
                          'vel_est': float(vel_est),
@@ -273,6 +291,10 @@ class TickRecorder(object):
                                'ax_max_machines': np.array(kw['ax_max_machines'], dtype=float),
                                'local_gg': [float(kw['local_gg'][0]), float(kw['local_gg'][1])]
                                if not isinstance(kw['local_gg'], dict) else None,
+                               # location dependent friction: the rows are a function of the path coordinates (friction_map), so the
+                               # replay rebuilds them from ITS paths; kept here: the rows of the first key as a cross-check
+                               'local_gg_first': None if not isinstance(kw['local_gg'], dict)
+                               else np.array(list(kw['local_gg'].values())[0][0], dtype=float),
                                'incl_emerg_traj': bool(kw.get('incl_emerg_traj', False))}
             cur['backup_available'] = getattr(oth, P + 'backup_nodes') is not None
             out = o_vel(oth, **kw)

@@ -17,6 +17,23 @@ import numpy as np
 from helpers import assert_close_rel, assert_xy_close, assert_coeff_close, REL_TOL, KAPPA_FLOOR, load_golden
 
 
+def friction_map(xy):
+    """Location dependent friction used by the 'ggmap' recording (oracle/gen_golden.py) and its replay: rows [ax, ay] as a smooth
+    function of the path coordinates -- grip between 2.6 and 5.4 m/s^2 in patches of ~150 m, ay different from ax."""
+    xy = np.asarray(xy, dtype=float).reshape(-1, 2)
+    a = 4.0 + 1.4 * np.sin(0.021 * xy[:, 0] + 0.7) * np.cos(0.017 * xy[:, 1] - 0.3)
+    return np.column_stack((a, 0.9 * a + 0.35))
+
+
+def local_gg_of_tick(t, path_param):
+    """local_gg argument of calc_vel_profile for a recorded tick: the constant tuple, or (recordings made with a location dependent
+    friction) the dict {key: [rows]} evaluated on ``path_param`` = {key: (rows, 5)} of THIS planner's paths."""
+    va = t['vel_args']
+    if va.get('local_gg') is not None:
+        return tuple(va['local_gg'])
+    return {k: [friction_map(pp[:, 0:2])] for k, pp in path_param.items()}
+
+
 def vehicles_of_tick(t):
     out = []
     for k in range(len(t['obj_radius'])):
@@ -97,8 +114,13 @@ def replay(planner, lat, ticks, scen=0, n_ticks=None, others=None):
                 assert_close_rel(pp[:, 4], epp[:, 4], what="%s/%s el" % (what, k))
                 assert_coeff_close(got['coeff'][k], full['coeff'][k], what="%s/%s coeff" % (what, k))
         va = t['vel_args']
+        lgg = local_gg_of_tick(t, got['path_param'])
+        if isinstance(lgg, dict):
+            first = got['keys'][0]
+            assert_close_rel(lgg[first][0], va['local_gg_first'], what="%s: friction rows of '%s'" % (what, first))
+            seen['ggmap'] = seen.get('ggmap', 0) + 1
         planner.calc_vel_profile([t['pos_est']] * n, va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'],
-                                 local_gg=tuple(va['local_gg']), ax_max_machines=va['ax_max_machines'],
+                                 local_gg=[lgg] * n if isinstance(lgg, dict) else lgg, ax_max_machines=va['ax_max_machines'],
                                  safety_d=va['safety_d'], incl_emerg_traj=va['incl_emerg_traj'])
         traj, ids, ref = planner.trajectories(scen)
         er = t['ref_idx']
