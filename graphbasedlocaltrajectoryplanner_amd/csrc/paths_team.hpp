@@ -58,18 +58,6 @@ __device__ __forceinline__ const T& at(const T* p, int i)
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + (unsigned)((unsigned)i * (unsigned)sizeof(T)));
 }
 
-// c, or +inf where bit `lane` of `mask` is set: two v_cndmask_b32 that take the 64-bit lane mask (a ballot kept in an SGPR pair) as their
-// select operand. Written as (mask >> lane) & 1 the compiler materialises the bit per lane first (two v_and, a 64-bit compare, then the
-// two selects): 7 instructions per edge chunk and filter in the sweep's inner loop.
-__device__ __forceinline__ double sel_inf(double c, unsigned long long mask)
-{
-    int lo = __double2loint(c), hi = __double2hiint(c);
-    const int inf_hi = 0x7ff00000;
-    asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(lo) : "v"(lo), "s"(mask));
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(hi), "v"(inf_hi), "s"(mask));
-    return __hiloint2double(hi, lo);
-}
-
 struct TeamLds {                 // dynamic-LDS plan (byte offsets), computed once per lattice on the host
     int kpad, hmax, etmax;
     int words_blocked, words_zone;
@@ -418,6 +406,8 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
         vtile = __builtin_amdgcn_readfirstlane(vtile);
     }
 
+    long long* const adbg = a == 0 ? lp.dbg : nullptr;        // experiment build: phase stamps 8 .. 13 of the first primitive's assembly
+    dbg_stamp(adbg, 8);
     // backtrack along the LDS parent table (lane 0), count exact ties on the way; rank of the in-edge -> pedge (as rank
     // first, resolved to edge ids by all lanes afterwards: the global in_ptr loads are then independent)
     bool staged = false;
@@ -515,6 +505,7 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
     }
     wave_sync_lds();
 
+    dbg_stamp(adbg, 9);
     // gather: rows per edge, node row indices, knots, element lengths (:260-297)
     int run = 0;
     for (int i0 = 0; i0 < N; i0 += 64) {
@@ -539,6 +530,7 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
     for (int i = lane; i <= N; i += 64) o_idx[i] = pidx[i];
     if (lane == 0) out.n_pts[slot] = n_pts;
 
+    dbg_stamp(adbg, 10);
     // tph.calc_splines (main_online_path_gen.py:299-309) as the equivalent clamped C2 spline in the cumulated
     // el_lengths parameter: tridiagonal system in the knot slopes m_i, Thomas algorithm. Everything that does not depend
     // on the elimination order is prepared by all lanes (reciprocal segment lengths, diagonal, right-hand sides of x and
@@ -613,6 +605,7 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
     }
     wave_sync_lds();
 
+    dbg_stamp(adbg, 11);
     // coefficients per segment, t in [0, 1]: a0 = k_i, a1 = m_i h, a2 = 3 d - 2 T0 - T1, a3 = -2 d + T0 + T1
     for (int i = lane; i < N; i += 64) {
         const double h = el[i];
@@ -628,6 +621,7 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
         }
     }
 
+    dbg_stamp(adbg, 12);
     // tph.interp_splines(stepnum_fixed) + tph.calc_head_curv_an (:311-322); column 4 keeps the offline spacing
     for (int r = lane; r < n_pts; r += 64) {
         int lo = 0, hi = N;                                // segment i with pidx[i] <= r < pidx[i+1] (last: <=)
@@ -668,6 +662,7 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
         }
         if (vel_x) { vel_x[r] = x; vel_y[r] = y; }
     }
+    dbg_stamp(adbg, 13);
     if (out.job_cnt && lane == 0) out.job_slot[vtile] = make_int2(slot, n_pts);
     wp.n_pts = n_pts; wp.n_nodes = J + 1;
     { int gl = sc.sl + J; if (gl >= L) gl -= L; wp.goal_layer = gl; }
@@ -692,7 +687,7 @@ struct LayerArgs {
 
 template <class P, int NW, int CH, unsigned ACT>
 __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, const TeamLds& lp, unsigned char* smem,
-                                           const LayerArgs& A, const EdgeRegs (&er)[CH], const unsigned long long (&blkm)[CH],
+                                           const LayerArgs& A, const EdgeRegs (&er)[CH], const unsigned blk,
                                            int wave, int lane)
 {
     const unsigned* blocked_bits = reinterpret_cast<const unsigned*>(smem + lp.off_blocked);
@@ -739,7 +734,8 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
         if (ci >= 2 && (ci * NW) * 64 >= A.ne) continue;
         const int dst = sw_dst(er[ci].meta);
         const double c_pr = er[ci].c;                                                  // planning_range: every edge
-        const double c_np = (ACT & ~(1u << F_PR)) ? sel_inf(c_pr, blkm[ci]) : c_pr;   // other filters: unblocked edges
+        // other filters: unblocked edges (bit ci of `blk`: this lane's edge of chunk ci is blocked)
+        const double c_np = ((ACT & ~(1u << F_PR)) && ((blk >> ci) & 1u)) ? INFINITY : c_pr;
 #pragma unroll
         for (int f = 0; f < NFILT; ++f) {
             if (!((ACT >> f) & 1u)) continue;
@@ -889,7 +885,6 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int L = lat.L;
     constexpr int NT = NW * 64;
-    constexpr int CH = NW == 1 ? P::ch1 : 1;          // register chunks of 64 * NW edges prefetched per layer transition
 
     short* pos_layer = reinterpret_cast<short*>(smem + lp.off_pos_layer);
     unsigned char* pos_veh = smem + lp.off_pos_veh;
@@ -1254,9 +1249,17 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     // Edge-parallel (team_layer): the edges of a transition (cost + packed source / destination / rank) are loaded with
     // coalesced loads one layer AHEAD into registers, so that the global latency hides behind the LDS work of the current
     // layer; all active filters share the edge registers.
-    {
+    // The sweeps run on SWN waves of the team (= all of them). Round 3 tried ONE sweeping wave inside the four-wave latency kernels (a
+    // layer = a handful of LDS round trips of one wave instead of four workgroup barriers): SLOWER -- k_tick 77 -> 85 us, C5 (600 layers)
+    // 1.69 -> 2.01 ms. A wave that is alone on its SIMD issues an instruction every ~13 cycles; four waves that split edges and filters
+    // each run a quarter of the instructions, which outweighs the barriers.
+    auto sweeps = [&](auto swn_tag) {
+        constexpr int SWN = decltype(swn_tag)::value;
+        constexpr int SNT = SWN * 64;
+        constexpr int CH = SWN == 1 ? P::ch1 : 1;     // register chunks of 64 * SWN edges prefetched per layer transition
+        const int swave = SWN == 1 ? 0 : wave;
         // initial frontier of every filter that starts at layer 0
-        for (int f = wave; f < NFILT; f += NW) {
+        for (int f = swave; f < NFILT; f += SWN) {
             const bool own_start = (need >> f) & 1u || (f == F_DEF && share_prefix);
             if (!own_start) continue;
             const int K0 = lay[0].y & 0xffff;
@@ -1267,16 +1270,19 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             if (lane == 0) { ts.start_ok[f] = ok; best[f * hm] = -1; }
         }
         EdgeRegs er[CH], en[CH];
-        unsigned long long bm[CH], bn[CH];
-        auto prefetch = [&](int j, EdgeRegs (&dr)[CH], unsigned long long (&db)[CH]) {
+        // blocked flags of the lane's edges, bit ci = chunk ci, for the current (bm) and the next (bn) transition. One VECTOR register
+        // each: as ballots (one scalar pair per chunk and buffer) they were twelve scalar registers that the compiler kept spilling
+        // and reloading inside the layer loop.
+        unsigned bm = 0u, bn = 0u;
+        auto prefetch = [&](int j, EdgeRegs (&dr)[CH], unsigned& db) {
             const int4 ly = lay[j];
             unsigned bw[CH]; int sh[CH];
             const bool look = j > 63 || ((touched >> j) & 1ull);  // uniform: can this transition hold a blocked edge at all?
 #pragma unroll
             for (int ci = 0; ci < CH; ++ci) {
                 bw[ci] = 0u; sh[ci] = 32;
-                if (ci >= 2 && ly.z + ci * NT >= ly.w) continue;   // uniform: chunks 0 and 1 are always loaded, the rest on demand
-                const int e = ly.z + (ci * NW + wave) * 64 + lane;
+                if (ci >= 2 && ly.z + ci * SNT >= ly.w) continue;   // uniform: chunks 0 and 1 are always loaded, the rest on demand
+                const int e = ly.z + (ci * SWN + swave) * 64 + lane;
                 // lanes beyond the transition load the SENTINEL edge (index E: cost +inf, source = destination = node 0): a fixed
                 // number of loads in flight lets the compiler wait precisely, and the sweep needs no "is this lane an edge" select
                 const int ec = e < ly.w ? e : lat.E;
@@ -1286,15 +1292,18 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                     bw[ci] = blocked_bits[el_ >> 5]; sh[ci] = (e < ly.w) ? (el_ & 31) : 32;
                 }
             }
+            db = 0u;
+            if (look) {
 #pragma unroll
-            for (int ci = 0; ci < CH; ++ci) db[ci] = look ? __ballot(sh[ci] < 32 && ((bw[ci] >> (sh[ci] & 31)) & 1u)) : 0ull;
+                for (int ci = 0; ci < CH; ++ci) db |= (sh[ci] < 32 ? ((bw[ci] >> (sh[ci] & 31)) & 1u) : 0u) << ci;
+            }
         };
-        team_sync<NW>();
+        team_sync<SWN>();
         prefetch(1, er, bm);
         // `planning_range` (every edge) and `default` (unblocked edges) only differ from the first transition on that holds a
         // blocked edge: in front of it the planning_range sweep is not run, `default`'s frontier, parents and reachability are
         // copied when the sweeps part (one-wave batch form; a transition with edges beyond the register image parts conservatively)
-        bool pr_shared = NW == 1 && !P::par_global && ((need >> F_PR) & 1u) && (((need >> F_DEF) & 1u) || share_prefix);
+        bool pr_shared = SWN == 1 && !P::par_global && ((need >> F_PR) & 1u) && (((need >> F_DEF) & 1u) || share_prefix);
         auto copy_def_to_pr = [&](int jn, int buf) {          // layers [0, jn) are complete, frontier of layer jn - 1 in buffer `buf`
             for (int n = lane; n < kpad; n += 64) dist[(size_t)(F_PR * 2 + buf) * kpad + n] = dist[(size_t)(F_DEF * 2 + buf) * kpad + n];
             const int roww = kpad * P::par_entry / 4;           // 4-byte words per layer row (kpad is a multiple of 4)
@@ -1303,7 +1312,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             for (int w = roww + lane; w < jn * roww; w += 64) p0[w] = p1[w];
             for (int r = lane; r < jn; r += 64) best[F_PR * hm + r] = best[F_DEF * hm + r];
             if (lane == 0) ts.start_ok[F_PR] = ts.start_ok[F_DEF];
-            team_sync<NW>();
+            team_sync<SWN>();
         };
         // The layer loop is split into RUNS of layers that share one configuration (set of advancing filters, `planning_range` still
         // riding on `default` or not): the per-layer decisions (which filters advance, first own layer of left / right, ...) are taken
@@ -1331,8 +1340,9 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
         };
         auto rotate = [&]() {
 #pragma unroll
-            for (int ci = 0; ci < CH; ++ci) { er[ci] = en[ci]; bm[ci] = bn[ci]; }
-            team_sync<NW>();
+            for (int ci = 0; ci < CH; ++ci) er[ci] = en[ci];
+            bm = bn;
+            team_sync<SWN>();
         };
         // layers j0 .. j1 for the compile-time filter set of `act_tag`; stops in front of the first layer that needs something else:
         // why = 1: `planning_range` has to part from `default` here (a blocked edge, or edges beyond the register image),
@@ -1343,16 +1353,11 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             int j = j0;
             for (; j <= j1; ++j) {
                 const int4 ly = lay[j];
-                if (riding) {
-                    unsigned long long anyb = 0ull;
-#pragma unroll
-                    for (int ci = 0; ci < CH; ++ci) anyb |= bm[ci];
-                    if (anyb != 0ull || ly.w - ly.z > CH * NT) { why = 1; break; }
-                }
+                if (riding) { if (__ballot(bm != 0u) != 0ull || ly.w - ly.z > CH * SNT) { why = 1; break; } }
                 if constexpr (!P::fixed) { if ((ly.y & 0xffff) > 64) { why = 2; break; } }
                 const LayerArgs A = layer_args(j, ly, from_def && j == j0);
                 if (j < H) prefetch(j + 1, en, bn);                // global loads in flight during this layer's LDS work
-                team_layer<P, NW, CH, ACT>(lat, sc, lp, smem, A, er, bm, wave, lane);
+                team_layer<P, SWN, CH, ACT>(lat, sc, lp, smem, A, er, bm, swave, lane);
                 rotate();
             }
             return j;
@@ -1361,7 +1366,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
         auto serial_layer = [&](int j, unsigned actm, bool from_def) {
             const LayerArgs A = layer_args(j, lay[j], from_def);
             if (j < H) prefetch(j + 1, en, bn);
-            for (int f = wave; f < NFILT; f += NW) {
+            for (int f = swave; f < NFILT; f += SWN) {
                 if (!((actm >> f) & 1u)) continue;
                 const int fprev = (A.from_def && (f == F_LEFT || f == F_RIGHT)) ? F_DEF : f;
                 double* dcur = dist + (size_t)(f * 2 + A.cur) * kpad;
@@ -1395,11 +1400,8 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                 default:
                     // riding `planning_range` parts in front of a layer that holds blocked edges here as well
                     if (pr_shared) {
-                        unsigned long long anyb = 0ull;
-#pragma unroll
-                        for (int ci = 0; ci < CH; ++ci) anyb |= bm[ci];
                         const int4 ly = lay[j];
-                        if (anyb != 0ull || ly.w - ly.z > CH * NT) { jn = j; why = 1; break; }
+                        if (__ballot(bm != 0u) != 0ull || ly.w - ly.z > CH * SNT) { jn = j; why = 1; break; }
                     }
                     serial_layer(j, actm, from_def); jn = j + 1; break;
             }
@@ -1412,12 +1414,15 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
         // goal node of the last layer for every filter that reached it (virtual goal edges, GraphBase.py:188-194)
         if (!LTPL_ABLATED(lp, 2)) {
             const int4 lyH = lay[H];
-            for (int f = wave; f < NFILT; f += NW)
+            for (int f = swave; f < NFILT; f += SWN)
                 if (((need >> f) & 1u) && best[f * hm + H] == -2) {
                     const int g = team_goal(lat, dist + (size_t)(f * 2 + (H & 1)) * kpad, lyH.x, lyH.y & 0xffff, lane);
                     if (lane == 0) best[f * hm + H] = g;
                 }
         }
+    };
+    sweeps(std::integral_constant<int, NW>());
+    {
         if (share_prefix && wave == 0 && lane == 0) { ts.start_ok[F_LEFT] = ts.start_ok[F_DEF]; ts.start_ok[F_RIGHT] = ts.start_ok[F_DEF]; }
         team_sync<NW>();
     }
