@@ -26,6 +26,26 @@ _ARRAYS = ("nodes_in_layer", "raceline_index", "s_raceline", "refline", "racelin
            "edge_src", "edge_cost", "edge_len", "edge_coeff", "samp_ptr", "samples", "glob_rl")
 
 
+NO_VIRT_GOAL_STEP = 1.0e12
+
+
+def goal_order_cost(raceline_index, nodes_in_layer):
+    """Goal costs that make the virtual-goal search pick the node ``GraphBase.search_graph_layer`` picks WITHOUT virtual goal nodes
+    (``virt_goal_n=False``, params/ltpl_config_offline.ini:25; GraphBase.py:896-927): there the end layer's nodes are tried one by one
+    -- the race-line node first, then the smaller indices down to 0, then the larger ones upwards -- and the first node a path
+    reaches wins. A cost of ``NO_VIRT_GOAL_STEP * (position in that order)`` per node, twelve orders of magnitude above any path
+    cost, makes "cheapest path + goal cost" choose exactly that node; the path TO it is the same shortest path in both forms. (Where
+    a filter has removed a node of the end layer the reference does not skip it: it raises or stops trying -- an error path that is
+    not reproduced: removed nodes are simply unreachable here.)"""
+    rl = np.asarray(raceline_index, dtype=np.int64)
+    K = np.asarray(nodes_in_layer, dtype=np.int64)
+    out = []
+    for l in range(len(K)):
+        n = np.arange(K[l])
+        out.append(np.where(n <= rl[l], rl[l] - n, n).astype(np.float64) * NO_VIRT_GOAL_STEP)
+    return np.concatenate(out) if out else np.zeros(0)
+
+
 class Lattice(object):
     """Immutable SoA lattice. All float arrays are C-contiguous float64, all index arrays int32."""
 
@@ -201,11 +221,7 @@ class Lattice(object):
         Build the SoA lattice from a (reference) ``GraphBase`` through its public API only: ``get_edges`` (648),
         ``get_edge`` (444), ``get_node_info`` (221) and the public attributes of GraphBase.py:93-119.
         """
-        if not getattr(gb, "virt_goal_node", True):
-            # GraphBase.search_graph_layer's else-branch (GraphBase.py:896-927: race-line node first, then its neighbours one by
-            # one) is a different search; this backend always searches to the virtual goal vertex of the end layer
-            raise ValueError("lattices built with virt_goal_n=False (params/ltpl_config_offline.ini:25) are not supported: "
-                             "the backend implements the virtual-goal-node search only")
+        virt = bool(getattr(gb, "virt_goal_node", True))
         L = int(gb.num_layers)
         nodes_in_layer = np.array([gb.nodes_in_layer[l] for l in range(L)], dtype=np.int32)
         layer_off = np.zeros(L + 1, dtype=np.int64)
@@ -224,6 +240,8 @@ class Lattice(object):
                 node_psi[v] = psi
                 # GraphBase.py:188 (same operation order)
                 vgoal[v] = abs(int(rl_idx[l]) - n) * gb.lat_resolution * gb.virt_goal_node_cost
+        if not virt:
+            vgoal = goal_order_cost(rl_idx, nodes_in_layer)
 
         edges = gb.get_edges()
         recs = []

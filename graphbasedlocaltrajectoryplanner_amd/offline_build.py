@@ -149,8 +149,6 @@ def edges_on_device(lib, device=-1):
 def build_lattice(track: dict, cfg: dict, evaluate_edges) -> Lattice:
     """``track``: arrays of ``import_track_csv``; ``cfg``: offline parameters; ``evaluate_edges``: the per-edge arithmetic
     (``edges_on_device`` in the product)."""
-    if not cfg.get("virt_goal_n", True):
-        raise ValueError("virt_goal_n=False is not supported (the backend searches to the virtual goal vertex only)")
     if cfg["lat_offset"] <= 0:
         raise ValueError('Requested to small lateral offset! A lateral offset larger than zero must be allowed!')
     refline, normvec, alpha = np.asarray(track["refline"], float), np.asarray(track["normvec"], float), np.asarray(track["alpha"], float)
@@ -265,6 +263,11 @@ def build_lattice(track: dict, cfg: dict, evaluate_edges) -> Lattice:
     samp_ptr = np.concatenate(([0], np.cumsum(ns)))
     samples = np.concatenate([ev["samples"][e, :n, :] for e, n in zip(order, ns)], axis=0) if order.size else np.zeros((0, 5))
     vgoal = np.abs(rl_idx[node_layer] - (np.arange(V) - layer_off[node_layer])) * res * cfg["w_virt_goal"]
+    if not cfg.get("virt_goal_n", True):
+        # no virtual goal nodes (params/ltpl_config_offline.ini:25): GraphBase.search_graph_layer tries the end layer's nodes in a fixed
+        # order instead (GraphBase.py:896-927); goal costs that reproduce that choice: lattice.goal_order_cost
+        from .lattice import goal_order_cost
+        vgoal = goal_order_cost(rl_idx, nodes_in_layer)
     return Lattice(num_layers=L, lat_resolution=res, lat_offset=cfg["lat_offset"], veh_width=cfg["veh_width"],
                    veh_length=cfg["veh_length"], sampled_resolution=cfg["stepsize_approx"], vel_decrease_lat=cfg["vel_decrease_lat"],
                    min_plan_horizon=cfg["min_plan_horizon"], plan_horizon_mode=cfg["plan_horizon_mode"], closed=closed,

@@ -98,17 +98,27 @@ class StaticObjects(object):
 
 
 def record_ticks(name, n_ticks, dummies_f, zones, vel_kwargs=None, action_pref=("right", "left", "straight", "follow"),
-                 full_every=25, online_overrides=None):
+                 full_every=25, online_overrides=None, offline_overrides=None, seams=False, expect_lattice=None):
     """``online_overrides``: {(section, key): value} applied to a COPY of params/ltpl_config_online.ini (the reference reads the file
     named in path_dict; the reference tree itself is read-only)."""
-    gl, clock, ltpl_obj, gb, path_dict = rs.make_planner(CACHE, online_overrides=online_overrides)
+    gl, clock, ltpl_obj, gb, path_dict = rs.make_planner(CACHE, online_overrides=online_overrides, offline_overrides=offline_overrides)
+    if expect_lattice is not None:
+        expect_lattice(Lattice.from_graph_base(gb))
     seam = rs.SeamRecorder(gl, gb)
     rec = rs.TickRecorder(gl, clock, seam)
-    rs.run_loop(gl, clock, ltpl_obj, path_dict, n_ticks=n_ticks, dt=0.05, dummies=dummies_f(gl), zones=zones,
-                vel_kwargs=vel_kwargs, action_pref=action_pref)
+    try:
+        rs.run_loop(gl, clock, ltpl_obj, path_dict, n_ticks=n_ticks, dt=0.05, dummies=dummies_f(gl), zones=zones,
+                    vel_kwargs=vel_kwargs, action_pref=action_pref)
+    except ValueError as e:
+        # (virt_goal_n=False: GraphBase.search_graph_layer looks up end-layer nodes that do not exist, GraphBase.py:917 -- the
+        #  reference itself ends the run there; the ticks up to that point are complete)
+        print("%s: the reference raised after %d ticks: %s" % (name, len(rec.ticks), e))
     ticks = rec.export(full_every=full_every)
     rec.uninstall()
     seam.uninstall()
+    if seams:
+        sel = select_path_ticks(seam.path_calls, every=12)
+        save_records(os.path.join(GOLDEN, name + "_path_calls.npz"), [dict(seam.path_calls[i], tick=i) for i in sel])
     save_records(os.path.join(GOLDEN, name + "_ticks.npz"), ticks, packed=True)
     import collections
     print("%s: %d ticks, %d with full arrays; offered sets %s" % (
@@ -146,6 +156,16 @@ def main_ticks(only=None):
                  vel_kwargs=lambda t, paths: {'local_gg': {k: [friction_map(v[0][:, 0:2])] for k, v in paths.items()},
                                               'gg_scale': 1.0 if t < 350 else 0.8, 'incl_emerg_traj': (t % 4 == 0)},
                  action_pref=("left", "right", "straight", "follow"))
+    # LATTICE.virt_goal_n = False (stock: True): no virtual goal vertices, GraphBase.search_graph_layer tries the end layer's nodes one
+    # by one (GraphBase.py:896-927). Nodes, edges and costs of the lattice are those of the stock build (asserted); only the goal rule
+    # differs, which the product expresses as goal costs (lattice.goal_order_cost).
+    def same_but_goal(lat_nv):
+        from graphbasedlocaltrajectoryplanner_amd.lattice import goal_order_cost
+        for k in ("in_ptr", "edge_src", "edge_cost", "samp_ptr", "samples", "node_pos", "raceline_index", "nodes_in_layer"):
+            assert np.array_equal(getattr(lat_nv, k), getattr(lat, k)), k
+        assert np.array_equal(lat_nv.vgoal_cost, goal_order_cost(lat.raceline_index, lat.nodes_in_layer))
+    record_ticks("novirt", 700, lambda gl: rs.opponents_c2(gl, 8), rs.ZONE_EXAMPLE, offline_overrides={('LATTICE', 'virt_goal_n'): 'False'},
+                 seams=True, expect_lattice=same_but_goal)
     # SMOOTHING.filt_window_width = 5 (stock: 1): tph.conv_filt on every exported velocity profile (OTH.py:928-930) and on the backup
     # profile (:988-990; the friction drop at tick 200 triggers the backup branch)
     record_ticks("filt5", 320, lambda gl: [Dummy(gl)(dynamic=True, vel_scale=0.4, s0=200.0)], None,

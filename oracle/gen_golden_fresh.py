@@ -204,5 +204,57 @@ def main():
     print("%d records, %.2f MB" % (len(recs), os.path.getsize(os.path.join(GOLDEN, "fresh_ticks.npz")) / 1e6))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "novirt"):
     main()
+
+
+def main_novirt():
+    """Seam-(1) calls on a lattice built WITHOUT virtual goal nodes (LATTICE.virt_goal_n = False) whose END LAYER is obstructed around
+    its race-line node: GraphBase.search_graph_layer then walks the end layer's nodes in its fixed order (GraphBase.py:896-927) and the
+    goal is NOT the one the virtual-goal search would pick. -> tests/golden/novirt_goal_calls.npz (SeamRecorder format).
+    Calls in which the reference itself raises (it looks up end-layer nodes that do not exist, GraphBase.py:917) are left out."""
+    warnings.simplefilter("ignore")
+    gl, clock, ltpl_obj, gb, path_dict = rs.make_planner(CACHE, offline_overrides={('LATTICE', 'virt_goal_n'): 'False'})
+    lat = Lattice.from_graph_base(gb)
+    rec = rs.SeamRecorder(gl, gb)
+    mopg = gl.online_graph.src.main_online_path_gen.main_online_path_gen          # the recorder's wrapper
+    rng = np.random.default_rng(99)
+    L = lat.num_layers
+    raised = 0
+    # start layers whose END layer has its race-line node well inside (room on both sides): there the fixed order "smaller indices
+    # first" and the virtual-goal rule "closest to the race line" disagree when the obstruction sits on the side of the smaller indices
+    inner = [l for l in range(L) if 9 <= int(lat.raceline_index[lat.horizon_end_layer(l)]) <= int(lat.nodes_in_layer[lat.horizon_end_layer(l)]) - 6]
+    for i in range(90):
+        sl = int(inner[int(rng.integers(0, len(inner)))]) if i % 2 == 0 else int(rng.integers(0, L))
+        sn = int(lat.raceline_index[sl])
+        el = lat.horizon_end_layer(sl)
+        rl = int(lat.raceline_index[el])
+        K = int(lat.nodes_in_layer[el])
+        veh = []
+        # one or two discs on / beside the end layer's race-line node; offsets biased to the side of the smaller indices
+        for off in ([-2], [-1], [1], [-2, -1], [0, -3], [-3])[i % 6]:
+            n = int(np.clip(rl + off, 0, K - 1))
+            p = lat.node_pos[lat.layer_off[el] + n]
+            veh.append(Veh(p, float(rng.uniform(0.6, 2.2)), np.asarray(p, dtype=float).reshape(1, 2) + 0.2, 0.0))
+        # an opponent closer by on every third call: the [follow, left, right] template with an obstructed goal layer
+        if i % 3 == 2:
+            ol = (sl + 5) % L
+            p = lat.node_pos[lat.layer_off[ol] + int(lat.raceline_index[ol])]
+            veh.insert(0, Veh(p, 2.0, np.asarray(p, dtype=float).reshape(1, 2) + 0.3, 8.0))
+        gb.remove_nodes_filter(layer_ids=[], node_ids=[], applied_filter="overtaking_zones", base=None)
+        n_before = len(rec.path_calls)
+        try:
+            mopg(graph_base=gb, start_node=[sl, sn], obj_veh=veh, obj_zone=[DoneZone()], last_action_id=None, max_solutions=1,
+                 const_path_seg=None, pos_est=None, last_solution_nodes=None, w_last_edges=W_LAST)
+        except ValueError:
+            raised += 1
+            del rec.path_calls[n_before:]
+    rec.uninstall()
+    calls = [dict(c, tick=k) for k, c in enumerate(rec.path_calls)]
+    off = sum(int(c['out']['nodes'][k][-1][1] != lat.raceline_index[c['out']['nodes'][k][-1][0]]) for c in calls for k in c['out']['keys'])
+    save_records(os.path.join(GOLDEN, "novirt_goal_calls.npz"), calls, packed=True)
+    print("novirt goal calls: %d kept, %d raised in the reference, %d paths end off the race line" % (len(calls), raised, off))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "novirt":
+    main_novirt()

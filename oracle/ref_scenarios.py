@@ -127,7 +127,7 @@ class SeamRecorder(object):
         self._orig = {}
 
 
-def make_planner(cache_dir, clock=None, track="monteblanco", online_overrides=None):
+def make_planner(cache_dir, clock=None, track="monteblanco", online_overrides=None, offline_overrides=None):
     """Graph_LTPL instance (reference facade) initialised like the example scripts, visualisation / logging off.
     ``online_overrides``: {(section, key): value} written into a copy of the reference's online parameter file."""
     graph_ltpl, clock = ref_env.load_reference(clock)
@@ -143,6 +143,21 @@ def make_planner(cache_dir, clock=None, track="monteblanco", online_overrides=No
         with open(mod, "w") as fh:
             cp.write(fh)
         path_dict['ltpl_online_param_path'] = mod
+    if offline_overrides:
+        # a modified copy of the OFFLINE parameter file: its md5 keys the graph cache (main_offline_callback.py:57-68), so the
+        # variant gets its own pickle next to the stock one
+        import configparser
+        cp = configparser.ConfigParser()
+        cp.optionxform = str
+        cp.read(path_dict['ltpl_offline_param_path'])
+        tag = "_".join("%s%s" % (k, v) for (_, k), v in sorted(offline_overrides.items()))
+        for (sec, key), val in offline_overrides.items():
+            cp.set(sec, key, str(val))
+        mod = os.path.join(cache_dir, "ltpl_config_offline_%s.ini" % tag)
+        with open(mod, "w") as fh:
+            cp.write(fh)
+        path_dict['ltpl_offline_param_path'] = mod
+        path_dict['graph_store_path'] = os.path.join(cache_dir, "stored_graph_%s_%s.pckl" % (track, tag))
     ltpl_obj = graph_ltpl.Graph_LTPL.Graph_LTPL(path_dict=path_dict, visual_mode=False, log_to_file=False)
     ltpl_obj.graph_init()
     graph_base = ltpl_obj._Graph_LTPL__graph_base
