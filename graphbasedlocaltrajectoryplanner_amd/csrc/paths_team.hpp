@@ -374,42 +374,17 @@ __device__ LTPL_RESWEEP_ATTR void team_resweep(const DevLat& lat, const DevPaths
 #else
 #define LTPL_ASSEMBLE_ATTR __forceinline__
 #endif
+// ---- backtrack: node per layer along the parent tables -> pidx[0 .. J] (LDS path scratch `pw`), for 2-byte parent entries also the
+//      in-edge ranks -> pedge[0 .. J-1]; writes out.n_nodes / n_ties of the slot
 template <class P>
-__device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const Scen& sc,
-                                  const TeamLds& lp, unsigned char* smem, int a, int f, int J, int name, int reduced,
-                                  int jcl, bool share_prefix, int lane, unsigned char* pw,
-                                  double* vel_kappa, double* vel_len, double* vel_x, double* vel_y, int vtile_in)
+__device__ __forceinline__ void team_backtrack(const DevPathsOut& out, const TeamLds& lp, unsigned char* smem, int slot, int f, int J,
+                                               int jcl, bool share_prefix, int lane, unsigned char* pw)
 {
-    const int L = lat.L, hm = P::hmax(lp), N = J, s = sc.s;
-    const int slot = s * LTPL_MAX_ACTIONS + a;
+    const int hm = P::hmax(lp);
     const unsigned char* par = par_base<P>(lp, smem);
     const int* best = reinterpret_cast<const int*>(smem + P::off_best(lp));
     double* kx = reinterpret_cast<double*>(pw);
-    double* ky = kx + hm; double* el = ky + hm; double* mx = el + hm; double* my = mx + hm;
-    double* cpx = my + hm; double* cpy = cpx + hm;
-    int* pedge = reinterpret_cast<int*>(cpy + hm); int* pidx = pedge + hm + 1;
-    int* o_nodes = out.nodes + (size_t)slot * out.cap_nodes;
-    int* o_idx = out.node_idx + (size_t)slot * out.cap_nodes;
-    double* o_coeff = out.coeff + (size_t)slot * out.cap_nodes * 8;
-    double* o_pp = out.path_param + (size_t)slot * out.cap_pts * 5;
-    WavePath wp; wp.valid = 1; wp.name = name; wp.reduced = reduced;
-    // batch pipeline: take a job of the velocity stage (class 0 = generic profile, 1 = follow); the planes are tiled by job
-    // (one-wave batch form: the job indices of all paths of the scenario were reserved with ONE atomic in the decision phase --
-    //  vtile_in; the four-wave forms reserve per path here)
-    int vtile = vtile_in;
-    if (out.job_cnt && vtile_in < 0) {
-        if (lane == 0) {
-            const int cls = name == LTPL_ACT_FOLLOW ? 1 : 0;
-            const int jb = atomicAdd(&out.job_cnt[cls], 1);
-            vtile = cls ? out.n_slots_pad + jb : jb;
-        }
-        vtile = __builtin_amdgcn_readfirstlane(vtile);
-    }
-
-    long long* const adbg = a == 0 ? lp.dbg : nullptr;        // experiment build: phase stamps 8 .. 13 of the first primitive's assembly
-    dbg_stamp(adbg, 8);
-    // backtrack along the LDS parent table (lane 0), count exact ties on the way; rank of the in-edge -> pedge (as rank
-    // first, resolved to edge ids by all lanes afterwards: the global in_ptr loads are then independent)
+    int* pedge = reinterpret_cast<int*>(kx + 7 * hm); int* pidx = pedge + hm + 1;
     bool staged = false;
     if constexpr (P::par_global) {
         // Parent tables in global memory: a lane-0 chase would pay one global round trip per layer. Blocks of 64 table rows
@@ -474,13 +449,35 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
         out.n_ties[slot] = ties;
     }
     wave_sync_lds();
+}
+
+// ---- everything behind the backtrack: edge look-up, gather, spline, re-sampling (main_online_path_gen.py:260-328). Needs the path's
+//      nodes in pidx[0 .. N] (and, with `by_rank`, the in-edge ranks in pedge[0 .. N-1]) and nothing else of the team's LDS. (Round 3
+//      ran it as a kernel of its own over the slots of a batch -- one wave per action slot, 78 VGPRs, the one-wave path kernel ending
+//      behind the backtrack: 31.5 instead of 33.0 M ticks/s. Fused, the instruction-heavy assembly of one scenario overlaps the
+//      latency-bound sweeps of its neighbours on the SIMD; apart, the hand-over and the second launch cost more than the higher
+//      occupancy returns.) Returns the number of path samples.
+__device__ __forceinline__ int team_assemble_rest(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, int s, int sl, int flags,
+                                                  int hm, bool by_rank, int slot, int N, int lane, unsigned char* pw, long long* adbg,
+                                                  bool skip_pp, double* vel_kappa, double* vel_len, double* vel_x, double* vel_y, int vtile)
+{
+    const int L = lat.L;
+    double* kx = reinterpret_cast<double*>(pw);
+    double* ky = kx + hm; double* el = ky + hm; double* mx = el + hm; double* my = mx + hm;
+    double* cpx = my + hm; double* cpy = cpx + hm;
+    int* pedge = reinterpret_cast<int*>(cpy + hm); int* pidx = pedge + hm + 1;
+    int* o_nodes = out.nodes + (size_t)slot * out.cap_nodes;
+    int* o_idx = out.node_idx + (size_t)slot * out.cap_nodes;
+    double* o_coeff = out.coeff + (size_t)slot * out.cap_nodes * 8;
+    double* o_pp = out.path_param + (size_t)slot * out.cap_pts * 5;
+    wave_sync_lds();
     for (int i0 = 0; i0 <= N; i0 += 64) {
         const int i = i0 + lane;
         int node = 0, e = 0;
         if (i <= N) node = pidx[i];
         if (i >= 1 && i <= N) {
-            int b = sc.sl + i; if (b >= L) b -= L;
-            if constexpr (P::par_entry == 2) e = at(lat.in_ptr, lat.layer_off[b] + node) + pedge[i - 1];
+            int b = sl + i; if (b >= L) b -= L;
+            if (by_rank) e = at(lat.in_ptr, lat.layer_off[b] + node) + pedge[i - 1];
             else {
                 // the table only holds the source NODE: look the in-edge (source -> node) up in the node's CSC segment
                 // (sorted by source): its first 16 sources in two (unaligned) 8-byte loads, longer segments serially
@@ -538,7 +535,7 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
     {
         // end slopes: tangent = (cos(psi + pi/2), sin(psi + pi/2)) = (-sin psi, cos psi); lane 0 <- psi_s, lane 1 <- psi_e
         double ang = 0.0;
-        if (lane == 0) ang = (sc.flags & LTPL_FLAG_HAS_PSI_S) ? in.psi_s[s] : el[N];
+        if (lane == 0) ang = (flags & LTPL_FLAG_HAS_PSI_S) ? in.psi_s[s] : el[N];
         if (lane == 1) ang = cpy[0];
         double sn, cs;
         sincos(ang, &sn, &cs);
@@ -647,7 +644,7 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
         if (psi_r >= D_PI) psi_r -= 2.0 * D_PI;
         const double kap = (xd * ydd - yd * xdd) * fast_rcp(q * sqrt(q));
         const double len_r = at(lat.slen, pedge[i] + k);
-        if (!LTPL_ABLATED(lp, 16))           // (experiment build: LTPL_ABLATE bit 16 drops the path_param stores, timing only)
+        if (!skip_pp)           // (experiment build: LTPL_ABLATE bit 16 drops the path_param stores, timing only)
         { store2_u(row, x, y); store2_u(row + 2, psi_r, kap); row[4] = len_r; }
         if (vel_kappa) { vel_kappa[r] = kap; vel_len[r] = len_r; }
         if (out.vke) {                                    // planes of the batch velocity stage, blocked by 8 rows (kep_base / kep_row):
@@ -664,9 +661,41 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
     }
     dbg_stamp(adbg, 13);
     if (out.job_cnt && lane == 0) out.job_slot[vtile] = make_int2(slot, n_pts);
+    wave_sync_lds();
+    return n_pts;
+}
+
+template <class P>
+__device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const Scen& sc,
+                                  const TeamLds& lp, unsigned char* smem, int a, int f, int J, int name, int reduced,
+                                  int jcl, bool share_prefix, int lane, unsigned char* pw,
+                                  double* vel_kappa, double* vel_len, double* vel_x, double* vel_y, int vtile_in)
+{
+    const int hm = P::hmax(lp), s = sc.s;
+    const int slot = s * LTPL_MAX_ACTIONS + a;
+    WavePath wp; wp.valid = 1; wp.name = name; wp.reduced = reduced;
+    // batch pipeline: take a job of the velocity stage (class 0 = generic profile, 1 = follow); the planes are tiled by job
+    // (one-wave batch form: the job indices of all paths of the scenario were reserved with ONE atomic in the decision phase --
+    //  vtile_in; the four-wave forms reserve per path here)
+    int vtile = vtile_in;
+    if (out.job_cnt && vtile_in < 0) {
+        if (lane == 0) {
+            const int cls = name == LTPL_ACT_FOLLOW ? 1 : 0;
+            const int jb = atomicAdd(&out.job_cnt[cls], 1);
+            vtile = cls ? out.n_slots_pad + jb : jb;
+        }
+        vtile = __builtin_amdgcn_readfirstlane(vtile);
+    }
+    long long* const adbg = a == 0 ? lp.dbg : nullptr;        // experiment build: phase stamps 8 .. 13 of the first primitive's assembly
+    dbg_stamp(adbg, 8);
+    team_backtrack<P>(out, lp, smem, slot, f, J, jcl, share_prefix, lane, pw);
+    const int end_node = reinterpret_cast<const int*>(reinterpret_cast<double*>(pw) + 7 * hm)[hm + 1 + J];      // pidx[J]
+    const int n_pts = team_assemble_rest(lat, in, out, s, sc.sl, sc.flags, hm, P::par_entry == 2, slot, J, lane, pw, adbg,
+                                         LTPL_ABLATED(lp, 16), vel_kappa, vel_len, vel_x, vel_y, vtile);
+    const int L = lat.L;
     wp.n_pts = n_pts; wp.n_nodes = J + 1;
     { int gl = sc.sl + J; if (gl >= L) gl -= L; wp.goal_layer = gl; }
-    wp.end_node = best[f * hm + J] & 0xffff;
+    wp.end_node = end_node;
     wave_sync_lds();
     return wp;
 }
