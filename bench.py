@@ -216,6 +216,37 @@ def dropin_latency(hip, lat, max_ticks):
     return us, keys_ok
 
 
+def closed_loop_rate(hip, lat, n_planners, n_ticks):
+    """State-carrying closed loop of a BATCH of planners (ltpl_planner_*: the OnlineTrajectoryHandler state machine in C++ behind the ABI,
+    one seam-(1) launch and one seam-(2) launch per tick for all planners): every planner is fed the recorded inputs of the C2 loop and
+    carries its own iterative memory from tick to tick. Host-inclusive (Python packing, H2D, kernels, D2H of the path slabs, host state
+    machine). Returns planner-ticks per second and whether planner 0 still offers the recorded action sets."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle.fixture_io import load_records          # fixture reader only (the recording is the input stream)
+    import planner_replay as pr
+    from graphbasedlocaltrajectoryplanner_amd.planner import Planner
+    ticks = load_records(os.path.join(ROOT, "tests", "golden", "c2_ticks.npz"))[:n_ticks + 10]
+    n = n_planners
+    pl = Planner(hip, n)
+    st = ticks[0]['start']
+    for s_ in range(n):
+        pl.set_start(s_, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+    ok, t_sum = True, 0.0
+    for k, t in enumerate(ticks):
+        veh = [pr.vehicles_of_tick(t)] * n
+        zg = [pr.zone_gids_of_tick(lat, t)] * n
+        va = t['vel_args']
+        t0 = time.perf_counter()
+        pl.calc_paths([t['action_id_sel']] * n, [t['t']] * n, veh, zg)
+        pl.calc_vel_profile([t['pos_est']] * n, va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'], local_gg=tuple(va['local_gg']),
+                            ax_max_machines=va['ax_max_machines'], safety_d=va['safety_d'], incl_emerg_traj=va['incl_emerg_traj'])
+        if k >= 10:
+            t_sum += time.perf_counter() - t0
+        ok = ok and list(pl.trajectories(0)[0].keys()) == t['vel']['keys']
+    pl.close()
+    return n * (len(ticks) - 10) / t_sum, ok
+
+
 def worker(args):
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -337,6 +368,11 @@ def worker(args):
                                        "what": "ltpl_tick_batch_compact: host buffers in, trajectories [s,x,y,psi,kappa,vx,ax] "
                                                "(115 export rows, Graph_LTPL.py:401-406) packed on the device and DMA-written into "
                                                "page-locked host memory; capacity_slab_* = ltpl_tick_batch with full capacity slabs"}
+            # state-carrying closed loop of a batch of planners (host state machine + two launches per tick): host-bound, reported as is
+            clr, clok = closed_loop_rate(hip, lat, 256, 60)
+            extra["closed_loop"] = {"planner_ticks_per_s": clr, "planners": 256, "ticks": 60, "keys_match_recording": clok,
+                                    "what": "256 planners x 60 consecutive ticks through ltpl_planner_calc_paths / _calc_vel_profile, every "
+                                            "planner carrying its own iterative memory; host-inclusive (packing, PCIe, host state machine)"}
         traffic = read_traffic(args.batch, args.workload)            # measured HBM bytes per launch of the dominant kernel (PMC), or None
         issue_pmc = read_issue(args.batch, args.workload)
         issue = None

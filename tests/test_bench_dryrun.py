@@ -123,6 +123,8 @@ def test_the_line_carries_the_drivers_contract(monkeypatch, capsys):
     assert l["ticks"] == 4 and l["p50"] > 0 and l["device_us"] == pytest.approx(900.0)
     assert l["dropin_ticks"] == 40 and l["dropin_keys_match_recording"] is True
     assert out["extra"]["pcie_inclusive"]["scenarios_per_call"] == 64 and out["extra"]["three_slot_paths_per_tick"] >= 1.0
+    cl = out["extra"]["closed_loop"]
+    assert cl["planners"] == 256 and cl["planner_ticks_per_s"] > 0 and cl["keys_match_recording"] is True
     assert 1.0 <= out["paths_per_tick"] <= 4.0
     # order of the device calls: resident inputs before any run, and the sample re-uploaded for the device-only latency
     assert hip.calls[0] == "batch_upload" and hip.calls.count("batch_upload") == 3
