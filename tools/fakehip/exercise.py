@@ -61,6 +61,7 @@ def exercise(name, lat):
         batch = _capi.PathsBatch(scen, w_last_edges=W)
         res = hip.plan_paths(batch)
         tolerant(lambda: res.action_sets(0, scen[0]['start_node'][0], lat.num_layers))
+        tolerant(lambda: hip.plan_paths_mask(batch))           # + the blocked-edge export (sweep order -> CSC order on the host)
         vplan = rng.uniform(0.0, 60.0, n)
         pos = np.array([lat.node_pos[lat.layer_off[sc['start_node'][0]] + sc['start_node'][1]] for sc in scen])
         vt = _capi.TickVelBatch(_capi.VelParamSet(len_veh=lat.veh_length), n, vplan, vplan + 0.5, pos,
@@ -74,7 +75,7 @@ def exercise(name, lat):
         hip.batch_last_paths_ms()
         hip.batch_run_profile(reps=2)
         hip.batch_download()
-        calls[0] += 8
+        calls[0] += 9
     if name == "monteblanco":
         # capacity maxima of one scenario: 96 vehicles / 192 positions; and one over
         hip.plan_paths(_capi.PathsBatch(crowded(lat, 3, 96, 1, seed=1), w_last_edges=W))

@@ -1,21 +1,17 @@
 #!/bin/bash
-# First gpurun call of a round (one box acquisition for everything that was prepared without a GPU at the end of round 2):
+# First gpurun call of a round (one box acquisition for the checks that need hardware but no profiler):
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_first_call.sh'
 # 1. the regular GPU suite + smoke (must stay green)
-# 2. the GPU legs of the additional tracks (zalazone, millbrook, lvms, berlin, modena) -- never run on hardware so far; under their
-#    own timeout so that a hang cannot take the box down with it
-# 3. the planner / edge-case GPU tests through a build of the library with libstdc++ assertions in its host code
+#    (since round 3 the suite includes the GPU legs of the additional tracks: zalazone, millbrook, lvms, berlin, modena)
+# 2. the planner / edge-case GPU tests through a build of the library with libstdc++ assertions in its host code
 #    (-D_GLIBCXX_ASSERTIONS: vector bounds on REAL kernel results; the sanitizer runs of tools/fakehip only see empty results)
-# 4. closed-loop rate of 256 planners with 1 / 4 / 8 host threads
+# 3. closed-loop rate of 256 planners with 1 / 4 / 8 host threads
 # Logs under gpurun_out/first_call/.
 set -u
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/first_call; mkdir -p $OUT
 timeout 900 python -m pytest tests -m gpu -x -q > $OUT/gpu_suite.log 2>&1; echo "gpu suite: exit $?" | tee $OUT/summary.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke: exit $?" | tee -a $OUT/summary.txt
-LTPL_GPU_OTHER_TRACKS=1 timeout 600 python -m pytest tests/test_other_tracks.py -m gpu -q > $OUT/other_tracks.log 2>&1
-echo "other tracks (GPU legs): exit $?" | tee -a $OUT/summary.txt
-tail -3 $OUT/other_tracks.log | tee -a $OUT/summary.txt
 mkdir -p /tmp/ltpl_assert
 if /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -D_GLIBCXX_ASSERTIONS -Wno-unused-function \
      -o /tmp/ltpl_assert/libltpl_hip.so graphbasedlocaltrajectoryplanner_amd/csrc/ltpl_hip.hip > $OUT/assert_build.log 2>&1; then
@@ -26,5 +22,5 @@ if /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -f
 else
   echo "host assertions build: compile failed (see assert_build.log)" | tee -a $OUT/summary.txt
 fi
-# 4. batches of planners: serial host loops vs the opt-in worker threads
+# 3. batches of planners: serial host loops vs the opt-in worker threads
 for T in 1 4 8; do LTPL_PLANNER_THREADS=$T timeout 300 python tools/planner_batch_rate.py --planners 256 --ticks 200 2>&1 | tail -1 | tee -a $OUT/summary.txt; done
