@@ -1,0 +1,608 @@
+// fleet_dev.hpp -- included at the end of ltpl_hip.hip. The FLEET (include/ltpl_hip.h, ABI v5): N planners whose iterative memory
+// (the state of OnlineTrajectoryHandler) lives in DEVICE memory and is advanced by kernels -- one wave64 per planner runs the
+// wave-uniform state machine of fleet_core.hpp -- around the launches of the path kernel (seam 1) and the velocity kernel (seam 2):
+//
+//   calc_paths        H2D inputs | k_fleet_paths_pre | k_paths | k_fleet_paths_post
+//   calc_vel_profile  H2D inputs | k_fleet_vel_a | k_vel_profile (<= 5 jobs per planner) | k_fleet_vel_b | k_vel_profile (backup brake jobs)
+//                     | k_fleet_vel_c | k_vel_profile (emergency jobs) | k_fleet_vel_d
+//
+// No host work per planner and no host synchronisation inside a tick (the per-call entry points synchronise once at their end to
+// report errors; the tape form replays pre-uploaded inputs for many ticks without any). The host planner (planner_core.hpp) stays
+// the form for single vehicles; both are pinned to the same tick recordings of the reference (tests/test_gpu_fleet.py, and through the
+// one-lane host build of the same source tests/test_fleet_host_logic.py).
+
+// exec policy of the device build: one wave64, lane = threadIdx.x
+struct WaveX {
+    static constexpr int W = 64;
+    int l;
+    __device__ int lane() const { return l; }
+    // hand-over of GLOBAL memory between the lanes of the wave (they share the CU's vector cache: workgroup scope is enough)
+    __device__ void sync() const
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    __device__ void argmin(double& d, int& i) const { double k2 = 0.0; wave_min3(d, k2, i); }
+    __device__ bool any(bool b) const { return __ballot(b) != 0ull; }
+    template <class P> __device__ int find_first(int n, P pred) const { return wave_find_first(n, l, pred); }
+    // out[i] = term(0) + ... + term(i) in the sequential order of np.cumsum, systolic (see wave_cumsum_seq)
+    template <class T> __device__ void scan_seq(int n, T term, double* out) const
+    {
+        double carry = 0.0;
+        for (int base = 0; base < n; base += 64) {
+            const int cnt = (n - base) < 64 ? (n - base) : 64;
+            const double e = term((l < cnt) ? base + l : base + cnt - 1);
+            double s_in = carry, s_out = 0.0;
+            for (int it = 0; it < cnt; it += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s_out = s_in + e; s_in = wave_shr1_f64(s_out, carry); }
+            }
+            if (l < cnt) out[base + l] = s_out;
+            carry = readlane_f64(s_out, cnt - 1);
+        }
+    }
+};
+
+static_assert(sizeof(fleet::VelJob) == sizeof(DevVelJob) && offsetof(fleet::VelJob, obj_y) == offsetof(DevVelJob, obj_y), "job layouts must agree");
+
+struct FleetArgs { fleet::Dims D; fleet::FLat lat; fleet::FCfg cfg; unsigned char* state; int* err_word; const int* rng_end; };
+
+__device__ __forceinline__ void fleet_store(const WaveX& x, const fleet::Block& B, const fleet::PlannerS& S, int p, int* err_word)
+{
+    x.sync();
+    if (x.lane() == 0) {
+        *B.S() = S;
+        if (S.err) atomicCAS(err_word, 0, ((p + 1) << 12) | (S.err & 0xfff));
+    }
+}
+
+__global__ __launch_bounds__(64) void k_fleet_paths_pre(FleetArgs F, fleet::FObj ob, fleet::FPathsIn pin)
+{
+    const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, &F.D};
+    fleet::PlannerS S = *B.S();
+    if (!S.err) fleet::paths_pre(x, F.lat, F.cfg, B, S, p, ob, pin);
+    if (!S.err && F.rng_end[S.start_node[0]] < 0) fleet::fail(S, LTPL_ERR_INVALID_ARG, fleet::E_NO_RANGE);
+    if (S.err && x.lane() == 0) {
+        // the path kernel still runs for this planner: give it a harmless scenario (its result is not looked at)
+        int l0 = 0; while (l0 < F.lat.L - 1 && F.rng_end[l0] < 0) ++l0;
+        pin.start_layer[p] = l0; pin.start_node[p] = F.lat.rl_idx[l0]; pin.flags[p] = LTPL_FLAG_ACTION_SETS; pin.last_action[p] = LTPL_ACT_NONE;
+        pin.const_closest[p] = -1; pin.psi_s[p] = 0.0; pin.n_last[p] = 0;
+    }
+    fleet_store(x, B, S, p, F.err_word);
+}
+
+__global__ __launch_bounds__(64) void k_fleet_paths_post(FleetArgs F, fleet::FPathsOut po)
+{
+    const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, &F.D};
+    fleet::PlannerS S = *B.S();
+    if (!S.err) fleet::paths_post(x, F.lat, B, S, p, po);
+    fleet_store(x, B, S, p, F.err_word);
+}
+
+__global__ __launch_bounds__(64) void k_fleet_ref_idx(FleetArgs F, const double* px, const double* py)
+{
+    const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, &F.D};
+    fleet::PlannerS S = *B.S();
+    if (!S.err) { fleet::ref_idx(x, F.cfg, B, S, px[p], py[p]); S.ref_done = 1; }
+    fleet_store(x, B, S, p, F.err_word);
+}
+
+__global__ __launch_bounds__(64) void k_fleet_vel_a(FleetArgs F, fleet::FObj ob, fleet::FVelIn vin, fleet::FJobs JA)
+{
+    const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, &F.D};
+    fleet::PlannerS S = *B.S();
+    fleet::vel_a(x, F.lat, F.cfg, B, S, p, ob, vin, JA);
+    fleet_store(x, B, S, p, F.err_word);
+}
+
+__global__ __launch_bounds__(64) void k_fleet_vel_b(FleetArgs F, fleet::FJobs JA, fleet::FJobs JB)
+{
+    const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, &F.D};
+    fleet::PlannerS S = *B.S();
+    fleet::vel_b(x, F.cfg, B, S, p, JA, JB);
+    fleet_store(x, B, S, p, F.err_word);
+}
+
+__global__ __launch_bounds__(64) void k_fleet_vel_c(FleetArgs F, fleet::FVelIn vin, fleet::FJobs JB, fleet::FJobs JC)
+{
+    const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, &F.D};
+    fleet::PlannerS S = *B.S();
+    fleet::vel_c(x, F.cfg, B, S, p, vin, JB, JC);
+    fleet_store(x, B, S, p, F.err_word);
+}
+
+__global__ __launch_bounds__(64) void k_fleet_vel_d(FleetArgs F, fleet::FVelIn vin, fleet::FJobs JC)
+{
+    const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, &F.D};
+    fleet::PlannerS S = *B.S();
+    fleet::vel_d(x, B, S, p, vin, JC);
+    fleet_store(x, B, S, p, F.err_word);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+struct FleetJobsDev { fleet::VelJob* jobs = nullptr; double* pool = nullptr; double* out = nullptr; int* flags = nullptr; int per = 0;
+                      fleet::FJobs view() const { return fleet::FJobs{jobs, pool, out, flags, per}; } };
+
+// the inputs of one tick in device memory (one arena per tick of a tape, or the fleet's own for the per-call entry points)
+struct FleetTickIn {
+    void* d_buf = nullptr; size_t cap = 0;
+    fleet::FObj ob{}; const int* zone_off = nullptr; const int* zone_gid = nullptr;
+    fleet::FVelIn vin{}; const double* axm = nullptr; int n_axm = 0; double vel_max = 0.0; int any_emerg = 0;
+    bool has_paths = false, has_vel = false;
+};
+
+struct ltpl_fleet {
+    ltpl_handle* h = nullptr;
+    std::string err;
+    fleet::Dims D{}; fleet::FCfg cfg{}; ltpl_planner_config pc{};
+    FleetArgs args{};
+    unsigned char* d_state = nullptr; int* d_err = nullptr; const double* d_w_last = nullptr; int n_w_last = 0;
+    std::vector<void*> allocs;
+    // seam (1) arrays
+    fleet::FPathsIn pin{}; DevPathsOut dout{}; void* d_out = nullptr;
+    FleetJobsDev JA, JB, JC;
+    FleetTickIn cur, curv;                            // inputs of the per-call entry points: calc_paths / calc_vel_profile
+    void* h_stage = nullptr; size_t h_stage_cap = 0;  // page-locked staging of the inputs
+    std::vector<FleetTickIn> tape;
+    std::vector<unsigned char> image;                 // host image of one planner block (queries)
+    bool began = false;
+    size_t vel_lds = 0;
+    ~ltpl_fleet()
+    {
+        if (h) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); --h->n_planners; }
+        for (void* p : allocs) (void)hipFree(p);
+        if (cur.d_buf) (void)hipFree(cur.d_buf);
+        if (curv.d_buf) (void)hipFree(curv.d_buf);
+        for (FleetTickIn& t : tape) if (t.d_buf) (void)hipFree(t.d_buf);
+        if (h_stage) (void)hipHostFree(h_stage);
+    }
+};
+static std::string* abi_err_of(const ltpl_fleet* f) { return f ? const_cast<std::string*>(&f->err) : nullptr; }
+
+#define FLEET_TRY(f, call)                                                                                            \
+    do {                                                                                                              \
+        hipError_t e_ = (call);                                                                                       \
+        if (e_ != hipSuccess) { (f)->err = std::string(#call) + ": " + hipGetErrorString(e_); return LTPL_ERR_HIP; }  \
+    } while (0)
+
+template <class T>
+static int fleet_alloc(ltpl_fleet* f, size_t n, T** out, bool zero = true)
+{
+    void* p = nullptr;
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    FLEET_TRY(f, hipMalloc(&p, bytes));
+    f->allocs.push_back(p);
+    if (zero) FLEET_TRY(f, hipMemset(p, 0, bytes));
+    *out = static_cast<T*>(p);
+    return LTPL_OK;
+}
+template <class T>
+static int fleet_upload(ltpl_fleet* f, const std::vector<T>& v, const T** out)
+{
+    T* p = nullptr;
+    int rc = fleet_alloc(f, v.size(), &p, false);
+    if (rc) return rc;
+    if (!v.empty()) FLEET_TRY(f, hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    *out = p;
+    return LTPL_OK;
+}
+
+static int fleet_jobs_alloc(ltpl_fleet* f, FleetJobsDev* J, int per)
+{
+    const size_t n = (size_t)f->D.N * (size_t)per;
+    if (n * 4 * (size_t)f->D.R > 0x7fffffffull) { f->err = "fleet: job pool offsets exceed 31 bits (fewer planners per fleet)"; return LTPL_ERR_CAPACITY; }
+    J->per = per;
+    int rc;
+    if ((rc = fleet_alloc(f, n, &J->jobs))) return rc;
+    if ((rc = fleet_alloc(f, n * 4 * (size_t)f->D.R, &J->pool))) return rc;
+    if ((rc = fleet_alloc(f, n * (size_t)f->D.R, &J->out))) return rc;
+    return fleet_alloc(f, n * 2, &J->flags);
+}
+
+extern "C" int ltpl_fleet_create(ltpl_handle* h, const ltpl_planner_config* cfg, ltpl_fleet** out)
+try {
+    g_create_error.clear();
+    if (!h || !out) { g_create_error = "fleet: null argument"; return LTPL_ERR_INVALID_ARG; }
+    if (!h->has_hostlat) { g_create_error = "fleet: the lattice was created without raceline_x / raceline_y / node_psi"; return LTPL_ERR_UNSUPPORTED; }
+    int rc = fleet::check_config(cfg, &g_create_error);
+    if (rc) return rc;
+    if (hipSetDevice(h->device) != hipSuccess) { g_create_error = "fleet: hipSetDevice failed"; return LTPL_ERR_HIP; }
+    std::unique_ptr<ltpl_fleet> f(new ltpl_fleet());
+    f->h = h; ++h->n_planners;
+    f->cfg = fleet::fcfg_of(cfg); f->pc = *cfg; f->pc.w_last_edges = nullptr;
+    f->D = fleet::make_dims(cfg->n_scen, h->caps.max_path_nodes, h->caps.max_path_pts);
+    const int N = f->D.N;
+    auto bail = [&](int code) { g_create_error = f->err; return code; };
+    if ((rc = fleet_alloc(f.get(), f->D.stride * (size_t)N, &f->d_state))) return bail(rc);
+    if ((rc = fleet_alloc(f.get(), 4, &f->d_err))) return bail(rc);
+    {   // all planners start without memory (the fields whose "nothing" is not zero)
+        std::vector<unsigned char> img(f->D.stride, 0);
+        fleet::PlannerS* S = reinterpret_cast<fleet::PlannerS*>(img.data());
+        S->em_base_id = S->action_forced = S->sel_action = S->raw_action = LTPL_ACT_NONE; S->closest_obj_index = -1; S->const_rows = -1; S->old_gg_scale = 1.0;
+        for (int p = 0; p < N; ++p)
+            if (hipMemcpy(f->d_state + f->D.stride * (size_t)p, img.data(), sizeof(fleet::PlannerS), hipMemcpyHostToDevice) != hipSuccess) { g_create_error = "fleet: state upload failed"; return LTPL_ERR_HIP; }
+    }
+    // lattice tables of the state machine
+    const ltplp::HostLat& hl = h->hostlat;
+    fleet::FLat fl = fleet::flat_of(hl);
+    fl.layer_off = h->lat.layer_off; fl.rl_idx = h->lat.rl_idx; fl.s_rl = h->lat.s_rl; fl.vel_rl = h->lat.vel_rl; fl.node_x = h->lat.node_x; fl.node_y = h->lat.node_y;
+    if ((rc = fleet_upload(f.get(), hl.race_x, &fl.race_x))) return bail(rc);
+    if ((rc = fleet_upload(f.get(), hl.race_y, &fl.race_y))) return bail(rc);
+    std::vector<double> wl(cfg->n_w_last > 0 ? cfg->w_last_edges : nullptr, cfg->n_w_last > 0 ? cfg->w_last_edges + cfg->n_w_last : nullptr);
+    f->n_w_last = cfg->n_w_last; wl.push_back(0.0);
+    if ((rc = fleet_upload(f.get(), wl, &f->d_w_last))) return bail(rc);
+    f->args.D = f->D; f->args.lat = fl; f->args.cfg = f->cfg; f->args.state = f->d_state; f->args.err_word = f->d_err; f->args.rng_end = h->lat.rng_end;
+    // seam (1)
+    if ((rc = fleet_alloc(f.get(), (size_t)N, &f->pin.start_layer))) return bail(rc);
+    if ((rc = fleet_alloc(f.get(), (size_t)N, &f->pin.start_node))) return bail(rc);
+    if ((rc = fleet_alloc(f.get(), (size_t)N, &f->pin.flags))) return bail(rc);
+    if ((rc = fleet_alloc(f.get(), (size_t)N, &f->pin.last_action))) return bail(rc);
+    if ((rc = fleet_alloc(f.get(), (size_t)N, &f->pin.const_closest))) return bail(rc);
+    if ((rc = fleet_alloc(f.get(), (size_t)N, &f->pin.psi_s))) return bail(rc);
+    if ((rc = fleet_alloc(f.get(), (size_t)N, &f->pin.n_last))) return bail(rc);
+    if ((rc = fleet_alloc(f.get(), (size_t)N * LTPL_MAX_LAST_NODES, &f->pin.last_layer))) return bail(rc);
+    if ((rc = fleet_alloc(f.get(), (size_t)N * LTPL_MAX_LAST_NODES, &f->pin.last_node))) return bail(rc);
+    {
+        OutLayout lo; layout_out(N, f->D.cn, f->D.cp, &lo);
+        unsigned char* d = nullptr;
+        if ((rc = fleet_alloc(f.get(), lo.total, &d))) return bail(rc);
+        bind_out(d, lo, f->D.cn, f->D.cp, &f->dout);
+    }
+    if ((rc = fleet_jobs_alloc(f.get(), &f->JA, fleet::JOBS_A))) return bail(rc);
+    if ((rc = fleet_jobs_alloc(f.get(), &f->JB, 1))) return bail(rc);
+    if ((rc = fleet_jobs_alloc(f.get(), &f->JC, 1))) return bail(rc);
+    f->vel_lds = vel_scratch_bytes(f->D.R, true, false);
+    if (f->vel_lds > 150 * 1024) return bail((f->err = "fleet: velocity profile too long for the LDS-resident solver", LTPL_ERR_CAPACITY));
+    f->image.resize(f->D.stride);
+    *out = f.release();
+    return LTPL_OK;
+} LTPL_ABI_CATCH(nullptr)
+
+extern "C" int ltpl_fleet_destroy(ltpl_fleet* f) { delete f; return LTPL_OK; }
+extern "C" int ltpl_fleet_get_caps(const ltpl_fleet* f, ltpl_planner_caps* c) { if (!f || !c) return LTPL_ERR_INVALID_ARG; fleet::caps_of(f->D, c); return LTPL_OK; }
+extern "C" const char* ltpl_fleet_last_error(const ltpl_fleet* f) { return f ? f->err.c_str() : g_create_error.c_str(); }
+
+// error word of the kernels -> status + message; clears the word
+static int fleet_check(ltpl_fleet* f)
+{
+    int w = 0;
+    FLEET_TRY(f, hipMemcpyAsync(&w, f->d_err, sizeof(int), hipMemcpyDeviceToHost, f->h->stream));
+    FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
+    if (!w) return LTPL_OK;
+    FLEET_TRY(f, hipMemsetAsync(f->d_err, 0, sizeof(int), f->h->stream));
+    const int p = (w >> 12) - 1, e = w & 0xfff;
+    f->err = fleet::err_text(p, e) + " (the fleet keeps the planner's error state: set a new start pose to clear it)";
+    return e & 0xff;
+}
+
+extern "C" int ltpl_fleet_set_start(ltpl_fleet* f, int32_t p, double x, double y, double heading, double vel, double mho, int32_t* in_track, int32_t* cor_heading)
+try {
+    if (!f || !in_track || !cor_heading) return LTPL_ERR_INVALID_ARG;
+    if (p < 0 || p >= f->D.N) { f->err = "fleet: planner index out of range"; return LTPL_ERR_INVALID_ARG; }
+    FLEET_TRY(f, hipSetDevice(f->h->device));
+    FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
+    fleet::PlannerS prev;
+    unsigned char* blk = f->d_state + f->D.stride * (size_t)p;
+    FLEET_TRY(f, hipMemcpy(&prev, blk, sizeof(prev), hipMemcpyDeviceToHost));
+    const int rc = fleet::start_block(f->h->hostlat, f->D, x, y, heading, vel, mho, in_track, cor_heading, f->image.data(), &prev, &f->err);
+    if (rc) return rc;
+    FLEET_TRY(f, hipMemcpy(blk, f->image.data(), f->D.stride, hipMemcpyHostToDevice));
+    return LTPL_OK;
+} LTPL_ABI_CATCH(abi_err_of(f))
+
+static int fleet_stage(ltpl_fleet* f, size_t bytes)
+{
+    if (bytes <= f->h_stage_cap) return LTPL_OK;
+    FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
+    if (f->h_stage) (void)hipHostFree(f->h_stage);
+    f->h_stage = nullptr; f->h_stage_cap = 0;
+    const size_t cap = align_up(bytes + bytes / 2, 4096);
+    FLEET_TRY(f, hipHostMalloc(&f->h_stage, cap, hipHostMallocDefault));
+    f->h_stage_cap = cap;
+    return LTPL_OK;
+}
+
+// packs both halves of a tick's inputs into ONE device arena (t->d_buf) and binds the views; `pin` / `vin` may be null (that half keeps its
+// previous binding only if the arena is not reallocated, so the per-call entry points always pass what they need)
+static int fleet_pack_inputs(ltpl_fleet* f, FleetTickIn* t, const ltpl_planner_paths_in* pin, const ltpl_planner_vel_in* vin, bool use_zones)
+{
+    const int N = f->D.N;
+    Arena a;
+    size_t o_pa = 0, o_tn = 0, o_vo = 0, o_po = 0, o_ra = 0, o_ve = 0, o_px = 0, o_py = 0, o_zo = 0, o_zg = 0;
+    int nv = 0, np_ = 0, nz = 0;
+    if (pin) {
+        if (!pin->prev_action || !pin->t_now || !pin->veh_off || !pin->pos_off) { f->err = "fleet: null input"; return LTPL_ERR_INVALID_ARG; }
+        if (pin->veh_off[0] != 0 || pin->pos_off[0] != 0) { f->err = "offset arrays must start at 0"; return LTPL_ERR_INVALID_ARG; }
+        nv = pin->veh_off[N];
+        if (nv < 0) { f->err = "negative offsets"; return LTPL_ERR_INVALID_ARG; }
+        np_ = pin->pos_off[nv];
+        for (int s = 0; s < N; ++s) {
+            const int c = pin->veh_off[s + 1] - pin->veh_off[s];
+            if (c < 0 || c > MAX_VEH) { f->err = "more than 96 vehicles for one planner"; return LTPL_ERR_CAPACITY; }
+            const int q = pin->pos_off[pin->veh_off[s + 1]] - pin->pos_off[pin->veh_off[s]];
+            if (q < 0 || q > MAX_POS) { f->err = "more than 192 obstacle positions for one planner"; return LTPL_ERR_CAPACITY; }
+            for (int v = pin->veh_off[s]; v < pin->veh_off[s + 1]; ++v)
+                if (pin->pos_off[v + 1] - pin->pos_off[v] < 1) { f->err = "vehicle without position"; return LTPL_ERR_INVALID_ARG; }
+        }
+        if (use_zones) {
+            if (!pin->zone_off || pin->zone_off[0] != 0) { f->err = "fleet: zone offsets missing"; return LTPL_ERR_INVALID_ARG; }
+            nz = pin->zone_off[N];
+            for (int i = 0; i < nz; ++i) if (pin->zone_gid[i] < 0 || pin->zone_gid[i] >= f->h->lat.V) { f->err = "zone node id out of range"; return LTPL_ERR_INVALID_ARG; }
+        }
+        o_pa = a.add(4 * (size_t)N); o_tn = a.add(8 * (size_t)N); o_vo = a.add(4 * (size_t)(N + 1)); o_po = a.add(4 * (size_t)(nv + 1));
+        o_ra = a.add(8 * (size_t)(nv + 1)); o_ve = a.add(8 * (size_t)(nv + 1)); o_px = a.add(8 * (size_t)(np_ + 1)); o_py = a.add(8 * (size_t)(np_ + 1));
+        o_zo = a.add(4 * (size_t)(N + 1)); o_zg = a.add(4 * (size_t)(nz + 1));
+    }
+    size_t o_v[8] = {0}, o_em = 0, o_axm = 0;
+    if (vin) {
+        if (!vin->pos_est_x || !vin->pos_est_y || !vin->vel_est || !vin->vel_max || !vin->gg_scale || !vin->gg_ax || !vin->gg_ay || !vin->safety_d ||
+            !vin->ax_max_machines || vin->n_ax_max_machines < 1) { f->err = "fleet: null input"; return LTPL_ERR_INVALID_ARG; }
+        if (vin->gg_row_off || vin->gg_rows) { f->err = fleet::err_text(0, LTPL_ERR_UNSUPPORTED | (fleet::E_GG_DICT << 8)); return LTPL_ERR_UNSUPPORTED; }
+        if (vin->n_ax_max_machines > 64) { f->err = "ax_max_machines with more than 64 rows"; return LTPL_ERR_CAPACITY; }
+        for (int s = 1; s < N; ++s) if (vin->vel_max[s] != vin->vel_max[0]) { f->err = "fleet: vel_max must be the same for all planners of a call"; return LTPL_ERR_UNSUPPORTED; }
+        for (int k = 0; k < 8; ++k) o_v[k] = a.add(8 * (size_t)N);
+        o_em = a.add(4 * (size_t)N); o_axm = a.add(16 * (size_t)vin->n_ax_max_machines);
+    }
+    int rc = fleet_stage(f, a.size);
+    if (rc) return rc;
+    if (a.size > t->cap) {
+        FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
+        if (t->d_buf) (void)hipFree(t->d_buf);
+        t->d_buf = nullptr; t->cap = 0; t->has_paths = t->has_vel = false;
+        const size_t cap = align_up(a.size + a.size / 2, 4096);
+        FLEET_TRY(f, hipMalloc(&t->d_buf, cap));
+        t->cap = cap;
+    }
+    // the staging buffer is reused by the next call: wait for the previous copy out of it
+    FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
+    unsigned char* hb = static_cast<unsigned char*>(f->h_stage); unsigned char* db = static_cast<unsigned char*>(t->d_buf);
+    if (pin) {
+        memcpy(hb + o_pa, pin->prev_action, 4 * (size_t)N); memcpy(hb + o_tn, pin->t_now, 8 * (size_t)N);
+        memcpy(hb + o_vo, pin->veh_off, 4 * (size_t)(N + 1)); memcpy(hb + o_po, pin->pos_off, 4 * (size_t)(nv + 1));
+        if (nv) { memcpy(hb + o_ra, pin->veh_radius, 8 * (size_t)nv); if (pin->veh_vel) memcpy(hb + o_ve, pin->veh_vel, 8 * (size_t)nv); else memset(hb + o_ve, 0, 8 * (size_t)nv); }
+        if (np_) { memcpy(hb + o_px, pin->pos_x, 8 * (size_t)np_); memcpy(hb + o_py, pin->pos_y, 8 * (size_t)np_); }
+        if (use_zones) { memcpy(hb + o_zo, pin->zone_off, 4 * (size_t)(N + 1)); if (nz) memcpy(hb + o_zg, pin->zone_gid, 4 * (size_t)nz); }
+        else memset(hb + o_zo, 0, 4 * (size_t)(N + 1));
+        t->ob = fleet::FObj{reinterpret_cast<const int*>(db + o_pa), reinterpret_cast<const double*>(db + o_tn), reinterpret_cast<const int*>(db + o_vo),
+                            reinterpret_cast<const int*>(db + o_po), reinterpret_cast<const double*>(db + o_ra), reinterpret_cast<const double*>(db + o_ve),
+                            reinterpret_cast<const double*>(db + o_px), reinterpret_cast<const double*>(db + o_py)};
+        t->zone_off = reinterpret_cast<const int*>(db + o_zo); t->zone_gid = reinterpret_cast<const int*>(db + o_zg);
+        t->has_paths = true;
+    }
+    if (vin) {
+        const double* src[8] = {vin->pos_est_x, vin->pos_est_y, vin->vel_est, vin->vel_max, vin->gg_scale, vin->gg_ax, vin->gg_ay, vin->safety_d};
+        for (int k = 0; k < 8; ++k) memcpy(hb + o_v[k], src[k], 8 * (size_t)N);
+        int any = 0;
+        if (vin->incl_emerg_traj) { memcpy(hb + o_em, vin->incl_emerg_traj, 4 * (size_t)N); for (int s = 0; s < N; ++s) any |= vin->incl_emerg_traj[s]; }
+        else memset(hb + o_em, 0, 4 * (size_t)N);
+        memcpy(hb + o_axm, vin->ax_max_machines, 16 * (size_t)vin->n_ax_max_machines);
+        auto dp = [&](int k) { return reinterpret_cast<const double*>(db + o_v[k]); };
+        t->vin = fleet::FVelIn{dp(0), dp(1), dp(2), dp(3), dp(4), dp(5), dp(6), dp(7), reinterpret_cast<const int*>(db + o_em)};
+        t->axm = reinterpret_cast<const double*>(db + o_axm); t->n_axm = vin->n_ax_max_machines; t->vel_max = vin->vel_max[0]; t->any_emerg = any;
+        t->has_vel = true;
+    }
+    if (a.size) FLEET_TRY(f, hipMemcpyAsync(t->d_buf, f->h_stage, a.size, hipMemcpyHostToDevice, f->h->stream));
+    return LTPL_OK;
+}
+
+static int fleet_launch_paths(ltpl_fleet* f, const FleetTickIn& t, bool pre, bool rest)
+{
+    ltpl_handle* h = f->h; const int N = f->D.N; hipStream_t st = h->stream;
+    if (pre) {
+        hipLaunchKernelGGL(k_fleet_paths_pre, dim3(N), dim3(64), 0, st, f->args, t.ob, f->pin);
+        FLEET_TRY(f, hipGetLastError());
+    }
+    if (!rest) return LTPL_OK;
+    DevPathsIn di;
+    di.n_scen = N; di.n_w_last = f->n_w_last; di.w_last = f->d_w_last;
+    di.start_layer = f->pin.start_layer; di.start_node = f->pin.start_node; di.flags = f->pin.flags; di.last_action = f->pin.last_action;
+    di.const_closest = f->pin.const_closest; di.psi_s = f->pin.psi_s;
+    di.veh_off = t.ob.veh_off; di.pos_off = t.ob.pos_off; di.veh_radius = t.ob.radius; di.pos_x = t.ob.px; di.pos_y = t.ob.py;
+    di.zone_off = t.zone_off; di.zone_gid = t.zone_gid;
+    di.n_last = f->pin.n_last; di.last_layer = f->pin.last_layer; di.last_node = f->pin.last_node;
+    const int nw = (N >= h->nw1_min_scen && h->batch_nw == 1) ? 1 : NUM_WAVES;
+    const int rc = launch_paths(h, nw, N, st, di, f->dout);
+    if (rc) { f->err = h->err; return rc; }
+    const fleet::FPathsOut po{f->dout.closest_obj_index, f->dout.n_actions, f->dout.action_id, f->dout.valid, f->dout.reduced, f->dout.n_nodes, f->dout.n_pts,
+                              f->dout.nodes, f->dout.node_idx, f->dout.coeff, f->dout.path_param};
+    hipLaunchKernelGGL(k_fleet_paths_post, dim3(N), dim3(64), 0, st, f->args, po);
+    FLEET_TRY(f, hipGetLastError());
+    return LTPL_OK;
+}
+
+static int fleet_launch_vel_jobs(ltpl_fleet* f, const ltpl_vel_params& vp, const double* d_axm, const FleetJobsDev& J)
+{
+    ltpl_handle* h = f->h;
+    DevVelParams p;
+    int rc = make_vel_params(h, &vp, d_axm, &p);
+    if (rc) { f->err = h->err; return rc; }
+    vel_kernel_t kern = vel_kernel_of(vel_variant(&vp));
+    if (f->vel_lds > 48 * 1024) FLEET_TRY(f, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->vel_lds));
+    DoneSignal done; done.host_flag = nullptr; done.dev_count = nullptr; done.seq = 0u;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(f->D.N * J.per)), dim3(64), f->vel_lds, h->stream, h->lat, p, reinterpret_cast<const DevVelJob*>(J.jobs),
+                       J.pool, J.out, J.flags, f->D.R, (long long*)nullptr, done);
+    FLEET_TRY(f, hipGetLastError());
+    return LTPL_OK;
+}
+
+static int fleet_launch_vel(ltpl_fleet* f, const FleetTickIn& t)
+{
+    ltpl_handle* h = f->h; const int N = f->D.N; hipStream_t st = h->stream;
+    static const double one_row[2] = {0.0, 0.0};
+    ltpl_vel_params vp; memset(&vp, 0, sizeof(vp));
+    vp.dyn_model_exp = f->pc.dyn_model_exp; vp.drag_coeff = f->pc.drag_coeff; vp.m_veh = f->pc.m_veh; vp.len_veh = h->hostlat.veh_length;
+    vp.n_ax_max_machines = t.n_axm; vp.ax_max_machines = one_row;      // (the table itself is read on the device: t.axm)
+    vp.follow_control_type = f->pc.follow_control_type; vp.c_p = f->pc.c_p; vp.k_p = f->pc.k_p; vp.k_d = f->pc.k_d; vp.tan_w = f->pc.tan_w; vp.v_max = t.vel_max;
+    int rc;
+    hipLaunchKernelGGL(k_fleet_vel_a, dim3(N), dim3(64), 0, st, f->args, t.ob, t.vin, f->JA.view());
+    FLEET_TRY(f, hipGetLastError());
+    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA))) return rc;
+    hipLaunchKernelGGL(k_fleet_vel_b, dim3(N), dim3(64), 0, st, f->args, f->JA.view(), f->JB.view());
+    FLEET_TRY(f, hipGetLastError());
+    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JB))) return rc;
+    hipLaunchKernelGGL(k_fleet_vel_c, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JB.view(), f->JC.view());
+    FLEET_TRY(f, hipGetLastError());
+    if (t.any_emerg) {
+        ltpl_vel_params ve = vp; ve.dyn_model_exp = 1.0; ve.drag_coeff = 0.854; ve.m_veh = 1160.0;       // calc_brake_emergency.py:4-6,31-36
+        if ((rc = fleet_launch_vel_jobs(f, ve, t.axm, f->JC))) return rc;
+        hipLaunchKernelGGL(k_fleet_vel_d, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JC.view());
+        FLEET_TRY(f, hipGetLastError());
+    }
+    return LTPL_OK;
+}
+
+static int fleet_enter(ltpl_fleet* f)
+{
+    FLEET_TRY(f, hipSetDevice(f->h->device));
+    drop_resident(f->h);            // (the path kernel's LDS plan / parent slabs are shared with the handle's other entry points)
+    return LTPL_OK;
+}
+
+extern "C" int ltpl_fleet_calc_paths_begin(ltpl_fleet* f, const ltpl_planner_paths_in* in)
+try {
+    if (!f || !in) return LTPL_ERR_INVALID_ARG;
+    int rc = fleet_enter(f);
+    if (rc) return rc;
+    if ((rc = fleet_pack_inputs(f, &f->cur, in, nullptr, false))) return rc;
+    if ((rc = fleet_launch_paths(f, f->cur, true, false))) return rc;
+    f->began = true;
+    return fleet_check(f);
+} LTPL_ABI_CATCH(abi_err_of(f))
+
+extern "C" int ltpl_fleet_calc_paths_finish(ltpl_fleet* f, const int32_t* zone_off, const int32_t* zone_gid)
+try {
+    if (!f) return LTPL_ERR_INVALID_ARG;
+    if (!zone_off || !f->began) { f->err = "fleet: calc_paths_finish without calc_paths_begin"; return LTPL_ERR_INVALID_ARG; }
+    f->began = false;
+    int rc = fleet_enter(f);
+    if (rc) return rc;
+    // the zone lists go into their own small arena behind the tick's inputs
+    const int N = f->D.N, nz = zone_off[N];
+    if (zone_off[0] != 0 || nz < 0) { f->err = "offset arrays must start at 0"; return LTPL_ERR_INVALID_ARG; }
+    for (int i = 0; i < nz; ++i) if (zone_gid[i] < 0 || zone_gid[i] >= f->h->lat.V) { f->err = "zone node id out of range"; return LTPL_ERR_INVALID_ARG; }
+    int* d_zo = nullptr; int* d_zg = nullptr;
+    struct Guard { void* a = nullptr; void* b = nullptr; ~Guard() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } g;
+    FLEET_TRY(f, hipMalloc(reinterpret_cast<void**>(&d_zo), 4 * (size_t)(N + 1))); g.a = d_zo;
+    FLEET_TRY(f, hipMalloc(reinterpret_cast<void**>(&d_zg), 4 * (size_t)(nz + 1))); g.b = d_zg;
+    FLEET_TRY(f, hipMemcpy(d_zo, zone_off, 4 * (size_t)(N + 1), hipMemcpyHostToDevice));
+    if (nz) FLEET_TRY(f, hipMemcpy(d_zg, zone_gid, 4 * (size_t)nz, hipMemcpyHostToDevice));
+    FleetTickIn t = f->cur; t.zone_off = d_zo; t.zone_gid = d_zg;
+    if ((rc = fleet_launch_paths(f, t, false, true))) return rc;
+    return fleet_check(f);
+} LTPL_ABI_CATCH(abi_err_of(f))
+
+extern "C" int ltpl_fleet_calc_paths(ltpl_fleet* f, const ltpl_planner_paths_in* in)
+try {
+    if (!f || !in) return LTPL_ERR_INVALID_ARG;
+    int rc = fleet_enter(f);
+    if (rc) return rc;
+    if ((rc = fleet_pack_inputs(f, &f->cur, in, nullptr, true))) return rc;
+    if ((rc = fleet_launch_paths(f, f->cur, true, true))) return rc;
+    return fleet_check(f);
+} LTPL_ABI_CATCH(abi_err_of(f))
+
+extern "C" int ltpl_fleet_get_ref_idx(ltpl_fleet* f, const double* px, const double* py)
+try {
+    if (!f || !px || !py) return LTPL_ERR_INVALID_ARG;
+    int rc = fleet_enter(f);
+    if (rc) return rc;
+    const size_t n = (size_t)f->D.N;
+    double* d = nullptr;
+    struct Guard { void* a = nullptr; ~Guard() { if (a) (void)hipFree(a); } } g;
+    FLEET_TRY(f, hipMalloc(reinterpret_cast<void**>(&d), 16 * n)); g.a = d;
+    FLEET_TRY(f, hipMemcpy(d, px, 8 * n, hipMemcpyHostToDevice));
+    FLEET_TRY(f, hipMemcpy(d + n, py, 8 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fleet_ref_idx, dim3(f->D.N), dim3(64), 0, f->h->stream, f->args, (const double*)d, (const double*)(d + n));
+    FLEET_TRY(f, hipGetLastError());
+    return fleet_check(f);
+} LTPL_ABI_CATCH(abi_err_of(f))
+
+extern "C" int ltpl_fleet_calc_vel_profile(ltpl_fleet* f, const ltpl_planner_vel_in* in)
+try {
+    if (!f || !in) return LTPL_ERR_INVALID_ARG;
+    int rc = fleet_enter(f);
+    if (rc) return rc;
+    if (!f->cur.has_paths) { f->err = "fleet: calc_vel_profile before calc_paths"; return LTPL_ERR_INVALID_ARG; }
+    // the objects of the tick stay where calc_paths put them: the velocity inputs go into a second arena
+    FleetTickIn& v = f->curv;
+    if ((rc = fleet_pack_inputs(f, &v, nullptr, in, false))) return rc;
+    FleetTickIn t = f->cur; t.vin = v.vin; t.axm = v.axm; t.n_axm = v.n_axm; t.vel_max = v.vel_max; t.any_emerg = v.any_emerg;
+    if ((rc = fleet_launch_vel(f, t))) return rc;
+    return fleet_check(f);
+} LTPL_ABI_CATCH(abi_err_of(f))
+
+static int fleet_fetch(ltpl_fleet* f, int p)
+{
+    if (p < 0 || p >= f->D.N) { f->err = "fleet: planner index out of range"; return LTPL_ERR_INVALID_ARG; }
+    FLEET_TRY(f, hipSetDevice(f->h->device));
+    FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
+    FLEET_TRY(f, hipMemcpy(f->image.data(), f->d_state + f->D.stride * (size_t)p, f->D.stride, hipMemcpyDeviceToHost));
+    return LTPL_OK;
+}
+extern "C" int ltpl_fleet_get_paths(ltpl_fleet* f, int32_t p, ltpl_planner_paths_view* v)
+try {
+    if (!f || !v) return LTPL_ERR_INVALID_ARG;
+    const int rc = fleet_fetch(f, p);
+    return rc ? rc : fleet::paths_view(f->D, f->image.data(), v);
+} LTPL_ABI_CATCH(abi_err_of(f))
+extern "C" int ltpl_fleet_get_trajectories(ltpl_fleet* f, int32_t p, ltpl_planner_traj_view* v)
+try {
+    if (!f || !v) return LTPL_ERR_INVALID_ARG;
+    const int rc = fleet_fetch(f, p);
+    return rc ? rc : fleet::traj_view(f->D, f->image.data(), v);
+} LTPL_ABI_CATCH(abi_err_of(f))
+
+// ---- tape: pre-uploaded inputs of many ticks, replayed without host synchronisation ------------------------------------------------
+extern "C" int ltpl_fleet_tape_clear(ltpl_fleet* f)
+try {
+    if (!f) return LTPL_ERR_INVALID_ARG;
+    FLEET_TRY(f, hipSetDevice(f->h->device));
+    FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
+    for (FleetTickIn& t : f->tape) if (t.d_buf) (void)hipFree(t.d_buf);
+    f->tape.clear();
+    return LTPL_OK;
+} LTPL_ABI_CATCH(abi_err_of(f))
+
+extern "C" int ltpl_fleet_tape_append(ltpl_fleet* f, const ltpl_planner_paths_in* pin, const ltpl_planner_vel_in* vin)
+try {
+    if (!f || !pin || !vin) return LTPL_ERR_INVALID_ARG;
+    FLEET_TRY(f, hipSetDevice(f->h->device));
+    FleetTickIn t;
+    const int rc = fleet_pack_inputs(f, &t, pin, vin, true);
+    if (rc) { if (t.d_buf) (void)hipFree(t.d_buf); return rc; }
+    f->tape.push_back(t);
+    return LTPL_OK;
+} LTPL_ABI_CATCH(abi_err_of(f))
+
+extern "C" int ltpl_fleet_tape_run(ltpl_fleet* f, int32_t first, int32_t count, float* ms_total)
+try {
+    if (!f) return LTPL_ERR_INVALID_ARG;
+    if (first < 0 || count < 1 || (size_t)first + (size_t)count > f->tape.size()) { f->err = "fleet: tape range out of bounds"; return LTPL_ERR_INVALID_ARG; }
+    int rc = fleet_enter(f);
+    if (rc) return rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct Guard { hipEvent_t* a; hipEvent_t* b; ~Guard() { if (*a) (void)hipEventDestroy(*a); if (*b) (void)hipEventDestroy(*b); } } g{&e0, &e1};
+    FLEET_TRY(f, hipEventCreate(&e0)); FLEET_TRY(f, hipEventCreate(&e1));
+    FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
+    FLEET_TRY(f, hipEventRecord(e0, f->h->stream));
+    for (int i = first; i < first + count; ++i) {
+        const FleetTickIn& t = f->tape[(size_t)i];
+        if ((rc = fleet_launch_paths(f, t, true, true))) return rc;
+        if ((rc = fleet_launch_vel(f, t))) return rc;
+    }
+    FLEET_TRY(f, hipEventRecord(e1, f->h->stream));
+    FLEET_TRY(f, hipEventSynchronize(e1));
+    if (ms_total) FLEET_TRY(f, hipEventElapsedTime(ms_total, e0, e1));
+    f->cur.has_paths = false;           // (the objects of the last tick live in the tape: a per-call calc_vel_profile needs its own calc_paths first)
+    return fleet_check(f);
+} LTPL_ABI_CATCH(abi_err_of(f))

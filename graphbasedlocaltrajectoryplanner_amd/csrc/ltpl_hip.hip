@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,7 @@
 
 #include "../../include/ltpl_hip.h"
 #include "planner_api.hpp"
+#include "fleet_api.hpp"
 #include "capsule.hpp"
 
 #define WG_THREADS 256
@@ -768,6 +770,7 @@ __global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p, 
     const int lane = threadIdx.x;
     dbg_stamp(dbg, 0);
     const DevVelJob jb = jobs[blockIdx.x];
+    if (jb.n <= 0) { signal_done(done); return; }          // unused slot of a fleet's job table (fleet_dev.hpp); seam (2) itself rejects empty jobs
     VelScratch vs = carve_vel_scratch(smem, cap, true, false, nullptr, nullptr);
     vs.dbg = dbg;
     const int n = jb.n;
@@ -3525,3 +3528,8 @@ extern "C" int ltpl_planner_get_ref_idx(ltpl_planner* p, const double* px, const
 extern "C" int ltpl_planner_calc_vel_profile(ltpl_planner* p, const ltpl_planner_vel_in* in) try { return ltplp::api_calc_vel_profile(p, in); } LTPL_ABI_CATCH(abi_err_of(p))
 extern "C" int ltpl_planner_get_paths(const ltpl_planner* p, int32_t scen, ltpl_planner_paths_view* v) try { return ltplp::api_get_paths(p, scen, v); } LTPL_ABI_CATCH(abi_err_of(p))
 extern "C" int ltpl_planner_get_trajectories(const ltpl_planner* p, int32_t scen, ltpl_planner_traj_view* v) try { return ltplp::api_get_trajectories(p, scen, v); } LTPL_ABI_CATCH(abi_err_of(p))
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fleet (ABI v5): planners with device-resident state
+// ---------------------------------------------------------------------------------------------------------------------
+#include "fleet_dev.hpp"

@@ -1,0 +1,99 @@
+"""
+ctypes binding of the fleet entry points (``ltpl_fleet_*``, include/ltpl_hip.h ABI v5): the planner of ``planner.py`` -- the
+iterative memory of the reference's ``OnlineTrajectoryHandler`` (graph_ltpl/online_graph/src/OnlineTrajectoryHandler.py:24-1040) -- for
+MANY vehicles on one lattice with the state in device memory. Every stage the host planner runs per vehicle on the CPU runs as a kernel
+with one wave64 per planner (csrc/fleet_core.hpp); arguments, views and accessors are those of ``Planner``.
+
+The tape form pre-uploads the inputs of many ticks and advances all planners through them without host synchronisation
+(``tape_append`` / ``tape_append_groups`` / ``tape_run``): the closed-loop, state-carrying throughput of the hot path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from .planner import KEY_IDS, Planner, PlannerPathsIn, PlannerVelIn
+
+
+class Fleet(Planner):
+    def __init__(self, backend, n_planners, **config):
+        Planner.__init__(self, backend, n_scen=n_planners, prefix="ltpl_fleet_", **config)
+
+    def _declare(self):
+        Planner._declare(self)
+        f = self._fn
+        f("tape_clear").argtypes = [C.c_void_p]
+        f("tape_append").argtypes = [C.c_void_p, C.POINTER(PlannerPathsIn), C.POINTER(PlannerVelIn)]
+        f("tape_run").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
+
+    # ---- tape ---------------------------------------------------------------------------------------------------------------
+    def tape_clear(self):
+        self._check(self._fn("tape_clear")(self.handle))
+
+    def tape_append(self, prev_actions, t_now, vehicles, zone_gids, pos_est, vel_est, **vel_kwargs):
+        """Inputs of one tick, arguments as ``calc_paths`` followed by ``calc_vel_profile``."""
+        pi, keep1 = self._pack_paths_in(prev_actions, t_now, vehicles, zone_gids)
+        vi, keep2 = self._pack_vel_in(pos_est, vel_est, **vel_kwargs)
+        self._check(self._fn("tape_append")(self.handle, C.byref(pi), C.byref(vi)))
+
+    def tape_append_groups(self, groups, ax_max_machines=((100.0, 5.0),)):
+        """Inputs of one tick for planners that come in GROUPS with identical inputs (vectorised: no Python loop over planners).
+        ``groups``: list of (count, dict) in planner order; dict keys: prev_action (name), t_now, vehicles [(radius, vel, positions)],
+        zone_gids, pos_est, vel_est, vel_max, gg_scale, local_gg (ax, ay), safety_d, incl_emerg_traj."""
+        if sum(c for c, _ in groups) != self.n_scen:
+            raise ValueError("tape_append_groups: the group sizes must add up to the number of planners")
+        i32, f64 = np.int32, np.float64
+        acts, ts, veh_cnt, pos_cnt, rad, vel, px, py, zcnt, zg = [], [], [], [], [], [], [], [], [], []
+        vcols = [[] for _ in range(8)]
+        emerg = []
+        for cnt, g in groups:
+            a = g["prev_action"]
+            acts.append(np.full(cnt, KEY_IDS.get(a, _capi.ACT_NONE) if isinstance(a, str) else _capi.ACT_NONE, i32))
+            ts.append(np.full(cnt, float(g["t_now"]), f64))
+            vs = g["vehicles"]
+            veh_cnt.append(np.full(cnt, len(vs), np.int64))
+            pc = np.array([len(v[2]) for v in vs], np.int64)
+            pos_cnt.append(np.tile(pc, cnt))
+            rad.append(np.tile(np.array([float(v[0]) for v in vs], f64), cnt))
+            vel.append(np.tile(np.array([float(v[1]) for v in vs], f64), cnt))
+            pp = np.concatenate([np.asarray(v[2], f64).reshape(-1, 2) for v in vs]) if vs else np.zeros((0, 2))
+            px.append(np.tile(pp[:, 0], cnt)); py.append(np.tile(pp[:, 1], cnt))
+            z = np.asarray(sorted(set(int(q) for q in (g.get("zone_gids") or []))), i32)
+            zcnt.append(np.full(cnt, len(z), np.int64)); zg.append(np.tile(z, cnt))
+            lg = g.get("local_gg", (5.0, 5.0))
+            if type(lg) not in (tuple, list) or len(lg) != 2:
+                raise ValueError("Provided local_gg does not satisfy requested format! Read parameter documentation.")
+            vals = (g["pos_est"][0], g["pos_est"][1], g["vel_est"], g.get("vel_max", 100.0), g.get("gg_scale", 1.0), lg[0], lg[1],
+                    g.get("safety_d", 30.0))
+            for k in range(8):
+                vcols[k].append(np.full(cnt, float(vals[k]), f64))
+            emerg.append(np.full(cnt, int(bool(g.get("incl_emerg_traj", False))), i32))
+
+        def cat(lst, dt, pad):
+            a = np.concatenate(lst).astype(dt) if lst else np.zeros(0, dt)
+            return np.ascontiguousarray(a if a.size else np.full(1, pad, dt))
+
+        def csr(counts):
+            c = np.concatenate(counts) if counts else np.zeros(0, np.int64)
+            return np.ascontiguousarray(np.concatenate(([0], np.cumsum(c))).astype(i32))
+        arrs = dict(prev_action=cat(acts, i32, -1), t_now=cat(ts, f64, 0.0), veh_off=csr(veh_cnt), pos_off=csr(pos_cnt),
+                    veh_radius=cat(rad, f64, 0.0), veh_vel=cat(vel, f64, 0.0), pos_x=cat(px, f64, 0.0), pos_y=cat(py, f64, 0.0),
+                    zone_off=csr(zcnt), zone_gid=cat(zg, i32, 0))
+        pi = PlannerPathsIn()
+        for k, a in arrs.items():
+            setattr(pi, k, a.ctypes.data)
+        v = [cat(c, f64, 0.0) for c in vcols]
+        em = cat(emerg, i32, 0)
+        axm = np.ascontiguousarray(np.asarray(ax_max_machines, f64).reshape(-1, 2))
+        vi = PlannerVelIn()
+        for name, a in zip(("pos_est_x", "pos_est_y", "vel_est", "vel_max", "gg_scale", "gg_ax", "gg_ay", "safety_d"), v):
+            setattr(vi, name, a.ctypes.data)
+        vi.incl_emerg_traj, vi.ax_max_machines, vi.n_ax_max_machines = em.ctypes.data, axm.ctypes.data, axm.shape[0]
+        vi.gg_row_off, vi.gg_rows = None, None
+        self._check(self._fn("tape_append")(self.handle, C.byref(pi), C.byref(vi)))
+
+    def tape_run(self, first, count):
+        """Advance all planners through ticks [first, first + count) of the tape; returns the device time in ms."""
+        ms = C.c_float(0.0)
+        self._check(self._fn("tape_run")(self.handle, int(first), int(count), C.byref(ms)))
+        return float(ms.value)

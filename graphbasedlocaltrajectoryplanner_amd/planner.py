@@ -286,11 +286,10 @@ class Planner(object):
         return ref["cut_index_pos"], ref["cut_layer"], ref["vel_plan"], ref["vel_course"], ref["acc_plan"]
 
     # ---- Graph_LTPL.calc_vel_profile --------------------------------------------------------------------------------------
-    def calc_vel_profile(self, pos_est, vel_est, vel_max=100.0, gg_scale=1.0, local_gg=(5.0, 5.0),
-                         ax_max_machines=((100.0, 5.0),), safety_d=30.0, incl_emerg_traj=False):
-        """``local_gg``: the constant form (ax, ay) -- or, location dependent friction (OTH.py:649-666), a dict {action id: [ndarray
-        (rows, 2)]} with one row [ax, ay] per coordinate of that action's path (``paths(scen)['path_param'][key]``); for a batch a
-        list with one such dict (or tuple) per planner. ``incl_emerg_traj``: bool or one per planner."""
+    def _pack_vel_in(self, pos_est, vel_est, vel_max=100.0, gg_scale=1.0, local_gg=(5.0, 5.0),
+                     ax_max_machines=((100.0, 5.0),), safety_d=30.0, incl_emerg_traj=False):
+        """The input struct of calc_vel_profile (ltpl_planner_vel_in) filled from the reference's arguments; returns (struct, objects
+        that must stay alive until the C call returned)."""
         n = self.n_scen
         per = list(local_gg) if isinstance(local_gg, list) else [local_gg] * n
         if len(per) != n:
@@ -348,6 +347,15 @@ class Planner(object):
         i.incl_emerg_traj = st.ai
         i.gg_row_off = None if gg_off is None else gg_off.ctypes.data
         i.gg_rows = None if gg_rows is None else gg_rows.ctypes.data
+        return i, (st, gg_off, gg_rows)
+
+    def calc_vel_profile(self, pos_est, vel_est, vel_max=100.0, gg_scale=1.0, local_gg=(5.0, 5.0),
+                         ax_max_machines=((100.0, 5.0),), safety_d=30.0, incl_emerg_traj=False):
+        """``local_gg``: the constant form (ax, ay) -- or, location dependent friction (OTH.py:649-666), a dict {action id: [ndarray
+        (rows, 2)]} with one row [ax, ay] per coordinate of that action's path (``paths(scen)['path_param'][key]``); for a batch a
+        list with one such dict (or tuple) per planner. ``incl_emerg_traj``: bool or one per planner."""
+        i, keep = self._pack_vel_in(pos_est, vel_est, vel_max=vel_max, gg_scale=gg_scale, local_gg=local_gg,
+                                    ax_max_machines=ax_max_machines, safety_d=safety_d, incl_emerg_traj=incl_emerg_traj)
         self._check(self._fn("calc_vel_profile")(self.handle, C.byref(i)))
 
     # ---- accessors ----------------------------------------------------------------------------------------------------------

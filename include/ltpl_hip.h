@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LTPL_ABI_VERSION 4
+#define LTPL_ABI_VERSION 5
 
 /* status codes */
 #define LTPL_OK               0
@@ -533,6 +533,46 @@ int ltpl_planner_calc_vel_profile(ltpl_planner* planner, const ltpl_planner_vel_
 /* copy-out of planner `scen`'s state (fills the counts, copies the arrays whose pointers are non-NULL) */
 int ltpl_planner_get_paths(const ltpl_planner* planner, int32_t scen, ltpl_planner_paths_view* view);
 int ltpl_planner_get_trajectories(const ltpl_planner* planner, int32_t scen, ltpl_planner_traj_view* view);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * ABI v5 -- the FLEET: the same planner (the iterative memory of OnlineTrajectoryHandler, OTH.py:24-1040) for MANY vehicles on
+ * one lattice with the state in DEVICE memory. Every stage of a tick that ltpl_planner_* runs on the host per planner
+ * (OTH.py:308-414 in front of seam (1), :429-513 behind it, get_ref_idx :518-601, the slicing / job construction / trajectory
+ * assembly / backup and emergency branches of calc_vel_profile :603-1040) runs as a kernel with one wave64 per planner
+ * (csrc/fleet_core.hpp) between the launches of the path kernel and the velocity kernel: no host work per planner, no host
+ * synchronisation inside a tick. Entry points and structs are those of ltpl_planner_* (same argument meaning, same views), so a
+ * caller switches by the prefix. Differences, all reported and none silent:
+ *   - local_gg only in its constant form (gg_row_off / gg_rows must be NULL -> LTPL_ERR_UNSUPPORTED; the dict form stays with
+ *     ltpl_planner_*);
+ *   - the conditions on which the reference raises (OTH.py:334, :712, :830, :919, :923, :1029, ...) are detected per planner on the
+ *     device: the call returns the status of the FIRST failing planner ("fleet: planner N: ..."), that planner keeps its error
+ *     state (its later ticks are skipped) until ltpl_fleet_set_start gives it a new pose; the other planners are not affected;
+ *   - calc_time_buffer_len <= 16; capacities as ltpl_planner_caps.
+ * The TAPE form replays pre-uploaded inputs: ltpl_fleet_tape_append packs the inputs of one tick (both calls' arguments) into
+ * device memory, ltpl_fleet_tape_run advances all planners through ticks [first, first + count) back to back on the handle's
+ * stream and reports the device time between the first and the last launch -- the closed-loop throughput of the hot path with
+ * state carried from tick to tick (bench.py extra.closed_loop_device).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ltpl_fleet ltpl_fleet;
+
+int ltpl_fleet_create(ltpl_handle* handle, const ltpl_planner_config* cfg /* n_scen = planners */, ltpl_fleet** out_fleet);
+int ltpl_fleet_destroy(ltpl_fleet* fleet);
+int ltpl_fleet_get_caps(const ltpl_fleet* fleet, ltpl_planner_caps* caps);
+const char* ltpl_fleet_last_error(const ltpl_fleet* fleet);
+/* OnlineTrajectoryHandler.set_initial_pose for one planner (computed on the host, uploaded as that planner's state) */
+int ltpl_fleet_set_start(ltpl_fleet* fleet, int32_t planner, double x, double y, double heading, double vel,
+                         double max_heading_offset, int32_t* in_track, int32_t* cor_heading);
+int ltpl_fleet_calc_paths(ltpl_fleet* fleet, const ltpl_planner_paths_in* in);
+int ltpl_fleet_calc_paths_begin(ltpl_fleet* fleet, const ltpl_planner_paths_in* in);
+int ltpl_fleet_calc_paths_finish(ltpl_fleet* fleet, const int32_t* zone_off, const int32_t* zone_gid);
+int ltpl_fleet_get_ref_idx(ltpl_fleet* fleet, const double* pos_est_x, const double* pos_est_y);
+int ltpl_fleet_calc_vel_profile(ltpl_fleet* fleet, const ltpl_planner_vel_in* in);
+/* copy-out of one planner's state (a device-to-host copy of its block, then as ltpl_planner_get_*) */
+int ltpl_fleet_get_paths(ltpl_fleet* fleet, int32_t planner, ltpl_planner_paths_view* view);
+int ltpl_fleet_get_trajectories(ltpl_fleet* fleet, int32_t planner, ltpl_planner_traj_view* view);
+int ltpl_fleet_tape_clear(ltpl_fleet* fleet);
+int ltpl_fleet_tape_append(ltpl_fleet* fleet, const ltpl_planner_paths_in* paths_in, const ltpl_planner_vel_in* vel_in);
+int ltpl_fleet_tape_run(ltpl_fleet* fleet, int32_t first, int32_t count, float* ms_total /* may be NULL */);
 
 #ifdef __cplusplus
 }

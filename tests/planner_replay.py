@@ -72,6 +72,35 @@ def check_traj(got, exp, what):
             assert_close_rel(got[:, col], exp[:, col], what="%s %s" % (what, name))
 
 
+def check_trajectories(traj, ids, ref, t, what):
+    """Outputs of get_ref_idx + calc_vel_profile of one tick against the recording (digests every tick, full arrays on selected ticks)."""
+    full = t['full']
+    er = t['ref_idx']
+    assert ref['cut_index_pos'] == er['cut_index_pos'] and ref['cut_layer'] == er['cut_layer'], \
+        "%s: cut (%d, %d) vs (%d, %d)" % (what, ref['cut_index_pos'], ref['cut_layer'], er['cut_index_pos'], er['cut_layer'])
+    assert abs(ref['vel_plan'] - er['vel_plan']) <= 1e-5 * max(abs(er['vel_plan']), 1.0), "%s: vel_plan" % what
+    assert abs(ref['acc_plan'] - er['acc_plan']) <= 1e-5 * max(abs(er['acc_plan']), 5.0), "%s: acc_plan" % what
+    assert ref['vel_course'].shape == er['vel_course'].shape, "%s: vel_course length" % what
+    if er['vel_course'].size:
+        assert np.max(np.abs(ref['vel_course'] - er['vel_course'])) <= 1e-5 * max(float(np.max(np.abs(er['vel_course']))), 1.0)
+    ev = t['vel']
+    assert list(traj.keys()) == ev['keys'], "%s: trajectory keys %s vs %s" % (what, list(traj.keys()), ev['keys'])
+    assert ids == ev['traj_id'], "%s: trajectory ids" % what
+    for k in ev['keys']:
+        dg = ev['digest'][k]
+        tr = traj[k][0]
+        assert tr.shape[0] == dg[0], "%s/%s: trajectory rows %d vs %d" % (what, k, tr.shape[0], dg[0])
+        vs = max(abs(dg[4]) / max(dg[0], 1), 1.0)
+        assert abs(tr[-1, 0] - dg[1]) <= 1e-5 * max(abs(dg[1]), 1.0), "%s/%s: s_end" % (what, k)
+        assert abs(tr[0, 5] - dg[2]) <= 1e-5 * max(vs, abs(dg[2])), "%s/%s: vx[0] %g vs %g" % (what, k, tr[0, 5], dg[2])
+        assert abs(tr[-1, 5] - dg[3]) <= 1e-5 * max(vs, abs(dg[3])), "%s/%s: vx[-1]" % (what, k)
+        assert abs(float(np.sum(tr[:, 5])) - dg[4]) <= 1e-5 * max(abs(dg[4]), 1.0), "%s/%s: sum vx %g vs %g" % (
+            what, k, float(np.sum(tr[:, 5])), dg[4])
+    if full is not None:
+        for k in ev['keys']:
+            check_traj(traj[k][0], full['traj'][k], "%s/%s" % (what, k))
+
+
 def replay(planner, lat, ticks, scen=0, n_ticks=None, others=None):
     """Drive planner ``scen`` through ``ticks``; ``others``: callable(tick) -> (prev_actions, vehicles, zones, pos, vel,
     kwargs lists) filler for the remaining planners of a batch (default: replicate the recorded inputs)."""
@@ -123,30 +152,9 @@ def replay(planner, lat, ticks, scen=0, n_ticks=None, others=None):
                                  local_gg=[lgg] * n if isinstance(lgg, dict) else lgg, ax_max_machines=va['ax_max_machines'],
                                  safety_d=va['safety_d'], incl_emerg_traj=va['incl_emerg_traj'])
         traj, ids, ref = planner.trajectories(scen)
-        er = t['ref_idx']
-        assert ref['cut_index_pos'] == er['cut_index_pos'] and ref['cut_layer'] == er['cut_layer'], \
-            "%s: cut (%d, %d) vs (%d, %d)" % (what, ref['cut_index_pos'], ref['cut_layer'], er['cut_index_pos'], er['cut_layer'])
-        assert abs(ref['vel_plan'] - er['vel_plan']) <= 1e-5 * max(abs(er['vel_plan']), 1.0), "%s: vel_plan" % what
-        assert abs(ref['acc_plan'] - er['acc_plan']) <= 1e-5 * max(abs(er['acc_plan']), 5.0), "%s: acc_plan" % what
-        assert ref['vel_course'].shape == er['vel_course'].shape, "%s: vel_course length" % what
-        if er['vel_course'].size:
-            assert np.max(np.abs(ref['vel_course'] - er['vel_course'])) <= 1e-5 * max(float(np.max(np.abs(er['vel_course']))), 1.0)
+        check_trajectories(traj, ids, ref, t, what)
         ev = t['vel']
-        assert list(traj.keys()) == ev['keys'], "%s: trajectory keys %s vs %s" % (what, list(traj.keys()), ev['keys'])
-        assert ids == ev['traj_id'], "%s: trajectory ids" % what
-        for k in ev['keys']:
-            dg = ev['digest'][k]
-            tr = traj[k][0]
-            assert tr.shape[0] == dg[0], "%s/%s: trajectory rows %d vs %d" % (what, k, tr.shape[0], dg[0])
-            vs = max(abs(dg[4]) / max(dg[0], 1), 1.0)
-            assert abs(tr[-1, 0] - dg[1]) <= 1e-5 * max(abs(dg[1]), 1.0), "%s/%s: s_end" % (what, k)
-            assert abs(tr[0, 5] - dg[2]) <= 1e-5 * max(vs, abs(dg[2])), "%s/%s: vx[0] %g vs %g" % (what, k, tr[0, 5], dg[2])
-            assert abs(tr[-1, 5] - dg[3]) <= 1e-5 * max(vs, abs(dg[3])), "%s/%s: vx[-1]" % (what, k)
-            assert abs(float(np.sum(tr[:, 5])) - dg[4]) <= 1e-5 * max(abs(dg[4]), 1.0), "%s/%s: sum vx %g vs %g" % (
-                what, k, float(np.sum(tr[:, 5])), dg[4])
         if full is not None:
-            for k in ev['keys']:
-                check_traj(traj[k][0], full['traj'][k], "%s/%s" % (what, k))
             seen['full'] += 1
         seen['keys'].update(ev['keys'])
         seen['dropped'] += len([k for k in exp['keys'] if k not in ev['keys']])

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(lib_path)
     for sym in declared_symbols():
         assert hasattr(lib, sym), "libltpl_hip.so does not export %s" % sym
-    assert lib.ltpl_version() == 4          # v4: ltpl_planner_vel_in carries location dependent friction rows
+    assert lib.ltpl_version() == 5          # v5: ltpl_fleet_* (planners with device-resident state)
 
 
 def test_product_fails_loudly_without_library(monteblanco, tmp_path):

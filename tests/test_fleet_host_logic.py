@@ -1,0 +1,136 @@
+"""
+CPU (build container and GPU box alike): the FLEET state machine (csrc/fleet_core.hpp: the planner's iterative memory as wave-uniform
+SPMD code over plain-data state, which libltpl_hip.so runs with one wave64 per planner on device-resident state, ABI v5) compiled with its
+one-lane host policy and replayed in closed loop against the tick-level recordings of the UNMODIFIED reference (tests/golden/*_ticks.npz).
+The arithmetic of the two seams is the oracle's here (oracle/fleet_host_shim.cpp, test infrastructure); tests/test_gpu_fleet.py runs the
+same replays through the kernels. What this pins without a GPU: every index rule, slice, stitch, job and branch of the source the device
+executes -- the lane-parallel execution itself is what the GPU tests add.
+"""
+import numpy as np
+import pytest
+
+import planner_replay as pr
+
+
+@pytest.fixture(scope="module")
+def fleet_backend(monteblanco):
+    from oracle.fleet_host import HostFleetBackend
+    return HostFleetBackend(monteblanco)
+
+
+@pytest.mark.parametrize("name,must_see", [
+    ("c2", {"straight", "follow", "left", "right"}),          # 2 500 ticks, 8 opponents + zone: all four primitives
+    ("c1", {"straight", "follow"}),                           # static obstacle + wall: reduced horizon, blocked track
+    ("zonewall", {"straight", "follow", "right"}),            # horizon back-off
+    ("ggdrop", {"straight"}),                                 # recursive-infeasibility backup branch (OTH.py:947-1006)
+    ("overtake", {"follow", "left", "right", "emergency"}),   # dropped overtakes (OTH.py:1007-1015), emergency profile
+])
+def test_closed_loop_replay_matches_reference_recordings(fleet_backend, monteblanco, name, must_see):
+    ticks = pr.load_ticks(name)
+    seen = pr.replay(fleet_backend.planner(1), monteblanco, ticks)
+    assert must_see <= seen['keys'], seen
+    assert seen['full'] >= 15
+    if name == "overtake":
+        assert seen['dropped'] > 50 and seen['emergency'] > 100
+
+
+def test_velocity_smoothing_window(fleet_backend, monteblanco):
+    ticks = pr.load_ticks("filt5")
+    seen = pr.replay(fleet_backend.planner(1, filt_window_width=5), monteblanco, ticks)
+    assert seen['full'] >= 15 and {"follow", "right"} <= seen['keys']
+    with pytest.raises(AssertionError):
+        pr.replay(fleet_backend.planner(1), monteblanco, ticks, n_ticks=60)
+    with pytest.raises(Exception, match="odd"):
+        fleet_backend.planner(1, filt_window_width=4)
+
+
+def test_closed_loop_replay_on_an_open_track(open_lattice):
+    from oracle.fleet_host import HostFleetBackend
+    ticks = pr.load_ticks("open")
+    seen = pr.replay(HostFleetBackend(open_lattice).planner(1), open_lattice, ticks)
+    assert {"straight", "follow", "right"} <= seen['keys'] and seen['full'] >= 15
+
+
+@pytest.mark.parametrize("track", ["millbrook", "berlin"])    # one-node layers with a range of almost a lap; 40 nodes per layer
+def test_closed_loop_replay_on_other_tracks(track):
+    from oracle.fleet_host import HostFleetBackend
+    from test_other_tracks import lattice_of
+    lat = lattice_of(track)
+    seen = pr.replay(HostFleetBackend(lat).planner(1), lat, pr.load_ticks(track))
+    assert seen['full'] >= 15
+
+
+def test_fleet_equals_the_host_planner_bit_for_bit(fleet_backend, monteblanco):
+    """Same inputs, same arithmetic behind the seams: the fleet's state machine and the product's host planner (planner_core.hpp) must
+    produce IDENTICAL arrays tick by tick, not just arrays within the recording's tolerance."""
+    from oracle.planner_host import HostPlannerBackend
+    ticks = pr.load_ticks("overtake")
+    a, b = fleet_backend.planner(1), HostPlannerBackend(monteblanco).planner(1)
+    st = ticks[0]['start']
+    for pl in (a, b):
+        pl.set_start(0, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+    for t in ticks[:400]:
+        veh, zg, va = pr.vehicles_of_tick(t), pr.zone_gids_of_tick(monteblanco, t), t['vel_args']
+        out = []
+        for pl in (a, b):
+            pl.calc_paths([t['action_id_sel']], [t['t']], [veh], [zg])
+            p = pl.paths(0)
+            pl.calc_vel_profile([t['pos_est']], va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'], local_gg=tuple(va['local_gg']),
+                                ax_max_machines=va['ax_max_machines'], safety_d=va['safety_d'], incl_emerg_traj=va['incl_emerg_traj'])
+            out.append((p, pl.trajectories(0), pl.paths(0)))
+        (pa, ta, qa), (pb, tb, qb) = out
+        for x, y in ((pa, pb), (qa, qb)):
+            assert x['keys'] == y['keys'] and x['nodes'] == y['nodes'] and x['node_idx'] == y['node_idx'] and x['start_node'] == y['start_node']
+            for k in x['keys']:
+                assert np.array_equal(x['path_param'][k], y['path_param'][k]) and np.array_equal(x['coeff'][k], y['coeff'][k]), (t['tick'], k)
+        assert list(ta[0].keys()) == list(tb[0].keys()) and ta[1] == tb[1]
+        for k in ta[0]:
+            assert np.array_equal(ta[0][k][0], tb[0][k][0]), (t['tick'], k)
+        assert ta[2]['cut_index_pos'] == tb[2]['cut_index_pos'] and np.array_equal(ta[2]['vel_course'], tb[2]['vel_course'])
+
+
+def test_planners_of_a_fleet_are_independent(fleet_backend, monteblanco):
+    ticks = pr.load_ticks("zonewall")
+    fleet = fleet_backend.planner(3)
+    pr.replay(fleet, monteblanco, ticks, scen=2, n_ticks=150)
+    a, b = fleet.trajectories(0), fleet.trajectories(2)
+    assert list(a[0].keys()) == list(b[0].keys())
+    for k in a[0]:
+        assert (a[0][k][0] == b[0][k][0]).all()
+
+
+def test_a_failing_planner_keeps_its_error_and_does_not_disturb_the_others(fleet_backend, monteblanco):
+    """The fleet reports the conditions on which the reference raises per planner (include/ltpl_hip.h, ABI v5): planner 0 never got a start
+    pose -> every call returns its error, planner 1 replays the recording regardless; a start pose clears the error."""
+    from graphbasedlocaltrajectoryplanner_amd._capi import BackendError
+    ticks = pr.load_ticks("c1")
+    fleet = fleet_backend.planner(2)
+    st = ticks[0]['start']
+    fleet.set_start(1, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+    for t in ticks[:80]:
+        veh, zg, va = pr.vehicles_of_tick(t), pr.zone_gids_of_tick(monteblanco, t), t['vel_args']
+        with pytest.raises(BackendError, match="planner 0: no start node"):
+            fleet.calc_paths([t['action_id_sel']] * 2, [t['t']] * 2, [veh] * 2, [zg] * 2)
+        with pytest.raises(BackendError, match="planner 0"):
+            fleet.calc_vel_profile([t['pos_est']] * 2, va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'], local_gg=tuple(va['local_gg']),
+                                   ax_max_machines=va['ax_max_machines'], safety_d=va['safety_d'], incl_emerg_traj=va['incl_emerg_traj'])
+        traj, ids, ref = fleet.trajectories(1)
+        pr.check_trajectories(traj, ids, ref, t, "tick %d" % t['tick'])
+    fleet.set_start(0, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+    t = ticks[0]
+    fleet.set_start(1, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+    fleet.calc_paths([t['action_id_sel']] * 2, [t['t']] * 2, [pr.vehicles_of_tick(t)] * 2, [pr.zone_gids_of_tick(monteblanco, t)] * 2)
+    assert fleet.paths(0)['keys'] == fleet.paths(1)['keys'] == t['paths']['keys']
+
+
+def test_location_dependent_friction_is_refused(fleet_backend, monteblanco):
+    from graphbasedlocaltrajectoryplanner_amd._capi import BackendError
+    ticks = pr.load_ticks("c1")
+    fleet = fleet_backend.planner(1)
+    st = ticks[0]['start']
+    fleet.set_start(0, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+    t = ticks[0]
+    fleet.calc_paths([t['action_id_sel']], [t['t']], [pr.vehicles_of_tick(t)], [pr.zone_gids_of_tick(monteblanco, t)])
+    pp = fleet.paths(0)['path_param']
+    with pytest.raises(BackendError, match="dict form"):
+        fleet.calc_vel_profile([t['pos_est']], 0.0, local_gg={k: [np.full((v.shape[0], 2), 5.0)] for k, v in pp.items()})
