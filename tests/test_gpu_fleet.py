@@ -1,0 +1,138 @@
+"""
+GPU: the FLEET (ltpl_fleet_*, include/ltpl_hip.h ABI v5) -- planners whose iterative memory lives in device memory and is advanced by
+kernels (one wave64 per planner, csrc/fleet_core.hpp) around the path kernel and the velocity kernel -- replayed in closed loop against the
+tick recordings of the unmodified reference, through the per-call entry points and through the tape (many ticks back to back without host
+synchronisation), and compared with the host planner (ltpl_planner_*) on the same device arithmetic.
+"""
+import numpy as np
+import pytest
+
+import planner_replay as pr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip(monteblanco):
+    from graphbasedlocaltrajectoryplanner_amd import _capi
+    return _capi.HipBackend(monteblanco)
+
+
+@pytest.mark.parametrize("name,n,must_see", [
+    ("c2", 1, {"straight", "follow", "left", "right"}),
+    ("c1", 1, {"straight", "follow"}),
+    ("zonewall", 3, {"straight", "follow", "right"}),
+    ("ggdrop", 1, {"straight"}),                              # backup branch: second velocity launch
+    ("overtake", 70, {"follow", "left", "right", "emergency"}),   # >= 64 planners: one-wave batch path kernel; emergency: third launch
+])
+def test_closed_loop_replay_matches_reference_recordings(hip, monteblanco, name, n, must_see):
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    ticks = pr.load_ticks(name)
+    fleet = Fleet(hip, n)
+    seen = pr.replay(fleet, monteblanco, ticks, scen=n - 1)
+    assert must_see <= seen['keys'] and seen['full'] >= 15, seen
+    fleet.close()
+
+
+def test_velocity_smoothing_window(hip, monteblanco):
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    fleet = Fleet(hip, 1, filt_window_width=5)
+    seen = pr.replay(fleet, monteblanco, pr.load_ticks("filt5"))
+    assert seen['full'] >= 15
+    fleet.close()
+
+
+def test_open_track(open_lattice):
+    from graphbasedlocaltrajectoryplanner_amd import _capi
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    hip = _capi.HipBackend(open_lattice)
+    fleet = Fleet(hip, 2)
+    seen = pr.replay(fleet, open_lattice, pr.load_ticks("open"), scen=1)
+    assert {"straight", "follow", "right"} <= seen['keys'] and seen['full'] >= 15
+    fleet.close()
+
+
+@pytest.mark.parametrize("track", ["millbrook", "berlin"])
+def test_other_tracks(track):
+    from graphbasedlocaltrajectoryplanner_amd import _capi
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    from test_other_tracks import lattice_of
+    lat = lattice_of(track)
+    fleet = Fleet(_capi.HipBackend(lat), 1)
+    seen = pr.replay(fleet, lat, pr.load_ticks(track))
+    assert seen['full'] >= 15
+    fleet.close()
+
+
+def group_inputs(lat, t):
+    va = t['vel_args']
+    return dict(prev_action=t['action_id_sel'], t_now=t['t'], vehicles=pr.vehicles_of_tick(t), zone_gids=pr.zone_gids_of_tick(lat, t),
+                pos_est=t['pos_est'], vel_est=va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'], local_gg=tuple(va['local_gg']),
+                safety_d=va['safety_d'], incl_emerg_traj=va['incl_emerg_traj'])
+
+
+def test_tape_of_mixed_recordings(hip, monteblanco):
+    """192 planners in four groups, each group replaying another recording (c2 / overtake / zonewall / ggdrop: all primitives, dropped
+    overtakes, emergency profiles, the backup branch), 300 ticks back to back from pre-uploaded inputs without any host synchronisation;
+    then planners of every group against the recording's tick 299, and against the host planner's state after the same ticks."""
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    from graphbasedlocaltrajectoryplanner_amd.planner import Planner
+    names, per, T = ("c2", "overtake", "zonewall", "ggdrop"), 48, 300
+    recs = [pr.load_ticks(nm) for nm in names]
+    fleet = Fleet(hip, per * len(names))
+    for g, ticks in enumerate(recs):
+        st = ticks[0]['start']
+        for p in (g * per, g * per + 1, g * per + per - 1):           # the planners looked at below (+ one that is not: see the skip)
+            fleet.set_start(p, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+    # planners without a start pose would stop the run with their error: give all the same pose of their group
+    for g, ticks in enumerate(recs):
+        st = ticks[0]['start']
+        for p in range(g * per + 2, g * per + per - 1):
+            fleet.set_start(p, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+    for k in range(T):
+        fleet.tape_append_groups([(per, group_inputs(monteblanco, ticks[k])) for ticks in recs], ax_max_machines=recs[0][k]['vel_args']['ax_max_machines'])
+    ms = fleet.tape_run(0, T)
+    assert ms > 0.0
+    for g, ticks in enumerate(recs):
+        t = ticks[T - 1]
+        for p in (g * per, g * per + per - 1):
+            traj, ids, ref = fleet.trajectories(p)
+            pr.check_trajectories(traj, ids, ref, t, "%s tick %d planner %d" % (names[g], t['tick'], p))
+    # the host planner on the same device arithmetic, same ticks: identical state
+    host = Planner(hip, 1)
+    ticks = recs[1]
+    st = ticks[0]['start']
+    host.set_start(0, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+    for t in ticks[:T]:
+        va = t['vel_args']
+        host.calc_paths([t['action_id_sel']], [t['t']], [pr.vehicles_of_tick(t)], [pr.zone_gids_of_tick(monteblanco, t)])
+        host.calc_vel_profile([t['pos_est']], va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'], local_gg=tuple(va['local_gg']),
+                              ax_max_machines=va['ax_max_machines'], safety_d=va['safety_d'], incl_emerg_traj=va['incl_emerg_traj'])
+    ta, tb = fleet.trajectories(per + 5), host.trajectories(0)
+    assert list(ta[0].keys()) == list(tb[0].keys()) and ta[1] == tb[1] and ta[2]['cut_index_pos'] == tb[2]['cut_index_pos']
+    for k in ta[0]:
+        assert ta[0][k][0].shape == tb[0][k][0].shape
+        assert np.max(np.abs(ta[0][k][0] - tb[0][k][0])) <= 1e-9 * max(1.0, float(np.max(np.abs(tb[0][k][0])))), k
+    pa, pb = fleet.paths(per + 5), host.paths(0)
+    assert pa['keys'] == pb['keys'] and pa['nodes'] == pb['nodes'] and pa['node_idx'] == pb['node_idx']
+    host.close()
+    fleet.close()
+
+
+def test_a_failing_planner_keeps_its_error_and_does_not_disturb_the_others(hip, monteblanco):
+    from graphbasedlocaltrajectoryplanner_amd._capi import BackendError
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    ticks = pr.load_ticks("c1")
+    fleet = Fleet(hip, 2)
+    st = ticks[0]['start']
+    fleet.set_start(1, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+    for t in ticks[:60]:
+        veh, zg, va = pr.vehicles_of_tick(t), pr.zone_gids_of_tick(monteblanco, t), t['vel_args']
+        with pytest.raises(BackendError, match="planner 0: no start node"):
+            fleet.calc_paths([t['action_id_sel']] * 2, [t['t']] * 2, [veh] * 2, [zg] * 2)
+        with pytest.raises(BackendError, match="planner 0"):
+            fleet.calc_vel_profile([t['pos_est']] * 2, va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'], local_gg=tuple(va['local_gg']),
+                                   ax_max_machines=va['ax_max_machines'], safety_d=va['safety_d'], incl_emerg_traj=va['incl_emerg_traj'])
+        traj, ids, ref = fleet.trajectories(1)
+        pr.check_trajectories(traj, ids, ref, t, "tick %d" % t['tick'])
+    fleet.close()

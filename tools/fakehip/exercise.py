@@ -122,6 +122,35 @@ def exercise(name, lat):
             print("    (planner with empty / garbage kernel results: %s)" % str(e)[:100])
         pl.close()
         calls[0] += 4
+    # the fleet entry points (state in "device" memory; the kernels do nothing here, so every planner keeps its start state): packing of
+    # the per-call inputs, the grouped tape inputs, the query views
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    for n_pl in (1, 70):
+        fl = Fleet(hip, n_pl)
+        sl = 5
+        g0 = lat.layer_off[sl] + lat.raceline_index[sl]
+        pos = lat.node_pos[g0]
+        for s in range(n_pl):
+            fl.set_start(s, pos, float(lat.node_psi[g0]), 0.0)
+        veh = [[(2.5, 10.0, p[:2]), (2.0, 3.0, p[2:3])] for _ in range(n_pl)]
+        try:
+            fl.calc_paths(["straight"] * n_pl, 0.0, veh, [[1, 2, 3]] * n_pl)
+            fl.paths(0)
+            fl.calc_vel_profile([pos] * n_pl, 0.0, incl_emerg_traj=True)
+            fl.trajectories(n_pl - 1)
+            fl.calc_paths_begin(["straight"] * n_pl, 0.0, veh)
+            fl.calc_paths_finish([[4, 5]] * n_pl)
+            fl.get_ref_idx([pos] * n_pl, scen=0)
+            grp = dict(prev_action="straight", t_now=0.1, vehicles=veh[0], zone_gids=[7, 8], pos_est=pos, vel_est=1.0, incl_emerg_traj=True)
+            for k in range(3):
+                fl.tape_append_groups([(n_pl - n_pl // 2, grp), (n_pl // 2, dict(grp, vehicles=[]))] if n_pl > 1 else [(1, grp)])
+            fl.tape_append(["straight"] * n_pl, 0.2, veh, None, [pos] * n_pl, 0.0)
+            fl.tape_run(0, 4)
+            fl.tape_clear()
+        except (_capi.BackendError, KeyError, ValueError, IndexError) as e:
+            print("    (fleet with empty kernel results: %s)" % str(e)[:100])
+        fl.close()
+        calls[0] += 12
     hip.close()
 
 
