@@ -247,6 +247,40 @@ def closed_loop_rate(hip, lat, n_planners, n_ticks):
     return n * (len(ticks) - 10) / t_sum, ok
 
 
+def closed_loop_device_rate(hip, lat, n_planners, n_ticks):
+    """State-carrying closed loop of a FLEET (ltpl_fleet_*, ABI v5): the planners' iterative memory lives in device memory and every stage
+    of the tick that ltpl_planner_* runs on the host runs as a kernel (one wave64 per planner) between the path kernel and the velocity
+    kernel; the recorded inputs of the C2 loop are uploaded as a tape and all planners advance through ``n_ticks`` consecutive ticks back to
+    back without host synchronisation. Returns planner-ticks per second (device time from the first to the last launch, hipEvents) and
+    whether the first and the last planner reproduce the reference's recorded tick (cut indices, trajectory keys / ids, digests 1e-5)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle.fixture_io import load_records          # fixture reader only (the recording is the input stream and the expected output)
+    import planner_replay as pr
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    ticks = load_records(os.path.join(ROOT, "tests", "golden", "c2_ticks.npz"))[:n_ticks]
+    fleet = Fleet(hip, n_planners)
+    st = ticks[0]['start']
+    for p in range(n_planners):
+        fleet.set_start(p, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+    for t in ticks:
+        va = t['vel_args']
+        fleet.tape_append_groups([(n_planners, dict(
+            prev_action=t['action_id_sel'], t_now=t['t'], vehicles=pr.vehicles_of_tick(t), zone_gids=pr.zone_gids_of_tick(lat, t),
+            pos_est=t['pos_est'], vel_est=va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'], local_gg=tuple(va['local_gg']),
+            safety_d=va['safety_d'], incl_emerg_traj=va['incl_emerg_traj']))], ax_max_machines=va['ax_max_machines'])
+    ms = fleet.tape_run(0, len(ticks))
+    ok = True
+    try:
+        for p in (0, n_planners - 1):
+            traj, ids, ref = fleet.trajectories(p)
+            pr.check_trajectories(traj, ids, ref, ticks[-1], "planner %d" % p)
+    except AssertionError as e:
+        sys.stderr.write("closed_loop_device: %s\n" % e)
+        ok = False
+    fleet.close()
+    return n_planners * len(ticks) / (ms * 1e-3), ms / len(ticks), ok
+
+
 def worker(args):
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -373,6 +407,15 @@ def worker(args):
             extra["closed_loop"] = {"planner_ticks_per_s": clr, "planners": 256, "ticks": 60, "keys_match_recording": clok,
                                     "what": "256 planners x 60 consecutive ticks through ltpl_planner_calc_paths / _calc_vel_profile, every "
                                             "planner carrying its own iterative memory; host-inclusive (packing, PCIe, host state machine)"}
+            # the same closed loop with the planners' state in device memory (fleet): no host work per planner
+            n_fp, n_ft = getattr(args, 'fleet_planners', 8192), getattr(args, 'fleet_ticks', 200)
+            cdr, cd_ms, cdok = closed_loop_device_rate(hip, lat, n_fp, n_ft)
+            extra["closed_loop_device"] = {"planner_ticks_per_s": cdr, "planners": n_fp, "ticks": n_ft, "ms_per_fleet_tick": cd_ms,
+                                           "matches_recording": cdok,
+                                           "what": "ltpl_fleet_*: planners with device-resident iterative memory replay consecutive ticks of the "
+                                                   "reference's C2 recording from a pre-uploaded tape (state machine stages as kernels, one wave "
+                                                   "per planner, around k_paths / k_vel_profile; device time, no host synchronisation inside); "
+                                                   "first and last planner checked against the recording's last tick"}
         traffic = read_traffic(args.batch, args.workload)            # measured HBM bytes per launch of the dominant kernel (PMC), or None
         issue_pmc = read_issue(args.batch, args.workload)
         issue = None
@@ -469,6 +512,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--latency-ticks", type=int, default=2000)
     ap.add_argument("--dropin-ticks", type=int, default=2500)
+    ap.add_argument("--fleet-planners", type=int, default=8192, help="extra.closed_loop_device: planners of the fleet")
+    ap.add_argument("--fleet-ticks", type=int, default=200, help="extra.closed_loop_device: consecutive ticks")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--exact-steps", action="store_true", help="time exactly --steps steps (no repetition up to 2 s)")

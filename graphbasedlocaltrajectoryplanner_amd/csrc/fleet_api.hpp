@@ -52,7 +52,7 @@ inline int start_block(const ltplp::HostLat& lat, const Dims& D, double x, doubl
     PlannerS keep{}; const bool carry = prev != nullptr;
     if (carry) keep = *prev;
     std::memset(image, 0, D.stride);
-    Block B{image, &D};
+    Block B{image, D};
     PlannerS& S = *B.S();
     if (carry) {
         S.traj_base_id = keep.traj_base_id; S.n_calc = keep.n_calc; std::memcpy(S.calc_buffer, keep.calc_buffer, sizeof(S.calc_buffer));
@@ -81,7 +81,7 @@ inline void caps_of(const Dims& D, ltpl_planner_caps* c) { c->cap_rows = D.R; c-
 
 inline int paths_view(const Dims& D, const unsigned char* image, ltpl_planner_paths_view* v)
 {
-    Block B{const_cast<unsigned char*>(image), &D};
+    Block B{const_cast<unsigned char*>(image), D};
     const PlannerS& S = *B.S();
     v->n_keys = 0;
     v->start_node[0] = S.has_start ? S.start_node[0] : -1; v->start_node[1] = S.has_start ? S.start_node[1] : -1;
@@ -100,7 +100,7 @@ inline int paths_view(const Dims& D, const unsigned char* image, ltpl_planner_pa
 
 inline int traj_view(const Dims& D, const unsigned char* image, ltpl_planner_traj_view* v)
 {
-    Block B{const_cast<unsigned char*>(image), &D};
+    Block B{const_cast<unsigned char*>(image), D};
     const PlannerS& S = *B.S();
     v->n_keys = 0;
     v->cut_index_pos = S.cut_index_pos; v->cut_layer = S.cut_layer; v->vel_plan = S.vel_plan; v->acc_plan = S.acc_plan;

@@ -114,18 +114,18 @@ inline Dims make_dims(int N, int max_path_nodes, int max_path_pts)
 }
 
 struct Block {                      // one planner's memory
-    unsigned char* b; const Dims* D;
+    unsigned char* b; Dims D;
     FLT_FN PlannerS* S() const { return reinterpret_cast<PlannerS*>(b); }
-    FLT_FN unsigned char* slot(int set, int k) const { return b + D->o_traj + D->traj_bytes * (size_t)(set * KEYS + k); }
+    FLT_FN unsigned char* slot(int set, int k) const { return b + D.o_traj + D.traj_bytes * (size_t)(set * KEYS + k); }
     FLT_FN double* pp(int set, int k) const { return reinterpret_cast<double*>(slot(set, k)); }
-    FLT_FN double* coeff(int set, int k) const { return reinterpret_cast<double*>(slot(set, k) + D->o_coeff()); }
-    FLT_FN int* nodes(int set, int k) const { return reinterpret_cast<int*>(slot(set, k) + D->o_nodes()); }
-    FLT_FN int* nidx(int set, int k) const { return reinterpret_cast<int*>(slot(set, k) + D->o_nidx()); }
-    FLT_FN double* bp(int k) const { return reinterpret_cast<double*>(b + D->o_bp + align256(sizeof(double) * (size_t)D->R * 7) * (size_t)k); }
-    FLT_FN double* velc() const { return reinterpret_cast<double*>(b + D->o_velc); }
-    FLT_FN double* sarr(int k) const { return reinterpret_cast<double*>(b + D->o_sarr + align256(sizeof(double) * (size_t)D->R) * (size_t)k); }
-    FLT_FN double* vx(int k) const { return reinterpret_cast<double*>(b + D->o_vx + align256(sizeof(double) * (size_t)D->R) * (size_t)k); }
-    FLT_FN double* scr(int k) const { return reinterpret_cast<double*>(b + D->o_scr + align256(sizeof(double) * (size_t)D->R) * (size_t)k); }
+    FLT_FN double* coeff(int set, int k) const { return reinterpret_cast<double*>(slot(set, k) + D.o_coeff()); }
+    FLT_FN int* nodes(int set, int k) const { return reinterpret_cast<int*>(slot(set, k) + D.o_nodes()); }
+    FLT_FN int* nidx(int set, int k) const { return reinterpret_cast<int*>(slot(set, k) + D.o_nidx()); }
+    FLT_FN double* bp(int k) const { return reinterpret_cast<double*>(b + D.o_bp + align256(sizeof(double) * (size_t)D.R * 7) * (size_t)k); }
+    FLT_FN double* velc() const { return reinterpret_cast<double*>(b + D.o_velc); }
+    FLT_FN double* sarr(int k) const { return reinterpret_cast<double*>(b + D.o_sarr + align256(sizeof(double) * (size_t)D.R) * (size_t)k); }
+    FLT_FN double* vx(int k) const { return reinterpret_cast<double*>(b + D.o_vx + align256(sizeof(double) * (size_t)D.R) * (size_t)k); }
+    FLT_FN double* scr(int k) const { return reinterpret_cast<double*>(b + D.o_scr + align256(sizeof(double) * (size_t)D.R) * (size_t)k); }
 };
 
 // lattice tables the state machine reads (device pointers on the device, host vectors in the harness)
@@ -380,7 +380,7 @@ FLT_FN void paths_pre(const X& x, const FLat& lat, const FCfg& cfg, const Block&
 template <class X>
 FLT_FN void paths_post(const X& x, const FLat& lat, const Block& B, PlannerS& S, int p, const FPathsOut& po)
 {
-    const Dims& D = *B.D;
+    const Dims& D = B.D;
     const int A = LTPL_MAX_ACTIONS, cn = D.cn, cp = D.cp;
     const int set = S.cur_set, nset = 1 - set;
     const int lsel = S.const_exists ? find_last(S, S.sel_action) : -1;
@@ -546,7 +546,7 @@ FLT_FN int make_job(const X& x, const Dims& D, const FJobs& J, int p, int& n_job
 template <class X>
 FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, PlannerS& S, int p, const FObj& ob, const FVelIn& vin, const FJobs& J)
 {
-    const Dims& D = *B.D;
+    const Dims& D = B.D;
     for (int j = x.lane(); j < J.per_planner; j += X::W) J.jobs[p * J.per_planner + j].n = 0;
     x.sync();
     if (S.err) return;
@@ -658,7 +658,7 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
 template <class X>
 FLT_FN void vel_b(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int p, const FJobs& JA, const FJobs& JB)
 {
-    const Dims& D = *B.D;
+    const Dims& D = B.D;
     if (x.lane() == 0) JB.jobs[p * JB.per_planner].n = 0;
     x.sync();
     if (S.err) return;
@@ -765,7 +765,7 @@ FLT_FN void vel_b(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int 
 template <class X>
 FLT_FN void vel_c(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int p, const FVelIn& vin, const FJobs& JB, const FJobs& JC)
 {
-    const Dims& D = *B.D;
+    const Dims& D = B.D;
     if (x.lane() == 0) JC.jobs[p * JC.per_planner].n = 0;
     x.sync();
     if (S.err) return;
@@ -833,7 +833,7 @@ FLT_FN void vel_c(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int 
 template <class X>
 FLT_FN void vel_d(const X& x, const Block& B, PlannerS& S, int p, const FVelIn& vin, const FJobs& JC)
 {
-    const Dims& D = *B.D;
+    const Dims& D = B.D;
     if (S.err || !(vin.incl_emerg && vin.incl_emerg[p])) return;
     const double* base = B.bp(S.bp_slot[0]); const int m = S.bp_rows[0];
     const double* v = JC.out + (size_t)(p * JC.per_planner) * D.R;

@@ -48,20 +48,32 @@ static_assert(sizeof(fleet::VelJob) == sizeof(DevVelJob) && offsetof(fleet::VelJ
 
 struct FleetArgs { fleet::Dims D; fleet::FLat lat; fleet::FCfg cfg; unsigned char* state; int* err_word; const int* rng_end; };
 
-__device__ __forceinline__ void fleet_store(const WaveX& x, const fleet::Block& B, const fleet::PlannerS& S, int p, int* err_word)
+// The planner's scalars (PlannerS, ~1 KB) live in LDS while a kernel works on them: every lane executes the scalar control flow on the SAME
+// copy (uniform reads are LDS broadcasts; all lanes store the same value to the same address, in lockstep), instead of 64 private copies in
+// scratch memory (first version: 2 x 64 KB of scratch traffic per planner and kernel, six kernels per tick -- the fleet was bound by it).
+static_assert(sizeof(fleet::PlannerS) % 8 == 0, "PlannerS is copied in 8-byte words");
+__device__ __forceinline__ void fleet_load(const WaveX& x, const fleet::Block& B, fleet::PlannerS* S)
+{
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(B.S());
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(S);
+    for (int i = x.lane(); i < (int)(sizeof(fleet::PlannerS) / 8); i += 64) dst[i] = src[i];
+    x.sync();
+}
+__device__ __forceinline__ void fleet_store(const WaveX& x, const fleet::Block& B, const fleet::PlannerS* S, int p, int* err_word)
 {
     x.sync();
-    if (x.lane() == 0) {
-        *B.S() = S;
-        if (S.err) atomicCAS(err_word, 0, ((p + 1) << 12) | (S.err & 0xfff));
-    }
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(S);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(B.S());
+    for (int i = x.lane(); i < (int)(sizeof(fleet::PlannerS) / 8); i += 64) dst[i] = src[i];
+    if (x.lane() == 0 && S->err) atomicCAS(err_word, 0, ((p + 1) << 12) | (S->err & 0xfff));
 }
 
 __global__ __launch_bounds__(64) void k_fleet_paths_pre(FleetArgs F, fleet::FObj ob, fleet::FPathsIn pin)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
-    const fleet::Block B{F.state + F.D.stride * (size_t)p, &F.D};
-    fleet::PlannerS S = *B.S();
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D};
+    __shared__ fleet::PlannerS S;
+    fleet_load(x, B, &S);
     if (!S.err) fleet::paths_pre(x, F.lat, F.cfg, B, S, p, ob, pin);
     if (!S.err && F.rng_end[S.start_node[0]] < 0) fleet::fail(S, LTPL_ERR_INVALID_ARG, fleet::E_NO_RANGE);
     if (S.err && x.lane() == 0) {
@@ -70,61 +82,67 @@ __global__ __launch_bounds__(64) void k_fleet_paths_pre(FleetArgs F, fleet::FObj
         pin.start_layer[p] = l0; pin.start_node[p] = F.lat.rl_idx[l0]; pin.flags[p] = LTPL_FLAG_ACTION_SETS; pin.last_action[p] = LTPL_ACT_NONE;
         pin.const_closest[p] = -1; pin.psi_s[p] = 0.0; pin.n_last[p] = 0;
     }
-    fleet_store(x, B, S, p, F.err_word);
+    fleet_store(x, B, &S, p, F.err_word);
 }
 
 __global__ __launch_bounds__(64) void k_fleet_paths_post(FleetArgs F, fleet::FPathsOut po)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
-    const fleet::Block B{F.state + F.D.stride * (size_t)p, &F.D};
-    fleet::PlannerS S = *B.S();
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D};
+    __shared__ fleet::PlannerS S;
+    fleet_load(x, B, &S);
     if (!S.err) fleet::paths_post(x, F.lat, B, S, p, po);
-    fleet_store(x, B, S, p, F.err_word);
+    fleet_store(x, B, &S, p, F.err_word);
 }
 
 __global__ __launch_bounds__(64) void k_fleet_ref_idx(FleetArgs F, const double* px, const double* py)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
-    const fleet::Block B{F.state + F.D.stride * (size_t)p, &F.D};
-    fleet::PlannerS S = *B.S();
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D};
+    __shared__ fleet::PlannerS S;
+    fleet_load(x, B, &S);
     if (!S.err) { fleet::ref_idx(x, F.cfg, B, S, px[p], py[p]); S.ref_done = 1; }
-    fleet_store(x, B, S, p, F.err_word);
+    fleet_store(x, B, &S, p, F.err_word);
 }
 
 __global__ __launch_bounds__(64) void k_fleet_vel_a(FleetArgs F, fleet::FObj ob, fleet::FVelIn vin, fleet::FJobs JA)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
-    const fleet::Block B{F.state + F.D.stride * (size_t)p, &F.D};
-    fleet::PlannerS S = *B.S();
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D};
+    __shared__ fleet::PlannerS S;
+    fleet_load(x, B, &S);
     fleet::vel_a(x, F.lat, F.cfg, B, S, p, ob, vin, JA);
-    fleet_store(x, B, S, p, F.err_word);
+    fleet_store(x, B, &S, p, F.err_word);
 }
 
 __global__ __launch_bounds__(64) void k_fleet_vel_b(FleetArgs F, fleet::FJobs JA, fleet::FJobs JB)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
-    const fleet::Block B{F.state + F.D.stride * (size_t)p, &F.D};
-    fleet::PlannerS S = *B.S();
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D};
+    __shared__ fleet::PlannerS S;
+    fleet_load(x, B, &S);
     fleet::vel_b(x, F.cfg, B, S, p, JA, JB);
-    fleet_store(x, B, S, p, F.err_word);
+    fleet_store(x, B, &S, p, F.err_word);
 }
 
 __global__ __launch_bounds__(64) void k_fleet_vel_c(FleetArgs F, fleet::FVelIn vin, fleet::FJobs JB, fleet::FJobs JC)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
-    const fleet::Block B{F.state + F.D.stride * (size_t)p, &F.D};
-    fleet::PlannerS S = *B.S();
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D};
+    __shared__ fleet::PlannerS S;
+    fleet_load(x, B, &S);
     fleet::vel_c(x, F.cfg, B, S, p, vin, JB, JC);
-    fleet_store(x, B, S, p, F.err_word);
+    fleet_store(x, B, &S, p, F.err_word);
 }
 
 __global__ __launch_bounds__(64) void k_fleet_vel_d(FleetArgs F, fleet::FVelIn vin, fleet::FJobs JC)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
-    const fleet::Block B{F.state + F.D.stride * (size_t)p, &F.D};
-    fleet::PlannerS S = *B.S();
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D};
+    __shared__ fleet::PlannerS S;
+    fleet_load(x, B, &S);
     fleet::vel_d(x, B, S, p, vin, JC);
-    fleet_store(x, B, S, p, F.err_word);
+    fleet_store(x, B, &S, p, F.err_word);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -261,7 +279,7 @@ try {
     if ((rc = fleet_jobs_alloc(f.get(), &f->JA, fleet::JOBS_A))) return bail(rc);
     if ((rc = fleet_jobs_alloc(f.get(), &f->JB, 1))) return bail(rc);
     if ((rc = fleet_jobs_alloc(f.get(), &f->JC, 1))) return bail(rc);
-    f->vel_lds = vel_scratch_bytes(f->D.R, true, false);
+    f->vel_lds = vel_scratch_bytes(f->D.R, false, false);
     if (f->vel_lds > 150 * 1024) return bail((f->err = "fleet: velocity profile too long for the LDS-resident solver", LTPL_ERR_CAPACITY));
     f->image.resize(f->D.stride);
     *out = f.release();
@@ -426,7 +444,7 @@ static int fleet_launch_vel_jobs(ltpl_fleet* f, const ltpl_vel_params& vp, const
     DevVelParams p;
     int rc = make_vel_params(h, &vp, d_axm, &p);
     if (rc) { f->err = h->err; return rc; }
-    vel_kernel_t kern = vel_kernel_of(vel_variant(&vp));
+    vel_kernel_t kern = vel_kernel_const_of(vel_variant(&vp));
     if (f->vel_lds > 48 * 1024) FLEET_TRY(f, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->vel_lds));
     DoneSignal done; done.host_flag = nullptr; done.dev_count = nullptr; done.seq = 0u;
     hipLaunchKernelGGL(kern, dim3((unsigned)(f->D.N * J.per)), dim3(64), f->vel_lds, h->stream, h->lat, p, reinterpret_cast<const DevVelJob*>(J.jobs),

@@ -760,8 +760,9 @@ static size_t vel_scratch_bytes(int cap, bool with_gg, bool with_xy)
     return (b + 15) / 16 * 16;
 }
 
-// seam (2): one wave per job
-template <int EM, bool AXM1>
+// seam (2): one wave per job. GG = false: the job's friction limits are constant along the path (the fleet's jobs: rows 0 of loc_gg hold
+// them) -- three LDS arrays less per wave (occupancy of the fleet's velocity launches is LDS-bound) and no per-point loads of the limits
+template <int EM, bool AXM1, bool GG = true>
 __global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p, const DevVelJob* jobs,
                                                     const double* pool, double* out_pool, int* out_flags, int cap,
                                                     long long* dbg, DoneSignal done)
@@ -771,29 +772,32 @@ __global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p, 
     dbg_stamp(dbg, 0);
     const DevVelJob jb = jobs[blockIdx.x];
     if (jb.n <= 0) { signal_done(done); return; }          // unused slot of a fleet's job table (fleet_dev.hpp); seam (2) itself rejects empty jobs
-    VelScratch vs = carve_vel_scratch(smem, cap, true, false, nullptr, nullptr);
+    VelScratch vs = carve_vel_scratch(smem, cap, GG, false, nullptr, nullptr);
     vs.dbg = dbg;
     const int n = jb.n;
     for (int i = lane; i < n; i += 64) {
         vs.kabs[i] = fabs(pool[jb.off_kappa + i]);
-        vs.gax[i] = pool[jb.off_gg + 2 * i];
-        const double ay = pool[jb.off_gg + 2 * i + 1];
-        vs.gay[i] = ay; vs.igay[i] = 1.0 / ay;
+        if constexpr (GG) {
+            vs.gax[i] = pool[jb.off_gg + 2 * i];
+            const double ay = pool[jb.off_gg + 2 * i + 1];
+            vs.gay[i] = ay; vs.igay[i] = 1.0 / ay;
+        }
     }
+    const double cax = GG ? 1.0 : pool[jb.off_gg], cay = GG ? 1.0 : pool[jb.off_gg + 1];
     for (int i = lane; i < 2 * p.n_axm; i += 64) vs.axm[i] = p.axm[i];
     for (int i = lane; i < jb.n_el; i += 64) vs.el[i] = pool[jb.off_el + i];
     wave_sync_lds();
     dbg_stamp(dbg, 1);
     int too_close = 0, vel_bound = 1;
     if (jb.mode == LTPL_VEL_FB) {
-        fb_profile<EM, AXM1, true>(n, vs, 1.0, 1.0, p, p.v_max, jb.v_start, jb.has_v_end != 0, jb.v_end, lane);
+        fb_profile<EM, AXM1, GG>(n, vs, cax, cay, p, p.v_max, jb.v_start, jb.has_v_end != 0, jb.v_end, lane);
     } else if (jb.mode == LTPL_VEL_BRAKE) {
-        brake_profile<EM, true>(n, vs.w, vs, 1.0, 1.0, jb.v_start, p, lane);
+        brake_profile<EM, GG>(n, vs.w, vs, cax, cay, jb.v_start, p, lane);
     } else {
         FollowIn fi; fi.v_start = jb.v_start; fi.v_ego = jb.v_ego; fi.v_obj = jb.v_obj; fi.safety_d = jb.safety_d;
         fi.obj_dist = jb.obj_dist; fi.obj_x = jb.obj_x; fi.obj_y = jb.obj_y;
-        follow_profile<EM, AXM1, true>(lat, n, jb.n_el, vs, 1.0, 1.0, p, fi, lane, &too_close, &vel_bound, false,
-                                       jb.mode == LTPL_VEL_FOLLOW_CONTROLLED);
+        follow_profile<EM, AXM1, GG>(lat, n, jb.n_el, vs, cax, cay, p, fi, lane, &too_close, &vel_bound, false,
+                                     jb.mode == LTPL_VEL_FOLLOW_CONTROLLED);
     }
     dbg_stamp(dbg, 2);
     for (int i = lane; i < n; i += 64) out_pool[jb.off_out + i] = sqrt(vs.w[i]);
@@ -2723,6 +2727,14 @@ static vel_kernel_t vel_kernel_of(int v)
         case 0: return k_vel_profile<0, false>; case 1: return k_vel_profile<0, true>;
         case 2: return k_vel_profile<1, false>; case 3: return k_vel_profile<1, true>;
         case 4: return k_vel_profile<2, false>; default: return k_vel_profile<2, true>;
+    }
+}
+static vel_kernel_t vel_kernel_const_of(int v)          // constant friction limits per job (fleet)
+{
+    switch (v) {
+        case 0: return k_vel_profile<0, false, false>; case 1: return k_vel_profile<0, true, false>;
+        case 2: return k_vel_profile<1, false, false>; case 3: return k_vel_profile<1, true, false>;
+        case 4: return k_vel_profile<2, false, false>; default: return k_vel_profile<2, true, false>;
     }
 }
 static tick_kernel_t tick_kernel_of(int v, bool plan_a = false)

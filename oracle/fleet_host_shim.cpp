@@ -40,7 +40,7 @@ struct HostFleet {
     JobSet JA, JB, JC;
     bool began = false;
     FObj obj() { return FObj{prev_action.data(), t_now.data(), veh_off.data(), pos_off.data(), radius.data(), vel.data(), px.data(), py.data()}; }
-    Block block(int p) { return Block{state.data() + D.stride * (size_t)p, &D}; }
+    Block block(int p) { return Block{state.data() + D.stride * (size_t)p, D}; }
     int first_error()
     {
         for (int p = 0; p < D.N; ++p) { const int e = block(p).S()->err; if (e) { err = err_text(p, e); return e & 0xff; } }

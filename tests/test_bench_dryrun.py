@@ -17,6 +17,38 @@ import bench
 from graphbasedlocaltrajectoryplanner_amd import _capi
 from oracle.oracle_lib import OracleBackend
 from oracle.planner_host import HostPlannerBackend       # bound to the real Planner class before the test patches the name
+from oracle.fleet_host import HostFleetBackend
+from graphbasedlocaltrajectoryplanner_amd import fleet as fleet_mod
+
+
+class StandInFleet(object):
+    """Fleet's surface as bench.py uses it, on the one-lane host build of the fleet state machine (oracle/fleet_host.py): the tape is kept in
+    Python and replayed through the per-call entry points."""
+
+    def __init__(self, hip, n_planners, **cfg):
+        self.p = hip.fleet_host.planner(n_planners, **cfg)
+        self.n, self.tape = n_planners, []
+
+    def set_start(self, *a, **k):
+        return self.p.set_start(*a, **k)
+
+    def tape_append_groups(self, groups, ax_max_machines=((100.0, 5.0),)):
+        self.tape.append((groups, ax_max_machines))
+
+    def tape_run(self, first, count):
+        for groups, axm in self.tape[first:first + count]:
+            per = [g for c, g in groups for _ in range(c)]
+            self.p.calc_paths([g["prev_action"] for g in per], [g["t_now"] for g in per], [g["vehicles"] for g in per], [g["zone_gids"] for g in per])
+            g0 = per[0]
+            self.p.calc_vel_profile([g["pos_est"] for g in per], [g["vel_est"] for g in per], vel_max=g0["vel_max"], gg_scale=g0["gg_scale"],
+                                    local_gg=g0["local_gg"], ax_max_machines=axm, safety_d=g0["safety_d"], incl_emerg_traj=g0["incl_emerg_traj"])
+        return 1.5 * count
+
+    def trajectories(self, p):
+        return self.p.trajectories(p)
+
+    def close(self):
+        self.p.close()
 
 
 class StandInBackend(object):
@@ -25,6 +57,7 @@ class StandInBackend(object):
     def __init__(self, lattice, device=-1):
         self.orc = OracleBackend(lattice)
         self.host = HostPlannerBackend(lattice)
+        self.fleet_host = HostFleetBackend(lattice)
         self.caps = self.orc.caps
         self.calls = []
         self._resident = None
@@ -75,6 +108,7 @@ def run_worker(monkeypatch, capsys, **over):
 
     monkeypatch.setattr(_capi, "HipBackend", backend)
     monkeypatch.setattr(planner_mod, "Planner", lambda hip, n_scen=1, **cfg: hip.host.planner(n_scen, **cfg))
+    monkeypatch.setattr(fleet_mod, "Fleet", StandInFleet)
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
@@ -82,7 +116,7 @@ def run_worker(monkeypatch, capsys, **over):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         monkeypatch.delenv(k, raising=False)
     args = dict(gpus=1, steps=3, warmup=1, batch=64, cpu_sample=8, latency_ticks=4, dropin_ticks=40, no_cpu=False,
-                no_extra=False, exact_steps=True, workload="c2")
+                no_extra=False, exact_steps=True, workload="c2", fleet_planners=3, fleet_ticks=40)
     args.update(over)
     bench.worker(argparse.Namespace(**args))
     lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
@@ -125,6 +159,8 @@ def test_the_line_carries_the_drivers_contract(monkeypatch, capsys):
     assert out["extra"]["pcie_inclusive"]["scenarios_per_call"] == 64 and out["extra"]["three_slot_paths_per_tick"] >= 1.0
     cl = out["extra"]["closed_loop"]
     assert cl["planners"] == 256 and cl["planner_ticks_per_s"] > 0 and cl["keys_match_recording"] is True
+    cd = out["extra"]["closed_loop_device"]
+    assert cd["planners"] == 3 and cd["ticks"] == 40 and cd["matches_recording"] is True and cd["planner_ticks_per_s"] == pytest.approx(3 * 40 / 0.06)
     assert 1.0 <= out["paths_per_tick"] <= 4.0
     # order of the device calls: resident inputs before any run, and the sample re-uploaded for the device-only latency
     assert hip.calls[0] == "batch_upload" and hip.calls.count("batch_upload") == 3

@@ -38,14 +38,14 @@ def main():
     n = a.planners
     sizes = [n // len(names)] * len(names)
     sizes[0] += n - sum(sizes)
-    fleet = Fleet(hip, n)
-    t0 = time.perf_counter()
-    for k in range(a.ticks):
-        fleet.tape_append_groups([(sz, group_inputs(lat, ticks[k])) for sz, ticks in zip(sizes, recs)],
-                                 ax_max_machines=recs[0][k]['vel_args']['ax_max_machines'])
-    t_tape = time.perf_counter() - t0
     best = None
     for rep in range(a.reps):
+        fleet = Fleet(hip, n)                     # (a fresh fleet per repetition: trajectory ids count up over a planner's life)
+        t0 = time.perf_counter()
+        for k in range(a.ticks):
+            fleet.tape_append_groups([(sz, group_inputs(lat, ticks[k])) for sz, ticks in zip(sizes, recs)],
+                                     ax_max_machines=recs[0][k]['vel_args']['ax_max_machines'])
+        t_tape = time.perf_counter() - t0
         p = 0
         t0 = time.perf_counter()
         for sz, ticks in zip(sizes, recs):
@@ -60,6 +60,8 @@ def main():
         best = ms if best is None else min(best, ms)
         print("rep %d: %d planners x %d ticks: device %.1f ms (wall %.1f ms) = %.3f M planner-ticks/s; %.3f ms per tick of the fleet "
               "(tape upload %.1f s, start poses %.1f s)" % (rep, n, a.ticks, ms, wall * 1e3, n * a.ticks / ms / 1e3, ms / a.ticks, t_tape, t_start))
+        if rep + 1 < a.reps:
+            fleet.close()
     p = 0
     for sz, ticks, nm in zip(sizes, recs, names):
         t = ticks[a.ticks - 1]
