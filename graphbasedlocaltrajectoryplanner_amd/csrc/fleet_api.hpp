@@ -124,7 +124,8 @@ inline std::string err_text(int planner, int err)
         "end node is None", "follow profile shorter than the path (OTH.py:830)", "velocity profile shorter than the path (OTH.py:919)",
         "fewer than 6 rows (IndexError, OTH.py:923)", "cut_layer beyond the backup plan", "backup plan shorter than the cut index",
         "backup brake profile length mismatch", "emergency profile without any trajectory (IndexError, OTH.py:1029)", "calc_time_buffer_len above 16",
-        "local_gg in its dict form is not supported by the fleet (use the host planner)", "more velocity jobs than slots", "start layer without a planning range (end of an open track)"};
+        "local_gg in its dict form is not supported by the fleet (use the host planner)", "more velocity jobs than slots", "start layer without a planning range (end of an open track)",
+        "velocity job longer than max_path_pts + 64 points"};
     const int site = (err >> 8) & 0xff;
     return "fleet: planner " + std::to_string(planner) + ": " + (site > 0 && site < (int)(sizeof(sites) / sizeof(sites[0])) ? sites[site] : "error");
 }

@@ -40,7 +40,7 @@ FLT_FN double inf() { return HUGE_VAL; }
 
 // error sites (S.err = LTPL_ERR_* | site << 8)
 enum Site { E_BACKUP_KEY = 1, E_NO_START, E_CAP_ROWS, E_CAP_NODES, E_CUT_LAYER, E_BRAKE_PREFIX, E_FOLLOW_EMPTY, E_NO_NODES, E_END_NONE,
-            E_FOLLOW_SHORT, E_VX_SHORT, E_ROW5, E_BACKUP_CUT, E_BACKUP_SHORT, E_BACKUP_LEN, E_EMERG_EMPTY, E_CALC_BUF, E_GG_DICT, E_CAP_JOBS, E_NO_RANGE };
+            E_FOLLOW_SHORT, E_VX_SHORT, E_ROW5, E_BACKUP_CUT, E_BACKUP_SHORT, E_BACKUP_LEN, E_EMERG_EMPTY, E_CALC_BUF, E_GG_DICT, E_CAP_JOBS, E_NO_RANGE, E_CAP_VEL };
 
 // ---------------------------------------------------------------------------------------------------------------------
 // plain-data state
@@ -86,6 +86,7 @@ struct PlannerS {
 
 struct Dims {
     int N, R, CN, cn, cp;
+    int RV;                         // points per velocity job (LDS-resident solver): cp + 64 <= R
     size_t stride;                  // bytes per planner block
     size_t o_traj, traj_bytes, o_bp, o_velc, o_sarr, o_vx, o_scr;
     FLT_FN size_t o_pp() const { return 0; }
@@ -101,6 +102,7 @@ inline Dims make_dims(int N, int max_path_nodes, int max_path_pts)
     Dims D;
     D.N = N; D.cn = max_path_nodes; D.cp = max_path_pts;
     D.R = 2 * max_path_pts + 64; D.CN = 2 * max_path_nodes + 8;            // = ltpl_planner_caps
+    D.RV = max_path_pts + 64;
     D.traj_bytes = align256(sizeof(double) * (size_t)D.R * 5 + sizeof(double) * (size_t)D.CN * 8 + sizeof(int) * (size_t)D.CN * 3);
     size_t o = align256(sizeof(PlannerS));
     D.o_traj = o; o += D.traj_bytes * 2 * KEYS;
@@ -524,11 +526,12 @@ FLT_FN void finalize_bp(const X& x, const FCfg& cfg, const double* s_arr, const 
     }
 }
 
+// job slot `slot` of planner p (slot 0 is reserved for the follow job of a tick: the device runs the follow jobs as their own launch)
 template <class X>
-FLT_FN int make_job(const X& x, const Dims& D, const FJobs& J, int p, int& n_jobs, int mode, const double* pv, double gax, double gay, int i0, int i1,
+FLT_FN int make_job(const X& x, const Dims& D, const FJobs& J, int p, int slot, int mode, const double* pv, double gax, double gay, int i0, int i1,
                     int n_el, double v_start, bool has_end, double v_end)
 {
-    const int j = p * J.per_planner + n_jobs;
+    const int j = p * J.per_planner + slot;
     VelJob jb{};
     jb.mode = mode; jb.n = i1 - i0; jb.n_el = n_el; jb.has_v_end = has_end ? 1 : 0; jb.v_start = v_start; jb.v_end = v_end;
     jb.off_kappa = j * 4 * D.R; jb.off_el = jb.off_kappa + D.R; jb.off_gg = jb.off_kappa + 2 * D.R; jb.off_out = j * D.R;
@@ -537,7 +540,7 @@ FLT_FN int make_job(const X& x, const Dims& D, const FJobs& J, int p, int& n_job
     for (int i = x.lane(); i < n_el; i += X::W) el[i] = pv[(size_t)(i0 + i) * 5 + 4];
     if (n_el < 1 && x.lane() == 0) el[0] = 0.0;
     if (x.lane() == 0) J.jobs[j] = jb;
-    return n_jobs++;
+    return slot;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -558,7 +561,7 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
     S.n_bp = 0; S.has_bp = 1; S.n_ids = 0;
     const int vel_idx = S.n_vel_course;
     const int set = S.cur_set;
-    int n_jobs = 0;
+    int n_jobs = 1;                                        // next free slot (0: the follow job)
     S.n_work = S.n_last;
     for (int k = 0; k < S.n_last; ++k) {
         const int sl = S.last_slot[k];
@@ -599,7 +602,8 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
         W.pref_idx = vel_idx; W.vel_start = S.vel_plan;
         const int pref = W.pref_idx;
         const double sgx = gax * gg_scale, sgy = gay * gg_scale;
-        if (n_jobs + (T.id == LTPL_ACT_FOLLOW ? 2 : 0) + ((T.id != LTPL_ACT_FOLLOW || T.red_len) ? 1 : 0) > J.per_planner) { fail(S, LTPL_ERR_CAPACITY, E_CAP_JOBS); return; }
+        if (n_jobs + (T.id == LTPL_ACT_FOLLOW ? 1 : 0) + ((T.id != LTPL_ACT_FOLLOW || T.red_len) ? 1 : 0) > J.per_planner) { fail(S, LTPL_ERR_CAPACITY, E_CAP_JOBS); return; }
+        if (m > D.RV) { fail(S, LTPL_ERR_CAPACITY, E_CAP_VEL); return; }
         if (T.id == LTPL_ACT_FOLLOW) {                                                              // :763-830
             if (m - pref < 1) { fail(S, LTPL_ERR_INVALID_ARG, E_FOLLOW_EMPTY); return; }
             double obj_dist = 0.0, v_obj = 0.0, ox = vin.pos_x[p], oy = vin.pos_y[p];
@@ -615,13 +619,15 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
                 const double s_sta = project_on_polyline(x, pl, S.pos_est[0], S.pos_est[1], false, true, cs, 1, m).s;
                 obj_dist = s_obj - s_sta;
             }
-            const int j = make_job(x, D, J, p, n_jobs, LTPL_VEL_FOLLOW_CONTROLLED, pv, sgx, sgy, pref, m, m - pref, W.vel_start, false, 0.0);
+            if (J.jobs[p * J.per_planner].n > 0) { fail(S, LTPL_ERR_CAPACITY, E_CAP_JOBS); return; }       // (two follow keys in one tick: not a thing)
+            const int j = make_job(x, D, J, p, 0, LTPL_VEL_FOLLOW_CONTROLLED, pv, sgx, sgy, pref, m, m - pref, W.vel_start, false, 0.0);
+            x.sync();
             if (x.lane() == 0) {
                 VelJob& jb = J.jobs[p * J.per_planner + j];
                 jb.v_ego = vin.vel_est[p]; jb.v_obj = v_obj; jb.safety_d = vin.safety_d[p]; jb.obj_dist = obj_dist; jb.obj_x = ox; jb.obj_y = oy;
             }
             W.job_follow = j;
-            W.job_free = make_job(x, D, J, p, n_jobs, LTPL_VEL_FB, pv, sgx, sgy, pref, m, m - pref - 1, W.vel_start, false, 0.0);
+            W.job_free = make_job(x, D, J, p, n_jobs++, LTPL_VEL_FB, pv, sgx, sgy, pref, m, m - pref - 1, W.vel_start, false, 0.0);
         }
         if (T.id != LTPL_ACT_FOLLOW || T.red_len) {                                                 // :834-903
             W.generic = 1;
@@ -645,7 +651,7 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
                 v_idx = m;
             }
             W.v_idx = v_idx;
-            if (v_idx - pref > 1) { W.job_fb = make_job(x, D, J, p, n_jobs, LTPL_VEL_FB, pv, sgx, sgy, pref, v_idx, v_idx - pref - 1, W.vel_start, true, v_end); W.has_fb = 1; }
+            if (v_idx - pref > 1) { W.job_fb = make_job(x, D, J, p, n_jobs++, LTPL_VEL_FB, pv, sgx, sgy, pref, v_idx, v_idx - pref - 1, W.vel_start, true, v_end); W.has_fb = 1; }
         }
         S.w[k] = W;
     }
@@ -733,11 +739,9 @@ FLT_FN void vel_b(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int 
                 const int i0 = S.cut_index_pos + vel_idx;
                 if (i0 >= br) { fail(S, LTPL_ERR_INVALID_ARG, E_BACKUP_SHORT); return; }
                 const double* bpp = B.pp(bs, bk) + (size_t)Bm.r0 * 5;
-                {   // brake job on the backup rows [i0, br): no gg_scale (:229-255)
-                    int nj = n_backup;
-                    const int j = make_job(x, D, JB, p, nj, LTPL_VEL_BRAKE, bpp, Bm.gax, Bm.gay, i0, br, br - i0 - 1, S.vel_plan, false, 0.0);
-                    W.job_backup = j; n_backup = nj;
-                }
+                if (br - i0 > D.RV) { fail(S, LTPL_ERR_CAPACITY, E_CAP_VEL); return; }
+                // brake job on the backup rows [i0, br): no gg_scale (:229-255)
+                W.job_backup = make_job(x, D, JB, p, n_backup++, LTPL_VEL_BRAKE, bpp, Bm.gax, Bm.gay, i0, br, br - i0 - 1, S.vel_plan, false, 0.0);
                 // the key's memory becomes the (trimmed) backup
                 double* tpp = B.pp(set, sl); double* tco = B.coeff(set, sl); int* tnd = B.nodes(set, sl); int* tni = B.nidx(set, sl);
                 const double* bco = B.coeff(bs, bk) + (size_t)Bm.c0 * 8; const int* bnd = B.nodes(bs, bk) + (size_t)Bm.n0 * 2; const int* bni = B.nidx(bs, bk) + Bm.i0;
@@ -815,6 +819,7 @@ FLT_FN void vel_c(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int 
         if (S.n_bp == 0) { fail(S, LTPL_ERR_INVALID_ARG, E_EMERG_EMPTY); return; }
         S.em_base_id = S.bp_id[0];
         const double* base = B.bp(S.bp_slot[0]); const int m = S.bp_rows[0];
+        if (m > D.RV) { fail(S, LTPL_ERR_CAPACITY, E_CAP_VEL); return; }
         const int j = p * JC.per_planner;
         VelJob jb{};
         jb.mode = LTPL_VEL_BRAKE; jb.n = m; jb.n_el = m - 1; jb.v_start = m > 0 ? base[5] : 0.0;

@@ -174,7 +174,7 @@ struct ltpl_fleet {
     std::vector<FleetTickIn> tape;
     std::vector<unsigned char> image;                 // host image of one planner block (queries)
     bool began = false;
-    size_t vel_lds = 0;
+    size_t vel_lds = 0, vel_lds_lite = 0;
     ~ltpl_fleet()
     {
         if (h) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); --h->n_planners; }
@@ -279,7 +279,7 @@ try {
     if ((rc = fleet_jobs_alloc(f.get(), &f->JA, fleet::JOBS_A))) return bail(rc);
     if ((rc = fleet_jobs_alloc(f.get(), &f->JB, 1))) return bail(rc);
     if ((rc = fleet_jobs_alloc(f.get(), &f->JC, 1))) return bail(rc);
-    f->vel_lds = vel_scratch_bytes(f->D.R, false, false);
+    f->vel_lds = vel_scratch_bytes(f->D.RV, false, false); f->vel_lds_lite = vel_scratch_bytes(f->D.RV, false, false, true);
     if (f->vel_lds > 150 * 1024) return bail((f->err = "fleet: velocity profile too long for the LDS-resident solver", LTPL_ERR_CAPACITY));
     f->image.resize(f->D.stride);
     *out = f.release();
@@ -438,18 +438,40 @@ static int fleet_launch_paths(ltpl_fleet* f, const FleetTickIn& t, bool pre, boo
     return LTPL_OK;
 }
 
-static int fleet_launch_vel_jobs(ltpl_fleet* f, const ltpl_vel_params& vp, const double* d_axm, const FleetJobsDev& J)
+// one launch of the velocity kernel over a job table. sel 1: forward-backward / brake jobs of all slots ("lite" LDS scratch); sel 2: the
+// follow jobs (slot 0 of every planner)
+static int fleet_launch_vel_jobs(ltpl_fleet* f, const ltpl_vel_params& vp, const double* d_axm, const FleetJobsDev& J, int sel)
 {
     ltpl_handle* h = f->h;
     DevVelParams p;
     int rc = make_vel_params(h, &vp, d_axm, &p);
     if (rc) { f->err = h->err; return rc; }
-    vel_kernel_t kern = vel_kernel_const_of(vel_variant(&vp));
-    if (f->vel_lds > 48 * 1024) FLEET_TRY(f, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->vel_lds));
+    vel_kernel_t kern = sel == 1 ? vel_kernel_const_of<1>(vel_variant(&vp)) : vel_kernel_const_of<2>(vel_variant(&vp));
+    const size_t lds = sel == 1 ? f->vel_lds_lite : f->vel_lds;
+    if (lds > 48 * 1024) FLEET_TRY(f, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     DoneSignal done; done.host_flag = nullptr; done.dev_count = nullptr; done.seq = 0u;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(f->D.N * J.per)), dim3(64), f->vel_lds, h->stream, h->lat, p, reinterpret_cast<const DevVelJob*>(J.jobs),
-                       J.pool, J.out, J.flags, f->D.R, (long long*)nullptr, done);
+    const unsigned blocks = (unsigned)(sel == 1 ? f->D.N * J.per : f->D.N);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, h->stream, h->lat, p, reinterpret_cast<const DevVelJob*>(J.jobs),
+                       J.pool, J.out, J.flags, f->D.RV, h->lp4.dbg, done, sel == 1 ? 1 : J.per);
     FLEET_TRY(f, hipGetLastError());
+#ifdef LTPL_EXPERIMENT
+    if (h->d_dbg && J.per > 1) {        // LTPL_DEBUG_TIMING=1 (experiment build): cycle stamps of the first 256 blocks of the launch, per slot index
+        std::vector<long long> v((size_t)256 * DBG_SLOTS);
+        if (hipMemcpy(v.data(), h->d_dbg, v.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            const int groups = sel == 1 ? J.per : 1;
+            for (int r = 0; r < groups; ++r) {
+                fprintf(stderr, "[ltpl dbg] fleet k_vel_profile sel %d slot %d:", sel, r);
+                for (int k = 0; k + 1 < 16; ++k) {
+                    double acc = 0; int cnt = 0;
+                    for (int b = r; b < 256; b += groups) { const long long a = v[(size_t)b * DBG_SLOTS + k], c = v[(size_t)b * DBG_SLOTS + k + 1]; if (a > 0 && c > a) { acc += (double)(c - a); ++cnt; } }
+                    fprintf(stderr, " %8.0f", cnt ? acc / cnt : 0.0);
+                }
+                fprintf(stderr, "\n");
+            }
+            (void)hipMemset(h->d_dbg, 0, v.size() * sizeof(long long));
+        }
+    }
+#endif
     return LTPL_OK;
 }
 
@@ -464,15 +486,16 @@ static int fleet_launch_vel(ltpl_fleet* f, const FleetTickIn& t)
     int rc;
     hipLaunchKernelGGL(k_fleet_vel_a, dim3(N), dim3(64), 0, st, f->args, t.ob, t.vin, f->JA.view());
     FLEET_TRY(f, hipGetLastError());
-    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA))) return rc;
+    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA, 2))) return rc;        // follow jobs first: the longest
+    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA, 1))) return rc;
     hipLaunchKernelGGL(k_fleet_vel_b, dim3(N), dim3(64), 0, st, f->args, f->JA.view(), f->JB.view());
     FLEET_TRY(f, hipGetLastError());
-    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JB))) return rc;
+    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JB, 1))) return rc;
     hipLaunchKernelGGL(k_fleet_vel_c, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JB.view(), f->JC.view());
     FLEET_TRY(f, hipGetLastError());
     if (t.any_emerg) {
         ltpl_vel_params ve = vp; ve.dyn_model_exp = 1.0; ve.drag_coeff = 0.854; ve.m_veh = 1160.0;       // calc_brake_emergency.py:4-6,31-36
-        if ((rc = fleet_launch_vel_jobs(f, ve, t.axm, f->JC))) return rc;
+        if ((rc = fleet_launch_vel_jobs(f, ve, t.axm, f->JC, 1))) return rc;
         hipLaunchKernelGGL(k_fleet_vel_d, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JC.view());
         FLEET_TRY(f, hipGetLastError());
     }

@@ -599,7 +599,9 @@ __device__ __forceinline__ void follow_profile(const DevLat& lat, int n, int n_e
     const int tc = (fi.obj_dist - safety_d) < 0.0;                                       // :147-149
     const double v_max = p.v_max;
 
+    dbg_stamp(vs.dbg, 4);
     brake_profile<EM, GGARR>(n, vs.wb, vs, cax, cay, fi.v_start, p, lane);   // :152-159
+    dbg_stamp(vs.dbg, 5);
     // arc length s = [0, cumsum(el[:-1])] (:203) next to the ego stop distance (:162-166)
     wave_cumsum_seq(vs.el, vs.s, n_el, lane);                  // s[i] = sum of el[0 .. i-1], sequential order
     // first point at or below 0.1 m/s on the brake profile; the ego stop distance is the arc length up to it (:162-166)
@@ -611,7 +613,9 @@ __device__ __forceinline__ void follow_profile(const DevLat& lat, int n, int n_e
     // opponent: closest point of the global race line (:172-179), brake scan with ggv [100, 14, 14] (:134,185-199)
     const int G = lat.G - 1;
     const double* grl = lat.glob_rl;
+    dbg_stamp(vs.dbg, 6);
     const int idx_s_opp = globrl_index_dev(lat, fi.obj_x, fi.obj_y, lane);
+    dbg_stamp(vs.dbg, 7);
     const double vel0 = grl[(size_t)idx_s_opp * 5 + 4];
     const double vel_start = fi.v_obj < vel0 ? fi.v_obj : vel0;                          // :182
     double opp_stop = 0.0, wopp = vel_start * vel_start;
@@ -641,6 +645,7 @@ __device__ __forceinline__ void follow_profile(const DevLat& lat, int n, int n_e
     }
     opp_stop = __shfl(opp_stop, 0);
 
+    dbg_stamp(vs.dbg, 11);
     // characteristic indices (:201-221)
     const double s_stop = fi.obj_dist - safety_d + opp_stop;                             // :206
     int stop_idx = wave_find_first(n_el - 1, lane, [&](int i) { return !(vs.s[i] < s_stop); });   // :208-209
@@ -659,6 +664,7 @@ __device__ __forceinline__ void follow_profile(const DevLat& lat, int n, int n_e
         }
     }
     v_end = __shfl(v_end, 0);
+    dbg_stamp(vs.dbg, 12);
 
     // control velocity (:232-239, get_control_vel :28-75)
     double v_control;
@@ -735,17 +741,20 @@ struct DevVelJob {
     double v_start, v_end, v_ego, v_obj, safety_d, obj_dist, obj_x, obj_y;
 };
 
+// `lite`: only what the forward-backward and brake profiles touch (w, kabs, el, machine table, run flags) -- no arc length, no follow scratch
 __device__ __forceinline__ VelScratch carve_vel_scratch(unsigned char* base, int cap, bool with_gg, bool with_xy,
-                                                        double** px, double** py)
+                                                        double** px, double** py, bool lite = false)
 {
     VelScratch vs;
     double* d = reinterpret_cast<double*>(base);
     const int c1 = cap + 2;
-    vs.w = d; d += c1; vs.kabs = d; d += c1; vs.el = d; d += c1; vs.s = d; d += c1; vs.wb = d; d += c1; vs.wc = d; d += c1;
+    vs.w = d; d += c1; vs.kabs = d; d += c1; vs.el = d; d += c1;
+    if (!lite) { vs.s = d; d += c1; vs.wb = d; d += c1; vs.wc = d; d += c1; }
+    else { vs.s = nullptr; vs.wb = nullptr; vs.wc = nullptr; }
     if (with_gg) { vs.gax = d; d += c1; vs.gay = d; d += c1; vs.igay = d; d += c1; }
     else { vs.gax = nullptr; vs.gay = nullptr; vs.igay = nullptr; }
     if (with_xy) { *px = d; d += c1; *py = d; d += c1; }
-    vs.chunk = d; d += 128;
+    if (!lite) { vs.chunk = d; d += 128; } else vs.chunk = nullptr;
     vs.axm = d; d += 128;
     vs.start = reinterpret_cast<unsigned char*>(d);
     vs.cap = cap;
@@ -753,26 +762,33 @@ __device__ __forceinline__ VelScratch carve_vel_scratch(unsigned char* base, int
     return vs;
 }
 
-static size_t vel_scratch_bytes(int cap, bool with_gg, bool with_xy)
+static size_t vel_scratch_bytes(int cap, bool with_gg, bool with_xy, bool lite = false)
 {
-    size_t arrays = 6 + (with_gg ? 3 : 0) + (with_xy ? 2 : 0);
-    size_t b = sizeof(double) * (arrays * (size_t)(cap + 2) + 256) + (size_t)cap + 16;
+    size_t arrays = (lite ? 3 : 6) + (with_gg ? 3 : 0) + (with_xy ? 2 : 0);
+    size_t b = sizeof(double) * (arrays * (size_t)(cap + 2) + (lite ? 128 : 256)) + (size_t)cap + 16;
     return (b + 15) / 16 * 16;
 }
 
 // seam (2): one wave per job. GG = false: the job's friction limits are constant along the path (the fleet's jobs: rows 0 of loc_gg hold
-// them) -- three LDS arrays less per wave (occupancy of the fleet's velocity launches is LDS-bound) and no per-point loads of the limits
-template <int EM, bool AXM1, bool GG = true>
+// them) -- three LDS arrays less per wave and no per-point loads of the limits. SEL (fleet): the occupancy of these launches is bound by
+// the LDS a wave needs and the recurrences are latency chains (~200 cycles per point), so the fleet runs the forward-backward / brake jobs
+// (SEL 1: three arrays, "lite" scratch) and the follow jobs (SEL 2: six arrays, job slot 0 of every planner) as two launches; a block
+// whose job belongs to the other launch returns at once. `job_stride`: block b works on job b * job_stride.
+template <int EM, bool AXM1, bool GG = true, int SEL = 0>
 __global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p, const DevVelJob* jobs,
                                                     const double* pool, double* out_pool, int* out_flags, int cap,
-                                                    long long* dbg, DoneSignal done)
+                                                    long long* dbg, DoneSignal done, int job_stride)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     dbg_stamp(dbg, 0);
-    const DevVelJob jb = jobs[blockIdx.x];
+    const int j = blockIdx.x * job_stride;
+    const DevVelJob jb = jobs[j];
     if (jb.n <= 0) { signal_done(done); return; }          // unused slot of a fleet's job table (fleet_dev.hpp); seam (2) itself rejects empty jobs
-    VelScratch vs = carve_vel_scratch(smem, cap, GG, false, nullptr, nullptr);
+    const bool follow = jb.mode == LTPL_VEL_FOLLOW || jb.mode == LTPL_VEL_FOLLOW_CONTROLLED;
+    if constexpr (SEL == 1) { if (follow) return; }
+    if constexpr (SEL == 2) { if (!follow) return; }
+    VelScratch vs = carve_vel_scratch(smem, cap, GG, false, nullptr, nullptr, SEL == 1);
     vs.dbg = dbg;
     const int n = jb.n;
     for (int i = lane; i < n; i += 64) {
@@ -793,7 +809,7 @@ __global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p, 
         fb_profile<EM, AXM1, GG>(n, vs, cax, cay, p, p.v_max, jb.v_start, jb.has_v_end != 0, jb.v_end, lane);
     } else if (jb.mode == LTPL_VEL_BRAKE) {
         brake_profile<EM, GG>(n, vs.w, vs, cax, cay, jb.v_start, p, lane);
-    } else {
+    } else if constexpr (SEL != 1) {
         FollowIn fi; fi.v_start = jb.v_start; fi.v_ego = jb.v_ego; fi.v_obj = jb.v_obj; fi.safety_d = jb.safety_d;
         fi.obj_dist = jb.obj_dist; fi.obj_x = jb.obj_x; fi.obj_y = jb.obj_y;
         follow_profile<EM, AXM1, GG>(lat, n, jb.n_el, vs, cax, cay, p, fi, lane, &too_close, &vel_bound, false,
@@ -801,7 +817,7 @@ __global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p, 
     }
     dbg_stamp(dbg, 2);
     for (int i = lane; i < n; i += 64) out_pool[jb.off_out + i] = sqrt(vs.w[i]);
-    if (lane == 0) { out_flags[2 * blockIdx.x] = too_close; out_flags[2 * blockIdx.x + 1] = vel_bound; }
+    if (lane == 0) { out_flags[2 * j] = too_close; out_flags[2 * j + 1] = vel_bound; }
     dbg_stamp(dbg, 3);
     signal_done(done);
 }
@@ -2710,7 +2726,7 @@ static int vel_variant(const ltpl_vel_params* vp)
     const int em = vp->dyn_model_exp == 1.0 ? 1 : (vp->dyn_model_exp == 2.0 ? 2 : 0);
     return em * 2 + (vp->n_ax_max_machines == 1 ? 1 : 0);
 }
-typedef void (*vel_kernel_t)(DevLat, DevVelParams, const DevVelJob*, const double*, double*, int*, int, long long*, DoneSignal);
+typedef void (*vel_kernel_t)(DevLat, DevVelParams, const DevVelJob*, const double*, double*, int*, int, long long*, DoneSignal, int);
 typedef void (*tick_kernel_t)(DevLat, DevPathsIn, DevPathsOut, TeamLds, DevVelParams, DevTickVelIn, DevTickVelOut, int, int, int);
 typedef void (*lanes_kernel_t)(DevLat, DevPathsIn, DevPathsOut, DevVelParams, DevTickVelIn, DevVelPrep, VelPlanes, int, int, int, long long*);
 static lanes_kernel_t lanes_kernel_of(int v)
@@ -2729,12 +2745,13 @@ static vel_kernel_t vel_kernel_of(int v)
         case 4: return k_vel_profile<2, false>; default: return k_vel_profile<2, true>;
     }
 }
-static vel_kernel_t vel_kernel_const_of(int v)          // constant friction limits per job (fleet)
+template <int SEL>
+static vel_kernel_t vel_kernel_const_of(int v)          // constant friction limits per job (fleet); SEL: see k_vel_profile
 {
     switch (v) {
-        case 0: return k_vel_profile<0, false, false>; case 1: return k_vel_profile<0, true, false>;
-        case 2: return k_vel_profile<1, false, false>; case 3: return k_vel_profile<1, true, false>;
-        case 4: return k_vel_profile<2, false, false>; default: return k_vel_profile<2, true, false>;
+        case 0: return k_vel_profile<0, false, false, SEL>; case 1: return k_vel_profile<0, true, false, SEL>;
+        case 2: return k_vel_profile<1, false, false, SEL>; case 3: return k_vel_profile<1, true, false, SEL>;
+        case 4: return k_vel_profile<2, false, false, SEL>; default: return k_vel_profile<2, true, false, SEL>;
     }
 }
 static tick_kernel_t tick_kernel_of(int v, bool plan_a = false)
@@ -2838,7 +2855,7 @@ try {
     if (polled) done = next_done_signal(h);
     hipLaunchKernelGGL(kern, dim3(n_jobs), dim3(64), lds, h->stream, h->lat, p,
                        reinterpret_cast<const DevVelJob*>(db + o_jobs), reinterpret_cast<const double*>(db + o_pool),
-                       reinterpret_cast<double*>(dob + o_vx), reinterpret_cast<int*>(dob + o_flags), cap, h->lp4.dbg, done);
+                       reinterpret_cast<double*>(dob + o_vx), reinterpret_cast<int*>(dob + o_flags), cap, h->lp4.dbg, done, 1);
     HIP_TRY(h, hipGetLastError());
     if (!zc) HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, aout.size, hipMemcpyDeviceToHost, h->stream));
     prof_enq.stop();
