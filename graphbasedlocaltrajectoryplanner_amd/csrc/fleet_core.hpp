@@ -161,7 +161,16 @@ struct VelJob {
     int off_kappa, off_el, off_gg, off_out;
     double v_start, v_end, v_ego, v_obj, safety_d, obj_dist, obj_x, obj_y;
 };
-struct FJobs { VelJob* jobs; double* pool; const double* out; const int* flags; int per_planner; };
+// Lane plane (device only, stage-A table): the forward-backward jobs of slots >= 1 are solved one LANE per job (k_fleet_fb_lanes), so their
+// operands go into a plane tiled by job and blocked by rows, (|kappa|, element length) as an fp32 pair (`ke`, layout = kep_base / kep_row of
+// the batch velocity stage); plane index q = p (per_planner - 1) + slot - 1. The results come back job-major in `out` like every other
+// job's. Null: operands through `pool` (host harness, follow and brake jobs).
+struct F2 { float x, y; };
+struct FJobs { VelJob* jobs; double* pool; const double* out; const int* flags; int per_planner; F2* ke; int ke_rows; };
+FLT_FN unsigned kep_base_f(int job, int plane_rows) { return ((unsigned)(job >> 6) * (unsigned)(plane_rows >> 3) * 64u + (unsigned)(job & 63)) * 8u; }
+FLT_FN unsigned kep_row_f(int r) { return ((unsigned)(r >> 3) << 9) + (unsigned)(r & 7); }
+// result i of the job in `slot` of planner p
+FLT_FN double job_out(const FJobs& J, const Dims& D, int p, int slot, int i) { return J.out[(size_t)(p * J.per_planner + slot) * D.R + i]; }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // exec policy of the host build: one lane
@@ -536,9 +545,18 @@ FLT_FN int make_job(const X& x, const Dims& D, const FJobs& J, int p, int slot, 
     jb.mode = mode; jb.n = i1 - i0; jb.n_el = n_el; jb.has_v_end = has_end ? 1 : 0; jb.v_start = v_start; jb.v_end = v_end;
     jb.off_kappa = j * 4 * D.R; jb.off_el = jb.off_kappa + D.R; jb.off_gg = jb.off_kappa + 2 * D.R; jb.off_out = j * D.R;
     double* kap = J.pool + jb.off_kappa; double* el = J.pool + jb.off_el; double* gg = J.pool + jb.off_gg;
-    for (int i = x.lane(); i < i1 - i0; i += X::W) { kap[i] = pv[(size_t)(i0 + i) * 5 + 3]; gg[(size_t)i * 2] = gax; gg[(size_t)i * 2 + 1] = gay; }
-    for (int i = x.lane(); i < n_el; i += X::W) el[i] = pv[(size_t)(i0 + i) * 5 + 4];
-    if (n_el < 1 && x.lane() == 0) el[0] = 0.0;
+    if (J.ke && mode == LTPL_VEL_FB && slot >= 1) {
+        F2* ke = J.ke + kep_base_f(p * (J.per_planner - 1) + slot - 1, J.ke_rows);
+        for (int i = x.lane(); i < i1 - i0; i += X::W) {
+            F2 r; r.x = (float)fabs(pv[(size_t)(i0 + i) * 5 + 3]); r.y = i < n_el ? (float)pv[(size_t)(i0 + i) * 5 + 4] : 0.0f;
+            ke[kep_row_f(i)] = r;
+        }
+        if (x.lane() == 0) { gg[0] = gax; gg[1] = gay; }
+    } else {
+        for (int i = x.lane(); i < i1 - i0; i += X::W) { kap[i] = pv[(size_t)(i0 + i) * 5 + 3]; gg[(size_t)i * 2] = gax; gg[(size_t)i * 2 + 1] = gay; }
+        for (int i = x.lane(); i < n_el; i += X::W) el[i] = pv[(size_t)(i0 + i) * 5 + 4];
+        if (n_el < 1 && x.lane() == 0) el[0] = 0.0;
+    }
     if (x.lane() == 0) J.jobs[j] = jb;
     return slot;
 }
@@ -686,24 +704,24 @@ FLT_FN void vel_b(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int 
                 const int jf = p * JA.per_planner + W.job_follow;
                 W.too_close = JA.flags[2 * jf]; W.vel_bound = JA.flags[2 * jf + 1];
                 const double* f = JA.out + (size_t)jf * D.R; const int nf = m - W.pref_idx;
-                const double* u = W.job_free >= 0 ? JA.out + (size_t)(p * JA.per_planner + W.job_free) * D.R : nullptr;   // np.minimum(vx_profile, vx_compl) (:310)
+                const bool has_u = W.job_free >= 0;                                                       // np.minimum(vx_profile, vx_compl) (:310)
                 int len = vel_idx + nf;
                 if (len > m) len = m;
                 if (len != m) { fail(S, LTPL_ERR_INVALID_ARG, E_FOLLOW_SHORT); return; }
                 for (int i = x.lane(); i < m; i += X::W) {
                     double v;
                     if (i < vel_idx) v = vc[i];
-                    else { v = f[i - vel_idx]; if (u) { const double w = u[i - vel_idx]; v = v < w ? v : w; } }
+                    else { v = f[i - vel_idx]; if (has_u) { const double w = job_out(JA, D, p, W.job_free, i - vel_idx); v = v < w ? v : w; } }
                     vxf[i] = v;
                 }
                 have_bp = true;
             }
             if (W.generic) {
-                const double* g = W.has_fb ? JA.out + (size_t)(p * JA.per_planner + W.job_fb) * D.R : nullptr;
+                const bool has_g = W.has_fb != 0;
                 int ng = W.has_fb ? W.v_idx - W.pref_idx : 1;
                 const int n_prof = ng;
                 if (W.v_idx != m || W.v_idx <= 2) ng += (m - W.v_idx > 0 ? m - W.v_idx : 0);                          // :901-903
-                const double g0 = g ? g[0] : 0.0;
+                const double g0 = has_g ? job_out(JA, D, p, W.job_fb, 0) : 0.0;
                 W.vel_bound = fabs(g0 - S.vel_plan) < cfg.v_max_offset ? 1 : 0;                                      // :906-911
                 int len = vel_idx + ng;
                 if (len > m) len = m;
@@ -711,7 +729,7 @@ FLT_FN void vel_b(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int 
                 for (int i = x.lane(); i < m; i += X::W) {
                     double v;
                     if (i < vel_idx) v = vc[i];
-                    else { const int q = i - vel_idx; v = (q < n_prof && g) ? g[q] : 0.0; }
+                    else { const int q = i - vel_idx; v = (q < n_prof && has_g) ? job_out(JA, D, p, W.job_fb, q) : 0.0; }
                     vxg[i] = v;
                 }
                 x.sync();

@@ -145,11 +145,49 @@ __global__ __launch_bounds__(64) void k_fleet_vel_d(FleetArgs F, fleet::FVelIn v
     fleet_store(x, B, &S, p, F.err_word);
 }
 
+// The forward-backward jobs of a tick (slots >= 1 of the stage-A table), one LANE per job: lane_fb_profile of the batch velocity stage on
+// the fleet's lane planes. The wave-per-job form computes every step of the recurrence on 64 lanes for one useful result (220 us per tick
+// of 8 192 planners); here a wave advances 64 profiles per step.
+static_assert(sizeof(fleet::F2) == sizeof(float2), "lane plane records are fp32 pairs");
+template <int EM, bool AXM1>
+__global__ __launch_bounds__(64) void k_fleet_fb_lanes(DevVelParams p, const DevVelJob* jobs, const double* pool, const float2* ke, int ke_rows,
+                                                       double* outp, int cap, int n_planners, int per, double* out)
+{
+    __shared__ double axm_s[128];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 2 * p.n_axm; i += 64) axm_s[i] = p.axm[i];
+    __syncthreads();
+    const int q = blockIdx.x * 64 + lane;
+    if (q >= n_planners * (per - 1)) return;
+    const int pl = q / (per - 1), slot = q % (per - 1) + 1;
+    const DevVelJob* jp = jobs + (size_t)pl * per + slot;
+    const int n = jp->n;
+    if (n <= 0 || jp->mode != LTPL_VEL_FB) return;
+    LaneProf L; L.KE = ke + kep_base(q, ke_rows);
+    double* D = outp + tile_base(q, cap);
+    const double cax = pool[jp->off_gg], cay = pool[jp->off_gg + 1];
+    lane_fb_profile<EM, AXM1>(L, D, 0, n, cax, cay, p, axm_s, p.v_max, jp->v_start, jp->has_v_end != 0, jp->v_end);
+    // results job-major like every other job's (a lane writes its own row: scattered 8-byte stores, but this launch leaves half of the
+    // SIMDs idle and runs next to the follow jobs -- the readers in k_fleet_vel_b then find coalesced rows)
+    double* o = out + jp->off_out;
+    for (int i = 0; i < n; ++i) o[i] = sqrt(D[(size_t)i * 64]);
+}
+typedef void (*fleet_lanes_kernel_t)(DevVelParams, const DevVelJob*, const double*, const float2*, int, double*, int, int, int, double*);
+static fleet_lanes_kernel_t fleet_lanes_kernel_of(int v)
+{
+    switch (v) {
+        case 0: return k_fleet_fb_lanes<0, false>; case 1: return k_fleet_fb_lanes<0, true>;
+        case 2: return k_fleet_fb_lanes<1, false>; case 3: return k_fleet_fb_lanes<1, true>;
+        case 4: return k_fleet_fb_lanes<2, false>; default: return k_fleet_fb_lanes<2, true>;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 struct FleetJobsDev { fleet::VelJob* jobs = nullptr; double* pool = nullptr; double* out = nullptr; int* flags = nullptr; int per = 0;
-                      fleet::FJobs view() const { return fleet::FJobs{jobs, pool, out, flags, per}; } };
+                      fleet::F2* ke = nullptr; int ke_rows = 0; double* outp = nullptr;          // lane planes (stage-A table only): operands, profile state
+                      fleet::FJobs view() const { return fleet::FJobs{jobs, pool, out, flags, per, ke, ke_rows}; } };
 
 // the inputs of one tick in device memory (one arena per tick of a tape, or the fleet's own for the per-call entry points)
 struct FleetTickIn {
@@ -169,6 +207,7 @@ struct ltpl_fleet {
     // seam (1) arrays
     fleet::FPathsIn pin{}; DevPathsOut dout{}; void* d_out = nullptr;
     FleetJobsDev JA, JB, JC;
+    hipStream_t stream2 = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr;      // the lane kernel of the forward-backward jobs runs next to the follow jobs
     FleetTickIn cur, curv;                            // inputs of the per-call entry points: calc_paths / calc_vel_profile
     void* h_stage = nullptr; size_t h_stage_cap = 0;  // page-locked staging of the inputs
     std::vector<FleetTickIn> tape;
@@ -178,6 +217,9 @@ struct ltpl_fleet {
     ~ltpl_fleet()
     {
         if (h) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); --h->n_planners; }
+        if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
+        if (ev_a) (void)hipEventDestroy(ev_a);
+        if (ev_b) (void)hipEventDestroy(ev_b);
         for (void* p : allocs) (void)hipFree(p);
         if (cur.d_buf) (void)hipFree(cur.d_buf);
         if (curv.d_buf) (void)hipFree(curv.d_buf);
@@ -277,8 +319,16 @@ try {
         bind_out(d, lo, f->D.cn, f->D.cp, &f->dout);
     }
     if ((rc = fleet_jobs_alloc(f.get(), &f->JA, fleet::JOBS_A))) return bail(rc);
+    {   // lane planes of the forward-backward jobs (slots 1 .. JOBS_A - 1), tiles of 64 jobs
+        const size_t tiles = ((size_t)N * (fleet::JOBS_A - 1) + 63) / 64;
+        f->JA.ke_rows = (f->D.RV + 7) / 8 * 8;
+        if ((rc = fleet_alloc(f.get(), tiles * 64 * (size_t)f->JA.ke_rows, &f->JA.ke))) return bail(rc);
+        if ((rc = fleet_alloc(f.get(), tiles * 64 * (size_t)f->D.RV, &f->JA.outp))) return bail(rc);
+    }
     if ((rc = fleet_jobs_alloc(f.get(), &f->JB, 1))) return bail(rc);
     if ((rc = fleet_jobs_alloc(f.get(), &f->JC, 1))) return bail(rc);
+    if (hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&f->ev_a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&f->ev_b, hipEventDisableTiming) != hipSuccess) return bail((f->err = "fleet: stream / event creation failed", LTPL_ERR_HIP));
     f->vel_lds = vel_scratch_bytes(f->D.RV, false, false); f->vel_lds_lite = vel_scratch_bytes(f->D.RV, false, false, true);
     if (f->vel_lds > 150 * 1024) return bail((f->err = "fleet: velocity profile too long for the LDS-resident solver", LTPL_ERR_CAPACITY));
     f->image.resize(f->D.stride);
@@ -486,8 +536,20 @@ static int fleet_launch_vel(ltpl_fleet* f, const FleetTickIn& t)
     int rc;
     hipLaunchKernelGGL(k_fleet_vel_a, dim3(N), dim3(64), 0, st, f->args, t.ob, t.vin, f->JA.view());
     FLEET_TRY(f, hipGetLastError());
-    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA, 2))) return rc;        // follow jobs first: the longest
-    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA, 1))) return rc;
+    {   // forward-backward jobs (slots >= 1), one lane per job, on the second stream: 512 long waves for 8 192 planners -- next to the follow jobs
+        DevVelParams p;
+        if ((rc = make_vel_params(h, &vp, t.axm, &p))) { f->err = h->err; return rc; }
+        const unsigned waves = (unsigned)(((size_t)N * (fleet::JOBS_A - 1) + 63) / 64);
+        FLEET_TRY(f, hipEventRecord(f->ev_a, st));
+        FLEET_TRY(f, hipStreamWaitEvent(f->stream2, f->ev_a, 0));
+        hipLaunchKernelGGL(fleet_lanes_kernel_of(vel_variant(&vp)), dim3(waves), dim3(64), 0, f->stream2, p, reinterpret_cast<const DevVelJob*>(f->JA.jobs),
+                           (const double*)f->JA.pool, reinterpret_cast<const float2*>(f->JA.ke), f->JA.ke_rows, f->JA.outp, f->D.RV, N, (int)fleet::JOBS_A,
+                           f->JA.out);
+        FLEET_TRY(f, hipGetLastError());
+        FLEET_TRY(f, hipEventRecord(f->ev_b, f->stream2));
+    }
+    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA, 2))) return rc;        // follow jobs (slot 0): one wave per job
+    FLEET_TRY(f, hipStreamWaitEvent(st, f->ev_b, 0));
     hipLaunchKernelGGL(k_fleet_vel_b, dim3(N), dim3(64), 0, st, f->args, f->JA.view(), f->JB.view());
     FLEET_TRY(f, hipGetLastError());
     if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JB, 1))) return rc;

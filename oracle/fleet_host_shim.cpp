@@ -24,7 +24,7 @@ struct JobSet {
         per = per_planner; jobs.assign((size_t)N * per, VelJob{}); pool.assign((size_t)N * per * 4 * R, 0.0); out.assign((size_t)N * per * R, 0.0);
         flags.assign((size_t)N * per * 2, 0);
     }
-    FJobs view() { return FJobs{jobs.data(), pool.data(), out.data(), flags.data(), per}; }
+    FJobs view() { return FJobs{jobs.data(), pool.data(), out.data(), flags.data(), per, nullptr, 0}; }
 };
 
 struct HostFleet {

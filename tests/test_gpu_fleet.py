@@ -111,8 +111,10 @@ def test_tape_of_mixed_recordings(hip, monteblanco):
     ta, tb = fleet.trajectories(per + 5), host.trajectories(0)
     assert list(ta[0].keys()) == list(tb[0].keys()) and ta[1] == tb[1] and ta[2]['cut_index_pos'] == tb[2]['cut_index_pos']
     for k in ta[0]:
-        assert ta[0][k][0].shape == tb[0][k][0].shape
-        assert np.max(np.abs(ta[0][k][0] - tb[0][k][0])) <= 1e-9 * max(1.0, float(np.max(np.abs(tb[0][k][0])))), k
+        # (not bit-equal: the fleet solves its forward-backward jobs one lane per job on fp32 (|kappa|, element length) operands like the
+        # batch velocity stage, the host planner goes through the wave-per-job fp64 kernel; 1e-5 relative is the contract)
+        pr.check_traj(ta[0][k][0], tb[0][k][0], "fleet vs host planner / %s" % k)
+        assert np.max(np.abs(ta[0][k][0][:, 5] - tb[0][k][0][:, 5])) <= 2e-6 * max(1.0, float(np.max(np.abs(tb[0][k][0][:, 5])))), k
     pa, pb = fleet.paths(per + 5), host.paths(0)
     assert pa['keys'] == pb['keys'] and pa['nodes'] == pb['nodes'] and pa['node_idx'] == pb['node_idx']
     host.close()
