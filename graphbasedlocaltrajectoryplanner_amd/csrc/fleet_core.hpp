@@ -214,6 +214,30 @@ FLT_FN double turn_angle(double ax, double ay, double bx, double by, double cx, 
 
 struct Foot { double s; int i0, i1; };
 
+// get_s_coord.py:34-47 picks the neighbour of the closest point by comparing |angle3pt(nb, pos, neighbour)| of the two neighbours. The wrapped
+// difference of two atan2 values is the angle between u = nb - pos and v = neighbour - pos in [0, pi], and the cosine is monotone there:
+// |ang1| > |ang2|  <=>  u.v1 / |v1| < u.v2 / |v2|  (|u| cancels). Two dot products and two square roots instead of four atan2 -- a projection
+// is a dependent chain in these kernels and fp64 atan2 is ~1 us of it. Degenerate vectors (pos on a polyline point) take the atan2 form.
+// Returns -1 / 0 / +1 for |ang1| < / == / > |ang2|. (Same rule as angle_order_dev of the velocity kernels.)
+// (out of line: four inlined fp64 atan2 per projection set the register budget of the kernels that project, for a branch that is taken
+// when a query sits exactly on a polyline point)
+#if defined(__HIPCC__)
+__host__ __device__ __attribute__((noinline))
+#endif
+inline int angle_order_atan2(double nx, double ny, double px, double py, double x1, double y1, double x2, double y2)
+{
+    const double a1 = fabs(turn_angle(nx, ny, px, py, x1, y1)), a2 = fabs(turn_angle(nx, ny, px, py, x2, y2));
+    return a1 > a2 ? 1 : (a1 < a2 ? -1 : 0);
+}
+FLT_FN int angle_order(double nx, double ny, double px, double py, double x1, double y1, double x2, double y2)
+{
+    const double ux = nx - px, uy = ny - py, v1x = x1 - px, v1y = y1 - py, v2x = x2 - px, v2y = y2 - py;
+    const double n1 = v1x * v1x + v1y * v1y, n2 = v2x * v2x + v2y * v2y, nu = ux * ux + uy * uy;
+    if (!(n1 > 0.0) || !(n2 > 0.0) || !(nu > 0.0)) return angle_order_atan2(nx, ny, px, py, x1, y1, x2, y2);
+    const double c1 = (ux * v1x + uy * v1y) * sqrt(n2), c2 = (ux * v2x + uy * v2y) * sqrt(n1);
+    return c1 < c2 ? 1 : (c1 > c2 ? -1 : 0);
+}
+
 // `s_arr[i * s_stride]` = the caller's s_array (n_s entries); see planner_core.hpp project_on_polyline for the index rules
 template <class X>
 FLT_FN Foot project_on_polyline(const X& x, const Poly& p, double qx, double qy, bool closed, bool want_s, const double* s_arr, int s_stride, int n_s)
@@ -223,11 +247,10 @@ FLT_FN Foot project_on_polyline(const X& x, const Poly& p, double qx, double qy,
     if (closed) { i1 = nb - 1; i2 = nb + 1; if (i2 > p.n - 1) i2 = 0; }
     else { i1 = nb - 1 > 0 ? nb - 1 : 0; i2 = nb + 1 < p.n - 1 ? nb + 1 : p.n - 1; }
     const int i1p = i1 < 0 ? i1 + p.n : i1;
-    const double a1 = fabs(turn_angle(p.px(nb), p.py(nb), qx, qy, p.px(i1p), p.py(i1p)));
-    const double a2 = fabs(turn_angle(p.px(nb), p.py(nb), qx, qy, p.px(i2), p.py(i2)));
+    const int ord = angle_order(p.px(nb), p.py(nb), qx, qy, p.px(i1p), p.py(i1p), p.px(i2), p.py(i2));      // |a1| vs |a2|
     Foot f; f.s = 0.0;
     if (want_s) {
-        const bool first = a1 > a2;
+        const bool first = ord > 0;
         const int ia = first ? i1p : nb, ib = first ? nb : i2;
         const double ax = p.px(ia), ay = p.py(ia), bx = p.px(ib), by = p.py(ib);
         const double t = ((qx - ax) * (bx - ax) + (qy - ay) * (by - ay)) / ((bx - ax) * (bx - ax) + (by - ay) * (by - ay));
@@ -240,7 +263,7 @@ FLT_FN Foot project_on_polyline(const X& x, const Poly& p, double qx, double qy,
         const double sv = shifted ? (k == 0 ? 0.0 : s_arr[(size_t)(k - 1) * s_stride]) : s_arr[(size_t)k * s_stride];
         f.s = sv + ds;
     }
-    if (a1 >= a2) { f.i0 = i1; f.i1 = nb; } else { f.i0 = nb; f.i1 = i2; }
+    if (ord >= 0) { f.i0 = i1; f.i1 = nb; } else { f.i0 = nb; f.i1 = i2; }
     return f;
 }
 
@@ -407,7 +430,8 @@ FLT_FN void paths_post(const X& x, const FLat& lat, const Block& B, PlannerS& S,
     for (int a = 0; a < po.n_actions[p]; ++a) {
         const size_t slot = (size_t)p * A + a;
         if (!po.valid[slot]) continue;
-        TrajM T{}; T.id = po.action_id[slot]; T.red_len = po.reduced[slot] != 0;
+        TrajM& T = S.tm[nset][nf];
+        T = TrajM{}; T.id = po.action_id[slot]; T.red_len = po.reduced[slot] != 0;
         const int nn = po.n_nodes[slot], npts = po.n_pts[slot];
         const int* nd = po.nodes + slot * cn; const int* ni = po.node_idx + slot * cn;
         const double* co = po.coeff + slot * cn * 8; const double* pp = po.pp + slot * cp * 5;
@@ -438,7 +462,6 @@ FLT_FN void paths_post(const X& x, const FLat& lat, const Block& B, PlannerS& S,
             if (x.lane() == 0) tpp[(size_t)j * 5 + 4] = el;
         }
         T.r0 = 0; T.rows = rows; T.c0 = 0; T.nc = n_co + (nn - 1 > 0 ? nn - 1 : 0); T.n0 = 0; T.nn = n_nodes + nn; T.i0 = 0; T.ni = n_idx + nn;
-        S.tm[nset][nf] = T;
         ++nf;
     }
     if (nf == 0 && lsel >= 0 && S.const_rows > 2) {
@@ -584,7 +607,8 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
     for (int k = 0; k < S.n_last; ++k) {
         const int sl = S.last_slot[k];
         TrajM& T = S.tm[set][sl];
-        Work W{}; W.vel_idx = vel_idx; W.job_follow = W.job_free = W.job_fb = W.job_backup = -1; W.vel_bound = 1;
+        Work& W = S.w[k];                                  // (in place: the scalars live in LDS on the device, a local copy costs ~20 registers)
+        W = Work{}; W.vel_idx = vel_idx; W.job_follow = W.job_free = W.job_fb = W.job_backup = -1; W.vel_bound = 1;
         if (S.n_ids < BPS) { S.id_key[S.n_ids] = T.id; S.id_val[S.n_ids] = S.traj_base_id + (T.id >= 0 && T.id <= 3 ? T.id : 9); ++S.n_ids; }
         const int rows = T.rows;
         const int c0 = S.cut_index_pos < 0 ? 0 : (S.cut_index_pos < rows ? S.cut_index_pos : rows);
@@ -610,7 +634,7 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
             x.sync();
         }
         W.n = m;
-        if (m == 0) { W.empty = 1; S.w[k] = W; continue; }
+        if (m == 0) { W.empty = 1; continue; }
         double* s_arr = B.sarr(k);
         if (x.lane() == 0) s_arr[0] = 0.0;
         x.scan_seq(m - 1, [&](int i) { return pv[(size_t)i * 5 + 4]; }, s_arr + 1);                  // :743
@@ -671,7 +695,6 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
             W.v_idx = v_idx;
             if (v_idx - pref > 1) { W.job_fb = make_job(x, D, J, p, n_jobs++, LTPL_VEL_FB, pv, sgx, sgy, pref, v_idx, v_idx - pref - 1, W.vel_start, true, v_end); W.has_fb = 1; }
         }
-        S.w[k] = W;
     }
     x.sync();
 }

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64) void k_fleet_ref_idx(FleetArgs F, const double*
     fleet_store(x, B, &S, p, F.err_word);
 }
 
-__global__ __launch_bounds__(64) void k_fleet_vel_a(FleetArgs F, fleet::FObj ob, fleet::FVelIn vin, fleet::FJobs JA)
+__global__ __launch_bounds__(64, 4) void k_fleet_vel_a(FleetArgs F, fleet::FObj ob, fleet::FVelIn vin, fleet::FJobs JA)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
     const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D};
