@@ -68,7 +68,7 @@ inline int start_block(const ltplp::HostLat& lat, const Dims& D, double x, doubl
         if (T.rows() > D.R || T.n_nodes() > D.CN) { *why = "fleet: start spline exceeds the row capacity"; return LTPL_ERR_CAPACITY; }
         TrajM& M = S.tm[0][0];
         M.id = T.id; M.red_len = T.red_len ? 1 : 0; M.rows = T.rows(); M.nc = (int)(T.coeff.size() / 8); M.nn = T.n_nodes(); M.ni = (int)T.node_idx.size();
-        std::memcpy(B.pp(0, 0), T.pp.data(), sizeof(double) * T.pp.size());
+        { const Rows r = B.pp(0, 0); for (int i = 0; i < T.rows(); ++i) for (int c = 0; c < 5; ++c) r.at(i, c) = T.pp[(size_t)i * 5 + c]; }
         std::memcpy(B.coeff(0, 0), T.coeff.data(), sizeof(double) * T.coeff.size());
         std::memcpy(B.nodes(0, 0), T.nodes.data(), sizeof(int) * T.nodes.size());
         std::memcpy(B.nidx(0, 0), T.node_idx.data(), sizeof(int) * T.node_idx.size());
@@ -90,7 +90,7 @@ inline int paths_view(const Dims& D, const unsigned char* image, ltpl_planner_pa
         const int sl = S.last_slot[i]; const TrajM& T = S.tm[S.cur_set][sl];
         const int k = v->n_keys++;
         v->key_id[k] = T.id; v->n_rows[k] = T.rows; v->n_nodes[k] = T.nn; v->red_len[k] = T.red_len;
-        if (v->path_param[k] && T.rows > 0) std::memcpy(v->path_param[k], B.pp(S.cur_set, sl) + (size_t)T.r0 * 5, sizeof(double) * 5 * (size_t)T.rows);
+        if (v->path_param[k]) { const Rows r = B.pp(S.cur_set, sl).from(T.r0); for (int i = 0; i < T.rows; ++i) for (int c = 0; c < 5; ++c) v->path_param[k][(size_t)i * 5 + c] = r.at(i, c); }   // (column-major in the state)
         if (v->coeff[k] && T.nc > 0) std::memcpy(v->coeff[k], B.coeff(S.cur_set, sl) + (size_t)T.c0 * 8, sizeof(double) * 8 * (size_t)T.nc);
         if (v->nodes[k] && T.nn > 0) std::memcpy(v->nodes[k], B.nodes(S.cur_set, sl) + (size_t)T.n0 * 2, sizeof(int) * 2 * (size_t)T.nn);
         if (v->node_idx[k] && T.ni > 0) std::memcpy(v->node_idx[k], B.nidx(S.cur_set, sl) + T.i0, sizeof(int) * (size_t)T.ni);
@@ -111,7 +111,7 @@ inline int traj_view(const Dims& D, const unsigned char* image, ltpl_planner_tra
     for (int i = 0; i < S.n_bp && v->n_keys < LTPL_PLANNER_MAX_KEYS; ++i) {
         const int k = v->n_keys++;
         v->key_id[k] = S.bp_id[i]; v->traj_id[k] = S.bp_traj_id[i]; v->n_rows[k] = S.bp_rows[i];
-        if (v->traj[k] && S.bp_rows[i] > 0) std::memcpy(v->traj[k], B.bp(S.bp_slot[i]), sizeof(double) * 7 * (size_t)S.bp_rows[i]);
+        if (v->traj[k]) { const Rows r = B.bp(S.bp_slot[i]); for (int q = 0; q < S.bp_rows[i]; ++q) for (int c = 0; c < 7; ++c) v->traj[k][(size_t)q * 7 + c] = r.at(q, c); }
     }
     return LTPL_OK;
 }

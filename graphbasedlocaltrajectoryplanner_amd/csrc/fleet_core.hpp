@@ -115,15 +115,26 @@ inline Dims make_dims(int N, int max_path_nodes, int max_path_pts)
     return D;
 }
 
+// Row tables of the state (path_param: 5 columns, trajectories: 7 columns) are stored COLUMN-major (column stride = R rows): the lanes of
+// a wave walk rows, so every access is a contiguous run of one column. Row-major rows of 40 / 56 bytes made each load / store instruction
+// touch 40-56 cache lines for 64 lanes (k_fleet_vel_b was bound by the L2 request rate of its trajectory stores). A window starting at row r
+// is `from(r)`.
+struct Rows {
+    double* p; int ld;
+    FLT_FN double& at(int i, int c) const { return p[(size_t)c * ld + i]; }
+    FLT_FN Rows from(int r) const { return Rows{p + r, ld}; }
+    FLT_FN const double* col(int c) const { return p + (size_t)c * ld; }
+};
+
 struct Block {                      // one planner's memory
     unsigned char* b; Dims D;
     FLT_FN PlannerS* S() const { return reinterpret_cast<PlannerS*>(b); }
     FLT_FN unsigned char* slot(int set, int k) const { return b + D.o_traj + D.traj_bytes * (size_t)(set * KEYS + k); }
-    FLT_FN double* pp(int set, int k) const { return reinterpret_cast<double*>(slot(set, k)); }
+    FLT_FN Rows pp(int set, int k) const { return Rows{reinterpret_cast<double*>(slot(set, k)), D.R}; }
     FLT_FN double* coeff(int set, int k) const { return reinterpret_cast<double*>(slot(set, k) + D.o_coeff()); }
     FLT_FN int* nodes(int set, int k) const { return reinterpret_cast<int*>(slot(set, k) + D.o_nodes()); }
     FLT_FN int* nidx(int set, int k) const { return reinterpret_cast<int*>(slot(set, k) + D.o_nidx()); }
-    FLT_FN double* bp(int k) const { return reinterpret_cast<double*>(b + D.o_bp + align256(sizeof(double) * (size_t)D.R * 7) * (size_t)k); }
+    FLT_FN Rows bp(int k) const { return Rows{reinterpret_cast<double*>(b + D.o_bp + align256(sizeof(double) * (size_t)D.R * 7) * (size_t)k), D.R}; }
     FLT_FN double* velc() const { return reinterpret_cast<double*>(b + D.o_velc); }
     FLT_FN double* sarr(int k) const { return reinterpret_cast<double*>(b + D.o_sarr + align256(sizeof(double) * (size_t)D.R) * (size_t)k); }
     FLT_FN double* vx(int k) const { return reinterpret_cast<double*>(b + D.o_vx + align256(sizeof(double) * (size_t)D.R) * (size_t)k); }
@@ -269,15 +280,15 @@ FLT_FN Foot project_on_polyline(const X& x, const Poly& p, double qx, double qy,
 
 // constant-segment test in front of seam (1) (main_online_path_gen.py:76-122); seg = rows [x, y, psi, kappa, el]
 template <class X>
-FLT_FN void const_segment_test(const X& x, const FLat& lat, const double* seg, int seg_rows, const double* pos_est, int n_veh,
+FLT_FN void const_segment_test(const X& x, const FLat& lat, bool has_seg, const Rows& seg, int seg_rows, const double* pos_est, int n_veh,
                                const int* pos_off, const double* px, const double* py, const double* radius, int* in_const, int* besides, int* closest)
 {
     *in_const = 0; *besides = 0; *closest = -1;
-    if (!seg || seg_rows < 2) return;
+    if (!has_seg || seg_rows < 2) return;
     const Poly rl{lat.race_x, lat.race_y, 1, lat.L};
-    const double sx = pos_est ? pos_est[0] : seg[0], sy = pos_est ? pos_est[1] : seg[1];
+    const double sx = pos_est ? pos_est[0] : seg.at(0, 0), sy = pos_est ? pos_est[1] : seg.at(0, 1);
     const double s_start = project_on_polyline(x, rl, sx, sy, true, true, lat.s_rl, 1, lat.L).s;
-    const double s_end = project_on_polyline(x, rl, seg[(size_t)(seg_rows - 1) * 5], seg[(size_t)(seg_rows - 1) * 5 + 1], true, true, lat.s_rl, 1, lat.L).s;
+    const double s_end = project_on_polyline(x, rl, seg.at(seg_rows - 1, 0), seg.at(seg_rows - 1, 1), true, true, lat.s_rl, 1, lat.L).s;
     double smallest = inf();
     for (int k = 0; k < n_veh; ++k) {
         const double vx = px[pos_off[k]], vy = py[pos_off[k]];
@@ -289,7 +300,7 @@ FLT_FN void const_segment_test(const X& x, const FLat& lat, const double* seg, i
             const double rr = radius[k] + lat.veh_width / 2, ref = rr * rr;
             bool hit = false;
             for (int i = x.lane(); i < seg_rows; i += X::W) {
-                const double dx = seg[(size_t)i * 5] - vx, dy = seg[(size_t)i * 5 + 1] - vy;
+                const double dx = seg.at(i, 0) - vx, dy = seg.at(i, 1) - vy;
                 if (dx * dx + dy * dy <= ref) hit = true;
             }
             if (x.any(hit)) *in_const = 1;
@@ -341,20 +352,20 @@ FLT_FN void paths_pre(const X& x, const FLat& lat, const FCfg& cfg, const Block&
         const double avg = sum / (double)S.n_calc;
         const double t_const = fmin(avg * cfg.calc_time_safety, 0.5);
         // index of the pose reached after t_const on the last trajectory (:370-378)
-        const double* bp = B.bp(S.bp_slot[bsel]); const int nb = S.bp_rows[bsel];
+        const Rows bp = B.bp(S.bp_slot[bsel]); const int nb = S.bp_rows[bsel];
         double* cum = B.scr(0);
-        x.scan_seq(nb - 2, [&](int i) { const double ds = bp[(size_t)(i + 2) * 7] - bp[(size_t)(i + 1) * 7], v = bp[(size_t)(i + 1) * 7 + 5];
+        x.scan_seq(nb - 2, [&](int i) { const double ds = bp.at(i + 2, 0) - bp.at(i + 1, 0), v = bp.at(i + 1, 5);
                                         return (v != 0.0) ? ds / v : inf(); }, cum);
         x.sync();
         const int ff = x.find_first(nb - 2, [&](int i) { return !(cum[i] <= t_const); });
         const int next_idx = (ff < nb - 2 ? ff : 0) + 1;
         // first node behind that pose (:381-393): project on the polyline of the node coordinates
-        const double* tp = B.pp(set, lsel) + (size_t)T.r0 * 5; const int* ni = B.nidx(set, lsel) + T.i0; const int* nd = B.nodes(set, lsel) + (size_t)T.n0 * 2;
+        const Rows tp = B.pp(set, lsel).from(T.r0); const int* ni = B.nidx(set, lsel) + T.i0; const int* nd = B.nodes(set, lsel) + (size_t)T.n0 * 2;
         double* ncx = B.scr(1); double* ncy = ncx + T.ni;
-        for (int i = x.lane(); i < T.ni; i += X::W) { const int r = ni[i]; ncx[i] = tp[(size_t)r * 5]; ncy[i] = tp[(size_t)r * 5 + 1]; }
+        for (int i = x.lane(); i < T.ni; i += X::W) { const int r = ni[i]; ncx[i] = tp.at(r, 0); ncy[i] = tp.at(r, 1); }
         x.sync();
         const Poly np_{ncx, ncy, 1, T.ni};
-        const Foot f = project_on_polyline(x, np_, bp[(size_t)next_idx * 7 + 1], bp[(size_t)next_idx * 7 + 2], false, false, nullptr, 0, 0);
+        const Foot f = project_on_polyline(x, np_, bp.at(next_idx, 1), bp.at(next_idx, 2), false, false, nullptr, 0, 0);
         S.start_node_idx = f.i1;
         S.loc_path_start_idx = ni[S.start_node_idx];
         S.start_node[0] = nd[(size_t)S.start_node_idx * 2]; S.start_node[1] = nd[(size_t)S.start_node_idx * 2 + 1];
@@ -369,8 +380,8 @@ FLT_FN void paths_pre(const X& x, const FLat& lat, const FCfg& cfg, const Block&
             for (int i = 0; i < T.nn; ++i) if (nd[(size_t)i * 2] == S.start_node[0] && nd[(size_t)i * 2 + 1] == S.start_node[1]) { idx = i; break; }
             if (idx >= 0) {
                 const int g = lat.layer_off[S.start_node[0]] + S.start_node[1];
-                const double* tp = B.pp(set, lsel) + (size_t)T.r0 * 5;
-                const Poly pl{tp, tp + 1, 5, T.rows};
+                const Rows tp = B.pp(set, lsel).from(T.r0);
+                const Poly pl{tp.col(0), tp.col(1), 1, T.rows};
                 S.loc_path_start_idx = closest_index(x, pl, lat.node_x[g], lat.node_y[g]);
                 S.start_node_idx = idx;
             }
@@ -378,19 +389,19 @@ FLT_FN void paths_pre(const X& x, const FLat& lat, const FCfg& cfg, const Block&
     }
     if (!S.has_start) { fail(S, LTPL_ERR_INVALID_ARG, E_NO_START); return; }
     // constant path segment (:412-414), test in front of seam (1), the packed inputs of seam (1) (:416-427)
-    const double* seg = nullptr; int seg_rows = 0;
+    Rows seg{nullptr, 0}; bool has_seg = false; int seg_rows = 0;
     S.const_rows = -1;
-    if (S.const_exists) { seg = B.pp(set, lsel) + (size_t)S.tm[set][lsel].r0 * 5; seg_rows = S.loc_path_start_idx + 1; S.const_rows = seg_rows; }
+    if (S.const_exists) { seg = B.pp(set, lsel).from(S.tm[set][lsel].r0); has_seg = true; seg_rows = S.loc_path_start_idx + 1; S.const_rows = seg_rows; }
     int in_const, besides, cc;
     const int v0 = ob.veh_off[p], nv = ob.veh_off[p + 1] - v0;
-    const_segment_test(x, lat, seg, seg_rows, S.has_pos ? S.pos_est : nullptr, nv, ob.pos_off + v0, ob.px, ob.py, ob.radius + v0, &in_const, &besides, &cc);
+    const_segment_test(x, lat, has_seg, seg, seg_rows, S.has_pos ? S.pos_est : nullptr, nv, ob.pos_off + v0, ob.px, ob.py, ob.radius + v0, &in_const, &besides, &cc);
     int fl = LTPL_FLAG_ACTION_SETS;
     if (in_const) fl |= LTPL_FLAG_OBJ_IN_CONST;
     if (besides) fl |= LTPL_FLAG_OBJ_BESIDES;
-    if (seg) fl |= LTPL_FLAG_HAS_PSI_S;
+    if (has_seg) fl |= LTPL_FLAG_HAS_PSI_S;
     int k = 0;
     if (x.lane() == 0) {
-        pin.psi_s[p] = seg ? seg[(size_t)(seg_rows - 1) * 5 + 2] : 0.0;
+        pin.psi_s[p] = has_seg ? seg.at(seg_rows - 1, 2) : 0.0;
         pin.start_layer[p] = S.start_node[0]; pin.start_node[p] = S.start_node[1];
         pin.flags[p] = fl; pin.last_action[p] = sel; pin.const_closest[p] = cc;
         for (int i = 0; i < LTPL_MAX_LAST_NODES; ++i) { pin.last_layer[(size_t)p * LTPL_MAX_LAST_NODES + i] = -1; pin.last_node[(size_t)p * LTPL_MAX_LAST_NODES + i] = -1; }
@@ -419,10 +430,10 @@ FLT_FN void paths_post(const X& x, const FLat& lat, const Block& B, PlannerS& S,
     const int set = S.cur_set, nset = 1 - set;
     const int lsel = S.const_exists ? find_last(S, S.sel_action) : -1;
     const int loc = S.loc_path_start_idx, sni = S.start_node_idx;
-    TrajM old{}; const double* opp = nullptr; const double* oco = nullptr; const int* ond = nullptr; const int* oni = nullptr;
+    TrajM old{}; Rows opp{nullptr, 0}; const double* oco = nullptr; const int* ond = nullptr; const int* oni = nullptr;
     if (lsel >= 0) {
         old = S.tm[set][lsel];
-        opp = B.pp(set, lsel) + (size_t)old.r0 * 5; oco = B.coeff(set, lsel) + (size_t)old.c0 * 8;
+        opp = B.pp(set, lsel).from(old.r0); oco = B.coeff(set, lsel) + (size_t)old.c0 * 8;
         ond = B.nodes(set, lsel) + (size_t)old.n0 * 2; oni = B.nidx(set, lsel) + old.i0;
     }
     S.closest_obj_index = po.closest_obj_index[p];
@@ -435,7 +446,7 @@ FLT_FN void paths_post(const X& x, const FLat& lat, const Block& B, PlannerS& S,
         const int nn = po.n_nodes[slot], npts = po.n_pts[slot];
         const int* nd = po.nodes + slot * cn; const int* ni = po.node_idx + slot * cn;
         const double* co = po.coeff + slot * cn * 8; const double* pp = po.pp + slot * cp * 5;
-        double* tpp = B.pp(nset, nf); double* tco = B.coeff(nset, nf); int* tnd = B.nodes(nset, nf); int* tni = B.nidx(nset, nf);
+        const Rows tpp = B.pp(nset, nf); double* tco = B.coeff(nset, nf); int* tnd = B.nodes(nset, nf); int* tni = B.nidx(nset, nf);
         int rows, n_idx, n_nodes = 0, n_co = 0, pre = 0;
         if (lsel >= 0) {
             pre = loc > 0 ? loc : 0;
@@ -445,8 +456,8 @@ FLT_FN void paths_post(const X& x, const FLat& lat, const Block& B, PlannerS& S,
         } else { rows = npts; n_idx = 0; }
         if (rows > D.R || (lsel >= 0 && pre > old.rows)) { fail(S, LTPL_ERR_CAPACITY, E_CAP_ROWS); return; }
         if (n_idx + nn > D.CN || n_nodes + nn > D.CN || n_co + nn > D.CN) { fail(S, LTPL_ERR_CAPACITY, E_CAP_NODES); return; }
-        for (int i = x.lane(); i < pre * 5; i += X::W) tpp[i] = opp[i];
-        for (int i = x.lane(); i < npts * 5; i += X::W) tpp[(size_t)pre * 5 + i] = pp[i];
+        for (int c = 0; c < 5; ++c) for (int i = x.lane(); i < pre; i += X::W) tpp.at(i, c) = opp.at(i, c);
+        for (int i = x.lane(); i < npts * 5; i += X::W) tpp.at(pre + i / 5, i % 5) = pp[i];          // (the path kernel's rows are row-major)
         for (int i = x.lane(); i < n_idx; i += X::W) tni[i] = oni[i];
         for (int i = x.lane(); i < nn; i += X::W) tni[n_idx + i] = ni[i] + (lsel >= 0 ? loc : 0);
         for (int i = x.lane(); i < n_nodes * 2; i += X::W) tnd[i] = ond[i];
@@ -456,10 +467,10 @@ FLT_FN void paths_post(const X& x, const FLat& lat, const Block& B, PlannerS& S,
         x.sync();
         if (lsel >= 0 && loc > 0 && old.rows == loc) {                                     // :449-454
             const int j = loc - 1;
-            const double dx = tpp[(size_t)(j + 1) * 5] - tpp[(size_t)j * 5], dy = tpp[(size_t)(j + 1) * 5 + 1] - tpp[(size_t)j * 5 + 1];
+            const double dx = tpp.at(j + 1, 0) - tpp.at(j, 0), dy = tpp.at(j + 1, 1) - tpp.at(j, 1);
             const double el = sqrt(dx * dx + dy * dy);
             x.sync();
-            if (x.lane() == 0) tpp[(size_t)j * 5 + 4] = el;
+            if (x.lane() == 0) tpp.at(j, 4) = el;
         }
         T.r0 = 0; T.rows = rows; T.c0 = 0; T.nc = n_co + (nn - 1 > 0 ? nn - 1 : 0); T.n0 = 0; T.nn = n_nodes + nn; T.i0 = 0; T.ni = n_idx + nn;
         ++nf;
@@ -469,8 +480,8 @@ FLT_FN void paths_post(const X& x, const FLat& lat, const Block& B, PlannerS& S,
         const int loc1 = loc + 1, sni1 = sni + 1;
         TrajM T{}; T.id = S.sel_action; T.red_len = 1;
         T.rows = loc1 < old.rows ? loc1 : old.rows; T.ni = sni1 < old.ni ? sni1 : old.ni; T.nn = sni1 < old.nn ? sni1 : old.nn; T.nc = sni1 < old.nc ? sni1 : old.nc;
-        double* tpp = B.pp(nset, 0); double* tco = B.coeff(nset, 0); int* tnd = B.nodes(nset, 0); int* tni = B.nidx(nset, 0);
-        for (int i = x.lane(); i < T.rows * 5; i += X::W) tpp[i] = opp[i];
+        const Rows tpp = B.pp(nset, 0); double* tco = B.coeff(nset, 0); int* tnd = B.nodes(nset, 0); int* tni = B.nidx(nset, 0);
+        for (int c = 0; c < 5; ++c) for (int i = x.lane(); i < T.rows; i += X::W) tpp.at(i, c) = opp.at(i, c);
         for (int i = x.lane(); i < T.ni; i += X::W) tni[i] = oni[i];
         for (int i = x.lane(); i < T.nn * 2; i += X::W) tnd[i] = ond[i];
         for (int i = x.lane(); i < T.nc * 8; i += X::W) tco[i] = oco[i];
@@ -495,22 +506,22 @@ FLT_FN void ref_idx(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, do
     int cut_index_layer = 0;
     S.n_vel_course = 0;
     if (valid_last) {
-        const double* bp = B.bp(S.bp_slot[b]); const int n = S.bp_rows[b];
-        const Poly pl{bp + 1, bp + 2, 7, n};
+        const Rows bp = B.bp(S.bp_slot[b]); const int n = S.bp_rows[b];
+        const Poly pl{bp.col(1), bp.col(2), 1, n};
         const Foot f = project_on_polyline(x, pl, px, py, false, false, nullptr, 0, 0);
         const int cut = f.i0;
         const int m = n - cut - 1;                                       // len(v_past) (:565-567)
         double* cum = B.scr(0);
-        x.scan_seq(m, [&](int i) { const double ds = bp[(size_t)(cut + i + 1) * 7] - bp[(size_t)(cut + i) * 7], v = bp[(size_t)(cut + i) * 7 + 5];
+        x.scan_seq(m, [&](int i) { const double ds = bp.at(cut + i + 1, 0) - bp.at(cut + i, 0), v = bp.at(cut + i, 5);
                                    return (v != 0.0) ? ds / v : inf(); }, cum);
         x.sync();
         const int ff = x.find_first(m, [&](int i) { return !(cum[i] <= cfg.delaycomp); });
         int vel_idx = (ff < m ? ff : 0) + 1;
         if (vel_idx > m - 1) vel_idx = m - 1;
         if (vel_idx < 0) vel_idx = 0;
-        S.vel_plan = bp[(size_t)(cut + vel_idx) * 7 + 5]; S.acc_plan = bp[(size_t)(cut + vel_idx) * 7 + 6];
+        S.vel_plan = bp.at(cut + vel_idx, 5); S.acc_plan = bp.at(cut + vel_idx, 6);
         double* vc = B.velc();
-        for (int i = x.lane(); i < vel_idx; i += X::W) vc[i] = bp[(size_t)(cut + i) * 7 + 5];
+        for (int i = x.lane(); i < vel_idx; i += X::W) vc[i] = bp.at(cut + i, 5);
         S.n_vel_course = vel_idx;
         S.cut_index_pos = S.last_cut_idx + cut;
         if (valid_this) {
@@ -541,26 +552,25 @@ FLT_FN double conv_filt_at(const double* vx, int n, int width, int i)
 
 // :925-941: vx filtered, ax from neighbours over np.diff(s), -5 at standstill
 template <class X>
-FLT_FN void finalize_bp(const X& x, const FCfg& cfg, const double* s_arr, const double* pv, const double* vx_raw, int n, double* bp)
+FLT_FN void finalize_bp(const X& x, const FCfg& cfg, const double* s_arr, const Rows& pv, const double* vx_raw, int n, const Rows& bp)
 {
     for (int i = x.lane(); i < n; i += X::W) {
-        double* r = bp + (size_t)i * 7;
         const double v = conv_filt_at(vx_raw, n, cfg.filt_window_width, i);
-        r[0] = s_arr[i]; r[1] = pv[(size_t)i * 5]; r[2] = pv[(size_t)i * 5 + 1]; r[3] = pv[(size_t)i * 5 + 2]; r[4] = pv[(size_t)i * 5 + 3];
-        r[5] = v;
+        bp.at(i, 0) = s_arr[i]; bp.at(i, 1) = pv.at(i, 0); bp.at(i, 2) = pv.at(i, 1); bp.at(i, 3) = pv.at(i, 2); bp.at(i, 4) = pv.at(i, 3);
+        bp.at(i, 5) = v;
         double ax = 0.0;
         if (i + 1 < n) {
             const double v1 = conv_filt_at(vx_raw, n, cfg.filt_window_width, i + 1);
             ax = (v1 * v1 - v * v) / (2 * (s_arr[i + 1] - s_arr[i]));
             if (fabs(v) <= 1e-8 && fabs(ax) <= 1e-8) ax = -5.0;
         }
-        r[6] = ax;
+        bp.at(i, 6) = ax;
     }
 }
 
 // job slot `slot` of planner p (slot 0 is reserved for the follow job of a tick: the device runs the follow jobs as their own launch)
 template <class X>
-FLT_FN int make_job(const X& x, const Dims& D, const FJobs& J, int p, int slot, int mode, const double* pv, double gax, double gay, int i0, int i1,
+FLT_FN int make_job(const X& x, const Dims& D, const FJobs& J, int p, int slot, int mode, const Rows& pv, double gax, double gay, int i0, int i1,
                     int n_el, double v_start, bool has_end, double v_end)
 {
     const int j = p * J.per_planner + slot;
@@ -571,13 +581,13 @@ FLT_FN int make_job(const X& x, const Dims& D, const FJobs& J, int p, int slot, 
     if (J.ke && mode == LTPL_VEL_FB && slot >= 1) {
         F2* ke = J.ke + kep_base_f(p * (J.per_planner - 1) + slot - 1, J.ke_rows);
         for (int i = x.lane(); i < i1 - i0; i += X::W) {
-            F2 r; r.x = (float)fabs(pv[(size_t)(i0 + i) * 5 + 3]); r.y = i < n_el ? (float)pv[(size_t)(i0 + i) * 5 + 4] : 0.0f;
+            F2 r; r.x = (float)fabs(pv.at(i0 + i, 3)); r.y = i < n_el ? (float)pv.at(i0 + i, 4) : 0.0f;
             ke[kep_row_f(i)] = r;
         }
         if (x.lane() == 0) { gg[0] = gax; gg[1] = gay; }
     } else {
-        for (int i = x.lane(); i < i1 - i0; i += X::W) { kap[i] = pv[(size_t)(i0 + i) * 5 + 3]; gg[(size_t)i * 2] = gax; gg[(size_t)i * 2 + 1] = gay; }
-        for (int i = x.lane(); i < n_el; i += X::W) el[i] = pv[(size_t)(i0 + i) * 5 + 4];
+        for (int i = x.lane(); i < i1 - i0; i += X::W) { kap[i] = pv.at(i0 + i, 3); gg[(size_t)i * 2] = gax; gg[(size_t)i * 2 + 1] = gay; }
+        for (int i = x.lane(); i < n_el; i += X::W) el[i] = pv.at(i0 + i, 4);
         if (n_el < 1 && x.lane() == 0) el[0] = 0.0;
     }
     if (x.lane() == 0) J.jobs[j] = jb;
@@ -616,7 +626,7 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
         if (S.cut_layer >= T.ni) { fail(S, LTPL_ERR_INVALID_ARG, E_CUT_LAYER); return; }
         const int cil = (B.nidx(set, sl) + T.i0)[S.cut_layer];
         W.cut_index_layer = cil;
-        const double* pv = B.pp(set, sl) + (size_t)(T.r0 + c0) * 5;               // action_set_path_param_vel: rows from cut_index_pos on
+        const Rows pv = B.pp(set, sl).from(T.r0 + c0);                           // action_set_path_param_vel: rows from cut_index_pos on
         W.c0 = T.r0 + c0;                                                        // (absolute row in the slot: the window below moves)
         {   // trim the memory for the next iteration, aligned with the nodes (:714-731): the windows move, node indices are re-based
             int* ni = B.nidx(set, sl) + T.i0 + S.cut_layer;
@@ -637,7 +647,7 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
         if (m == 0) { W.empty = 1; continue; }
         double* s_arr = B.sarr(k);
         if (x.lane() == 0) s_arr[0] = 0.0;
-        x.scan_seq(m - 1, [&](int i) { return pv[(size_t)i * 5 + 4]; }, s_arr + 1);                  // :743
+        x.scan_seq(m - 1, [&](int i) { return pv.at(i, 4); }, s_arr + 1);                            // :743
         x.sync();
         if (S.vel_plan > vel_max + 0.1) { fail(S, LTPL_ERR_UNSUPPORTED, E_BRAKE_PREFIX); return; }       // (the reference raises, OTH.py:919)
         S.old_gg_scale = gg_scale;
@@ -654,9 +664,9 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
                 const int vi = v0 + S.closest_obj_index;
                 ox = ob.px[ob.pos_off[vi]]; oy = ob.py[ob.pos_off[vi]]; v_obj = ob.vel ? ob.vel[vi] : 0.0;
                 double* cs = B.scr(0);                                                               // cumsum(path[:, 4]) (:777,782)
-                x.scan_seq(m, [&](int i) { return pv[(size_t)i * 5 + 4]; }, cs);
+                x.scan_seq(m, [&](int i) { return pv.at(i, 4); }, cs);
                 x.sync();
-                const Poly pl{pv, pv + 1, 5, m};
+                const Poly pl{pv.col(0), pv.col(1), 1, m};
                 const double s_obj = project_on_polyline(x, pl, ox, oy, false, true, cs, 1, m).s;
                 const double s_sta = project_on_polyline(x, pl, S.pos_est[0], S.pos_est[1], false, true, cs, 1, m).s;
                 obj_dist = s_obj - s_sta;
@@ -719,7 +729,7 @@ FLT_FN void vel_b(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int 
         const int m = W.n, vel_idx = W.vel_idx;
         W.vel_bound = 1;
         if (!W.empty) {
-            const double* pv = B.pp(set, sl) + (size_t)W.c0 * 5;
+            const Rows pv = B.pp(set, sl).from(W.c0);
             double* vxf = B.vx(0); double* vxg = B.vx(1);
             const double* vx = nullptr;
             bool have_bp = false;
@@ -779,12 +789,12 @@ FLT_FN void vel_b(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int 
                 const int c1 = cil < 0 ? 0 : (cil < br ? cil : br);
                 const int i0 = S.cut_index_pos + vel_idx;
                 if (i0 >= br) { fail(S, LTPL_ERR_INVALID_ARG, E_BACKUP_SHORT); return; }
-                const double* bpp = B.pp(bs, bk) + (size_t)Bm.r0 * 5;
+                const Rows bpp = B.pp(bs, bk).from(Bm.r0);
                 if (br - i0 > D.RV) { fail(S, LTPL_ERR_CAPACITY, E_CAP_VEL); return; }
                 // brake job on the backup rows [i0, br): no gg_scale (:229-255)
                 W.job_backup = make_job(x, D, JB, p, n_backup++, LTPL_VEL_BRAKE, bpp, Bm.gax, Bm.gay, i0, br, br - i0 - 1, S.vel_plan, false, 0.0);
                 // the key's memory becomes the (trimmed) backup
-                double* tpp = B.pp(set, sl); double* tco = B.coeff(set, sl); int* tnd = B.nodes(set, sl); int* tni = B.nidx(set, sl);
+                const Rows tpp = B.pp(set, sl); double* tco = B.coeff(set, sl); int* tnd = B.nodes(set, sl); int* tni = B.nidx(set, sl);
                 const double* bco = B.coeff(bs, bk) + (size_t)Bm.c0 * 8; const int* bnd = B.nodes(bs, bk) + (size_t)Bm.n0 * 2; const int* bni = B.nidx(bs, bk) + Bm.i0;
                 TrajM N = T;
                 N.r0 = 0; N.rows = br - c1; N.i0 = 0; N.ni = Bm.ni - cl;
@@ -792,7 +802,7 @@ FLT_FN void vel_b(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int 
                 N.c0 = 0; N.nc = Bm.nc - cc; N.n0 = 0; N.nn = Bm.nn - cnn;
                 N.gax = Bm.gax; N.gay = Bm.gay;
                 x.sync();
-                for (int i = x.lane(); i < N.rows * 5; i += X::W) tpp[i] = bpp[(size_t)c1 * 5 + i];
+                for (int c = 0; c < 5; ++c) for (int i = x.lane(); i < N.rows; i += X::W) tpp.at(i, c) = bpp.at(c1 + i, c);
                 for (int i = x.lane(); i < N.ni; i += X::W) tni[i] = bni[cl + i] - cil;
                 for (int i = x.lane(); i < N.nc * 8; i += X::W) tco[i] = bco[(size_t)cc * 8 + i];
                 for (int i = x.lane(); i < N.nn * 2; i += X::W) tnd[i] = bnd[(size_t)cnn * 2 + i];
@@ -824,7 +834,7 @@ FLT_FN void vel_c(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int 
         int rows = W.n;
         if (W.job_backup >= 0) {
             const TrajM& Bm = S.tm[S.backup_set][S.backup_slot];
-            const double* bpp = B.pp(S.backup_set, S.backup_slot) + (size_t)Bm.r0 * 5;
+            const Rows bpp = B.pp(S.backup_set, S.backup_slot).from(Bm.r0);
             const int c0 = S.cut_index_pos, br = Bm.rows, m = br - c0;
             const double* o = JB.out + (size_t)(p * JB.per_planner + W.job_backup) * D.R;
             const int no = br - (S.cut_index_pos + W.vel_idx);
@@ -832,20 +842,19 @@ FLT_FN void vel_c(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int 
             double* vraw = B.vx(0); double* s_arr = B.scr(0);
             for (int i = x.lane(); i < m; i += X::W) vraw[i] = i < S.n_vel_course ? vc[i] : o[i - S.n_vel_course];
             if (x.lane() == 0) s_arr[0] = 0.0;
-            x.scan_seq(m - 1, [&](int i) { return bpp[(size_t)(c0 + i) * 5 + 4]; }, s_arr + 1);
+            x.scan_seq(m - 1, [&](int i) { return bpp.at(c0 + i, 4); }, s_arr + 1);
             x.sync();
-            double* bp = B.bp(k);
+            const Rows bp = B.bp(k), q = bpp.from(c0);
             for (int i = x.lane(); i < m; i += X::W) {                                                 // :996-1004: ax over the element lengths themselves
-                double* r = bp + (size_t)i * 7; const double* q = bpp + (size_t)(c0 + i) * 5;
                 const double v = conv_filt_at(vraw, m, cfg.filt_window_width, i);
-                r[0] = s_arr[i]; r[1] = q[0]; r[2] = q[1]; r[3] = q[2]; r[4] = q[3]; r[5] = v;
+                bp.at(i, 0) = s_arr[i]; bp.at(i, 1) = q.at(i, 0); bp.at(i, 2) = q.at(i, 1); bp.at(i, 3) = q.at(i, 2); bp.at(i, 4) = q.at(i, 3); bp.at(i, 5) = v;
                 double ax = 0.0;
                 if (i + 1 < m) {
                     const double v1 = conv_filt_at(vraw, m, cfg.filt_window_width, i + 1);
-                    ax = (v1 * v1 - v * v) / (2 * q[4]);
+                    ax = (v1 * v1 - v * v) / (2 * q.at(i, 4));
                     if (fabs(v) <= 1e-8 && fabs(ax) <= 1e-8) ax = -5.0;
                 }
-                r[6] = ax;
+                bp.at(i, 6) = ax;
             }
             x.sync();
             rows = m;
@@ -859,16 +868,16 @@ FLT_FN void vel_c(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int 
     if (vin.incl_emerg && vin.incl_emerg[p]) {                                                        // :1028-1034
         if (S.n_bp == 0) { fail(S, LTPL_ERR_INVALID_ARG, E_EMERG_EMPTY); return; }
         S.em_base_id = S.bp_id[0];
-        const double* base = B.bp(S.bp_slot[0]); const int m = S.bp_rows[0];
+        const Rows base = B.bp(S.bp_slot[0]); const int m = S.bp_rows[0];
         if (m > D.RV) { fail(S, LTPL_ERR_CAPACITY, E_CAP_VEL); return; }
         const int j = p * JC.per_planner;
         VelJob jb{};
-        jb.mode = LTPL_VEL_BRAKE; jb.n = m; jb.n_el = m - 1; jb.v_start = m > 0 ? base[5] : 0.0;
+        jb.mode = LTPL_VEL_BRAKE; jb.n = m; jb.n_el = m - 1; jb.v_start = m > 0 ? base.at(0, 5) : 0.0;
         jb.off_kappa = j * 4 * D.R; jb.off_el = jb.off_kappa + D.R; jb.off_gg = jb.off_kappa + 2 * D.R; jb.off_out = j * D.R;
         double* kap = JC.pool + jb.off_kappa; double* el = JC.pool + jb.off_el; double* gg = JC.pool + jb.off_gg;
         const double gax = vin.gg_ax[p], gay = vin.gg_ay[p];
-        for (int i = x.lane(); i < m; i += X::W) { kap[i] = base[(size_t)i * 7 + 4]; gg[(size_t)i * 2] = gax; gg[(size_t)i * 2 + 1] = gay; }
-        for (int i = x.lane(); i + 1 < m; i += X::W) el[i] = base[(size_t)(i + 1) * 7] - base[(size_t)i * 7];
+        for (int i = x.lane(); i < m; i += X::W) { kap[i] = base.at(i, 4); gg[(size_t)i * 2] = gax; gg[(size_t)i * 2 + 1] = gay; }
+        for (int i = x.lane(); i + 1 < m; i += X::W) el[i] = base.at(i + 1, 0) - base.at(i, 0);
         if (m < 2 && x.lane() == 0) el[0] = 0.0;
         if (x.lane() == 0) JC.jobs[j] = jb;
     }
@@ -881,14 +890,12 @@ FLT_FN void vel_d(const X& x, const Block& B, PlannerS& S, int p, const FVelIn& 
 {
     const Dims& D = B.D;
     if (S.err || !(vin.incl_emerg && vin.incl_emerg[p])) return;
-    const double* base = B.bp(S.bp_slot[0]); const int m = S.bp_rows[0];
+    const Rows base = B.bp(S.bp_slot[0]), em = B.bp(BPS - 1); const int m = S.bp_rows[0];
     const double* v = JC.out + (size_t)(p * JC.per_planner) * D.R;
-    double* em = B.bp(BPS - 1);
     for (int i = x.lane(); i < m; i += X::W) {
-        double* r = em + (size_t)i * 7;
-        for (int c = 0; c < 5; ++c) r[c] = base[(size_t)i * 7 + c];
-        r[5] = v[i];
-        r[6] = (i + 1 < m) ? (v[i + 1] * v[i + 1] - v[i] * v[i]) / (2 * (base[(size_t)(i + 1) * 7] - base[(size_t)i * 7])) : 0.0;
+        for (int c = 0; c < 5; ++c) em.at(i, c) = base.at(i, c);
+        em.at(i, 5) = v[i];
+        em.at(i, 6) = (i + 1 < m) ? (v[i + 1] * v[i + 1] - v[i] * v[i]) / (2 * (base.at(i + 1, 0) - base.at(i, 0))) : 0.0;
     }
     const int q = S.n_bp++;
     S.bp_slot[q] = BPS - 1; S.bp_id[q] = LTPL_ACT_EMERGENCY; S.bp_rows[q] = m; S.bp_traj_id[q] = S.bp_traj_id[0];
