@@ -1,0 +1,145 @@
+"""
+A small closed-loop driver for DIFFERENTIAL runs of two planners (the host planner ltpl_planner_* and the fleet ltpl_fleet_*, or their CPU
+harness builds): seeded traffic on the race line (slow, fast, laterally offset vehicles with a short prediction), an ego that follows the
+trajectory it chose, random choice among the offered action sets (now and then 'emergency'), varying friction / safety distance / clock
+jitter. Both planners get the SAME inputs -- the ego's next pose is taken from planner A's trajectory -- and are compared after every call.
+Not a model of the reference's simulator: the point is to reach branches of the state machine the recordings visit rarely (emergency as
+previous action, blocked tracks, dropped keys, backup brake plans) with two implementations that must agree.
+"""
+import numpy as np
+
+from graphbasedlocaltrajectoryplanner_amd._capi import BackendError
+from graphbasedlocaltrajectoryplanner_amd.scenario_gen import raceline_state
+
+
+def same_paths(a, b, exact=True, what=""):
+    assert a['keys'] == b['keys'] and a['start_node'] == b['start_node'] and a['const_rows'] == b['const_rows'], (what, a['keys'], b['keys'])
+    assert a['closest_obj_index'] == b['closest_obj_index'] and a['nodes'] == b['nodes'] and a['node_idx'] == b['node_idx'] and a['red_len'] == b['red_len'], what
+    for k in a['keys']:
+        for name in ('path_param', 'coeff'):
+            x, y = a[name][k], b[name][k]
+            assert x.shape == y.shape, (what, k, name)
+            if exact:
+                assert np.array_equal(x, y), (what, k, name)
+            elif x.size:
+                assert float(np.max(np.abs(x - y))) <= 1e-6 * max(1.0, float(np.max(np.abs(y)))), (what, k, name)
+
+
+def same_trajectories(a, b, exact=True, what=""):
+    (ta, ia, ra), (tb, ib, rb) = a, b
+    assert list(ta.keys()) == list(tb.keys()) and ia == ib, (what, list(ta.keys()), list(tb.keys()), ia, ib)
+    assert ra['cut_index_pos'] == rb['cut_index_pos'] and ra['cut_layer'] == rb['cut_layer'] and ra['vel_course'].shape == rb['vel_course'].shape, what
+    for k in ta:
+        x, y = ta[k][0], tb[k][0]
+        assert x.shape == y.shape, (what, k)
+        if exact:
+            assert np.array_equal(x, y), (what, k)
+            assert ra['vel_plan'] == rb['vel_plan'] and np.array_equal(ra['vel_course'], rb['vel_course'])
+        elif x.size:
+            sc = np.array([1.0, 1.0, 1.0, 1.0, 1e3, 1.0, 1e3]) * np.maximum(1.0, np.max(np.abs(y), axis=0))
+            assert np.all(np.max(np.abs(x - y), axis=0) <= 2e-5 * sc), (what, k, np.max(np.abs(x - y), axis=0))
+
+
+def drive(lat, A, B, seed, n_ticks, exact=True, scen_a=0, scen_b=0):
+    """A, B: planners with n_scen planners each (the inputs are replicated); compares planner scen_a of A with scen_b of B."""
+    rng = np.random.default_rng(seed)
+    track = float(lat.glob_rl[-1, 0])
+    stats = {'ticks': 0, 'restarts': 0, 'errors': 0, 'keys': set(), 'emergency_prev': 0, 'dropped': 0, 'red_len': 0, 'no_paths': 0}
+
+    def restart():
+        while True:
+            s0 = float(rng.uniform(0.0, track))
+            x, y, psi, _ = raceline_state(lat, s0)
+            ok = None
+            for pl in (A, B):
+                r = [pl.set_start(s, (float(x), float(y)), float(psi), 0.0) for s in range(pl.n_scen)]
+                assert ok is None or r[0] == ok
+                ok = r[0]
+            if ok == (True, True):
+                return s0, (float(x), float(y))
+
+    s_ego, pos = restart()
+    n_veh = int(rng.integers(0, 5))
+    veh = [dict(s=s_ego + float(rng.uniform(20.0, 220.0)), f=float(rng.uniform(0.05, 0.9)), off=float(rng.uniform(-2.5, 2.5)),
+                r=float(rng.uniform(1.5, 3.0))) for _ in range(n_veh)]
+    statics, zone = [], None
+    l_ego = int(np.argmin(np.abs(lat.s_raceline - (s_ego % float(lat.s_raceline[-1])))))
+    if seed % 2 == 0:                                          # a wall of parked vehicles on every fourth node of a layer: reduced horizons, blocked track
+        lw = (l_ego + int(rng.integers(12, 30))) % lat.num_layers
+        for nn in range(0, int(lat.nodes_in_layer[lw]), 4):
+            q = lat.node_pos[lat.layer_off[lw] + nn]
+            statics.append((2.5, 0.0, np.array([[float(q[0]), float(q[1])]])))
+    if seed % 3 == 0:                                          # a zone that removes every node of two layers: horizon back-off
+        lz = (l_ego + int(rng.integers(10, 24))) % lat.num_layers
+        zone = [int(lat.layer_off[(lz + d) % lat.num_layers]) + nn for d in range(2) for nn in range(int(lat.nodes_in_layer[(lz + d) % lat.num_layers]))]
+    gg = (float(rng.uniform(3.0, 6.0)), float(rng.uniform(3.0, 6.0)))
+    t, action, vel_est = 0.0, 'straight', 0.0
+    for tick in range(n_ticks):
+        what = "seed %d tick %d" % (seed, tick)
+        t += float(rng.uniform(0.06, 0.14))
+        objs = []
+        for v in veh:
+            x, y, psi, vr = raceline_state(lat, v['s'])
+            i = int(np.argmin((lat.refline[:, 0] - x) ** 2 + (lat.refline[:, 1] - y) ** 2))
+            x, y = x + lat.normvec[i, 0] * v['off'], y + lat.normvec[i, 1] * v['off']
+            sp = float(vr) * v['f']
+            pred = [[x - np.sin(psi) * sp * 0.2, y + np.cos(psi) * sp * 0.2]]
+            objs.append((v['r'], sp, np.array([[x, y]] + pred)))
+            v['s'] += sp * 0.1
+        if rng.random() < 0.02 and veh:                        # a vehicle changes its mind
+            veh[int(rng.integers(0, len(veh)))]['f'] = float(rng.uniform(0.0, 0.9))
+        res = []
+        for pl, sc in ((A, scen_a), (B, scen_b)):
+            n = pl.n_scen
+            try:
+                pl.calc_paths([action] * n, [t] * n, [objs + statics] * n, None if zone is None else [zone] * n)
+                res.append(pl.paths(sc))
+            except BackendError as e:
+                res.append(e)
+        if isinstance(res[0], BackendError) or isinstance(res[1], BackendError):
+            assert isinstance(res[0], BackendError) and isinstance(res[1], BackendError), (what, res)
+            stats['errors'] += 1; stats['restarts'] += 1
+            s_ego, pos = restart(); action, vel_est = 'straight', 0.0
+            continue
+        same_paths(res[0], res[1], exact, what)
+        paths_keys = res[0]['keys']
+        stats['red_len'] += int(any(res[0]['red_len'].values()))
+        stats['no_paths'] += int(not res[0]['keys'])
+        emerg = bool(rng.random() < 0.5)
+        kw = dict(vel_max=float(rng.choice([100.0, 60.0])), gg_scale=float(rng.choice([1.0, 1.0, 0.8])), local_gg=gg,
+                  ax_max_machines=((0.0, 7.0), (40.0, 5.0), (100.0, 2.0)) if seed % 2 else ((100.0, 5.0),), safety_d=float(rng.choice([30.0, 15.0])),
+                  incl_emerg_traj=emerg)
+        if rng.random() < 0.01:
+            gg = (gg[0] * 0.7, gg[1] * 0.7)                    # friction drop: velocity bounds break, backup plans
+        res = []
+        for pl, sc in ((A, scen_a), (B, scen_b)):
+            n = pl.n_scen
+            try:
+                pl.calc_vel_profile([pos] * n, vel_est, **kw)
+                res.append(pl.trajectories(sc))
+            except BackendError as e:
+                res.append(e)
+        if isinstance(res[0], BackendError) or isinstance(res[1], BackendError):
+            assert isinstance(res[0], BackendError) and isinstance(res[1], BackendError), (what, res)
+            stats['errors'] += 1; stats['restarts'] += 1
+            s_ego, pos = restart(); action, vel_est = 'straight', 0.0
+            continue
+        same_trajectories(res[0], res[1], exact, what)
+        traj = res[0][0]
+        stats['dropped'] += len([k for k in paths_keys if k not in traj])
+        stats['ticks'] += 1
+        stats['keys'].update(traj.keys())
+        keys = [k for k in traj if k != 'emergency']
+        if not keys:
+            stats['restarts'] += 1
+            s_ego, pos = restart(); action, vel_est = 'straight', 0.0
+            continue
+        action = keys[int(rng.integers(0, len(keys)))] if rng.random() < 0.3 else keys[0]
+        rows = traj[action][0]
+        if 'emergency' in traj and rng.random() < 0.05:
+            action, rows = 'emergency', traj['emergency'][0]
+            stats['emergency_prev'] += 1
+        i = min(int(rng.integers(1, 4)), rows.shape[0] - 1)
+        pos = (float(rows[i, 1] + rng.normal(0.0, 0.05)), float(rows[i, 2] + rng.normal(0.0, 0.05)))
+        vel_est = float(rows[i, 5])
+    return stats

@@ -1,0 +1,46 @@
+"""
+CPU: differential closed loops of the fleet's state machine (csrc/fleet_core.hpp, one-lane host build) against the product's host planner
+(csrc/planner_core.hpp), both over the oracle's arithmetic: same inputs -> IDENTICAL outputs, call by call, on seeded traffic that reaches
+branches the recordings visit rarely (tests/fleet_differential.py). The host planner is the one pinned to the reference's recordings.
+"""
+import pytest
+
+from fleet_differential import drive
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_fleet_and_host_planner_agree_call_by_call(monteblanco, seed):
+    from oracle.fleet_host import HostFleetBackend
+    from oracle.planner_host import HostPlannerBackend
+    A, B = HostPlannerBackend(monteblanco).planner(1), HostFleetBackend(monteblanco).planner(2)
+    st = drive(monteblanco, A, B, seed, 500, exact=True, scen_b=1)
+    assert st['ticks'] >= 300, st
+
+
+def test_the_driver_reaches_the_rare_branches(monteblanco):
+    from oracle.planner_host import HostPlannerBackend
+    total = {'keys': set(), 'emergency_prev': 0, 'red_len': 0, 'errors': 0, 'dropped': 0, 'restarts': 0}
+    for seed in (1, 2, 3, 4, 5, 6):
+        A, B = HostPlannerBackend(monteblanco).planner(1), HostPlannerBackend(monteblanco).planner(1)
+        st = drive(monteblanco, A, B, seed, 500)
+        total['keys'] |= st['keys']
+        for k in ('emergency_prev', 'red_len', 'errors', 'dropped', 'restarts'):
+            total[k] += st[k]
+    assert {'straight', 'follow', 'left', 'right', 'emergency'} <= total['keys'], total
+    assert total['emergency_prev'] > 10 and total['red_len'] > 100 and total['dropped'] > 10, total
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 3, 4])
+def test_fleet_and_host_planner_agree_on_the_device(monteblanco, seed):
+    """The same on the MI355X: ltpl_fleet_* (device-resident state, 70 planners = one-wave batch path kernel) against ltpl_planner_* on the
+    same handle. Not bit-equal (the fleet solves forward-backward jobs one lane per job on fp32 operands): node lists, indices, keys and ids
+    identical, arrays to 1e-6 / 2e-5 relative."""
+    from graphbasedlocaltrajectoryplanner_amd import _capi
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    from graphbasedlocaltrajectoryplanner_amd.planner import Planner
+    hip = _capi.HipBackend(monteblanco)
+    A, B = Planner(hip, 1), Fleet(hip, 70)
+    st = drive(monteblanco, A, B, seed, 300, exact=False, scen_b=69)
+    assert st['ticks'] >= 200, st
+    A.close(); B.close()
