@@ -269,16 +269,44 @@ def closed_loop_device_rate(hip, lat, n_planners, n_ticks):
             pos_est=t['pos_est'], vel_est=va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'], local_gg=tuple(va['local_gg']),
             safety_d=va['safety_d'], incl_emerg_traj=va['incl_emerg_traj']))], ax_max_machines=va['ax_max_machines'])
     ms = fleet.tape_run(0, len(ticks))
-    ok = True
+    tape_ok = True
     try:
         for p in (0, n_planners - 1):
             traj, ids, ref = fleet.trajectories(p)
             pr.check_trajectories(traj, ids, ref, ticks[-1], "planner %d" % p)
     except AssertionError as e:
         sys.stderr.write("closed_loop_device: %s\n" % e)
-        ok = False
+        tape_ok = False
     fleet.close()
-    return n_planners * len(ticks) / (ms * 1e-3), ms / len(ticks), ok
+    # the same ticks with LIVE inputs: the host hands the fleet's inputs over every tick (arrays packed outside the timed region, as a
+    # simulator that already holds its vehicles' states as arrays would), two synchronous calls per tick -- host-inclusive wall time
+    fleet = Fleet(hip, n_planners)
+    for p in range(n_planners):
+        fleet.set_start(p, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+    n_live = min(len(ticks), 60)
+    packed = []
+    for t in ticks[:n_live]:
+        va = t['vel_args']
+        packed.append(fleet.pack_groups([(n_planners, dict(
+            prev_action=t['action_id_sel'], t_now=t['t'], vehicles=pr.vehicles_of_tick(t), zone_gids=pr.zone_gids_of_tick(lat, t),
+            pos_est=t['pos_est'], vel_est=va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'], local_gg=tuple(va['local_gg']),
+            safety_d=va['safety_d'], incl_emerg_traj=va['incl_emerg_traj']))], ax_max_machines=va['ax_max_machines']))
+    t_live, live_ok = 0.0, True
+    for k, (pi, vi, _keep) in enumerate(packed):
+        t0 = time.perf_counter()
+        fleet.calc_paths_packed(pi)
+        fleet.calc_vel_profile_packed(vi)
+        if k >= 5:
+            t_live += time.perf_counter() - t0
+    try:
+        traj, ids, ref = fleet.trajectories(n_planners - 1)
+        pr.check_trajectories(traj, ids, ref, ticks[n_live - 1], "live planner %d" % (n_planners - 1))
+    except AssertionError as e:
+        sys.stderr.write("closed_loop_device (live inputs): %s\n" % e)
+        live_ok = False
+    fleet.close()
+    live_rate = n_planners * max(n_live - 5, 1) / max(t_live, 1e-9)
+    return n_planners * len(ticks) / (ms * 1e-3), ms / len(ticks), tape_ok and live_ok, live_rate
 
 
 def worker(args):
@@ -409,13 +437,17 @@ def worker(args):
                                             "planner carrying its own iterative memory; host-inclusive (packing, PCIe, host state machine)"}
             # the same closed loop with the planners' state in device memory (fleet): no host work per planner
             n_fp, n_ft = getattr(args, 'fleet_planners', 8192), getattr(args, 'fleet_ticks', 200)
-            cdr, cd_ms, cdok = closed_loop_device_rate(hip, lat, n_fp, n_ft)
+            cdr, cd_ms, cdok, cd_live = closed_loop_device_rate(hip, lat, n_fp, n_ft)
             extra["closed_loop_device"] = {"planner_ticks_per_s": cdr, "planners": n_fp, "ticks": n_ft, "ms_per_fleet_tick": cd_ms,
+                                           "live_inputs_planner_ticks_per_s": cd_live,
                                            "matches_recording": cdok,
                                            "what": "ltpl_fleet_*: planners with device-resident iterative memory replay consecutive ticks of the "
                                                    "reference's C2 recording from a pre-uploaded tape (state machine stages as kernels, one wave "
                                                    "per planner, around k_paths / k_vel_profile; device time, no host synchronisation inside); "
-                                                   "first and last planner checked against the recording's last tick"}
+                                                   "first and last planner checked against the recording's last tick. live_inputs_*: "
+                                                   "the same loop through the per-call entry points, the host hands every tick's inputs "
+                                                   "over (pre-packed arrays -> page-locked staging -> H2D) and synchronises twice per tick; "
+                                                   "host wall time"}
         traffic = read_traffic(args.batch, args.workload)            # measured HBM bytes per launch of the dominant kernel (PMC), or None
         issue_pmc = read_issue(args.batch, args.workload)
         issue = None

@@ -36,12 +36,13 @@ class Fleet(Planner):
         vi, keep2 = self._pack_vel_in(pos_est, vel_est, **vel_kwargs)
         self._check(self._fn("tape_append")(self.handle, C.byref(pi), C.byref(vi)))
 
-    def tape_append_groups(self, groups, ax_max_machines=((100.0, 5.0),)):
-        """Inputs of one tick for planners that come in GROUPS with identical inputs (vectorised: no Python loop over planners).
+    def pack_groups(self, groups, ax_max_machines=((100.0, 5.0),)):
+        """Input structs of one tick for planners that come in GROUPS with identical inputs (vectorised: no Python loop over planners).
         ``groups``: list of (count, dict) in planner order; dict keys: prev_action (name), t_now, vehicles [(radius, vel, positions)],
-        zone_gids, pos_est, vel_est, vel_max, gg_scale, local_gg (ax, ay), safety_d, incl_emerg_traj."""
+        zone_gids, pos_est, vel_est, vel_max, gg_scale, local_gg (ax, ay), safety_d, incl_emerg_traj. Returns (paths struct, velocity struct,
+        keep-alive): pass the structs to ``calc_paths_packed`` / ``calc_vel_profile_packed`` / ``tape_append_packed``."""
         if sum(c for c, _ in groups) != self.n_scen:
-            raise ValueError("tape_append_groups: the group sizes must add up to the number of planners")
+            raise ValueError("pack_groups: the group sizes must add up to the number of planners")
         i32, f64 = np.int32, np.float64
         acts, ts, veh_cnt, pos_cnt, rad, vel, px, py, zcnt, zg = [], [], [], [], [], [], [], [], [], []
         vcols = [[] for _ in range(8)]
@@ -90,6 +91,18 @@ class Fleet(Planner):
             setattr(vi, name, a.ctypes.data)
         vi.incl_emerg_traj, vi.ax_max_machines, vi.n_ax_max_machines = em.ctypes.data, axm.ctypes.data, axm.shape[0]
         vi.gg_row_off, vi.gg_rows = None, None
+        return pi, vi, (arrs, v, em, axm)
+
+    def calc_paths_packed(self, pi):
+        """``calc_paths`` on an input struct of ``pack_groups`` (a caller that already holds its fleet's inputs as arrays pays no packing)."""
+        self._check(self._fn("calc_paths")(self.handle, C.byref(pi)))
+
+    def calc_vel_profile_packed(self, vi):
+        self._check(self._fn("calc_vel_profile")(self.handle, C.byref(vi)))
+
+    def tape_append_groups(self, groups, ax_max_machines=((100.0, 5.0),)):
+        """Inputs of one tick for planners that come in groups with identical inputs (see ``pack_groups``)."""
+        pi, vi, keep = self.pack_groups(groups, ax_max_machines)
         self._check(self._fn("tape_append")(self.handle, C.byref(pi), C.byref(vi)))
 
     def tape_run(self, first, count):

@@ -35,13 +35,23 @@ class StandInFleet(object):
     def tape_append_groups(self, groups, ax_max_machines=((100.0, 5.0),)):
         self.tape.append((groups, ax_max_machines))
 
+    def pack_groups(self, groups, ax_max_machines=((100.0, 5.0),)):
+        return (groups, ax_max_machines), (groups, ax_max_machines), None
+
+    def calc_paths_packed(self, packed):
+        per = [g for c, g in packed[0] for _ in range(c)]
+        self.p.calc_paths([g["prev_action"] for g in per], [g["t_now"] for g in per], [g["vehicles"] for g in per], [g["zone_gids"] for g in per])
+
+    def calc_vel_profile_packed(self, packed):
+        per = [g for c, g in packed[0] for _ in range(c)]
+        g0 = per[0]
+        self.p.calc_vel_profile([g["pos_est"] for g in per], [g["vel_est"] for g in per], vel_max=g0["vel_max"], gg_scale=g0["gg_scale"],
+                                local_gg=g0["local_gg"], ax_max_machines=packed[1], safety_d=g0["safety_d"], incl_emerg_traj=g0["incl_emerg_traj"])
+
     def tape_run(self, first, count):
-        for groups, axm in self.tape[first:first + count]:
-            per = [g for c, g in groups for _ in range(c)]
-            self.p.calc_paths([g["prev_action"] for g in per], [g["t_now"] for g in per], [g["vehicles"] for g in per], [g["zone_gids"] for g in per])
-            g0 = per[0]
-            self.p.calc_vel_profile([g["pos_est"] for g in per], [g["vel_est"] for g in per], vel_max=g0["vel_max"], gg_scale=g0["gg_scale"],
-                                    local_gg=g0["local_gg"], ax_max_machines=axm, safety_d=g0["safety_d"], incl_emerg_traj=g0["incl_emerg_traj"])
+        for packed in self.tape[first:first + count]:
+            self.calc_paths_packed(packed)
+            self.calc_vel_profile_packed(packed)
         return 1.5 * count
 
     def trajectories(self, p):
@@ -161,6 +171,7 @@ def test_the_line_carries_the_drivers_contract(monkeypatch, capsys):
     assert cl["planners"] == 256 and cl["planner_ticks_per_s"] > 0 and cl["keys_match_recording"] is True
     cd = out["extra"]["closed_loop_device"]
     assert cd["planners"] == 3 and cd["ticks"] == 40 and cd["matches_recording"] is True and cd["planner_ticks_per_s"] == pytest.approx(3 * 40 / 0.06)
+    assert cd["live_inputs_planner_ticks_per_s"] > 0
     assert 1.0 <= out["paths_per_tick"] <= 4.0
     # order of the device calls: resident inputs before any run, and the sample re-uploaded for the device-only latency
     assert hip.calls[0] == "batch_upload" and hip.calls.count("batch_upload") == 3

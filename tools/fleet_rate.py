@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--ticks", type=int, default=200)
     ap.add_argument("--mix", action="store_true", help="four groups: c2 / overtake / zonewall / c1 instead of c2 only")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--live", type=int, default=0, help="also time this many ticks through the per-call entry points (inputs handed over by the host every tick)")
     a = ap.parse_args()
     lat = Lattice.load(os.path.join(ROOT, "tests", "golden", "monteblanco_lattice.npz"))
     hip = _capi.HipBackend(lat)
@@ -72,6 +73,27 @@ def main():
     print("parity: first and last planner of every group equal the recording's tick %d (trajectory digests%s)" % (
         a.ticks - 1, " + full arrays" if any(t['full'] is not None for t in [r[a.ticks - 1] for r in recs]) else ""))
     print("closed_loop_device_ticks_per_s %.0f" % (n * a.ticks / best * 1e3))
+    if a.live:
+        fleet.close()
+        fleet = Fleet(hip, n)
+        p = 0
+        for sz, ticks in zip(sizes, recs):
+            st = ticks[0]['start']
+            for q in range(p, p + sz):
+                fleet.set_start(q, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+            p += sz
+        packed = [fleet.pack_groups([(sz, group_inputs(lat, ticks[k])) for sz, ticks in zip(sizes, recs)],
+                                    ax_max_machines=recs[0][k]['vel_args']['ax_max_machines']) for k in range(a.live)]
+        tp = tv = 0.0
+        for k, (pi, vi, _keep) in enumerate(packed):
+            t0 = time.perf_counter(); fleet.calc_paths_packed(pi); t1 = time.perf_counter(); fleet.calc_vel_profile_packed(vi); t2 = time.perf_counter()
+            if k >= 5:
+                tp += t1 - t0; tv += t2 - t1
+        m = max(a.live - 5, 1)
+        print("live inputs (per-call entry points, host wall time): calc_paths %.3f ms + calc_vel_profile %.3f ms per tick of the fleet = %.3f M "
+              "planner-ticks/s" % (tp / m * 1e3, tv / m * 1e3, n * m / (tp + tv) / 1e6))
+        traj, ids, ref = fleet.trajectories(0)
+        pr.check_trajectories(traj, ids, ref, recs[0][a.live - 1], "live planner 0")
 
 
 if __name__ == "__main__":
