@@ -32,6 +32,13 @@ inline int check_config(const ltpl_planner_config* cfg, std::string* why)
     return LTPL_OK;
 }
 
+// scratch rows of a planner block hold two coordinate lists of a path's nodes (paths_pre) and the job tables address rows with ints
+inline int check_dims(const Dims& D, std::string* why)
+{
+    if (2 * D.CN > D.R || D.RV > D.R) { *why = "fleet: lattice with more path nodes than the block's scratch rows hold (2 (2 max_path_nodes + 8) > 2 max_path_pts + 64)"; return LTPL_ERR_CAPACITY; }
+    return LTPL_OK;
+}
+
 inline FCfg fcfg_of(const ltpl_planner_config* cfg)
 {
     FCfg c{}; c.v_max_offset = cfg->v_max_offset; c.delaycomp = cfg->delaycomp; c.calc_time_safety = cfg->calc_time_safety;

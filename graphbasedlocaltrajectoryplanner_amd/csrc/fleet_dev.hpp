@@ -283,6 +283,7 @@ try {
     f->D = fleet::make_dims(cfg->n_scen, h->caps.max_path_nodes, h->caps.max_path_pts);
     const int N = f->D.N;
     auto bail = [&](int code) { g_create_error = f->err; return code; };
+    if ((rc = fleet::check_dims(f->D, &f->err))) return bail(rc);
     if ((rc = fleet_alloc(f.get(), f->D.stride * (size_t)N, &f->d_state))) return bail(rc);
     if ((rc = fleet_alloc(f.get(), 4, &f->d_err))) return bail(rc);
     {   // all planners start without memory (the fields whose "nothing" is not zero)

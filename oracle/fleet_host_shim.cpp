@@ -82,6 +82,7 @@ int oracle_fleet_create(const ltpl_lattice_desc* d, int max_path_nodes, int max_
     F.d = d; F.flat = flat_of(F.lat); F.cfg = fcfg_of(cfg); F.pc = *cfg;
     if (cfg->n_w_last > 0) F.w_last.assign(cfg->w_last_edges, cfg->w_last_edges + cfg->n_w_last);
     F.D = make_dims(cfg->n_scen, max_path_nodes, max_path_pts);
+    if ((rc = check_dims(F.D, &g_err))) { delete f; return rc; }
     F.state.assign(F.D.stride * (size_t)cfg->n_scen, 0);
     for (int p = 0; p < cfg->n_scen; ++p) { PlannerS* S = F.block(p).S(); S->em_base_id = S->action_forced = S->sel_action = S->raw_action = LTPL_ACT_NONE; S->closest_obj_index = -1; S->const_rows = -1; S->old_gg_scale = 1.0; }
     F.JA.init(F.D.N, JOBS_A, F.D.R); F.JB.init(F.D.N, 1, F.D.R); F.JC.init(F.D.N, 1, F.D.R);
