@@ -134,3 +134,28 @@ def test_location_dependent_friction_is_refused(fleet_backend, monteblanco):
     pp = fleet.paths(0)['path_param']
     with pytest.raises(BackendError, match="dict form"):
         fleet.calc_vel_profile([t['pos_est']], 0.0, local_gg={k: [np.full((v.shape[0], 2), 5.0)] for k, v in pp.items()})
+
+
+class _SplitCalls(object):
+    """Planner proxy: calc_paths as its two halves (the caller owns the zone bookkeeping between them, Graph_LTPL.py:300-340) and
+    get_ref_idx as its own call in front of calc_vel_profile (Graph_LTPL.py:380-387)."""
+
+    def __init__(self, planner):
+        self._p = planner
+
+    def __getattr__(self, name):
+        return getattr(self._p, name)
+
+    def calc_paths(self, prev_actions, t_now, vehicles, zone_gids=None):
+        self._p.calc_paths_begin(prev_actions, t_now, vehicles)
+        assert self._p.start_node(0)[0] >= 0
+        self._p.calc_paths_finish(zone_gids)
+
+    def calc_vel_profile(self, pos_est, vel_est, **kw):
+        self._p.get_ref_idx(pos_est, scen=0)
+        self._p.calc_vel_profile(pos_est, vel_est, **kw)
+
+
+def test_split_entry_points_equal_the_fused_ones(fleet_backend, monteblanco):
+    seen = pr.replay(_SplitCalls(fleet_backend.planner(2)), monteblanco, pr.load_ticks("zonewall"), scen=1)
+    assert seen['full'] >= 15

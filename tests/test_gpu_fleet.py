@@ -138,3 +138,12 @@ def test_a_failing_planner_keeps_its_error_and_does_not_disturb_the_others(hip, 
         traj, ids, ref = fleet.trajectories(1)
         pr.check_trajectories(traj, ids, ref, t, "tick %d" % t['tick'])
     fleet.close()
+
+
+def test_split_entry_points_equal_the_fused_ones(hip, monteblanco):
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    from test_fleet_host_logic import _SplitCalls
+    fleet = Fleet(hip, 2)
+    seen = pr.replay(_SplitCalls(fleet), monteblanco, pr.load_ticks("zonewall"), scen=1)
+    assert seen['full'] >= 15
+    fleet.close()
