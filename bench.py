@@ -383,7 +383,10 @@ def worker(args):
         achieved = ab_paths / (dom_ms * 1e-3) / 1e9
         extra = {}
         lat_us, device_us, drop_us, drop_ok = np.zeros(0), None, np.zeros(0), None
-        if args.latency_ticks > 0:
+        # N > 1 is the scaling run: whole-job throughput only. The single-GPU legs (latency, extras, the CPU baseline and the parity
+        # full-size CPU baseline) belong to the N = 1 line -- the other ranks would sit in the final barrier while rank 0 runs them
+        solo = world == 1
+        if args.latency_ticks > 0 and solo:
             lat_us, single = single_tick_latency(hip, lat, scen, vel, batch, args.latency_ticks)
             # device-only time of one single-scenario tick (latency method): the same fused kernel launched
             # back to back on a device-resident scenario, HIP events on the library's stream
@@ -392,7 +395,7 @@ def worker(args):
             device_us = hip.batch_run(reps=200, timed=True) / 200 * 1e3
             if args.workload == "c2":
                 drop_us, drop_ok = dropin_latency(hip, lat, args.dropin_ticks)
-        if args.workload == "c2" and not args.no_extra:
+        if args.workload == "c2" and not args.no_extra and solo:
             # companion number: every scenario has an opponent 20-80 m ahead, so the [follow, left, right] template is live
             n3 = min(args.batch, 8192)
             scen3, batch3, vel3 = make_batch(lat, n3, seed=1001, workload="c2_near")
@@ -517,7 +520,7 @@ def worker(args):
             "extra": extra,
         }
         if not args.no_cpu:
-            ns = min(args.cpu_sample, args.batch)
+            ns = min(args.cpu_sample if solo else min(args.cpu_sample, 256), args.batch)      # (N > 1: a short sample, for the parity check of rank 0's shard)
             out["cpu_baseline"], ref = cpu_baseline(lat, scen, vel, ns)
             ok, detail = parity_check(res, vres, ref, ns)
             out["parity_checked"] = bool(ok)
