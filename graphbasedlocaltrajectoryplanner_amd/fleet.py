@@ -93,6 +93,44 @@ class Fleet(Planner):
         vi.gg_row_off, vi.gg_rows = None, None
         return pi, vi, (arrs, v, em, axm)
 
+    def pack_arrays(self, prev_action, t_now, veh_off, pos_off, veh_radius, veh_vel, pos_x, pos_y, zone_off, zone_gid,
+                    pos_est, vel_est, vel_max=100.0, gg_scale=1.0, local_gg=(5.0, 5.0), safety_d=30.0, incl_emerg_traj=False,
+                    ax_max_machines=((100.0, 5.0),)):
+        """Input structs of one tick from the caller's own arrays (a simulator that holds its vehicles as arrays): the layout of
+        ``ltpl_planner_paths_in`` / ``ltpl_planner_vel_in`` (include/ltpl_hip.h) -- ``prev_action`` action ids (LTPL_ACT_*) per planner,
+        CSR offsets ``veh_off`` [n + 1] / ``pos_off`` [n_veh + 1] / ``zone_off`` [n + 1], own position of a vehicle first. Scalars are
+        broadcast. Returns (paths struct, velocity struct, keep-alive) like ``pack_groups``."""
+        n, i32, f64 = self.n_scen, np.int32, np.float64
+
+        def arr(a, dt, size=None, pad=None):
+            a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dt), (size,)) if size is not None else np.asarray(a, dt).reshape(-1))
+            return a if a.size else np.full(1, pad if pad is not None else 0, dt)
+        pe = np.asarray(pos_est, f64).reshape(-1, 2)
+        if pe.shape[0] == 1:
+            pe = np.broadcast_to(pe, (n, 2))
+        if pe.shape[0] != n:
+            raise ValueError("pos_est: one (x, y) per planner expected")
+        arrs = dict(prev_action=arr(prev_action, i32, n), t_now=arr(t_now, f64, n), veh_off=arr(veh_off, i32), pos_off=arr(pos_off, i32),
+                    veh_radius=arr(veh_radius, f64), veh_vel=arr(veh_vel, f64), pos_x=arr(pos_x, f64), pos_y=arr(pos_y, f64),
+                    zone_off=arr(zone_off, i32), zone_gid=arr(zone_gid, i32))
+        if arrs["veh_off"].size != n + 1 or arrs["zone_off"].size != n + 1 or arrs["pos_off"].size != int(arrs["veh_off"][-1]) + 1:
+            raise ValueError("pack_arrays: veh_off / zone_off need n + 1 entries, pos_off one more than the number of vehicles")
+        pi = PlannerPathsIn()
+        for k, a in arrs.items():
+            setattr(pi, k, a.ctypes.data)
+        if type(local_gg) not in (tuple, list) or len(local_gg) != 2:
+            raise ValueError("Provided local_gg does not satisfy requested format! Read parameter documentation.")
+        v = [np.ascontiguousarray(pe[:, 0]), np.ascontiguousarray(pe[:, 1]), arr(vel_est, f64, n), arr(vel_max, f64, n), arr(gg_scale, f64, n),
+             arr(local_gg[0], f64, n), arr(local_gg[1], f64, n), arr(safety_d, f64, n)]
+        em = arr(np.asarray(incl_emerg_traj).astype(i32), i32, n)
+        axm = np.ascontiguousarray(np.asarray(ax_max_machines, f64).reshape(-1, 2))
+        vi = PlannerVelIn()
+        for name, a in zip(("pos_est_x", "pos_est_y", "vel_est", "vel_max", "gg_scale", "gg_ax", "gg_ay", "safety_d"), v):
+            setattr(vi, name, a.ctypes.data)
+        vi.incl_emerg_traj, vi.ax_max_machines, vi.n_ax_max_machines = em.ctypes.data, axm.ctypes.data, axm.shape[0]
+        vi.gg_row_off, vi.gg_rows = None, None
+        return pi, vi, (arrs, v, em, axm)
+
     def calc_paths_packed(self, pi):
         """``calc_paths`` on an input struct of ``pack_groups`` (a caller that already holds its fleet's inputs as arrays pays no packing)."""
         self._check(self._fn("calc_paths")(self.handle, C.byref(pi)))
