@@ -121,10 +121,24 @@ def test_resident_batch_equals_tick_batch(monteblanco, hip_backend):
     ms = hip_backend.batch_run(reps=3, timed=True)
     assert ms > 0.0
     res2, vres2 = hip_backend.batch_download()
-    for name in ("nodes", "node_idx", "coeff", "path_param", "valid", "action_id", "n_pts", "reduced"):
+    for name in ("valid", "action_id", "n_pts", "n_nodes", "reduced"):
         assert np.array_equal(getattr(res, name), getattr(res2, name)), name
-    assert np.array_equal(vres.vx, vres2.vx) and np.array_equal(vres.ax, vres2.ax)
     assert np.array_equal(vres.vel_bound, vres2.vel_bound)
+    # (entries of the capacity slabs behind n_nodes / n_pts are unspecified -- include/ltpl_hip.h -- and the resident pipeline rotates through
+    # four buffer sets: compare what is defined, bit for bit)
+    for s, a in zip(*np.nonzero(res.valid)):
+        nn, npt = int(res.n_nodes[s, a]), int(res.n_pts[s, a])
+        assert np.array_equal(res.nodes[s, a, :nn], res2.nodes[s, a, :nn]) and np.array_equal(res.node_idx[s, a, :nn], res2.node_idx[s, a, :nn])
+        assert np.array_equal(res.coeff[s, a, :nn - 1], res2.coeff[s, a, :nn - 1]) and np.array_equal(res.path_param[s, a, :npt], res2.path_param[s, a, :npt])
+        assert np.array_equal(vres.vx[s, a, :npt], vres2.vx[s, a, :npt]) and np.array_equal(vres.ax[s, a, :npt], vres2.ax[s, a, :npt])
+    # ... and after a run that ends on every one of the buffer sets
+    for reps in (1, 2, 4, 5):
+        hip_backend.batch_run(reps=reps, timed=False)
+        res3, vres3 = hip_backend.batch_download()
+        assert np.array_equal(res.valid, res3.valid) and np.array_equal(res.n_pts, res3.n_pts)
+        for s, a in zip(*np.nonzero(res.valid)):
+            npt = int(res.n_pts[s, a])
+            assert np.array_equal(vres.vx[s, a, :npt], vres3.vx[s, a, :npt]) and np.array_equal(res.path_param[s, a, :npt], res3.path_param[s, a, :npt]), reps
 
 
 def test_tick_paths_equal_plan_paths(monteblanco, hip_backend):
