@@ -1846,17 +1846,23 @@ struct ltpl_handle {
     void* d_planes = nullptr; size_t d_planes_cap = 0;   // tiled profile planes of the lane kernel
     // second buffer set + stream of the device-resident batch: the velocity kernels of step k overlap the path kernel of
     // step k + 1 (ltpl_batch_run)
-    // Round 3: FOUR buffer sets and TWO velocity streams. With two sets the path kernel of step r + 2 waited for the velocity kernels of
+    // Round 3: THREE buffer sets and TWO velocity streams. With two sets the path kernel of step r + 2 waited for the velocity kernels of
     // step r, and those take a whole step when they share the chip with a path kernel (its four waves per SIMD hold the register file: a
     // velocity wave only gets on a SIMD when a path wave retires) -- the velocity chain was the critical path (0.99 ms per step against
     // 0.89 ms of path kernel). Chains of consecutive steps now run next to each other on alternating streams and the path kernel only
-    // waits for the chain four steps back: 0.947 ms per step (measured with the waits removed before it was built properly).
-    static constexpr int PIPE_SETS = 4;
-    struct TickLayout* resident_x[PIPE_SETS - 1] = {nullptr, nullptr, nullptr};    // sets 1 .. 3 (set 0 = `resident` on d_out / d_planes)
-    void* d_out_x[PIPE_SETS - 1] = {nullptr, nullptr, nullptr}; size_t d_out_x_cap[PIPE_SETS - 1] = {0, 0, 0};
-    void* d_planes_x[PIPE_SETS - 1] = {nullptr, nullptr, nullptr}; size_t d_planes_x_cap[PIPE_SETS - 1] = {0, 0, 0};
-    hipStream_t stream2 = nullptr, stream3 = nullptr;
-    hipEvent_t ev_paths[PIPE_SETS] = {nullptr, nullptr, nullptr, nullptr}, ev_vel[PIPE_SETS] = {nullptr, nullptr, nullptr, nullptr};
+    // waits for the chain three steps back: 0.947 ms per step (33.4 -> 34.4 M ticks/s).
+#ifndef LTPL_PIPE_SETS
+#define LTPL_PIPE_SETS 3               // (A/B on one box: 3, 4, 6 sets with two velocity streams all 34.3-34.4 M ticks/s; three or four streams: 33.4 M)
+#endif
+#ifndef LTPL_VEL_STREAMS
+#define LTPL_VEL_STREAMS 2
+#endif
+    static constexpr int PIPE_SETS = LTPL_PIPE_SETS, VEL_STREAMS = LTPL_VEL_STREAMS;
+    struct TickLayout* resident_x[PIPE_SETS - 1] = {};    // sets 1 .. (set 0 = `resident` on d_out / d_planes)
+    void* d_out_x[PIPE_SETS - 1] = {}; size_t d_out_x_cap[PIPE_SETS - 1] = {};
+    void* d_planes_x[PIPE_SETS - 1] = {}; size_t d_planes_x_cap[PIPE_SETS - 1] = {};
+    hipStream_t vel_stream[VEL_STREAMS] = {};
+    hipEvent_t ev_paths[PIPE_SETS] = {}, ev_vel[PIPE_SETS] = {};
     int last_set = 0;
     std::vector<hipEvent_t> ev_step;          // timing events around the path kernel of every step of the last timed run
     float last_paths_ms = 0.0f; int last_paths_n = 0;
@@ -2107,8 +2113,7 @@ extern "C" int ltpl_destroy(ltpl_handle* h)
         if (h->d_out_x[i]) (void)hipFree(h->d_out_x[i]);
         free_resident(h->resident_x[i]);
     }
-    if (h->stream2) (void)hipStreamDestroy(h->stream2);
-    if (h->stream3) (void)hipStreamDestroy(h->stream3);
+    for (int i = 0; i < ltpl_handle::VEL_STREAMS; ++i) if (h->vel_stream[i]) (void)hipStreamDestroy(h->vel_stream[i]);
     for (int i = 0; i < ltpl_handle::PIPE_SETS; ++i) { if (h->ev_paths[i]) (void)hipEventDestroy(h->ev_paths[i]); if (h->ev_vel[i]) (void)hipEventDestroy(h->ev_vel[i]); }
     for (hipEvent_t e : h->ev_step) (void)hipEventDestroy(e);
     if (h->h_in) (void)hipHostFree(h->h_in);
@@ -3202,8 +3207,7 @@ try {
     h->last_set = 0;
     if (t->pipeline && !h->no_overlap) {
         // further buffer sets for the software pipeline of ltpl_batch_run
-        if (!h->stream2) HIP_TRY(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-        if (!h->stream3) HIP_TRY(h, hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+        for (int i = 0; i < ltpl_handle::VEL_STREAMS; ++i) if (!h->vel_stream[i]) HIP_TRY(h, hipStreamCreateWithFlags(&h->vel_stream[i], hipStreamNonBlocking));
         for (int i = 0; i < ltpl_handle::PIPE_SETS; ++i) {
             if (!h->ev_paths[i]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_paths[i], hipEventDisableTiming));
             if (!h->ev_vel[i]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_vel[i], hipEventDisableTiming));
@@ -3243,7 +3247,7 @@ try {
     }
     h->last_paths_ms = 0.0f; h->last_paths_n = 0;
     if (h->resident_x[0]) {
-        // software pipeline over steps: path kernel of step r on `stream`, velocity kernels of step r on `stream2` / `stream3` (alternating:
+        // software pipeline over steps: path kernel of step r on `stream`, velocity kernels of step r on `vel_stream[r % VEL_STREAMS]` (alternating:
         // the chains of consecutive steps run next to each other), PIPE_SETS buffer sets; the path kernel of step r + PIPE_SETS waits
         // until the velocity kernels of step r released its set
         constexpr int K = ltpl_handle::PIPE_SETS;
@@ -3256,7 +3260,7 @@ try {
             if (rc) return rc;
             if (ms_total) HIP_TRY(h, hipEventRecord(h->ev_step[2 * (size_t)r + 1], h->stream));
             HIP_TRY(h, hipEventRecord(h->ev_paths[set], h->stream));
-            hipStream_t sv = (r & 1) ? h->stream3 : h->stream2;
+            hipStream_t sv = h->vel_stream[r % ltpl_handle::VEL_STREAMS];
             HIP_TRY(h, hipStreamWaitEvent(sv, h->ev_paths[set], 0));
             if ((rc = tick_launch_vel(h, T, sv))) return rc;
             HIP_TRY(h, hipEventRecord(h->ev_vel[set], sv));

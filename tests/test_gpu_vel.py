@@ -125,14 +125,14 @@ def test_resident_batch_equals_tick_batch(monteblanco, hip_backend):
         assert np.array_equal(getattr(res, name), getattr(res2, name)), name
     assert np.array_equal(vres.vel_bound, vres2.vel_bound)
     # (entries of the capacity slabs behind n_nodes / n_pts are unspecified -- include/ltpl_hip.h -- and the resident pipeline rotates through
-    # four buffer sets: compare what is defined, bit for bit)
+    # three buffer sets: compare what is defined, bit for bit)
     for s, a in zip(*np.nonzero(res.valid)):
         nn, npt = int(res.n_nodes[s, a]), int(res.n_pts[s, a])
         assert np.array_equal(res.nodes[s, a, :nn], res2.nodes[s, a, :nn]) and np.array_equal(res.node_idx[s, a, :nn], res2.node_idx[s, a, :nn])
         assert np.array_equal(res.coeff[s, a, :nn - 1], res2.coeff[s, a, :nn - 1]) and np.array_equal(res.path_param[s, a, :npt], res2.path_param[s, a, :npt])
         assert np.array_equal(vres.vx[s, a, :npt], vres2.vx[s, a, :npt]) and np.array_equal(vres.ax[s, a, :npt], vres2.ax[s, a, :npt])
     # ... and after a run that ends on every one of the buffer sets
-    for reps in (1, 2, 4, 5):
+    for reps in (1, 2, 3, 5):
         hip_backend.batch_run(reps=reps, timed=False)
         res3, vres3 = hip_backend.batch_download()
         assert np.array_equal(res.valid, res3.valid) and np.array_equal(res.n_pts, res3.n_pts)
