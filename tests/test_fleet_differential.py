@@ -44,3 +44,16 @@ def test_fleet_and_host_planner_agree_on_the_device(monteblanco, seed):
     st = drive(monteblanco, A, B, seed, 300, exact=False, scen_b=69)
     assert st['ticks'] >= 200, st
     A.close(); B.close()
+
+
+@pytest.mark.parametrize("track", ["zalazone", "millbrook", "lvms"])
+def test_fleet_and_host_planner_agree_on_other_tracks(track):
+    """The same differential loop on lattices of other plan classes (runtime LDS plan, one-node layers, a long oval)."""
+    import os
+    from graphbasedlocaltrajectoryplanner_amd.lattice import Lattice
+    from oracle.fleet_host import HostFleetBackend
+    from oracle.planner_host import HostPlannerBackend
+    lat = Lattice.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", track + "_lattice.npz"))
+    for seed in (2, 3):
+        st = drive(lat, HostPlannerBackend(lat).planner(1), HostFleetBackend(lat).planner(1), seed, 300, exact=True)
+        assert st['ticks'] >= 200, st
