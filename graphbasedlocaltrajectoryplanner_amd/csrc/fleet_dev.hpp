@@ -23,7 +23,7 @@ struct WaveX {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    __device__ void argmin(double& d, int& i) const { double k2 = 0.0; wave_min3(d, k2, i); }
+    __device__ void argmin(double& d, int& i) const { wave_min2(d, i); }
     __device__ bool any(bool b) const { return __ballot(b) != 0ull; }
     template <class P> __device__ int find_first(int n, P pred) const { return wave_find_first(n, l, pred); }
     // out[i] = term(0) + ... + term(i) in the sequential order of np.cumsum, systolic (see wave_cumsum_seq)

@@ -161,6 +161,18 @@ __device__ __forceinline__ void wave_min3(double& k1, double& k2, int& idx)
     }
 }
 
+// the same for (key, index) pairs: the closest-point searches carry no second key (half the shuffles of wave_min3)
+__device__ __forceinline__ void wave_min2(double& k, int& idx)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double o = __shfl_xor(k, m);
+        const int oi = __shfl_xor(idx, m);
+        const bool take = (o < k) || (o == k && oi < idx);
+        if (take) { k = o; idx = oi; }
+    }
+}
+
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total)
 {
     int x = v;
@@ -535,13 +547,13 @@ __device__ __forceinline__ int angle_order_dev(double nx, double ny, double px, 
 __device__ __forceinline__ double get_s_coord_dev(int n, const double* x, const double* y, int stride, const double* s_arr, int s_stride,
                                   double px, double py, bool closed, int lane, int* idx0)
 {
-    double bd = INFINITY, dummy = 0.0; int nb = 0x7fffffff;
+    double bd = INFINITY; int nb = 0x7fffffff;
     for (int i = lane; i < n; i += 64) {
         const double dx = x[(size_t)i * stride] - px, dy = y[(size_t)i * stride] - py;
         const double d2 = dx * dx + dy * dy;
         if (d2 < bd) { bd = d2; nb = i; }
     }
-    wave_min3(bd, dummy, nb);
+    wave_min2(bd, nb);
     int i1, i2;
     if (closed) { i1 = nb - 1; if (i1 < 0) i1 += n; i2 = nb + 1; if (i2 > n - 1) i2 = 0; }
     else { i1 = nb - 1 > 0 ? nb - 1 : 0; i2 = nb + 1 < n - 1 ? nb + 1 : n - 1; }
@@ -565,7 +577,7 @@ __device__ __forceinline__ double get_s_coord_dev(int n, const double* x, const 
 __device__ __forceinline__ int globrl_index_dev(const DevLat& lat, double px, double py, int lane)
 {
     const int G = lat.G - 1;
-    double bd = INFINITY, dummy = 0.0; int nb = 0x7fffffff;
+    double bd = INFINITY; int nb = 0x7fffffff;
     for (int i0 = 0; i0 < G; i0 += 256) {
         double xs[4], ys[4]; int id[4];
 #pragma unroll
@@ -576,7 +588,7 @@ __device__ __forceinline__ int globrl_index_dev(const DevLat& lat, double px, do
             if (d2 < bd) { bd = d2; nb = id[u]; }
         }
     }
-    wave_min3(bd, dummy, nb);
+    wave_min2(bd, nb);
     int i1 = nb - 1; if (i1 < 0) i1 += G;
     int i2 = nb + 1; if (i2 > G - 1) i2 = 0;
     const int ord = angle_order_dev(at(lat.grx, nb), at(lat.gry, nb), px, py, at(lat.grx, i1), at(lat.gry, i1), at(lat.grx, i2), at(lat.gry, i2));
