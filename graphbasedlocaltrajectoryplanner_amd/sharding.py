@@ -56,3 +56,10 @@ def tick_sharded(backend, scenarios, w_last_edges, vel_params, vel_plan, vel_est
     res = {k: np.concatenate([g[2][0][k] for g in gathered], axis=0) for k in RESULT_FIELDS}
     vres = {k: np.concatenate([g[2][1][k] for g in gathered], axis=0) for k in VEL_FIELDS}
     return 0, n, res, vres
+
+
+def fleet_shard(n_vehicles: int, rank: int, world: int):
+    """Planners [lo, hi) of a fleet of ``n_vehicles`` that rank ``rank`` owns (``fleet.Fleet``, ltpl_fleet_*): vehicles share nothing but
+    the read-only lattice, so a multi-GPU fleet is one fleet per rank on its block of vehicles -- weak scaling, no collective on the data
+    path, exactly as the scenario batches above. Inputs of a tick are sliced with the same bounds (CSR offsets re-based by the caller)."""
+    return shard_bounds(n_vehicles, rank, world)
