@@ -59,13 +59,17 @@ __device__ __forceinline__ void fleet_load(const WaveX& x, const fleet::Block& B
     for (int i = x.lane(); i < (int)(sizeof(fleet::PlannerS) / 8); i += 64) dst[i] = src[i];
     x.sync();
 }
+#define FLEET_ERR_SHIFT 13
+#define FLEET_ERR_MASK 0x1fff
+static_assert((fleet::E_CAP_VEL << 8 | 0xff) <= FLEET_ERR_MASK, "error word: site bits");
 __device__ __forceinline__ void fleet_store(const WaveX& x, const fleet::Block& B, const fleet::PlannerS* S, int p, int* err_word)
 {
     x.sync();
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(S);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(B.S());
     for (int i = x.lane(); i < (int)(sizeof(fleet::PlannerS) / 8); i += 64) dst[i] = src[i];
-    if (x.lane() == 0 && S->err) atomicCAS(err_word, 0, ((p + 1) << 12) | (S->err & 0xfff));
+    // error word: planner + 1 in bits 13.., S.err (code | site << 8; sites need FIVE bits -- E_CAP_VEL = 21) in the low 13 bits
+    if (x.lane() == 0 && S->err) atomicCAS(err_word, 0, ((p + 1) << FLEET_ERR_SHIFT) | (S->err & FLEET_ERR_MASK));
 }
 
 __global__ __launch_bounds__(64) void k_fleet_paths_pre(FleetArgs F, fleet::FObj ob, fleet::FPathsIn pin)
@@ -284,6 +288,7 @@ try {
     const int N = f->D.N;
     auto bail = [&](int code) { g_create_error = f->err; return code; };
     if ((rc = fleet::check_dims(f->D, &f->err))) return bail(rc);
+    if (N >= (1 << (31 - FLEET_ERR_SHIFT)) - 1) { f->err = "fleet: more planners than the error word can name (fewer planners per fleet)"; return bail(LTPL_ERR_CAPACITY); }
     if ((rc = fleet_alloc(f.get(), f->D.stride * (size_t)N, &f->d_state))) return bail(rc);
     if ((rc = fleet_alloc(f.get(), 4, &f->d_err))) return bail(rc);
     {   // all planners start without memory (the fields whose "nothing" is not zero)
@@ -349,7 +354,7 @@ static int fleet_check(ltpl_fleet* f)
     FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
     if (!w) return LTPL_OK;
     FLEET_TRY(f, hipMemsetAsync(f->d_err, 0, sizeof(int), f->h->stream));
-    const int p = (w >> 12) - 1, e = w & 0xfff;
+    const int p = (w >> FLEET_ERR_SHIFT) - 1, e = w & FLEET_ERR_MASK;
     f->err = fleet::err_text(p, e) + " (the fleet keeps the planner's error state: set a new start pose to clear it)";
     return e & 0xff;
 }
@@ -395,6 +400,7 @@ static int fleet_pack_inputs(ltpl_fleet* f, FleetTickIn* t, const ltpl_planner_p
         nv = pin->veh_off[N];
         if (nv < 0) { f->err = "negative offsets"; return LTPL_ERR_INVALID_ARG; }
         np_ = pin->pos_off[nv];
+        if ((nv > 0 && !pin->veh_radius) || (np_ > 0 && (!pin->pos_x || !pin->pos_y))) { f->err = "fleet: null vehicle / position arrays"; return LTPL_ERR_INVALID_ARG; }
         for (int s = 0; s < N; ++s) {
             const int c = pin->veh_off[s + 1] - pin->veh_off[s];
             if (c < 0 || c > MAX_VEH) { f->err = "more than 96 vehicles for one planner"; return LTPL_ERR_CAPACITY; }
@@ -405,7 +411,9 @@ static int fleet_pack_inputs(ltpl_fleet* f, FleetTickIn* t, const ltpl_planner_p
         }
         if (use_zones) {
             if (!pin->zone_off || pin->zone_off[0] != 0) { f->err = "fleet: zone offsets missing"; return LTPL_ERR_INVALID_ARG; }
+            for (int s = 0; s < N; ++s) if (pin->zone_off[s + 1] < pin->zone_off[s]) { f->err = "fleet: zone offsets must not decrease"; return LTPL_ERR_INVALID_ARG; }
             nz = pin->zone_off[N];
+            if (nz > 0 && !pin->zone_gid) { f->err = "fleet: zone node ids missing"; return LTPL_ERR_INVALID_ARG; }
             for (int i = 0; i < nz; ++i) if (pin->zone_gid[i] < 0 || pin->zone_gid[i] >= f->h->lat.V) { f->err = "zone node id out of range"; return LTPL_ERR_INVALID_ARG; }
         }
         o_pa = a.add(4 * (size_t)N); o_tn = a.add(8 * (size_t)N); o_vo = a.add(4 * (size_t)(N + 1)); o_po = a.add(4 * (size_t)(nv + 1));
@@ -593,6 +601,8 @@ try {
     // the zone lists go into their own small arena behind the tick's inputs
     const int N = f->D.N, nz = zone_off[N];
     if (zone_off[0] != 0 || nz < 0) { f->err = "offset arrays must start at 0"; return LTPL_ERR_INVALID_ARG; }
+    for (int s = 0; s < N; ++s) if (zone_off[s + 1] < zone_off[s]) { f->err = "fleet: zone offsets must not decrease"; return LTPL_ERR_INVALID_ARG; }
+    if (nz > 0 && !zone_gid) { f->err = "fleet: zone node ids missing"; return LTPL_ERR_INVALID_ARG; }
     for (int i = 0; i < nz; ++i) if (zone_gid[i] < 0 || zone_gid[i] >= f->h->lat.V) { f->err = "zone node id out of range"; return LTPL_ERR_INVALID_ARG; }
     int* d_zo = nullptr; int* d_zg = nullptr;
     struct Guard { void* a = nullptr; void* b = nullptr; ~Guard() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } g;

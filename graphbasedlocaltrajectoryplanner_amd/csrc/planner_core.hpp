@@ -411,6 +411,7 @@ struct Planner {
     {
         S.has_start = false; S.has_last = false; S.last.clear(); S.has_bp = false; S.last_bp.clear();
         S.has_stamp = false; S.last_cut_idx = 0; S.has_pos = false;
+        S.ref_done = false;                             // a reference index of the memory that is gone must not be reused
     }
 
     // -----------------------------------------------------------------------------------------------------------------
@@ -680,6 +681,7 @@ struct Planner {
                     S.veh.push_back(std::move(o));
                 }
                 S.closest_obj_index = -1;
+                S.ref_done = false;                 // new paths: a reference index computed for the previous memory is stale
                 const int rc = paths_pre(s, prev_action[s], t_now[s]);
                 if (rc) return rc;
             }
@@ -862,17 +864,24 @@ struct Planner {
 
         // Everything that can make the call fail is checked for ALL planners before any planner's memory is touched: an error of one
         // planner of a batch (the reference's ValueError / IndexError for that vehicle) must not leave the others half-trimmed.
+        // (A failing pre-check must leave NO trace: the reference index it computed belongs to this call's position estimate, so the
+        //  flag that lets stage A skip ref_idx is cleared again for every planner before the error is returned -- otherwise the next
+        //  calc_vel_profile without a get_ref_idx in front of it would cut with this call's stale indices.)
+        auto fail_pre = [&](int code, const std::string& msg) { for (Scn& S : sc) S.ref_done = false; return fail(code, msg); };
         for (int s = 0; s < n; ++s) {
             Scn& S = sc[(size_t)s];
             if (!S.ref_done) { ref_idx(S, req[s].pos_x, req[s].pos_y); S.ref_done = true; }      // (OTH.get_ref_idx: no iterative memory is cut here)
-            for (const Traj& T : S.last) {
+            for (size_t k = 0; k < S.last.size(); ++k) {
+                const Traj& T = S.last[k];
                 const int rows = T.rows(), m = rows - std::min(std::max(S.cut_index_pos, 0), rows);
                 if (S.cut_layer >= (int)T.node_idx.size())
-                    return fail(LTPL_ERR_INVALID_ARG, "planner " + std::to_string(s) + ": cut_layer beyond the node list (the reference raises IndexError, OTH.py:712)");
+                    return fail_pre(LTPL_ERR_INVALID_ARG, "planner " + std::to_string(s) + ": cut_layer beyond the node list (the reference raises IndexError, OTH.py:712)");
+                if (k < (size_t)LTPL_PLANNER_MAX_KEYS && req[s].gg_rows[k] && req[s].gg_n[k] > 0 && req[s].gg_n[k] != rows)
+                    return fail_pre(LTPL_ERR_INVALID_ARG, "planner " + std::to_string(s) + ": local_gg rows of a path do not match its coordinates (OTH.py:641-646)");
                 if (m > 0 && S.vel_plan > req[s].vel_max + 0.1)
-                    return fail(LTPL_ERR_UNSUPPORTED, "planner " + std::to_string(s) + ": vel_plan > vel_max + 0.1 (brake prefix): the reference raises ValueError at OTH.py:919");
+                    return fail_pre(LTPL_ERR_UNSUPPORTED, "planner " + std::to_string(s) + ": vel_plan > vel_max + 0.1 (brake prefix): the reference raises ValueError at OTH.py:919");
                 if (m > 0 && T.id == LTPL_ACT_FOLLOW && m - (int)S.vel_course.size() < 1)
-                    return fail(LTPL_ERR_INVALID_ARG, "planner " + std::to_string(s) + ": follow profile without points");
+                    return fail_pre(LTPL_ERR_INVALID_ARG, "planner " + std::to_string(s) + ": follow profile without points");
             }
         }
         std::vector<Work> work;
