@@ -223,6 +223,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? (P::fixed ? 4 : LTPL_RT_WAVES) 
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ TeamShared ts;
+#ifndef LTPL_NO_KARG_RELOAD
+    if constexpr (P::fixed) {
+        // compile-time plan classes: the argument structs are read from the kernarg segment phase by phase (karg_reload, paths_team.hpp)
+        // instead of being held in scalar registers -- and spilled into vector-register lanes -- from entry to last use; the by-value
+        // parameters only define the kernarg layout
+        const PathsKArgs* ka = paths_kargs();
+        (void)team_paths_body<NW, P, true>(ka->lat, ka->in, ka->out, ka->lp, smem, ts, nullptr, nullptr, nullptr, nullptr);
+        if constexpr (NW != 1) signal_done(ka->out.done);
+        return;
+    }
+#endif
     (void)team_paths_body<NW, P>(lat, in, out, lp, smem, ts, nullptr, nullptr, nullptr, nullptr);
     if constexpr (NW != 1) signal_done(out.done);          // (only the four-wave latency form is launched with a completion word)
 }
@@ -924,22 +935,25 @@ __device__ __forceinline__ void tick_vel_stage(const DevLat& lat, const DevPaths
     if (lane == 0) { vout.vel_bound[slot] = vel_bound; vout.too_close[slot] = too_close; }
 }
 
-template <int EM, bool AXM1, class P>
-__global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, DevPathsOut out, TeamLds lp,
-                                                     DevVelParams p, DevTickVelIn vin, DevTickVelOut vout,
-                                                     int vel_off, int vel_stride, int vel_cap)
+// body of k_tick. RL = true: every argument struct is a reference INTO THE KERNARG SEGMENT, re-read per stage (karg_reload, paths_team.hpp)
+template <int EM, bool AXM1, class P, bool RL>
+__device__ __forceinline__ void tick_body(const DevLat& lat_, const DevPathsIn& in_, const DevPathsOut& out_, const TeamLds& lp_,
+                                          const DevVelParams& p_, const DevTickVelIn& vin_, const DevTickVelOut& vout_,
+                                          int vel_off, int vel_stride, int vel_cap, unsigned char* smem, TeamShared& ts, int& sh_follow_n)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ TeamShared ts;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     VelScratch vs; double* px = nullptr; double* py = nullptr;
     if (wave < LTPL_MAX_ACTIONS) vs = carve_vel_scratch(smem + vel_off + (size_t)wave * vel_stride, vel_cap, false, true, &px, &py);
-    WavePath wp = team_paths_body<NUM_WAVES, P>(lat, in, out, lp, smem, ts, wave < LTPL_MAX_ACTIONS ? vs.kabs : nullptr,
-                                             wave < LTPL_MAX_ACTIONS ? vs.el : nullptr, px, py);
+    WavePath wp = team_paths_body<NUM_WAVES, P, RL>(lat_, in_, out_, lp_, smem, ts, wave < LTPL_MAX_ACTIONS ? vs.kabs : nullptr,
+                                                 wave < LTPL_MAX_ACTIONS ? vs.el : nullptr, px, py);
+    const DevLat& lat = *karg_reload<RL>(&lat_); const DevPathsIn& in = *karg_reload<RL>(&in_); const DevPathsOut& out = *karg_reload<RL>(&out_);
+    const TeamLds& lp = *karg_reload<RL>(&lp_);
+    // (the small parameter structs of the velocity stage by value: its recurrences must not depend on argument loads)
+    const DevVelParams p = *karg_reload<RL>(&p_);
+    const DevTickVelIn vin = *karg_reload<RL>(&vin_); const DevTickVelOut vout = *karg_reload<RL>(&vout_);
     const int s = blockIdx.x;
     // The fourth wave has no primitive of its own: it computes the unconstrained profile of the 'follow' slot
     // (calc_vel_profile_follow.py:297-307, independent of the controlled part) while wave 0 runs the brake / segment part.
-    __shared__ int sh_follow_n;
     if (wave < LTPL_MAX_ACTIONS) {
         for (int i = lane; i < 2 * p.n_axm; i += 64) vs.axm[i] = p.axm[i];
         if (wp.valid) for (int i = lane; i < wp.n_pts; i += 64) vs.kabs[i] = fabs(vs.kabs[i]);
@@ -964,7 +978,32 @@ __global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, 
         }
         __syncthreads();
     }
-    signal_done(out.done);
+    signal_done(karg_reload<RL>(&out)->done);
+}
+
+// the arguments of k_tick as they lie in the kernarg segment
+struct TickKArgs { PathsKArgs pk; DevVelParams p; DevTickVelIn vin; DevTickVelOut vout; int vel_off, vel_stride, vel_cap; };
+static_assert(sizeof(DevVelParams) % 8 == 0 && sizeof(DevTickVelIn) % 8 == 0 && sizeof(DevTickVelOut) % 8 == 0 && alignof(DevVelParams) == 8 &&
+              alignof(DevTickVelIn) == 8 && alignof(DevTickVelOut) == 8, "TickKArgs must mirror the kernarg layout of k_tick");
+
+template <int EM, bool AXM1, class P>
+__global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, DevPathsOut out, TeamLds lp,
+                                                     DevVelParams p, DevTickVelIn vin, DevTickVelOut vout,
+                                                     int vel_off, int vel_stride, int vel_cap)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ TeamShared ts;
+    __shared__ int sh_follow_n;
+#ifndef LTPL_NO_KARG_RELOAD
+    if constexpr (P::fixed) {
+        // (the by-value parameters only define the kernarg layout: see k_paths)
+        const TickKArgs* tk = (const TickKArgs*)(const TickKArgs LTPL_AS4*)__builtin_amdgcn_kernarg_segment_ptr();
+        tick_body<EM, AXM1, P, true>(tk->pk.lat, tk->pk.in, tk->pk.out, tk->pk.lp, tk->p, tk->vin, tk->vout, tk->vel_off, tk->vel_stride, tk->vel_cap,
+                                     smem, ts, sh_follow_n);
+        return;
+    }
+#endif
+    tick_body<EM, AXM1, P, false>(lat, in, out, lp, p, vin, vout, vel_off, vel_stride, vel_cap, smem, ts, sh_follow_n);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1875,6 +1914,9 @@ struct ltpl_handle {
     void* d_planes_x[PIPE_SETS - 1] = {}; size_t d_planes_x_cap[PIPE_SETS - 1] = {};
     hipStream_t vel_stream[VEL_STREAMS] = {};
     hipEvent_t ev_paths[PIPE_SETS] = {}, ev_vel[PIPE_SETS] = {};
+    // second stream for the path kernels of odd steps (LTPL_PATH_STREAMS=2): the drain of one path kernel -- its longest scenarios on a
+    // mostly idle chip -- overlaps the ramp of the next one
+    hipStream_t path_stream2 = nullptr; hipEvent_t ev_begin = nullptr; int path_streams = 1;
     int last_set = 0;
     std::vector<hipEvent_t> ev_step;          // timing events around the path kernel of every step of the last timed run
     float last_paths_ms = 0.0f; int last_paths_n = 0;
@@ -2126,6 +2168,8 @@ extern "C" int ltpl_destroy(ltpl_handle* h)
         free_resident(h->resident_x[i]);
     }
     for (int i = 0; i < ltpl_handle::VEL_STREAMS; ++i) if (h->vel_stream[i]) (void)hipStreamDestroy(h->vel_stream[i]);
+    if (h->path_stream2) (void)hipStreamDestroy(h->path_stream2);
+    if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     for (int i = 0; i < ltpl_handle::PIPE_SETS; ++i) { if (h->ev_paths[i]) (void)hipEventDestroy(h->ev_paths[i]); if (h->ev_vel[i]) (void)hipEventDestroy(h->ev_vel[i]); }
     for (hipEvent_t e : h->ev_step) (void)hipEventDestroy(e);
     if (h->h_in) (void)hipHostFree(h->h_in);
@@ -3220,6 +3264,12 @@ try {
     if (t->pipeline && !h->no_overlap) {
         // further buffer sets for the software pipeline of ltpl_batch_run
         for (int i = 0; i < ltpl_handle::VEL_STREAMS; ++i) if (!h->vel_stream[i]) HIP_TRY(h, hipStreamCreateWithFlags(&h->vel_stream[i], hipStreamNonBlocking));
+        {
+            const char* ps = getenv("LTPL_PATH_STREAMS");
+            h->path_streams = (ps && atoi(ps) == 2) ? 2 : 1;
+            if (h->path_streams == 2 && !h->path_stream2) HIP_TRY(h, hipStreamCreateWithFlags(&h->path_stream2, hipStreamNonBlocking));
+            if (!h->ev_begin) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming));
+        }
         for (int i = 0; i < ltpl_handle::PIPE_SETS; ++i) {
             if (!h->ev_paths[i]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_paths[i], hipEventDisableTiming));
             if (!h->ev_vel[i]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_vel[i], hipEventDisableTiming));
@@ -3263,15 +3313,21 @@ try {
         // the chains of consecutive steps run next to each other), PIPE_SETS buffer sets; the path kernel of step r + PIPE_SETS waits
         // until the velocity kernels of step r released its set
         constexpr int K = ltpl_handle::PIPE_SETS;
+        const bool two = h->path_streams == 2 && h->path_stream2;
+        if (two) {      // the second path stream starts behind everything queued on `stream` so far
+            HIP_TRY(h, hipEventRecord(h->ev_begin, h->stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->path_stream2, h->ev_begin, 0));
+        }
         for (int r = 0; r < reps; ++r) {
             const int set = r % K;
             const TickLayout& T = set ? *h->resident_x[set - 1] : *h->resident;
-            if (r >= K) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_vel[set], 0));
-            if (ms_total) HIP_TRY(h, hipEventRecord(h->ev_step[2 * (size_t)r], h->stream));
-            int rc = tick_launch_paths(h, T, h->stream);
+            hipStream_t sp = (two && (r & 1)) ? h->path_stream2 : h->stream;
+            if (r >= K) HIP_TRY(h, hipStreamWaitEvent(sp, h->ev_vel[set], 0));
+            if (ms_total) HIP_TRY(h, hipEventRecord(h->ev_step[2 * (size_t)r], sp));
+            int rc = tick_launch_paths(h, T, sp);
             if (rc) return rc;
-            if (ms_total) HIP_TRY(h, hipEventRecord(h->ev_step[2 * (size_t)r + 1], h->stream));
-            HIP_TRY(h, hipEventRecord(h->ev_paths[set], h->stream));
+            if (ms_total) HIP_TRY(h, hipEventRecord(h->ev_step[2 * (size_t)r + 1], sp));
+            HIP_TRY(h, hipEventRecord(h->ev_paths[set], sp));
             hipStream_t sv = h->vel_stream[r % ltpl_handle::VEL_STREAMS];
             HIP_TRY(h, hipStreamWaitEvent(sv, h->ev_paths[set], 0));
             if ((rc = tick_launch_vel(h, T, sv))) return rc;

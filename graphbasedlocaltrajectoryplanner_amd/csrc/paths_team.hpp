@@ -107,6 +107,47 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)
     return __hiloint2double(hi, lo);
 }
 
+// KERNEL ARGUMENTS RE-READ FROM THE KERNARG SEGMENT (round 4). The four argument structs hold ~90 pointers and scalars; passed by
+// value the compiler loads ALL of them into scalar registers at kernel entry, keeps them live to their last use and -- the register
+// file holds ~100 -- parks most of them in lanes of two vector registers: 257 v_writelane at entry and a v_readlane (a VECTOR
+// instruction in a kernel that is bound by vector-instruction issue) in front of nearly every use (1 046 static reloads in the one-wave
+// kernel; 18 of the 57 vector instructions of the mask's per-batch block, ~190 in the path assembly). With RL = true the body reads
+// the structs through a pointer into the kernarg segment (constant address space -> s_load_dword, scalar memory pipe, no vector
+// instruction, no register held across phases) that is passed through an empty asm statement at every phase boundary: the compiler
+// cannot merge loads across such a point, so every phase loads what IT needs and drops it afterwards.
+#define LTPL_AS4 __attribute__((address_space(4)))
+template <bool RL, class T>
+__device__ __forceinline__ const T* karg_reload(const T* p)
+{
+    if constexpr (RL) {
+        unsigned long long v = (unsigned long long)p;
+        asm volatile("" : "+s"(v));                                   // uniform: the address is kernarg base + constant
+        return (const T*)(const T LTPL_AS4*)v;                        // (address space inferred back through the cast: scalar loads)
+    } else return p;
+}
+// A value read from the kernarg segment that a LOOP uses: passed through an empty asm statement it is an ordinary scalar value for the
+// register allocator. (An s_load from the kernarg segment is REMATERIALISABLE: under register pressure the allocator re-issues the load
+// at the use instead of keeping the value -- seen inside the innermost loop of the serial sweep form, a scalar-memory round trip per edge.)
+template <class T> __device__ __forceinline__ T pin_sgpr(T v) { asm volatile("" : "+s"(v)); return v; }
+// (pointers: every pointer of the argument structs is a device-memory address; behind the asm statement the compiler no longer knows
+//  where it came from and would address it with FLAT instructions -- the cast pair states the address space again)
+template <class T> __device__ __forceinline__ T* pin_sgpr(T* p)
+{
+    unsigned long long v = (unsigned long long)p;                    // (through the integer: a pointer-to-pointer cast pair is folded away)
+    asm volatile("" : "+s"(v));
+    return (T*)(T __attribute__((address_space(1)))*)v;
+}
+
+// the four leading kernel arguments of k_paths / k_tick as they lie in the kernarg segment (all 8-byte aligned, sizes multiples of 8)
+struct PathsKArgs { DevLat lat; DevPathsIn in; DevPathsOut out; TeamLds lp; };
+static_assert(sizeof(DevLat) % 8 == 0 && sizeof(DevPathsIn) % 8 == 0 && sizeof(DevPathsOut) % 8 == 0 && sizeof(TeamLds) % 8 == 0 &&
+              alignof(DevLat) == 8 && alignof(DevPathsIn) == 8 && alignof(DevPathsOut) == 8 && alignof(TeamLds) == 8,
+              "PathsKArgs must mirror the kernarg layout of (DevLat, DevPathsIn, DevPathsOut, TeamLds)");
+__device__ __forceinline__ const PathsKArgs* paths_kargs()
+{
+    return (const PathsKArgs*)(const PathsKArgs LTPL_AS4*)__builtin_amdgcn_kernarg_segment_ptr();
+}
+
 // Parent tables: `default` and `overtake_left` are never both needed beyond the object layer (the templates either use
 // `default` itself or branch left / right off its prefix), so they share one table; three tables serve four filters.
 #define NPAR 3
@@ -196,10 +237,10 @@ struct Scen {
     int n_fac;
 };
 
-__device__ __forceinline__ bool team_node_removed(const unsigned* zone_bits, const DevLat& lat, const Scen& sc, int cl, int cn,
+__device__ __forceinline__ bool team_node_removed(const unsigned* zone_bits, int V, const Scen& sc, int cl, int cn,
                                                   int f, int layer, int n, int gid)
 {
-    int nl = gid - sc.n_base; if (nl < 0) nl += lat.V;
+    int nl = gid - sc.n_base; if (nl < 0) nl += V;
     if (zone_bits[nl >> 5] & (1u << (nl & 31))) return true;
     if (f == F_LEFT && layer == cl && n >= cn) return true;      // main_online_path_gen.py:148-152
     if (f == F_RIGHT && layer == cl && n < cn) return true;      // main_online_path_gen.py:155-159
@@ -261,18 +302,29 @@ __device__ __forceinline__ int team_goal(const DevLat& lat, const double* dcur, 
 // dcur[n] = min over in-edges (u, n) of dprev[u] + cost(u, n); strict '<' updates; among exact ties the predecessor with
 // the smaller dprev[u], then the smaller node id wins (= the order in which Dijkstra settles them). Used by the rare
 // re-sweep of reduced-horizon paths; the hot sweep is the edge-parallel form in team_paths_body.
-__device__ __forceinline__ void team_serial_node(const DevLat& lat, const Scen& sc, const unsigned* blocked_bits, int f, int n,
+// what the serial form reads of the lattice / the LDS plan, copied into registers in front of its loops (see SweepK)
+struct SerialK {
+    const int* in_ptr; const unsigned char* edge_src8; const double* edge_cost; const int* csc2sw; int E, V;
+    const unsigned* blocked_bits; const unsigned* zone_bits;
+};
+__device__ __forceinline__ SerialK serial_k(const DevLat& lat, const TeamLds& lp, unsigned char* smem)
+{
+    return SerialK{pin_sgpr(lat.in_ptr), pin_sgpr(lat.edge_src8), pin_sgpr(lat.edge_cost), pin_sgpr(lat.csc2sw), pin_sgpr(lat.E), pin_sgpr(lat.V),
+                   reinterpret_cast<const unsigned*>(smem + pin_sgpr(lp.off_blocked)), reinterpret_cast<const unsigned*>(smem + pin_sgpr(lp.off_zone))};
+}
+
+__device__ __forceinline__ void team_serial_node(const SerialK& K, const Scen& sc, const unsigned* blocked_bits, int f, int n,
                                                  int v, const double* dprev, int fac_src, int fac_dst, double fac,
                                                  double& bestc, int& bsrc, int& bk, int& tie)
 {
     double bestdu = INFINITY;
     bestc = INFINITY; bk = 0; bsrc = 0; tie = 0;
-    const int e0 = at(lat.in_ptr, v), e1 = at(lat.in_ptr, v + 1);
+    const int e0 = at(K.in_ptr, v), e1 = at(K.in_ptr, v + 1);
     for (int e = e0; e < e1; ++e) {
-        const int src = at(lat.edge_src8, e);
-        double c = at(lat.edge_cost, e);
+        const int src = at(K.edge_src8, e);
+        double c = at(K.edge_cost, e);
         if (f != F_PR) {
-            int el_ = at(lat.csc2sw, e) - sc.e_base; if (el_ < 0) el_ += lat.E;       // the edge bitmap is indexed in sweep order
+            int el_ = at(K.csc2sw, e) - sc.e_base; if (el_ < 0) el_ += K.E;       // the edge bitmap is indexed in sweep order
             if ((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u) continue;
         }
         const double du = dprev[src];
@@ -288,19 +340,19 @@ __device__ __forceinline__ void team_serial_node(const DevLat& lat, const Scen& 
 }
 
 template <class P>
-__device__ __forceinline__ bool team_relax_layer(const DevLat& lat, const DevPathsIn& in, const Scen& sc, const TeamLds& lp,
-                                                 unsigned char* smem, int cl, int cn, int f, int j, int b, int v0, int Kb,
+__device__ __forceinline__ bool team_relax_layer(const SerialK& K, const Scen& sc, const TeamLds& lp,
+                                                 int cl, int cn, int f, int j, int b, int v0, int Kb,
                                                  const double* dprev, double* dcur, unsigned char* par, size_t row, int lane,
                                                  int fac_src, int fac_dst, double fac)
 {
-    const unsigned* blocked_bits = reinterpret_cast<const unsigned*>(smem + lp.off_blocked);
-    const unsigned* zone_bits = reinterpret_cast<const unsigned*>(smem + lp.off_zone);
+    const unsigned* blocked_bits = K.blocked_bits;
+    const unsigned* zone_bits = K.zone_bits;
     bool any = false;
     for (int n = lane; n < Kb; n += 64) {
         const int v = v0 + n;
         double bestc = INFINITY; int bk = 0, bsrc = 0, tie = 0;
-        if (!team_node_removed(zone_bits, lat, sc, cl, cn, f, b, n, v))
-            team_serial_node(lat, sc, blocked_bits, f, n, v, dprev, fac_src, fac_dst, fac, bestc, bsrc, bk, tie);
+        if (!team_node_removed(zone_bits, K.V, sc, cl, cn, f, b, n, v))
+            team_serial_node(K, sc, blocked_bits, f, n, v, dprev, fac_src, fac_dst, fac, bestc, bsrc, bk, tie);
         dcur[n] = bestc;
         par_store<P>(par, row + n, bsrc, bk, tie);
         any = any || (bestc < INFINITY);
@@ -312,15 +364,13 @@ __device__ __forceinline__ bool team_relax_layer(const DevLat& lat, const DevPat
 // cost discount along the previous solution (gen_local_node_template.py:154-162) for the transition j-1 -> j: pair i of
 // the node list (factor w_last_edges[i]) applies to whatever transition its two nodes span -- normally i = j - 1 (the list
 // starts at the start node, OTH.py:393), but the seam accepts any alignment (GraphBase.factor_edge_cost, GraphBase.py:478-512)
-__device__ __forceinline__ void team_factor(const DevLat& lat, const DevPathsIn& in, const Scen& sc, int j, int b,
+__device__ __forceinline__ void team_factor(int L, const int* ll, const int* ln, const double* w_last, const Scen& sc, int j, int b,
                                             int& fac_src, int& fac_dst, double& fac)
 {
     fac_src = -1; fac_dst = -1; fac = 1.0;
-    const int* ll = in.last_layer + (size_t)sc.s * LTPL_MAX_LAST_NODES;
-    const int* ln = in.last_node + (size_t)sc.s * LTPL_MAX_LAST_NODES;
-    int pb = b - 1; if (pb < 0) pb += lat.L;
+    int pb = b - 1; if (pb < 0) pb += L;
     for (int i = 0; i < sc.n_fac; ++i)
-        if (ll[i] == pb && ll[i + 1] == b) { fac_src = ln[i]; fac_dst = ln[i + 1]; fac = in.w_last[i]; break; }
+        if (ll[i] == pb && ll[i + 1] == b) { fac_src = ln[i]; fac_dst = ln[i + 1]; fac = w_last[i]; break; }
 }
 
 #ifdef LTPL_NOINLINE_ASSEMBLE
@@ -337,27 +387,32 @@ __device__ LTPL_RESWEEP_ATTR void team_resweep(const DevLat& lat, const DevPaths
     double* dist = reinterpret_cast<double*>(smem + P::off_dist(lp));
     unsigned char* par = par_base<P>(lp, smem);
     int* best = reinterpret_cast<int*>(smem + P::off_best(lp));
-    const unsigned* zone_bits = reinterpret_cast<const unsigned*>(smem + lp.off_zone);
-    const int L = lat.L, kpad = P::kpad(lp);
+    // (everything the layer loop reads of the argument structs, once in front of it)
+    const SerialK K = serial_k(lat, lp, smem);
+    const int* const layer_off = pin_sgpr(lat.layer_off);
+    const int* const ll = pin_sgpr(in.last_layer) + (size_t)sc.s * LTPL_MAX_LAST_NODES;
+    const int* const ln = pin_sgpr(in.last_node) + (size_t)sc.s * LTPL_MAX_LAST_NODES;
+    const double* const w_last = pin_sgpr(in.w_last);
+    const int L = lat.L, kpad = P::kpad(lp), hm = P::hmax(lp);
     double* d0 = dist + (size_t)(f * 2) * kpad;
-    const int K0 = at(lat.layer_off, sc.sl + 1) - at(lat.layer_off, sc.sl);
+    const int K0 = at(layer_off, sc.sl + 1) - at(layer_off, sc.sl);
     const bool ok = sc.sn >= 0 && sc.sn < K0 &&
-                    !team_node_removed(zone_bits, lat, sc, ts.cl, ts.cn, f, sc.sl, sc.sn, at(lat.layer_off, sc.sl) + sc.sn);
+                    !team_node_removed(K.zone_bits, K.V, sc, ts.cl, ts.cn, f, sc.sl, sc.sn, at(layer_off, sc.sl) + sc.sn);
     for (int n = lane; n < kpad; n += 64) d0[n] = (ok && n == sc.sn) ? 0.0 : INFINITY;
     wave_sync_lds();
     for (int j = 1; j <= J; ++j) {
         int b = sc.sl + j; if (b >= L) b -= L;
-        const int v0 = at(lat.layer_off, b), Kb = at(lat.layer_off, b + 1) - v0;
+        const int v0 = at(layer_off, b), Kb = at(layer_off, b + 1) - v0;
         int fs, fd; double fac;
-        team_factor(lat, in, sc, j, b, fs, fd, fac);
+        team_factor(L, ll, ln, w_last, sc, j, b, fs, fd, fac);
         const double* dprev = dist + (size_t)(f * 2 + ((j - 1) & 1)) * kpad;
         double* dcur = dist + (size_t)(f * 2 + (j & 1)) * kpad;
-        (void)team_relax_layer<P>(lat, in, sc, lp, smem, ts.cl, ts.cn, f, j, b, v0, Kb, dprev, dcur,
-                                par, ((size_t)par_tab(f) * P::hmax(lp) + j) * kpad, lane, fs, fd, fac);
+        (void)team_relax_layer<P>(K, sc, lp, ts.cl, ts.cn, f, j, b, v0, Kb, dprev, dcur,
+                                par, ((size_t)par_tab(f) * hm + j) * kpad, lane, fs, fd, fac);
         wave_sync_lds();
     }
     int b = sc.sl + J; if (b >= L) b -= L;
-    const int v0 = at(lat.layer_off, b), Kb = at(lat.layer_off, b + 1) - v0;
+    const int v0 = at(layer_off, b), Kb = at(layer_off, b + 1) - v0;
     const int g = team_goal(lat, dist + (size_t)(f * 2 + (J & 1)) * kpad, v0, Kb, lane);
     if (lane == 0) best[f * P::hmax(lp) + J] = g;
     wave_sync_lds();
@@ -457,19 +512,23 @@ __device__ __forceinline__ void team_backtrack(const DevPathsOut& out, const Tea
 //      behind the backtrack: 31.5 instead of 33.0 M ticks/s. Fused, the instruction-heavy assembly of one scenario overlaps the
 //      latency-bound sweeps of its neighbours on the SIMD; apart, the hand-over and the second launch cost more than the higher
 //      occupancy returns.) Returns the number of path samples.
-__device__ __forceinline__ int team_assemble_rest(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, int s, int sl, int flags,
+template <bool RL = false>
+__device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevPathsIn& in_, const DevPathsOut& out_, int s, int sl, int flags,
                                                   int hm, bool by_rank, int slot, int N, int lane, unsigned char* pw, long long* adbg,
                                                   bool skip_pp, double* vel_kappa, double* vel_len, double* vel_x, double* vel_y, int vtile)
 {
+    // (RL: argument structs in the kernarg segment, re-read at every stage of the assembly -- see karg_reload)
+    const DevLat* latp = karg_reload<RL>(&lat_); const DevPathsIn* inp = karg_reload<RL>(&in_); const DevPathsOut* outp = karg_reload<RL>(&out_);
+#define lat (*latp)
+#define in (*inp)
+#define out (*outp)
+#define LTPL_KARGS() do { latp = karg_reload<RL>(latp); inp = karg_reload<RL>(inp); outp = karg_reload<RL>(outp); } while (0)
     const int L = lat.L;
     double* kx = reinterpret_cast<double*>(pw);
     double* ky = kx + hm; double* el = ky + hm; double* mx = el + hm; double* my = mx + hm;
     double* cpx = my + hm; double* cpy = cpx + hm;
     int* pedge = reinterpret_cast<int*>(cpy + hm); int* pidx = pedge + hm + 1;
     int* o_nodes = out.nodes + (size_t)slot * out.cap_nodes;
-    int* o_idx = out.node_idx + (size_t)slot * out.cap_nodes;
-    double* o_coeff = out.coeff + (size_t)slot * out.cap_nodes * 8;
-    double* o_pp = out.path_param + (size_t)slot * out.cap_pts * 5;
     wave_sync_lds();
     for (int i0 = 0; i0 <= N; i0 += 64) {
         const int i = i0 + lane;
@@ -503,6 +562,7 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat, const DevPa
     wave_sync_lds();
 
     dbg_stamp(adbg, 9);
+    LTPL_KARGS();
     // gather: rows per edge, node row indices, knots, element lengths (:260-297)
     int run = 0;
     for (int i0 = 0; i0 < N; i0 += 64) {
@@ -524,10 +584,14 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat, const DevPa
     }
     const int n_pts = run;
     wave_sync_lds();
-    for (int i = lane; i <= N; i += 64) o_idx[i] = pidx[i];
+    {
+        int* o_idx = out.node_idx + (size_t)slot * out.cap_nodes;
+        for (int i = lane; i <= N; i += 64) o_idx[i] = pidx[i];
+    }
     if (lane == 0) out.n_pts[slot] = n_pts;
 
     dbg_stamp(adbg, 10);
+    LTPL_KARGS();
     // tph.calc_splines (main_online_path_gen.py:299-309) as the equivalent clamped C2 spline in the cumulated
     // el_lengths parameter: tridiagonal system in the knot slopes m_i, Thomas algorithm. Everything that does not depend
     // on the elimination order is prepared by all lanes (reciprocal segment lengths, diagonal, right-hand sides of x and
@@ -603,7 +667,9 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat, const DevPa
     wave_sync_lds();
 
     dbg_stamp(adbg, 11);
+    LTPL_KARGS();
     // coefficients per segment, t in [0, 1]: a0 = k_i, a1 = m_i h, a2 = 3 d - 2 T0 - T1, a3 = -2 d + T0 + T1
+    double* o_coeff = out.coeff + (size_t)slot * out.cap_nodes * 8;
     for (int i = lane; i < N; i += 64) {
         const double h = el[i];
         {
@@ -619,7 +685,20 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat, const DevPa
     }
 
     dbg_stamp(adbg, 12);
+    LTPL_KARGS();
     // tph.interp_splines(stepnum_fixed) + tph.calc_head_curv_an (:311-322); column 4 keeps the offline spacing
+    double* o_pp = out.path_param + (size_t)slot * out.cap_pts * 5;
+    // (everything the row loop reads of the argument structs, once in front of it)
+    const double* const a_slen = pin_sgpr(lat.slen);
+    float2* a_vke = pin_sgpr(out.vke); double* a_vxy = nullptr;
+    if (a_vke) {                                          // planes of the batch velocity stage, blocked by 8 rows (kep_base / kep_row)
+        const int nrb = (out.cap_pts + 7) >> 3, nsp = out.n_slots_pad;
+        a_vke += ((size_t)(vtile >> 6) * nrb * 64 + (vtile & 63)) * KE_RB;
+        if (vtile >= nsp) {                               // follow job: (x, y) for the lane-per-job follow preparation
+            const int fj = vtile - nsp;
+            a_vxy = out.vxy + 2 * (((size_t)(fj >> 6) * nrb * 64 + (fj & 63)) * KE_RB);
+        }
+    }
     for (int r = lane; r < n_pts; r += 64) {
         int lo = 0, hi = N;                                // segment i with pidx[i] <= r < pidx[i+1] (last: <=)
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pidx[mid] <= r) lo = mid; else hi = mid; }
@@ -643,19 +722,15 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat, const DevPa
         double psi_r = atan2(-xd, yd);
         if (psi_r >= D_PI) psi_r -= 2.0 * D_PI;
         const double kap = (xd * ydd - yd * xdd) * fast_rcp(q * sqrt(q));
-        const double len_r = at(lat.slen, pedge[i] + k);
+        const double len_r = at(a_slen, pedge[i] + k);
         if (!skip_pp)           // (experiment build: LTPL_ABLATE bit 16 drops the path_param stores, timing only)
         { store2_u(row, x, y); store2_u(row + 2, psi_r, kap); row[4] = len_r; }
         if (vel_kappa) { vel_kappa[r] = kap; vel_len[r] = len_r; }
-        if (out.vke) {                                    // planes of the batch velocity stage, blocked by 8 rows (kep_base / kep_row):
+        if (a_vke) {
             // r = lane + 64 k, so kep_row(r) = kep_row(lane) + 64 (r - lane)
-            const int nrb = (out.cap_pts + 7) >> 3;
             const size_t ro = (size_t)(((lane >> 3) << 9) + (lane & 7)) + (size_t)(r - lane) * 64;
-            out.vke[((size_t)(vtile >> 6) * nrb * 64 + (vtile & 63)) * KE_RB + ro] = make_float2((float)fabs(kap), (float)len_r);
-            if (vtile >= out.n_slots_pad) {               // follow job: (x, y) for the lane-per-job follow preparation
-                const int fj = vtile - out.n_slots_pad;
-                store2(out.vxy + 2 * (((size_t)(fj >> 6) * nrb * 64 + (fj & 63)) * KE_RB + ro), x, y);
-            }
+            a_vke[ro] = make_float2((float)fabs(kap), (float)len_r);
+            if (a_vxy) store2(a_vxy + 2 * ro, x, y);
         }
         if (vel_x) { vel_x[r] = x; vel_y[r] = y; }
     }
@@ -663,9 +738,13 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat, const DevPa
     if (out.job_cnt && lane == 0) out.job_slot[vtile] = make_int2(slot, n_pts);
     wave_sync_lds();
     return n_pts;
+#undef LTPL_KARGS
+#undef lat
+#undef in
+#undef out
 }
 
-template <class P>
+template <class P, bool RL = false>
 __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const Scen& sc,
                                   const TeamLds& lp, unsigned char* smem, int a, int f, int J, int name, int reduced,
                                   int jcl, bool share_prefix, int lane, unsigned char* pw,
@@ -690,7 +769,7 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
     dbg_stamp(adbg, 8);
     team_backtrack<P>(out, lp, smem, slot, f, J, jcl, share_prefix, lane, pw);
     const int end_node = reinterpret_cast<const int*>(reinterpret_cast<double*>(pw) + 7 * hm)[hm + 1 + J];      // pidx[J]
-    const int n_pts = team_assemble_rest(lat, in, out, s, sc.sl, sc.flags, hm, P::par_entry == 2, slot, J, lane, pw, adbg,
+    const int n_pts = team_assemble_rest<RL>(lat, in, out, s, sc.sl, sc.flags, hm, P::par_entry == 2, slot, J, lane, pw, adbg,
                                          LTPL_ABLATED(lp, 16), vel_kappa, vel_len, vel_x, vel_y, vtile);
     const int L = lat.L;
     wp.n_pts = n_pts; wp.n_nodes = J + 1;
@@ -707,6 +786,14 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
 // then lane = destination node: parents, reachability, node filters (zone / overtake side), goal of the last layer. The
 // exact tie-break of the reference order only matters when the minimum is attained more than once: those nodes (rare)
 // re-scan their in-edges serially.
+// what the layer loop reads of the lattice / the LDS plan, copied into registers once in front of the sweeps (with the kernel
+// arguments re-read from the kernarg segment -- karg_reload -- nothing inside the loop may depend on an argument load)
+struct SweepK {
+    const double* sw_cost; const unsigned* sw_meta; int E, V;
+    const unsigned* blocked_bits; const unsigned* zone_bits;
+    bool zone_any;              // uniform: some node of the planning range is removed by a zone (else the node step skips the bit look-up)
+};
+
 struct LayerArgs {
     int j, b, v0, Kb, ne, eb, kpad, hm, cur, prv, H;
     int fs, fd, cl_hit, cn;                      // cl_hit: this layer is the closest object's layer
@@ -715,12 +802,12 @@ struct LayerArgs {
 };
 
 template <class P, int NW, int CH, unsigned ACT>
-__device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, const TeamLds& lp, unsigned char* smem,
+__device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, const TeamLds& lp, unsigned char* smem,
                                            const LayerArgs& A, const EdgeRegs (&er)[CH], const unsigned blk,
                                            int wave, int lane)
 {
-    const unsigned* blocked_bits = reinterpret_cast<const unsigned*>(smem + lp.off_blocked);
-    const unsigned* zone_bits = reinterpret_cast<const unsigned*>(smem + lp.off_zone);
+    const unsigned* blocked_bits = K.blocked_bits;
+    const unsigned* zone_bits = K.zone_bits;
     double* dist = reinterpret_cast<double*>(smem + P::off_dist(lp));
     unsigned char* par = par_base<P>(lp, smem);
     int* best = reinterpret_cast<int*>(smem + P::off_best(lp));
@@ -781,10 +868,10 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
         double* dumin = reinterpret_cast<double*>(smem + P::off_dumin(lp));
         for (int ei = CH * NT + tid; ei < A.ne; ei += NT) {
             const int e = A.eb + ei;
-            double c = at(lat.sw_cost, e);
-            const unsigned meta = at(lat.sw_meta, e);
+            double c = at(K.sw_cost, e);
+            const unsigned meta = at(K.sw_meta, e);
             const int src = sw_src(meta), dst = sw_dst(meta);
-            int el_ = e - sc.e_base; if (el_ < 0) el_ += lat.E;
+            int el_ = e - sc.e_base; if (el_ < 0) el_ += K.E;
             const bool unbl = !((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u);
             if (A.fs >= 0 && src == A.fs && dst == A.fd) c *= A.fac;
             const unsigned key = elect_key(meta);
@@ -842,7 +929,7 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
     for (int f = 0; f < NFILT; ++f)
         if ((ACT >> f) & 1u) { c_r[SL[f]] = nv ? cnt_all[f * kpad + n] : 0u; w_r[SL[f]] = nv ? widx_all[f * kpad + n] : 0xffffffffu; }
     bool zone_rem = false;
-    if (nv) { int nl = A.v0 + n - sc.n_base; if (nl < 0) nl += lat.V; zone_rem = (zone_bits[nl >> 5] >> (nl & 31)) & 1u; }
+    if (K.zone_any && nv) { int nl = A.v0 + n - sc.n_base; if (nl < 0) nl += K.V; zone_rem = (zone_bits[nl >> 5] >> (nl & 31)) & 1u; }
     // exact tie-break (rare): a node whose minimum is attained by several edges takes, in the reference's order, the
     // predecessor with the smaller distance first, then CSC order. Every wave reads the same counters, so the branch is
     // uniform over the team.
@@ -906,11 +993,21 @@ __device__ __forceinline__ void team_layer(const DevLat& lat, const Scen& sc, co
 // ---------------------------------------------------------------------------------------------------------------------
 // the team body. Returns, for every wave, the result of the LAST primitive the wave assembled (NW = 4: wave a <-> slot a)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NW, class P>
-__device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out,
-                                                    const TeamLds& lp, unsigned char* smem, TeamShared& ts,
+// RL = true: the four argument structs are references INTO THE KERNARG SEGMENT (paths_kargs()) and are re-read per phase (karg_reload);
+// RL = false: plain references to the kernel's by-value arguments, as before.
+template <int NW, class P, bool RL = false>
+__device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const DevPathsIn& in_, const DevPathsOut& out_,
+                                                    const TeamLds& lp_, unsigned char* smem, TeamShared& ts,
                                                     double* vel_kappa, double* vel_len, double* vel_x, double* vel_y)
 {
+    const DevLat* latp = karg_reload<RL>(&lat_); const DevPathsIn* inp = karg_reload<RL>(&in_);
+    const DevPathsOut* outp = karg_reload<RL>(&out_); const TeamLds* lpp = karg_reload<RL>(&lp_);
+    // (the body keeps its names: `lat`, `in`, `out`, `lp` are the CURRENT views; LTPL_KARGS() re-reads them at a phase boundary)
+#define lat (*latp)
+#define in (*inp)
+#define out (*outp)
+#define lp (*lpp)
+#define LTPL_KARGS() do { latp = karg_reload<RL>(latp); inp = karg_reload<RL>(inp); outp = karg_reload<RL>(outp); lpp = karg_reload<RL>(lpp); } while (0)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int L = lat.L;
     constexpr int NT = NW * 64;
@@ -991,12 +1088,16 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
         sc.NH = NH;
     }
     // zone-removed nodes of the "overtaking_zones" filter (gen_local_node_template.py:96; GraphBase.py:713-745)
-    for (int i = zone0 + tid; i < zone1; i += NT) {
-        int nl = in.zone_gid[i] - sc.n_base; if (nl < 0) nl += lat.V;
-        if (nl < sc.NH) atomicOr(&zone_bits[nl >> 5], 1u << (nl & 31));
+    {
+        const int* const zone_gid = in.zone_gid; const int V = lat.V;
+        for (int i = zone0 + tid; i < zone1; i += NT) {
+            int nl = zone_gid[i] - sc.n_base; if (nl < 0) nl += V;
+            if (nl < sc.NH) atomicOr(&zone_bits[nl >> 5], 1u << (nl & 31));
+        }
     }
 
     dbg_stamp(lp.dbg, 1);
+    LTPL_KARGS();
     // ---- phase 1: closest reference-line layer per obstacle position (get_intersec_edges.py:40-51) -----------------
     // lane = (layer segment, position): every lane scans its segment of the reference line for its position (strict '<'
     // keeps the first minimum), the segments of a position are then combined by log2(#segments) shuffle steps.
@@ -1020,8 +1121,9 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                 if (d2 < bd) { bd = d2; bl = l; }
             }
         } else {
+            const double* const ref_x = lat.ref_x; const double* const ref_y = lat.ref_y;
             for (int l = l0; l < l1; ++l) {
-                const double dx = at(lat.ref_x, l) - px, dy = at(lat.ref_y, l) - py;
+                const double dx = at(ref_x, l) - px, dy = at(ref_y, l) - py;
                 const double d2 = dx * dx + dy * dy;
                 if (d2 < bd) { bd = d2; bl = l; }
             }
@@ -1039,6 +1141,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     team_sync<NW>();
 
     dbg_stamp(lp.dbg, 2);
+    LTPL_KARGS();
     // ---- phase 2: obstacle x edge-sample mask (GraphBase.get_intersec_edges_in_range, GraphBase.py:567-646) --------
     // Window of a position with closest layer ol = layers [ol-1, ol+1] with the reference's wrap quirks (:597-600):
     // the transitions into layer ol and into layer ol+1 (the latter never across the seam); both end points must lie in
@@ -1049,6 +1152,9 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     // transitions of the planning range inside SOME obstacle window (bit j; every other transition cannot hold a blocked edge, so the
     // sweep's prefetch skips the bitmap look-up there); planning ranges beyond 63 layers: every transition is looked up
     unsigned long long touched = H <= 63 ? 0ull : ~0ull;
+    // (what the loops below read of the argument structs, once)
+    const float4* const m_cap = pin_sgpr(lat.edge_cap); const double* const m_sx = pin_sgpr(lat.sx); const double* const m_sy = pin_sgpr(lat.sy);
+    const float m_slack = pin_sgpr(lat.cull_slack); const int m_E = pin_sgpr(lat.E), m_shell_cap = pin_sgpr(lp.shell_cap);
     // shell list of this wave: entries (edge in sweep order | query lane << 24, packed sample range of the capsule record)
     uint2* shell = reinterpret_cast<uint2*>(smem + lp.off_shell) + (size_t)(NW == 1 ? 0 : wave) * lp.shell_cap;
     int n_shell = 0;                                               // uniform
@@ -1072,12 +1178,12 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             const double px = __shfl(mx, ql), py = __shfl(my, ql), pr = __shfl(mr, ql);
             bool hit = false;
             for (int k = slot; k < ns; k += 16) {
-                const double dx = at(lat.sx, k0 + k) - px, dy = at(lat.sy, k0 + k) - py;
+                const double dx = at(m_sx, k0 + k) - px, dy = at(m_sy, k0 + k) - py;
                 hit = hit || (dx * dx + dy * dy <= pr);
             }
             const unsigned long long hm = __ballot(tv && hit);
             if (tv && slot == 0 && ((hm >> (lane & 48)) & 0xffffull)) {
-                int el_ = e - sc.e_base; if (el_ < 0) el_ += lat.E;
+                int el_ = e - sc.e_base; if (el_ < 0) el_ += m_E;
                 atomicOr(&blocked_bits[el_ >> 5], 1u << (el_ & 31));
             }
         }
@@ -1138,14 +1244,14 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                         qr[q] = readlane_f64(mref, src_lane);
                         qxf[q] = (float)qx[q]; qyf[q] = (float)qy[q];
                         const float t = (float)readlane_f64(msq, src_lane);          // sqrt of the squared-distance threshold
-                        qlm[q] = t * 1.000001f + lat.cull_slack;                     // MISS  if dist(q, chord) > qlm + dev
-                        qlh[q] = t * 0.999999f - lat.cull_slack;                     // HIT   if dist^2 + (gap / 2)^2 <= (qlh - dev)^2
+                        qlm[q] = t * 1.000001f + m_slack;                            // MISS  if dist(q, chord) > qlm + dev
+                        qlh[q] = t * 0.999999f - m_slack;                            // HIT   if dist^2 + (gap / 2)^2 <= (qlh - dev)^2
                     } else { qlane[q] = 0; qx[q] = 0.0; qy[q] = 0.0; qr[q] = -1.0; qxf[q] = 0.0f; qyf[q] = 0.0f; qlm[q] = -1.0e30f; qlh[q] = -1.0e30f; }   // always MISS
                 }
                 for (int e0 = eb + wave * 64; e0 < ee; e0 += NT) {
                     // (predicated, not branched: the list bookkeeping below is wave-uniform)
                     const int e = min(e0 + lane, ee - 1);
-                    int el_ = e - sc.e_base; if (el_ < 0) el_ += lat.E;
+                    int el_ = e - sc.e_base; if (el_ < 0) el_ += m_E;
                     // lanes beyond the transition and edges already blocked by another object take no part
                     const bool live = e0 + lane < ee && !((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u);
                     // Two-sided cull on the edge's CAPSULE (chord A -> B between its first and last sample, `dev` = largest distance
@@ -1155,7 +1261,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                     //   some sample is at most sqrt(d^2 + hg2) + dev away -> HIT without touching the samples if that <= threshold
                     // and only the thin shell in between runs the reference's exact fp64 sample test. (Round 2: with a bounding
                     // CIRCLE nearly every edge of a window was "near" and loaded its samples -- 0.44 ms of a 1.05 ms launch.)
-                    const float4 c0 = at(lat.edge_cap, 2 * e), c1 = at(lat.edge_cap, 2 * e + 1);   // (Ax, Ay, ABx, ABy), (1 / |AB|^2, dev, hg2, samples)
+                    const float4 c0 = at(m_cap, 2 * e), c1 = at(m_cap, 2 * e + 1);   // (Ax, Ay, ABx, ABy), (1 / |AB|^2, dev, hg2, samples)
                     bool sure = false;
                     bool unsure_q[MQ];
 #pragma unroll
@@ -1179,7 +1285,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
 #pragma unroll
                     for (int q = 0; q < MQ; ++q) shell_push(sh && unsure_q[q], e, c1.w, qlane[q]);
                     (void)qx; (void)qy; (void)qr;
-                    if (n_shell + MQ * 64 > lp.shell_cap) flush_shell(mpx, mpy, mref);
+                    if (n_shell + MQ * 64 > m_shell_cap) flush_shell(mpx, mpy, mref);
                 }
             }
         }
@@ -1187,6 +1293,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     }
 
     dbg_stamp(lp.dbg, 3);
+    LTPL_KARGS();
     // ---- phase 3: closest object (gen_local_node_template.py:191-213) and action template (mopg.py:124-174) --------
     if (wave == 0) {
         // closest = smallest layer distance of the vehicle's LAST position; first vehicle wins ties
@@ -1274,6 +1381,17 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     }
 
     dbg_stamp(lp.dbg, 4);
+    LTPL_KARGS();
+    // does any zone node lie in the planning range at all? (every wave reads the complete bitmap: the same answer team-wide)
+    bool zone_any = true;
+#ifndef LTPL_NO_ZGATE
+    {
+        unsigned zw = 0u;
+        for (int i = lane; i < lp.words_zone; i += 64) zw |= zone_bits[i];
+        zone_any = __ballot(zw != 0u) != 0ull;
+    }
+#endif
+    const SweepK swk{pin_sgpr(lat.sw_cost), pin_sgpr(lat.sw_meta), pin_sgpr(lat.E), pin_sgpr(lat.V), blocked_bits, zone_bits, zone_any};
     // ---- phase 4: layered min-plus sweeps (GraphBase.search_graph_layer, GraphBase.py:854-894) ---------------------
     // Edge-parallel (team_layer): the edges of a transition (cost + packed source / destination / rank) are loaded with
     // coalesced loads one layer AHEAD into registers, so that the global latency hides behind the LDS work of the current
@@ -1293,7 +1411,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             if (!own_start) continue;
             const int K0 = lay[0].y & 0xffff;
             const bool ok = sc.sn >= 0 && sc.sn < K0 &&
-                            !team_node_removed(zone_bits, lat, sc, t_cl, t_cn, f, sc.sl, sc.sn, sc.n_base + sc.sn);
+                            !team_node_removed(zone_bits, swk.V, sc, t_cl, t_cn, f, sc.sl, sc.sn, sc.n_base + sc.sn);
             double* d0 = dist + (size_t)(f * 2) * kpad;
             for (int n = lane; n < kpad; n += 64) d0[n] = (ok && n == sc.sn) ? 0.0 : INFINITY;
             if (lane == 0) { ts.start_ok[f] = ok; best[f * hm] = -1; }
@@ -1314,10 +1432,10 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                 const int e = ly.z + (ci * SWN + swave) * 64 + lane;
                 // lanes beyond the transition load the SENTINEL edge (index E: cost +inf, source = destination = node 0): a fixed
                 // number of loads in flight lets the compiler wait precisely, and the sweep needs no "is this lane an edge" select
-                const int ec = e < ly.w ? e : lat.E;
-                dr[ci].c = at(lat.sw_cost, ec); dr[ci].meta = at(lat.sw_meta, ec);
+                const int ec = e < ly.w ? e : swk.E;
+                dr[ci].c = at(swk.sw_cost, ec); dr[ci].meta = at(swk.sw_meta, ec);
                 if (look) {
-                    int el_ = (e < ly.w ? e : ly.w - 1) - sc.e_base; if (el_ < 0) el_ += lat.E;
+                    int el_ = (e < ly.w ? e : ly.w - 1) - sc.e_base; if (el_ < 0) el_ += swk.E;
                     bw[ci] = blocked_bits[el_ >> 5]; sh[ci] = (e < ly.w) ? (el_ & 31) : 32;
                 }
             }
@@ -1348,7 +1466,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
         // once per run by the driver below, the loop of a run is specialised for its filter set at compile time and carries no template
         // logic. (As one loop with the decisions inside, the uniform booleans lived in scalar register PAIRS across the whole sweep and
         // were spilled: ~20 v_readlane reloads per layer.)
-        auto layer_args = [&](int j, const int4& ly, bool from_def) {
+        auto layer_args = [&](int j, const int4& ly, bool from_def, EdgeRegs (&er)[CH]) {
             LayerArgs A;
             int b = sc.sl + j; if (b >= L) b -= L;
             A.j = j; A.b = b; A.v0 = ly.x; A.Kb = ly.y & 0xffff; A.ne = ly.w - ly.z; A.eb = ly.z; A.kpad = kpad; A.hm = hm; A.cur = j & 1; A.prv = (j - 1) & 1;
@@ -1380,26 +1498,54 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
             constexpr unsigned ACT = decltype(act_tag)::value;
             why = 0;
             int j = j0;
+#ifndef LTPL_ROT2
             for (; j <= j1; ++j) {
                 const int4 ly = lay[j];
                 if (riding) { if (__ballot(bm != 0u) != 0ull || ly.w - ly.z > CH * SNT) { why = 1; break; } }
                 if constexpr (!P::fixed) { if ((ly.y & 0xffff) > 64) { why = 2; break; } }
-                const LayerArgs A = layer_args(j, ly, from_def && j == j0);
+                const LayerArgs A = layer_args(j, ly, from_def && j == j0, er);
                 if (j < H) prefetch(j + 1, en, bn);                // global loads in flight during this layer's LDS work
-                team_layer<P, SWN, CH, ACT>(lat, sc, lp, smem, A, er, bm, swave, lane);
+                team_layer<P, SWN, CH, ACT>(swk, sc, lp, smem, A, er, bm, swave, lane);
                 rotate();
             }
+#else
+            // Two layers per iteration with the two register images changing roles (round 4): the rotation `er = en` was 3 * CH + 1
+            // register moves per layer. One layer: `cur` holds this transition's edges, the next transition's are fetched into `nxt`.
+            // Returns false when the layer needs something else (`why`).
+            auto step = [&](EdgeRegs (&cur)[CH], unsigned& cb, EdgeRegs (&nxt)[CH], unsigned& nb) -> bool {
+                const int4 ly = lay[j];
+                if (riding) { if (__ballot(cb != 0u) != 0ull || ly.w - ly.z > CH * SNT) { why = 1; return false; } }
+                if constexpr (!P::fixed) { if ((ly.y & 0xffff) > 64) { why = 2; return false; } }
+                const LayerArgs A = layer_args(j, ly, from_def && j == j0, cur);
+                if (j < H) prefetch(j + 1, nxt, nb);               // global loads in flight during this layer's LDS work
+                team_layer<P, SWN, CH, ACT>(swk, sc, lp, smem, A, cur, cb, swave, lane);
+                team_sync<SWN>();
+                ++j;
+                return true;
+            };
+            auto swap_back = [&]() {                               // the current image lives in `en`: back into `er` (once per run at most)
+#pragma unroll
+                for (int ci = 0; ci < CH; ++ci) er[ci] = en[ci];
+                bm = bn;
+            };
+            while (j <= j1) {
+                if (!step(er, bm, en, bn)) break;
+                if (j > j1) { swap_back(); break; }
+                if (!step(en, bn, er, bm)) { swap_back(); break; }
+            }
+#endif
             return j;
         };
         // one layer in the serial form (lane = node): more than 64 nodes in the layer, or a filter set without a specialisation
         auto serial_layer = [&](int j, unsigned actm, bool from_def) {
-            const LayerArgs A = layer_args(j, lay[j], from_def);
+            const LayerArgs A = layer_args(j, lay[j], from_def, er);
             if (j < H) prefetch(j + 1, en, bn);
+            const SerialK srk = serial_k(lat, lp, smem);          // (rare path: read here, not held across the edge-parallel runs)
             for (int f = swave; f < NFILT; f += SWN) {
                 if (!((actm >> f) & 1u)) continue;
                 const int fprev = (A.from_def && (f == F_LEFT || f == F_RIGHT)) ? F_DEF : f;
                 double* dcur = dist + (size_t)(f * 2 + A.cur) * kpad;
-                const bool any = team_relax_layer<P>(lat, in, sc, lp, smem, t_cl, t_cn, f, j, A.b, A.v0, A.Kb,
+                const bool any = team_relax_layer<P>(srk, sc, lp, t_cl, t_cn, f, j, A.b, A.v0, A.Kb,
                                                   dist + (size_t)(fprev * 2 + A.prv) * kpad, dcur,
                                                   par, ((size_t)par_tab(f) * hm + j) * kpad, lane, A.fs, A.fd, A.fac);
                 if (lane == 0) best[f * hm + j] = any ? -2 : -1;
@@ -1462,6 +1608,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
         team_sync<NW>();
     }
     dbg_stamp(lp.dbg, 5);
+    LTPL_KARGS();
     // ---- phase 5: search loop with horizon back-off (main_online_path_gen.py:187-248); uniform, every thread ---------
     // per action slot, ONE packed word (valid | reduced << 1 | (name + 1) << 2 | layer distance << 8): these uniform values live across the
     // whole assembly; as four int arrays they ended up as a VGPR tuple in scratch once the kernel was at its 128-register budget
@@ -1544,6 +1691,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
     }
 
     dbg_stamp(lp.dbg, 6);
+    LTPL_KARGS();
     // ---- phase 6: wave (a mod NW) assembles primitive a --------------------------------------------------------------
     WavePath wp; wp.valid = 0; wp.n_pts = 0; wp.n_nodes = 0; wp.name = LTPL_ACT_NONE; wp.reduced = 0; wp.goal_layer = -1;
     wp.end_node = -1;
@@ -1562,9 +1710,14 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat, const Dev
                 vtile_in = __builtin_amdgcn_readlane(job_base, cls) + k + (cls ? out.n_slots_pad : 0);
             }
         }
-        wp = team_assemble<P>(lat, in, out, sc, lp, smem, a, filt[a], slot_j(a), slot_name(a), slot_red(a), jcl, sp, lane, pw,
-                           vel_kappa, vel_len, vel_x, vel_y, vtile_in);
+        wp = team_assemble<P, RL>(lat, in, out, sc, lp, smem, a, filt[a], slot_j(a), slot_name(a), slot_red(a), jcl, sp, lane, pw,
+                               vel_kappa, vel_len, vel_x, vel_y, vtile_in);
     }
     dbg_stamp(lp.dbg, 7);
     return wp;
+#undef LTPL_KARGS
+#undef lat
+#undef in
+#undef out
+#undef lp
 }
