@@ -66,70 +66,96 @@ def make_batch(lat, n, seed, workload="c2"):
     return scen, batch, vel
 
 
-def cpu_baseline(lat, scen_batch, vel, n_sample):
-    """Oracle (plain-C restatement, oracle/ltpl_oracle.c) on the first n_sample scenarios of rank 0's shard, 1 core.
-    Returns the JSON object and the oracle's results (used as the checker of `parity_checked`)."""
+def sample_indices(n_batch, n_sample):
+    """Scenario indices of the CPU / parity sample: spread evenly over the WHOLE batch (first and last scenario included)."""
+    n_sample = max(1, min(n_sample, n_batch))
+    return np.unique(np.linspace(0, n_batch - 1, n_sample).round().astype(np.int64))
+
+
+def cpu_baseline(lat, scen_batch, batch, vel, idx):
+    """Oracle (plain-C restatement, oracle/ltpl_oracle.c) on the scenarios ``idx`` of rank 0's shard (a strided sample of the whole
+    batch), 1 core. Returns the JSON object and the oracle's results (used as the checker of `parity_checked`)."""
     from oracle.oracle_lib import OracleBackend
     orc = OracleBackend(lat)
-    scen = scen_batch[:n_sample]
-    batch = _capi.PathsBatch(scen, w_last_edges=W_LAST)
-    n_veh = int(batch.veh_off[-1])
-    v = _capi.TickVelBatch(vel.params, len(scen), vel.vel_plan[:n_sample], vel.vel_est[:n_sample],
-                           np.column_stack((vel.pos_x[:n_sample], vel.pos_y[:n_sample])), vel.veh_vel[:n_veh])
-    ref = orc.tick_batch(batch, v)                              # warm caches; kept as the parity reference
+    scen = [scen_batch[int(i)] for i in idx]
+    sub = _capi.PathsBatch(scen, w_last_edges=W_LAST)
+    vo = np.asarray(batch.veh_off)
+    veh_vel = np.concatenate([vel.veh_vel[vo[int(i)]:vo[int(i) + 1]] for i in idx]) if len(idx) else np.zeros(0)
+    v = _capi.TickVelBatch(vel.params, len(scen), vel.vel_plan[idx], vel.vel_est[idx],
+                           np.column_stack((vel.pos_x[idx], vel.pos_y[idx])), veh_vel)
+    ref = orc.tick_batch(sub, v)                                # warm caches; kept as the parity reference
     t0 = time.perf_counter()
     reps = 0
     while True:
-        orc.tick_batch(batch, v)
+        orc.tick_batch(sub, v)
         reps += 1
         el = time.perf_counter() - t0
         if el > 10.0 or reps >= 200:
             break
     return {"value": len(scen) * reps / el, "unit": "ticks/s", "cores": 1, "kind": "port",
-            "sample": "%d scenarios of the same workload x %d passes through oracle_tick_batch (plain C, -O2, single thread, "
-                      "timed in this run on the GPU box's host; the reference's own Python over the dependency shims was "
-                      "measured once in the build container: ~32 ticks/s on 1 core, /root/reference is absent here)"
+            "sample": "%d scenarios spread evenly over the batch of the timed region x %d passes through oracle_tick_batch (plain C, "
+                      "-O2, single thread, timed in this run on the GPU box's host; the reference's own Python over the dependency shims "
+                      "was measured once in the build container: ~32 ticks/s on 1 core, /root/reference is absent here)"
                       % (len(scen), reps)}, ref
 
 
-def parity_check(res, vres, ref, n):
-    """GPU results of the first n scenarios against the oracle's (integers bit-exact, floats 1e-5 relative, each quantity against its own
-    scale). The oracle's fused tick is itself pinned to the unmodified reference: tests/test_fresh_tick_golden.py."""
+def parity_check(res, vres, ref, idx):
+    """GPU results of the scenarios ``idx`` of the TIMED batch against the oracle's results of the same scenarios: every integer output
+    bit-exact, every float quantity within 1e-5 relative against ITS OWN scale (tests/helpers.py) -- reported per quantity. The oracle's
+    fused tick is itself pinned to the unmodified reference: tests/test_fresh_tick_golden.py."""
     ores, ovres = ref
-    msgs = []
+    ints = {k: 0 for k in ("n_actions", "closest_obj_index", "closest_obj_node", "end_layer", "action_id", "valid", "reduced", "goal_layer",
+                           "n_nodes", "n_pts", "n_ties", "nodes", "node_idx", "vel_bound", "too_close", "el_length_column")}
+    worst = {k: 0.0 for k in ("x", "y", "psi", "kappa", "coeff_a0", "coeff_a1", "coeff_a2", "coeff_a3", "vx", "ax")}
+    n_paths = 0
 
-    def same(name, a, b):
-        if not np.array_equal(a, b):
-            msgs.append(name)
+    def rel(name, a, b, scale):
+        worst[name] = max(worst[name], float(np.max(np.abs(a - b))) / scale if a.size else 0.0)
 
-    same("n_actions", res.n_actions[:n], ores.n_actions[:n])
-    same("closest_obj_index", res.closest_obj_index[:n], ores.closest_obj_index[:n])
-    for name in ("action_id", "valid", "reduced", "goal_layer", "n_nodes", "n_pts"):
-        same(name, getattr(res, name)[:n], getattr(ores, name)[:n])
-    same("vel_bound", vres.vel_bound[:n] * res.valid[:n], ovres.vel_bound[:n] * ores.valid[:n])
-    worst = 0.0
-    for s in range(n):
-        for a in range(int(ores.n_actions[s])):
-            if not ores.valid[s, a] or not res.valid[s, a]:
+    for k, s in enumerate(idx):
+        s = int(s)
+        for name in ("n_actions", "closest_obj_index", "end_layer"):
+            ints[name] += int(getattr(res, name)[s] != getattr(ores, name)[k])
+        ints["closest_obj_node"] += int(not np.array_equal(res.closest_obj_node[s], ores.closest_obj_node[k]))
+        na = int(ores.n_actions[k])
+        for name in ("action_id", "valid", "reduced", "goal_layer"):
+            ints[name] += int(not np.array_equal(getattr(res, name)[s, :na], getattr(ores, name)[k, :na]))
+        for a in range(na):
+            if not ores.valid[k, a] or not res.valid[s, a]:
                 continue
-            nn, npts = int(ores.n_nodes[s, a]), int(ores.n_pts[s, a])
-            if not np.array_equal(res.nodes[s, a, :nn], ores.nodes[s, a, :nn]):
-                msgs.append("nodes[%d,%d]" % (s, a))
+            n_paths += 1
+            nn, npts = int(ores.n_nodes[k, a]), int(ores.n_pts[k, a])
+            for name in ("n_nodes", "n_pts", "n_ties"):
+                ints[name] += int(getattr(res, name)[s, a] != getattr(ores, name)[k, a])
+            ints["vel_bound"] += int(vres.vel_bound[s, a] != ovres.vel_bound[k, a])
+            ints["too_close"] += int(vres.too_close[s, a] != ovres.too_close[k, a])
+            if int(res.n_nodes[s, a]) != nn or int(res.n_pts[s, a]) != npts or not np.array_equal(res.nodes[s, a, :nn], ores.nodes[k, a, :nn]):
+                ints["nodes"] += 1
                 continue
-            # every quantity against ITS OWN scale (tests/helpers.py): coordinates and a0 against the extent of the path, a1 / a2 / a3
-            # per coefficient order, curvature with a 1e-4 1/m floor, vx with a 1 m/s floor
-            co, oco = res.coeff[s, a, :nn - 1], ores.coeff[s, a, :nn - 1]
-            pairs = [(res.path_param[s, a, :npts, c], ores.path_param[s, a, :npts, c],
-                      max(float(np.ptp(ores.path_param[s, a, :npts, c])), 1.0)) for c in (0, 1)]
-            pairs += [(co[:, c], oco[:, c], max(float(np.ptp(oco[:, c])), 1.0)) for c in (0, 4)]
-            pairs += [(co[:, [k, 4 + k]], oco[:, [k, 4 + k]], max(float(np.max(np.abs(oco[:, [k, 4 + k]]))), 1e-3)) for k in (1, 2, 3)]
-            pairs.append((res.path_param[s, a, :npts, 3], ores.path_param[s, a, :npts, 3],
-                          max(float(np.max(np.abs(ores.path_param[s, a, :npts, 3]))), 1e-4)))
-            pairs.append((vres.vx[s, a, :npts], ovres.vx[s, a, :npts], max(float(np.max(np.abs(ovres.vx[s, a, :npts]))), 1.0)))
-            for arr, oarr, scale in pairs:
-                worst = max(worst, float(np.max(np.abs(arr - oarr))) / scale)
-    ok = not msgs and worst <= 1e-5
-    return ok, {"scenarios": int(n), "max_rel_err": worst, "mismatches": msgs[:8]}
+            ints["node_idx"] += int(not np.array_equal(res.node_idx[s, a, :nn], ores.node_idx[k, a, :nn]))
+            pp, opp = res.path_param[s, a, :npts], ores.path_param[k, a, :npts]
+            ints["el_length_column"] += int(not np.array_equal(pp[:, 4], opp[:, 4]))           # a copy of the lattice's numbers: bit-exact
+            rel("x", pp[:, 0], opp[:, 0], max(float(np.ptp(opp[:, 0])), 1.0))                  # against the extent of the path
+            rel("y", pp[:, 1], opp[:, 1], max(float(np.ptp(opp[:, 1])), 1.0))
+            dpsi = np.abs(np.mod(pp[:, 2] - opp[:, 2] + np.pi, 2 * np.pi) - np.pi)
+            worst["psi"] = max(worst["psi"], float(dpsi.max()) / np.pi)
+            rel("kappa", pp[:, 3], opp[:, 3], max(float(np.max(np.abs(opp[:, 3]))), 1e-4))   # floor 1e-4 1/m
+            co, oco = res.coeff[s, a, :nn - 1], ores.coeff[k, a, :nn - 1]
+            for c in (0, 4):
+                rel("coeff_a0", co[:, c], oco[:, c], max(float(np.ptp(oco[:, c])), 1.0))
+            for o in (1, 2, 3):
+                rel("coeff_a%d" % o, co[:, [o, 4 + o]], oco[:, [o, 4 + o]], max(float(np.max(np.abs(oco[:, [o, 4 + o]]))), 1e-3))
+            vx, ovx = vres.vx[s, a, :npts], ovres.vx[k, a, :npts]
+            rel("vx", vx, ovx, max(float(np.max(np.abs(ovx))), 1.0))                           # floor 1 m/s
+            rel("ax", vres.ax[s, a, :npts], ovres.ax[k, a, :npts], max(float(np.max(np.abs(ovx))) ** 2 / 2.0, 5.0))   # ax differentiates v^2
+    bad_ints = {k: v for k, v in ints.items() if v}
+    max_rel = max(worst.values()) if worst else 0.0
+    ok = not bad_ints and max_rel <= 1e-5
+    return ok, {"scenarios": int(len(idx)), "paths": n_paths, "sample": "evenly spread over the %d scenarios of the timed batch" % res.n_scen,
+                "max_rel_err": max_rel, "max_rel_err_by_quantity": worst,
+                "integer_outputs_compared_bit_exact": sorted(ints.keys()), "integer_mismatches": bad_ints,
+                "scales": "x, y, coeff_a0: extent of the path; coeff_a1..a3: largest magnitude of that order; kappa: floor 1e-4 1/m; "
+                          "psi: pi; vx: floor 1 m/s; ax: max(v^2 / 2, 5 m/s^2)"}
 
 
 def read_traffic(batch, workload):

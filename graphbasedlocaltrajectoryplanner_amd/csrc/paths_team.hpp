@@ -794,6 +794,13 @@ struct SweepK {
     bool zone_any;              // uniform: some node of the planning range is removed by a zone (else the node step skips the bit look-up)
 };
 
+// Counting and election in ONE LDS atomic (round 4): every edge that attains its destination's minimum adds `CW_ONE | key` to the node's
+// word -- the count of such edges in the high byte, and, when it is 1 (the normal case), the winner's election key (source << 8 | rank,
+// 16 bits) in the low bits. (Round 3: one atomic add on a counter and one atomic min on the key word per chunk, two arrays to reset and to
+// read back; the LDS pipe of a CU is ~78 % busy in this kernel, profiles/r04b_pmc_karg_reload.txt.) With two or more winners the low bits hold
+// the SUM of their keys (< 2^23 for 127 in-edges) and are not used: the exact tie-break below elects into `widx`.
+#define CW_SHIFT 24
+#define CW_ONE (1u << CW_SHIFT)
 struct LayerArgs {
     int j, b, v0, Kb, ne, eb, kpad, hm, cur, prv, H;
     int fs, fd, cl_hit, cn;                      // cl_hit: this layer is the closest object's layer
@@ -825,7 +832,7 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
     for (int n = tid; n < kpad; n += NT) {
 #pragma unroll
         for (int f = 0; f < NFILT; ++f)
-            if ((ACT >> f) & 1u) { dist[coff[f] + n] = INFINITY; cnt_all[f * kpad + n] = 0u; widx_all[f * kpad + n] = 0xffffffffu; }
+            if ((ACT >> f) & 1u) { dist[coff[f] + n] = INFINITY; cnt_all[f * kpad + n] = 0u; }
     }
     team_sync<NW>();
     // candidate sums are kept for the active filters only (compile-time compaction keeps the register image small)
@@ -885,8 +892,8 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
                 const double cd = du + c;
                 if (ROUND == 0) { atomicMin(reinterpret_cast<unsigned long long*>(&dist[coff[f] + dst]), (unsigned long long)__double_as_longlong(cd)); continue; }
                 if (dist[coff[f] + dst] != cd) continue;
-                if (ROUND == 1) { atomicAdd(&cnt_all[f * kpad + dst], 1u); atomicMin(&widx_all[f * kpad + dst], key); continue; }
-                if (cnt_all[f * kpad + dst] < 2u) continue;
+                if (ROUND == 1) { atomicAdd(&cnt_all[f * kpad + dst], CW_ONE | key); continue; }
+                if ((cnt_all[f * kpad + dst] >> CW_SHIFT) < 2u) continue;
                 if (ROUND == 2) atomicMin(reinterpret_cast<unsigned long long*>(&dumin[f * kpad + dst]), (unsigned long long)__double_as_longlong(du));
                 else if (dumin[f * kpad + dst] == du) atomicMin(&widx_all[f * kpad + dst], key);
             }
@@ -912,8 +919,7 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
 #pragma unroll
             for (int f = 0; f < NFILT; ++f)
                 if (((ACT >> f) & 1u) && got[ci][SL[f]] == cand[ci][SL[f]] && cand[ci][SL[f]] < INFINITY) {
-                    atomicAdd(&cnt_all[f * kpad + dst], 1u);
-                    atomicMin(&widx_all[f * kpad + dst], key);
+                    atomicAdd(&cnt_all[f * kpad + dst], CW_ONE | key);
                 }
         }
     }
@@ -927,7 +933,7 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
     unsigned c_r[NA], w_r[NA];
 #pragma unroll
     for (int f = 0; f < NFILT; ++f)
-        if ((ACT >> f) & 1u) { c_r[SL[f]] = nv ? cnt_all[f * kpad + n] : 0u; w_r[SL[f]] = nv ? widx_all[f * kpad + n] : 0xffffffffu; }
+        if ((ACT >> f) & 1u) { const unsigned cw = nv ? cnt_all[f * kpad + n] : 0u; c_r[SL[f]] = cw >> CW_SHIFT; w_r[SL[f]] = cw & (CW_ONE - 1u); }
     bool zone_rem = false;
     if (K.zone_any && nv) { int nl = A.v0 + n - sc.n_base; if (nl < 0) nl += K.V; zone_rem = (zone_bits[nl >> 5] >> (nl & 31)) & 1u; }
     // exact tie-break (rare): a node whose minimum is attained by several edges takes, in the reference's order, the
@@ -942,7 +948,7 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
             for (int m = tid; m < A.Kb; m += NT) {
 #pragma unroll
                 for (int f = 0; f < NFILT; ++f)
-                    if (((ACT >> f) & 1u) && cnt_all[f * kpad + m] >= 2u) { dumin[f * kpad + m] = INFINITY; widx_all[f * kpad + m] = 0xffffffffu; }
+                    if (((ACT >> f) & 1u) && (cnt_all[f * kpad + m] >> CW_SHIFT) >= 2u) { dumin[f * kpad + m] = INFINITY; widx_all[f * kpad + m] = 0xffffffffu; }
             }
             team_sync<NW>();
 #pragma unroll 1
@@ -955,7 +961,7 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
 #pragma unroll
                     for (int f = 0; f < NFILT; ++f) {
                         if (!((ACT >> f) & 1u) || !(cand[ci][SL[f]] < INFINITY)) continue;
-                        if (dist[coff[f] + dst] != cand[ci][SL[f]] || cnt_all[f * kpad + dst] < 2u) continue;
+                        if (dist[coff[f] + dst] != cand[ci][SL[f]] || (cnt_all[f * kpad + dst] >> CW_SHIFT) < 2u) continue;
                         const double du = dist[poff[f] + src];
                         if (round == 0) atomicMin(reinterpret_cast<unsigned long long*>(&dumin[f * kpad + dst]), (unsigned long long)__double_as_longlong(du));
                         else if (dumin[f * kpad + dst] == du) atomicMin(&widx_all[f * kpad + dst], key);
@@ -965,7 +971,7 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
                 team_sync<NW>();
             }
 #pragma unroll
-            for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) w_r[SL[f]] = nv ? widx_all[f * kpad + n] : 0xffffffffu;      // re-elected
+            for (int f = 0; f < NFILT; ++f) if (((ACT >> f) & 1u) && c_r[SL[f]] >= 2u) w_r[SL[f]] = widx_all[f * kpad + n];      // re-elected (tied nodes only)
         }
     }
     // node step: parents, node filters, reachability

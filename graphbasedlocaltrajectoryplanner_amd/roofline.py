@@ -2,7 +2,9 @@
 Algorithmic-byte model of one planning tick evaluated on the ACTUAL counts of a batch (fp64 = 8 B, int32 = 4 B).
 
     B_tick  = B_mask + B_sweep + B_path + B_vel
-    B_mask  = sum over obstacle positions of  16 N_L                          reference-line scan (x, y)
+    B_mask  = 16 N_L per scenario with an obstacle position                  reference line (x, y): staged ONCE per scenario in LDS and
+                                                                              scanned from there for every position (round 4; rounds 2 / 3
+                                                                              charged it per position: `mask_refline_per_position`)
               + for gated positions, per edge of their window transitions inside the planning range:
                 32 (the edge's capsule record) + 1/8 (its mask bit)
                 + 16 n_samples(e) only for SHELL edges: edges whose capsule cannot decide MISS / HIT for that position
@@ -97,7 +99,16 @@ def algorithmic_bytes(lat, batch: _capi.PathsBatch, res: _capi.PathsResult, lib=
     radius = np.asarray(batch.veh_radius[:max(int(veh_off[-1]), 1)], dtype=np.float64)
 
     # ---- mask ------------------------------------------------------------------------------------------------------------------
-    b_mask = 16 * L * n_pos
+    # reference line: the kernel stages it ONCE per scenario in LDS and scans it from there for every position (paths_team.hpp phase 0 /
+    # phase 1), so the memory side of this algorithm reads 16 N_L bytes per scenario that has a position at all. (Rounds 2 / 3 charged
+    # 16 N_L per POSITION -- what the reference's generator expression reads, SURVEY 8d -- which is 33 of 133 KB per C2 tick and 410 of
+    # 654 KB per C3 tick of bytes that never leave the LDS; kept as `mask_refline_per_position` for comparison.)
+    scen_has_pos = np.zeros(n, dtype=bool)
+    if n_pos:
+        scen_has_pos[np.unique(scen_of_pos)] = True
+    b_refline_once = 16 * L * int(scen_has_pos.sum())
+    b_refline_per_pos = 16 * L * n_pos
+    b_mask = b_refline_once
     b_mask_survey = 16 * L * n_pos
     n_window_edges = n_shell_edges = n_shell_samples = 0
     if n_pos:
@@ -160,6 +171,7 @@ def algorithmic_bytes(lat, batch: _capi.PathsBatch, res: _capi.PathsResult, lib=
     b_vel = int(np.sum(48 * n_p))
     return {"mask": int(b_mask), "sweep": b_sweep, "path": b_path, "vel": b_vel,
             "total": int(b_mask) + b_sweep + b_path + b_vel,
+            "mask_refline_per_position": int(b_mask) - b_refline_once + b_refline_per_pos,   # the round-3 figure of `mask`
             "mask_survey": int(b_mask_survey),                   # SURVEY 8d's figure: every window edge reads all its samples
             "sweep_survey": b_sweep_survey,                      # SURVEY 8d's figure: edge records once per executed sweep
             "window_edges": int(n_window_edges), "shell_edges": int(n_shell_edges), "shell_samples": int(n_shell_samples)}

@@ -15,6 +15,8 @@ state machine shows up and compounds.
 import numpy as np
 
 from helpers import assert_close_rel, assert_xy_close, assert_coeff_close, REL_TOL, KAPPA_FLOOR, load_golden
+from graphbasedlocaltrajectoryplanner_amd.tick_replay import (vehicles_of_tick, zone_gids_of_tick, check_traj,          # noqa: F401
+                                                            check_trajectories)
 
 
 def friction_map(xy):
@@ -32,73 +34,6 @@ def local_gg_of_tick(t, path_param):
     if va.get('local_gg') is not None:
         return tuple(va['local_gg'])
     return {k: [friction_map(pp[:, 0:2])] for k, pp in path_param.items()}
-
-
-def vehicles_of_tick(t):
-    out = []
-    for k in range(len(t['obj_radius'])):
-        pos = np.asarray(t['obj_pos'][k], dtype=float).reshape(1, 2)
-        pred = np.asarray(t['obj_pred'][k], dtype=float).reshape(-1, 2)
-        out.append((float(t['obj_radius'][k]), float(t['obj_vel'][k]), np.vstack((pos, pred))))
-    return out
-
-
-def zone_gids_of_tick(lat, t):
-    gids = []
-    for l, n in zip(t.get('zone_layers', ()), t.get('zone_nodes', ())):
-        l, n = int(l), int(n)
-        if 0 <= l < lat.num_layers and 0 <= n < lat.nodes_in_layer[l]:
-            gids.append(int(lat.layer_off[l]) + n)
-    return sorted(set(gids))
-
-
-def check_traj(got, exp, what):
-    assert got.shape == exp.shape, "%s: shape %s vs %s" % (what, got.shape, exp.shape)
-    if exp.shape[0] == 0:
-        return
-    for col, name in enumerate(("s", "x", "y", "psi", "kappa", "vx", "ax")):
-        if name == "psi":
-            d = np.abs(np.mod(got[:, col] - exp[:, col] + np.pi, 2 * np.pi) - np.pi)
-            assert float(d.max()) <= REL_TOL * np.pi, "%s psi" % what
-        elif name == "ax":
-            scale = max(float(np.max(np.abs(exp[:, 5]))) ** 2 / 2.0, 5.0)
-            assert float(np.max(np.abs(got[:, col] - exp[:, col]))) <= 1e-5 * scale, "%s ax: %g" % (
-                what, float(np.max(np.abs(got[:, col] - exp[:, col]))))
-        elif name == "kappa":
-            assert_close_rel(got[:, col], exp[:, col], what="%s kappa" % what, floor=KAPPA_FLOOR)
-        elif name in ("x", "y"):
-            assert_xy_close(got[:, col:col + 1], exp[:, col:col + 1], what="%s %s" % (what, name))
-        else:
-            assert_close_rel(got[:, col], exp[:, col], what="%s %s" % (what, name))
-
-
-def check_trajectories(traj, ids, ref, t, what):
-    """Outputs of get_ref_idx + calc_vel_profile of one tick against the recording (digests every tick, full arrays on selected ticks)."""
-    full = t['full']
-    er = t['ref_idx']
-    assert ref['cut_index_pos'] == er['cut_index_pos'] and ref['cut_layer'] == er['cut_layer'], \
-        "%s: cut (%d, %d) vs (%d, %d)" % (what, ref['cut_index_pos'], ref['cut_layer'], er['cut_index_pos'], er['cut_layer'])
-    assert abs(ref['vel_plan'] - er['vel_plan']) <= 1e-5 * max(abs(er['vel_plan']), 1.0), "%s: vel_plan" % what
-    assert abs(ref['acc_plan'] - er['acc_plan']) <= 1e-5 * max(abs(er['acc_plan']), 5.0), "%s: acc_plan" % what
-    assert ref['vel_course'].shape == er['vel_course'].shape, "%s: vel_course length" % what
-    if er['vel_course'].size:
-        assert np.max(np.abs(ref['vel_course'] - er['vel_course'])) <= 1e-5 * max(float(np.max(np.abs(er['vel_course']))), 1.0)
-    ev = t['vel']
-    assert list(traj.keys()) == ev['keys'], "%s: trajectory keys %s vs %s" % (what, list(traj.keys()), ev['keys'])
-    assert ids == ev['traj_id'], "%s: trajectory ids" % what
-    for k in ev['keys']:
-        dg = ev['digest'][k]
-        tr = traj[k][0]
-        assert tr.shape[0] == dg[0], "%s/%s: trajectory rows %d vs %d" % (what, k, tr.shape[0], dg[0])
-        vs = max(abs(dg[4]) / max(dg[0], 1), 1.0)
-        assert abs(tr[-1, 0] - dg[1]) <= 1e-5 * max(abs(dg[1]), 1.0), "%s/%s: s_end" % (what, k)
-        assert abs(tr[0, 5] - dg[2]) <= 1e-5 * max(vs, abs(dg[2])), "%s/%s: vx[0] %g vs %g" % (what, k, tr[0, 5], dg[2])
-        assert abs(tr[-1, 5] - dg[3]) <= 1e-5 * max(vs, abs(dg[3])), "%s/%s: vx[-1]" % (what, k)
-        assert abs(float(np.sum(tr[:, 5])) - dg[4]) <= 1e-5 * max(abs(dg[4]), 1.0), "%s/%s: sum vx %g vs %g" % (
-            what, k, float(np.sum(tr[:, 5])), dg[4])
-    if full is not None:
-        for k in ev['keys']:
-            check_traj(traj[k][0], full['traj'][k], "%s/%s" % (what, k))
 
 
 def replay(planner, lat, ticks, scen=0, n_ticks=None, others=None):
