@@ -176,7 +176,12 @@ struct VelJob {
 // operands go into a plane tiled by job and blocked by rows, (|kappa|, element length) as an fp32 pair (`ke`, layout = kep_base / kep_row of
 // the batch velocity stage); plane index q = p (per_planner - 1) + slot - 1. The results come back job-major in `out` like every other
 // job's. Null: operands through `pool` (host harness, follow and brake jobs).
-struct F2 { float x, y; };
+#ifdef LTPL_VEL_F64_OPERANDS
+typedef double ke_scalar_f;         // (operand records of the lane kernels as fp64 pairs: the precision A/B build, see ke_t in ltpl_hip.hip)
+#else
+typedef float ke_scalar_f;
+#endif
+struct F2 { ke_scalar_f x, y; };
 struct FJobs { VelJob* jobs; double* pool; const double* out; const int* flags; int per_planner; F2* ke; int ke_rows; };
 FLT_FN unsigned kep_base_f(int job, int plane_rows) { return ((unsigned)(job >> 6) * (unsigned)(plane_rows >> 3) * 64u + (unsigned)(job & 63)) * 8u; }
 FLT_FN unsigned kep_row_f(int r) { return ((unsigned)(r >> 3) << 9) + (unsigned)(r & 7); }
@@ -581,7 +586,7 @@ FLT_FN int make_job(const X& x, const Dims& D, const FJobs& J, int p, int slot, 
     if (J.ke && mode == LTPL_VEL_FB && slot >= 1) {
         F2* ke = J.ke + kep_base_f(p * (J.per_planner - 1) + slot - 1, J.ke_rows);
         for (int i = x.lane(); i < i1 - i0; i += X::W) {
-            F2 r; r.x = (float)fabs(pv.at(i0 + i, 3)); r.y = i < n_el ? (float)pv.at(i0 + i, 4) : 0.0f;
+            F2 r; r.x = (ke_scalar_f)fabs(pv.at(i0 + i, 3)); r.y = i < n_el ? (ke_scalar_f)pv.at(i0 + i, 4) : (ke_scalar_f)0;
             ke[kep_row_f(i)] = r;
         }
         if (x.lane() == 0) { gg[0] = gax; gg[1] = gay; }

@@ -152,9 +152,9 @@ __global__ __launch_bounds__(64) void k_fleet_vel_d(FleetArgs F, fleet::FVelIn v
 // The forward-backward jobs of a tick (slots >= 1 of the stage-A table), one LANE per job: lane_fb_profile of the batch velocity stage on
 // the fleet's lane planes. The wave-per-job form computes every step of the recurrence on 64 lanes for one useful result (220 us per tick
 // of 8 192 planners); here a wave advances 64 profiles per step.
-static_assert(sizeof(fleet::F2) == sizeof(float2), "lane plane records are fp32 pairs");
+static_assert(sizeof(fleet::F2) == sizeof(ke_t), "lane plane records: the pair type of the batch velocity stage");
 template <int EM, bool AXM1>
-__global__ __launch_bounds__(64) void k_fleet_fb_lanes(DevVelParams p, const DevVelJob* jobs, const double* pool, const float2* ke, int ke_rows,
+__global__ __launch_bounds__(64) void k_fleet_fb_lanes(DevVelParams p, const DevVelJob* jobs, const double* pool, const ke_t* ke, int ke_rows,
                                                        double* outp, int cap, int n_planners, int per, double* out)
 {
     __shared__ double axm_s[128];
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64) void k_fleet_fb_lanes(DevVelParams p, const Dev
     double* o = out + jp->off_out;
     for (int i = 0; i < n; ++i) o[i] = sqrt(D[(size_t)i * 64]);
 }
-typedef void (*fleet_lanes_kernel_t)(DevVelParams, const DevVelJob*, const double*, const float2*, int, double*, int, int, int, double*);
+typedef void (*fleet_lanes_kernel_t)(DevVelParams, const DevVelJob*, const double*, const ke_t*, int, double*, int, int, int, double*);
 static fleet_lanes_kernel_t fleet_lanes_kernel_of(int v)
 {
     switch (v) {
@@ -374,6 +374,41 @@ try {
     return LTPL_OK;
 } LTPL_ABI_CATCH(abi_err_of(f))
 
+// the same start pose for the planners [p0, p1) in ONE call (a fleet that starts from a grid, a benchmark that starts thousands of
+// planners): the start spline is computed once, its block image goes to the device once and is copied there planner by planner; what
+// set_initial_pose carries over from a planner's previous life (trajectory id counter, calculation-time buffer, ...: start_block) is read
+// back and patched per planner. (ltpl_fleet_set_start per planner: two synchronous copies of the whole block each -- 0.4 s for 8 192.)
+extern "C" int ltpl_fleet_set_start_range(ltpl_fleet* f, int32_t p0, int32_t p1, double x, double y, double heading, double vel, double mho,
+                                          int32_t* in_track, int32_t* cor_heading)
+try {
+    if (!f || !in_track || !cor_heading) return LTPL_ERR_INVALID_ARG;
+    if (p0 < 0 || p1 > f->D.N || p0 >= p1) { f->err = "fleet: planner range out of bounds"; return LTPL_ERR_INVALID_ARG; }
+    FLEET_TRY(f, hipSetDevice(f->h->device));
+    FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
+    const size_t cnt = (size_t)(p1 - p0), hs = sizeof(fleet::PlannerS);
+    std::vector<fleet::PlannerS> prev(cnt);
+    unsigned char* blk0 = f->d_state + f->D.stride * (size_t)p0;
+    FLEET_TRY(f, hipMemcpy2D(prev.data(), hs, blk0, f->D.stride, hs, cnt, hipMemcpyDeviceToHost));
+    const int rc = fleet::start_block(f->h->hostlat, f->D, x, y, heading, vel, mho, in_track, cor_heading, f->image.data(), nullptr, &f->err);
+    if (rc) return rc;
+    // the image once, then device-to-device into every block of the range (the first block receives it from the host)
+    FLEET_TRY(f, hipMemcpy(blk0, f->image.data(), f->D.stride, hipMemcpyHostToDevice));
+    for (size_t q = 1; q < cnt; ++q)
+        FLEET_TRY(f, hipMemcpyAsync(blk0 + f->D.stride * q, blk0, f->D.stride, hipMemcpyDeviceToDevice, f->h->stream));
+    // per-planner scalars: the image's header with the fields start_block carries over from the planner's state before the call
+    const fleet::PlannerS base = *reinterpret_cast<const fleet::PlannerS*>(f->image.data());
+    std::vector<fleet::PlannerS> hdr(cnt, base);
+    for (size_t q = 0; q < cnt; ++q) {
+        fleet::PlannerS& S = hdr[q]; const fleet::PlannerS& keep = prev[q];
+        S.traj_base_id = keep.traj_base_id; S.n_calc = keep.n_calc; std::memcpy(S.calc_buffer, keep.calc_buffer, sizeof(S.calc_buffer));
+        S.has_old_gg = keep.has_old_gg; S.cut_index_pos = keep.cut_index_pos; S.cut_layer = keep.cut_layer; S.vel_plan = keep.vel_plan; S.acc_plan = keep.acc_plan;
+        S.em_base_id = keep.em_base_id; S.closest_obj_index = keep.closest_obj_index; S.old_gg_scale = keep.old_gg_scale;
+    }
+    FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
+    FLEET_TRY(f, hipMemcpy2D(blk0, f->D.stride, hdr.data(), hs, hs, cnt, hipMemcpyHostToDevice));
+    return LTPL_OK;
+} LTPL_ABI_CATCH(abi_err_of(f))
+
 static int fleet_stage(ltpl_fleet* f, size_t bytes)
 {
     if (bytes <= f->h_stage_cap) return LTPL_OK;
@@ -552,7 +587,7 @@ static int fleet_launch_vel(ltpl_fleet* f, const FleetTickIn& t)
         FLEET_TRY(f, hipEventRecord(f->ev_a, st));
         FLEET_TRY(f, hipStreamWaitEvent(f->stream2, f->ev_a, 0));
         hipLaunchKernelGGL(fleet_lanes_kernel_of(vel_variant(&vp)), dim3(waves), dim3(64), 0, f->stream2, p, reinterpret_cast<const DevVelJob*>(f->JA.jobs),
-                           (const double*)f->JA.pool, reinterpret_cast<const float2*>(f->JA.ke), f->JA.ke_rows, f->JA.outp, f->D.RV, N, (int)fleet::JOBS_A,
+                           (const double*)f->JA.pool, reinterpret_cast<const ke_t*>(f->JA.ke), f->JA.ke_rows, f->JA.outp, f->D.RV, N, (int)fleet::JOBS_A,
                            f->JA.out);
         FLEET_TRY(f, hipGetLastError());
         FLEET_TRY(f, hipEventRecord(f->ev_b, f->stream2));

@@ -106,12 +106,34 @@ __device__ __forceinline__ void signal_done(const DoneSignal& d)
     }
 }
 
+// Operand records of the batch velocity stage (|kappa|, element length per path row). Default: an fp32 PAIR -- one 8-byte load per row and
+// lane, and 1 / |kappa| from v_rcp_f32; the profile state and every output stay fp64 (error budget used: 1.6e-6 of the 1e-5 tolerance).
+// -DLTPL_VEL_F64_OPERANDS builds the same kernels with fp64 operand records (16-byte loads, fp64 reciprocal): the A/B of round 4
+// (profiles/r04*_vel_precision.txt: ticks/s and max_rel_err of both builds).
+#ifdef LTPL_VEL_F64_OPERANDS
+typedef double ke_scalar;
+typedef double ke_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ke_t make_ke(double k, double e) { ke_t v; v.x = k; v.y = e; return v; }
+__device__ __forceinline__ double ke_rcp(const ke_t& r)        // 1 / |kappa|: hardware reciprocal + two Newton steps (0 -> NaN: treated as +inf by the callers' fmin)
+{
+    double q = __builtin_amdgcn_rcp(r.x);
+    q = fma(fma(-r.x, q, 1.0), q, q);
+    q = fma(fma(-r.x, q, 1.0), q, q);
+    return r.x == 0.0 ? (double)INFINITY : q;
+}
+#else
+typedef float ke_scalar;
+typedef float2 ke_t;
+__device__ __forceinline__ ke_t make_ke(double k, double e) { return make_float2((float)k, (float)e); }
+__device__ __forceinline__ double ke_rcp(const ke_t& r) { return (double)__builtin_amdgcn_rcpf(r.x); }     // 1 ulp in fp32, inf on straights
+#endif
+
 struct DevPathsOut {
     int cap_nodes, cap_pts;
     int* end_layer; int* closest_obj_index; int* closest_obj_node; int* n_actions;
     int* action_id; int* valid; int* reduced; int* goal_layer; int* n_nodes; int* n_pts; int* n_ties;
     int* nodes; int* node_idx; double* coeff; double* path_param;
-    float2* vke;                     // optional tiled plane (|kappa|, element length) as fp32 pairs for the batch velocity stage
+    ke_t* vke;                       // optional tiled plane (|kappa|, element length) as fp32 pairs for the batch velocity stage
     double* vxy;                     // optional tiled plane (x, y) of the FOLLOW jobs' path points (tile = follow job index): k_follow_prep
     // job compaction of the batch velocity stage (all nullptr outside the pipeline): every valid path takes a job index
     // from a counter of its class (0 = generic forward-backward profile, 1 = follow); its planes are tiled by JOB, so
@@ -238,7 +260,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? (P::fixed ? 4 : LTPL_RT_WAVES) 
     if constexpr (NW != 1) signal_done(out.done);          // (only the four-wave latency form is launched with a completion word)
 }
 typedef PlanFx<32, 32, 1> PlanA;      // <= 32 nodes per layer, <= 31 layers of planning range (Monteblanco, stock parameters)
-typedef PlanFx<32, 40, 1> PlanB;      // <= 32 nodes per layer, <= 39 layers (synthetic C3 oval)
+typedef PlanFx<32, 40, 1> PlanB;      // <= 32 nodes per layer, <= 39 layers (synthetic C3 oval; zalazone, lvms, modena of the reference's tracks)
+typedef PlanFx<48, 32, 1> PlanC;      // <= 48 nodes per layer, <= 31 layers (berlin: 40 nodes per layer -- round 3 ran it on the 204-register PlanRt kernel)
 typedef PlanFx<32, 32, NUM_WAVES> PlanA4;   // class A for the four-wave latency kernels (k_paths<4>, k_tick)
 
 
@@ -1026,7 +1049,7 @@ struct DevVelPrep {             // per-slot scalars produced by k_follow_prep (f
 };
 
 struct VelPlanes {              // tiled planes (doubles), tile index = job index: generic jobs [0, n_slots_pad), follow jobs behind
-    float2* KE;                 // (|kappa|, element length) as an fp32 pair: ONE 8-byte load per row and lane (the operands only enter
+    ke_t* KE;                   // (|kappa|, element length) as an fp32 pair: ONE 8-byte load per row and lane (the operands only enter
                                 // results with a 1e-5 tolerance; the profile state itself stays fp64)   n_slots_pad + n_scen_pad tiles
     double* P0;                 // type 0 result: follow -> "vx_profile" (:289/:294), else the generic profile     (same size)
     double* P1;                 // type 1 result: unconstrained profile of a follow job                n_scen_pad tiles
@@ -1043,7 +1066,7 @@ struct VelPlanes {              // tiled planes (doubles), tile index = job inde
 __device__ __forceinline__ size_t tile_base(int idx, int cap_pts) { return ((size_t)(idx >> 6) * cap_pts) * 64 + (idx & 63); }
 
 struct LaneProf {
-    const float2* KE;                     // tile-strided: element i at [i * 64]
+    const ke_t* KE;                       // tile-strided: element i at [i * 64]
 };
 
 // a / b with the hardware reciprocal and two Newton steps (~1 ulp; the velocity stage is checked to 1e-5 relative). b = 0
@@ -1084,12 +1107,12 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
     if (has_v_end && v_end < 0.0) v_end = 0.0;
     const double vmax2 = v_max * v_max, icay = 1.0 / cay, axm1 = axm_tab[1], dm = p.drag_m, axa = fabs(cax);
     const double vend2 = has_v_end ? v_end * v_end : INFINITY;
-    const float2* KEb = L.KE;                         // row r of this profile: KEb[kep_row(off + r)]
+    const ke_t* KEb = L.KE;                         // row r of this profile: KEb[kep_row(off + r)]
 #define KE_AT(r) KEb[kep_row(off + (r))]
     double* Dp = D + (size_t)off * 64;
-    const float2 rec0 = KE_AT(0);
+    const ke_t rec0 = KE_AT(0);
     double kabs_i = (double)rec0.x, e_i = (double)rec0.y;
-    double wi = fmin(cay * (double)__builtin_amdgcn_rcpf(rec0.x), vmax2);
+    double wi = fmin(cay * ke_rcp(rec0), vmax2);
     if (wi > v_start * v_start) wi = v_start * v_start;
     Dp[0] = wi;
     if (n < 2) return;
@@ -1104,12 +1127,12 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
         const double axg = axa * icay;
         double orig_p = wi, g_p = kabs_i * axg, e_p = e_i;      // operands of the row in front of the current step
         bool active = false, prev_acc = false;
-        float2 kr[LCHA], kn[LCHA];
+        ke_t kr[LCHA], kn[LCHA];
         const int nst = n - 1;
 #pragma unroll
         for (int c = 0; c < LCHA; ++c) { const int r = 1 + c < n ? 1 + c : n - 1; kr[c] = KE_AT(r); }
-        auto step = [&](const float2& rec, int i, bool valid) {
-            const double w0n = fmin(cay * (double)__builtin_amdgcn_rcpf(rec.x), vmax2);    // 1 / |kappa| in fp32 (1 ulp), inf on straights
+        auto step = [&](const ke_t& rec, int i, bool valid) {
+            const double w0n = fmin(cay * ke_rcp(rec), vmax2);    // 1 / |kappa| in fp32 (1 ulp), inf on straights
             const bool acc = w0n > orig_p;
             const bool act = active || (acc && !prev_acc);
             const double te = e_p + e_p;
@@ -1143,7 +1166,7 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
     } else {
         double orig_i = wi;
         bool active = false, prev_acc = false;
-        float2 kr[LCHF], kn[LCHF];
+        ke_t kr[LCHF], kn[LCHF];
 #pragma unroll
         for (int c = 0; c < LCHF; ++c) { const int r = 1 + c < n ? 1 + c : n - 1; kr[c] = KE_AT(r); }
         for (int base = 0; base < n - 1; base += LCHF) {
@@ -1151,7 +1174,7 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
             for (int c = 0; c < LCHF; ++c) {                   // operands of the next chunk (clamped rows: harmless re-reads at the end)
                 const int r = base + LCHF + 1 + c < n ? base + LCHF + 1 + c : n - 1;
 #ifdef LTPL_EXP_NOLOAD
-                kn[c] = make_float2(0.01f + 1e-6f * (float)r, 2.0f);
+                kn[c] = make_ke(0.01 + 1e-6 * (double)r, 2.0);
 #else
                 kn[c] = KE_AT(r);
 #endif
@@ -1196,14 +1219,14 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
         const double axg = axa * icay;
         double orig_p = wi, g_p = kabs_i * axg;
         bool active = false, prev_acc = false;
-        float2 kr[LCHB], kn[LCHB]; double wr[LCHB], wq[LCHB];
+        ke_t kr[LCHB], kn[LCHB]; double wr[LCHB], wq[LCHB];
         const int nst = n - 1;
 #pragma unroll
         for (int c = 0; c < LCHB; ++c) {
             const int r = n - 2 - c >= 0 ? n - 2 - c : 0;
             kr[c] = KE_AT(r); wr[c] = Dp[(size_t)r * 64];
         }
-        auto step = [&](const float2& rec, double wold, int i, bool valid) {
+        auto step = [&](const ke_t& rec, double wold, int i, bool valid) {
             const bool acc = wold > orig_p;
             const bool act = active || (acc && !prev_acc);
             const double te = 2.0 * (double)rec.y, tdm = te * dm, g_n = (double)rec.x * axg;
@@ -1239,7 +1262,7 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
     } else {
         double orig_i = wi;
         bool active = false, prev_acc = false;
-        float2 kr[LCHB], kn[LCHB]; double wr[LCHB], wq[LCHB];
+        ke_t kr[LCHB], kn[LCHB]; double wr[LCHB], wq[LCHB];
 #pragma unroll
         for (int c = 0; c < LCHB; ++c) {
             const int r = n - 2 - c >= 0 ? n - 2 - c : 0;
@@ -1439,7 +1462,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
 #pragma unroll
                 for (int c = 0; c < LCH; ++c) {
                     const int r = base + c < n ? base + c : n - 1;
-                    const float2 ke = L.KE[kep_row(r)]; k[c] = (double)ke.x; e[c] = (double)ke.y;
+                    const ke_t ke = L.KE[kep_row(r)]; k[c] = (double)ke.x; e[c] = (double)ke.y;
                 }
             };
             load_rows(0, kr, er);
@@ -1587,7 +1610,7 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
         const double* P1 = vp.P1 + tile_base(fjob ? j : 0, vp.cap_pts);
         const double* P2 = vp.P2 + tile_base(fjob ? j : 0, vp.cap_pts);
         const double* P3 = vp.P3 + tile_base(fjob ? j : 0, vp.cap_pts);
-        const float2* KE = vp.KE + kep_base(tile, vp.plane_rows);
+        const ke_t* KE = vp.KE + kep_base(tile, vp.plane_rows);
         const bool compose = follow && (flags & VF_COMPOSE);
         const int nd = compose ? vp.fseg[2 * j] : 0, stop_idx = compose ? vp.fseg[2 * j + 1] : 0;
         int vel_bound = follow ? ((flags & VF_BOUND_FOLLOW) ? 1 : 0) : ((flags & VF_BOUND_GENERIC) ? 1 : 0);
@@ -1615,8 +1638,12 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
         // rows beyond n - 1 are unused padding of the block -- never NaN-sensitive: their ax is discarded)
 #pragma unroll
         for (int c = 0; c < FCH; c += 2) {
+#ifdef LTPL_VEL_F64_OPERANDS
+            er[c] = KE[kep_row(base + c)].y; er[c + 1] = KE[kep_row(base + c + 1)].y;
+#else
             const float4 v = *reinterpret_cast<const float4*>(&KE[kep_row(base + c)]);
             er[c] = (double)v.y; er[c + 1] = (double)v.w;
+#endif
         }
 #pragma unroll
         for (int c = 0; c < FCH; ++c) {
@@ -1706,15 +1733,15 @@ __global__ __launch_bounds__(64) void k_follow_prep(DevLat lat, DevPathsIn in, D
     vl_stamp(dbg, drow, 2);
     if (__ballot(have) != 0ull) {
         const double* xy = vp.XY + 2 * kep_base(j, vp.plane_rows);         // pairs: row r of this lane's job at xy + 2 * kep_row(r)
-        const float2* KE = vp.KE + kep_base(out.n_slots_pad + j, vp.plane_rows);
+        const ke_t* KE = vp.KE + kep_base(out.n_slots_pad + j, vp.plane_rows);
         int nmax = n;
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(nmax, m); nmax = o > nmax ? o : nmax; }
         // one pass: closest path point of the object (o) and of the ego position (e), arc length in front of it and the element before
         double bo = INFINITY, be = INFINITY, so = 0.0, se = 0.0, po = 0.0, pe = 0.0, run = 0.0, e_prev = 0.0;
         int no = 0, ne = 0;
-        dbl2 pr[PCH], pn[PCH]; float2 kr[PCH], kn[PCH];
-        auto load_rows = [&](int base, dbl2 (&p)[PCH], float2 (&k)[PCH]) {
+        dbl2 pr[PCH], pn[PCH]; ke_t kr[PCH], kn[PCH];
+        auto load_rows = [&](int base, dbl2 (&p)[PCH], ke_t (&k)[PCH]) {
 #pragma unroll
             for (int c = 0; c < PCH; ++c) {
                 const int r = base + c < n ? base + c : n - 1;
@@ -1880,7 +1907,7 @@ struct ltpl_handle {
     DevLat lat{};
     TeamLds lp1{}, lp4{};            // LDS plans of the path kernel: one wave / four waves per scenario
     int batch_nw = 1;                // waves per scenario used for batches (LTPL_BATCH_NW)
-    int plan_class = 0;              // LDS plan of the one-wave batch kernel: 0 = runtime (PlanRt), 1 = PlanA, 2 = PlanB
+    int plan_class = 0;              // LDS plan of the one-wave batch kernel: 0 = runtime (PlanRt), 1 = PlanA, 2 = PlanB, 3 = PlanC
     int plan_class4 = 0;             // LDS plan of the four-wave kernels: 0 = runtime, 1 = PlanA4
     int long_horizon = 0;            // 1: parent tables in global memory (PlanRtG), velocity stage always through the lane kernels
     int nw1_min_scen = PIPELINE_MIN_SCEN;   // calls with at least this many scenarios use one-wave teams
@@ -1955,6 +1982,7 @@ static const void* paths_kernel_of(const ltpl_handle* h, int nw)
         switch (h->plan_class) {
             case 1: return reinterpret_cast<const void*>(k_paths<1, PlanA>);
             case 2: return reinterpret_cast<const void*>(k_paths<1, PlanB>);
+            case 3: return reinterpret_cast<const void*>(k_paths<1, PlanC>);
             default: return reinterpret_cast<const void*>(k_paths<1, PlanRt>);
         }
     }
@@ -1986,6 +2014,7 @@ static int launch_paths(ltpl_handle* h, int nw, int n_scen, hipStream_t st, cons
         else switch (h->plan_class) {
             case 1: hipLaunchKernelGGL((k_paths<1, PlanA>), grid, block, lp.total, st, h->lat, di, dout, lp); break;
             case 2: hipLaunchKernelGGL((k_paths<1, PlanB>), grid, block, lp.total, st, h->lat, di, dout, lp); break;
+            case 3: hipLaunchKernelGGL((k_paths<1, PlanC>), grid, block, lp.total, st, h->lat, di, dout, lp); break;
             default: hipLaunchKernelGGL((k_paths<1, PlanRt>), grid, block, lp.total, st, h->lat, di, dout, lp); break;
         }
     } else if (h->long_horizon) hipLaunchKernelGGL((k_paths<NUM_WAVES, PlanRtG>), grid, block, lp.total, st, h->lat, di, dout, lp);
@@ -2374,6 +2403,7 @@ try {
             h->plan_class4 = 1; make_fixed_plan(PlanA4(), &h->lp4);
         }
         else if (kmax <= PlanB::c_kpad && hmax + 1 <= PlanB::c_hmax && d->num_layers >= PlanB::c_hmax) { h->plan_class = 2; make_fixed_plan(PlanB(), &h->lp1); }
+        else if (kmax <= PlanC::c_kpad && hmax + 1 <= PlanC::c_hmax && d->num_layers >= PlanC::c_hmax) { h->plan_class = 3; make_fixed_plan(PlanC(), &h->lp1); }
     }
     if (const char* e = getenv("LTPL_BATCH_NW")) h->batch_nw = atoi(e) == 4 ? 4 : 1;
     h->zc_out = 1;
@@ -3025,7 +3055,7 @@ static void tick_bind_outputs(TickLayout* t, unsigned char* dob, double* planes)
     if (t->pipeline && planes) {
         const size_t tiles = (size_t)t->n_slots_pad + (size_t)t->n_scen_pad;
         const size_t per_all = (size_t)t->cap_pts * tiles, per_scen = (size_t)t->cap_pts * (size_t)t->n_scen_pad;
-        t->vp.KE = reinterpret_cast<float2*>(planes); t->vp.P0 = planes + 2 * per_all;       // (the second plane-sized region is unused)
+        t->vp.KE = reinterpret_cast<ke_t*>(planes); t->vp.P0 = planes + 2 * per_all;       // (the second plane-sized region is unused)
         t->vp.P1 = planes + 3 * per_all; t->vp.P2 = t->vp.P1 + per_scen; t->vp.P3 = t->vp.P2 + per_scen;
         t->vp.XY = t->vp.P3 + per_scen;
         const size_t plane_rows = align_up((size_t)t->cap_pts, 8);

@@ -690,7 +690,7 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
     double* o_pp = out.path_param + (size_t)slot * out.cap_pts * 5;
     // (everything the row loop reads of the argument structs, once in front of it)
     const double* const a_slen = pin_sgpr(lat.slen);
-    float2* a_vke = pin_sgpr(out.vke); double* a_vxy = nullptr;
+    ke_t* a_vke = pin_sgpr(out.vke); double* a_vxy = nullptr;
     if (a_vke) {                                          // planes of the batch velocity stage, blocked by 8 rows (kep_base / kep_row)
         const int nrb = (out.cap_pts + 7) >> 3, nsp = out.n_slots_pad;
         a_vke += ((size_t)(vtile >> 6) * nrb * 64 + (vtile & 63)) * KE_RB;
@@ -729,7 +729,7 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
         if (a_vke) {
             // r = lane + 64 k, so kep_row(r) = kep_row(lane) + 64 (r - lane)
             const size_t ro = (size_t)(((lane >> 3) << 9) + (lane & 7)) + (size_t)(r - lane) * 64;
-            a_vke[ro] = make_float2((float)fabs(kap), (float)len_r);
+            a_vke[ro] = make_ke(fabs(kap), len_r);
             if (a_vxy) store2(a_vxy + 2 * ro, x, y);
         }
         if (vel_x) { vel_x[r] = x; vel_y[r] = y; }

@@ -8,6 +8,7 @@ The tape form pre-uploads the inputs of many ticks and advances all planners thr
 (``tape_append`` / ``tape_append_groups`` / ``tape_run``): the closed-loop, state-carrying throughput of the hot path.
 """
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -22,9 +23,18 @@ class Fleet(Planner):
     def _declare(self):
         Planner._declare(self)
         f = self._fn
+        f("set_start_range").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         f("tape_clear").argtypes = [C.c_void_p]
         f("tape_append").argtypes = [C.c_void_p, C.POINTER(PlannerPathsIn), C.POINTER(PlannerVelIn)]
         f("tape_run").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
+
+    def set_start_range(self, first, past_last, pos, heading, vel=0.0, max_heading_offset=math.pi / 4):
+        """``set_start`` with the same pose for the planners [first, past_last) in one call (ltpl_fleet_set_start_range)."""
+        it, ch = C.c_int32(1), C.c_int32(1)
+        self._check(self._fn("set_start_range")(self.handle, int(first), int(past_last), float(pos[0]), float(pos[1]), float(heading),
+                                                float(vel), float(max_heading_offset), C.byref(it), C.byref(ch)))
+        return bool(it.value), bool(ch.value)
 
     # ---- tape ---------------------------------------------------------------------------------------------------------------
     def tape_clear(self):

@@ -562,6 +562,9 @@ const char* ltpl_fleet_last_error(const ltpl_fleet* fleet);
 /* OnlineTrajectoryHandler.set_initial_pose for one planner (computed on the host, uploaded as that planner's state) */
 int ltpl_fleet_set_start(ltpl_fleet* fleet, int32_t planner, double x, double y, double heading, double vel,
                          double max_heading_offset, int32_t* in_track, int32_t* cor_heading);
+/* the same start pose for the planners [first, past_last) in one call (start spline computed once, block image copied on the device) */
+int ltpl_fleet_set_start_range(ltpl_fleet* fleet, int32_t first, int32_t past_last, double x, double y, double heading, double vel,
+                               double max_heading_offset, int32_t* in_track, int32_t* cor_heading);
 int ltpl_fleet_calc_paths(ltpl_fleet* fleet, const ltpl_planner_paths_in* in);
 int ltpl_fleet_calc_paths_begin(ltpl_fleet* fleet, const ltpl_planner_paths_in* in);
 int ltpl_fleet_calc_paths_finish(ltpl_fleet* fleet, const int32_t* zone_off, const int32_t* zone_gid);

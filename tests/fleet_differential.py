@@ -8,6 +8,8 @@ previous action, blocked tracks, dropped keys, backup brake plans) with two impl
 """
 import numpy as np
 
+from graphbasedlocaltrajectoryplanner_amd.tick_replay import KAPPA_FLOOR
+
 from graphbasedlocaltrajectoryplanner_amd._capi import BackendError
 from graphbasedlocaltrajectoryplanner_amd.scenario_gen import raceline_state
 
@@ -36,8 +38,15 @@ def same_trajectories(a, b, exact=True, what=""):
             assert np.array_equal(x, y), (what, k)
             assert ra['vel_plan'] == rb['vel_plan'] and np.array_equal(ra['vel_course'], rb['vel_course'])
         elif x.size:
-            sc = np.array([1.0, 1.0, 1.0, 1.0, 1e3, 1.0, 1e3]) * np.maximum(1.0, np.max(np.abs(y), axis=0))
-            assert np.all(np.max(np.abs(x - y), axis=0) <= 2e-5 * sc), (what, k, np.max(np.abs(x - y), axis=0))
+            # per column, the scales of tick_replay.check_traj (columns s, x, y, psi, kappa, vx, ax): s against its end value, x / y against
+            # the extent of the trajectory, psi against pi, kappa with the 1e-4 1/m floor, vx with a 1 m/s floor, ax against v^2 / 2 (it
+            # differentiates v^2). Round 3 multiplied the kappa and ax scales by 1e3: two of seven columns were not compared in earnest.
+            err = np.max(np.abs(x - y), axis=0)
+            err[3] = float(np.max(np.abs(np.mod(x[:, 3] - y[:, 3] + np.pi, 2 * np.pi) - np.pi)))
+            vmax = float(np.max(np.abs(y[:, 5])))
+            sc = np.array([max(float(np.max(np.abs(y[:, 0]))), 1.0), max(float(np.ptp(y[:, 1])), 1.0), max(float(np.ptp(y[:, 2])), 1.0), np.pi,
+                           max(float(np.max(np.abs(y[:, 4]))), KAPPA_FLOOR), max(vmax, 1.0), max(vmax * vmax / 2.0, 5.0)])
+            assert np.all(err <= 2e-5 * sc), (what, k, err / sc)
 
 
 def drive(lat, A, B, seed, n_ticks, exact=True, scen_a=0, scen_b=0):

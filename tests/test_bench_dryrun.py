@@ -32,6 +32,11 @@ class StandInFleet(object):
     def set_start(self, *a, **k):
         return self.p.set_start(*a, **k)
 
+    def set_start_range(self, first, past_last, *a, **k):
+        for q in range(first, past_last):
+            r = self.p.set_start(q, *a, **k)
+        return r
+
     def tape_append_groups(self, groups, ax_max_machines=((100.0, 5.0),)):
         self.tape.append((groups, ax_max_machines))
 
@@ -45,8 +50,9 @@ class StandInFleet(object):
     def calc_vel_profile_packed(self, packed):
         per = [g for c, g in packed[0] for _ in range(c)]
         g0 = per[0]
-        self.p.calc_vel_profile([g["pos_est"] for g in per], [g["vel_est"] for g in per], vel_max=g0["vel_max"], gg_scale=g0["gg_scale"],
-                                local_gg=g0["local_gg"], ax_max_machines=packed[1], safety_d=g0["safety_d"], incl_emerg_traj=g0["incl_emerg_traj"])
+        self.p.calc_vel_profile([g["pos_est"] for g in per], [g["vel_est"] for g in per], vel_max=g0["vel_max"], gg_scale=[g["gg_scale"] for g in per],
+                                local_gg=g0["local_gg"], ax_max_machines=packed[1], safety_d=[g["safety_d"] for g in per],
+                                incl_emerg_traj=[g["incl_emerg_traj"] for g in per])
 
     def tape_run(self, first, count):
         for packed in self.tape[first:first + count]:
@@ -106,6 +112,9 @@ class StandInBackend(object):
     def batch_download(self):
         return self.orc.tick_batch(*self._resident)
 
+    def close(self):
+        pass
+
 
 def run_worker(monkeypatch, capsys, **over):
     import torch
@@ -126,7 +135,7 @@ def run_worker(monkeypatch, capsys, **over):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         monkeypatch.delenv(k, raising=False)
     args = dict(gpus=1, steps=3, warmup=1, batch=64, cpu_sample=8, latency_ticks=4, dropin_ticks=40, no_cpu=False,
-                no_extra=False, exact_steps=True, workload="c2", fleet_planners=3, fleet_ticks=40)
+                no_extra=False, exact_steps=True, workload="c2", fleet_planners=4, fleet_ticks=40, c3_batch=6, c5_ticks=2)
     args.update(over)
     bench.worker(argparse.Namespace(**args))
     lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
@@ -140,9 +149,10 @@ def test_the_line_carries_the_drivers_contract(monkeypatch, capsys):
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
         assert isinstance(out[key], typ), key
-    # no published reference number exists: the ratio is against BASELINE.json's stated target and says so
-    assert out["vs_baseline"] == pytest.approx(out["value"] / 10000.0) and "target" in out["vs_baseline_basis"]
-    assert out["unit"] == "ticks/s" and out["scaling"] == "weak" and out["dtype"] == "f64"
+    # no published reference number exists: vs_baseline is null; the ratio to BASELINE.json's stated target has its own name
+    assert out["vs_baseline"] is None and out["vs_target"] == pytest.approx(out["value"] / 10000.0) and "target" in out["vs_target_basis"]
+    assert out["unit"] == "ticks/s" and out["scaling"] == "weak" and out["dtype"].startswith("f64") and "f32" in out["dtype"]
+    assert len(out["per_rank_ms_per_step"]) == 1 and out["efficiency_vs_n1"] is None
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["timed_steps"] == 3
     assert "workload" in out["config"] and "model" not in out["config"]
     assert "ticks/s" in out["metric"] and out["value"] > 0 and np.isfinite(out["value"])
@@ -154,14 +164,19 @@ def test_the_line_carries_the_drivers_contract(monkeypatch, capsys):
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert r["kernel_ms"] == pytest.approx(0.8)                                # the live, in-region duration wins over the profile's
     assert r["traffic"] is None and r["traffic_frac"] is None                  # PMC summary is for the 32768-scenario grid only
-    assert r["issue"] is None and "issue" in r["limiter"]
+    assert r["issue"] is None and "issue" in r["limiter"] and r["binding"]["issue_frac"] is None
+    assert r["frac_refline_per_position"] >= r["frac"]                         # (the round-3 model charged the reference line per position)
     # the re-based byte model never exceeds the survey's (which charged every window edge all its samples, every sweep its own edges)
     assert r["split_per_tick"]["mask"] <= r["survey_model_per_tick"]["mask"] and r["split_per_tick"]["sweep"] <= r["survey_model_per_tick"]["sweep"]
     assert r["mask_counts_per_tick"]["shell_edges"] <= r["mask_counts_per_tick"]["window_edges"]
 
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "ticks/s" and c["value"] > 0 and "8 scenarios" in c["sample"]
-    assert out["parity_checked"] is True and out["parity_detail"]["scenarios"] == 8 and not out["parity_detail"]["mismatches"]
+    pd = out["parity_detail"]
+    assert out["parity_checked"] is True and pd["scenarios"] == 8 and not pd["integer_mismatches"] and pd["paths"] >= 8
+    assert set(pd["max_rel_err_by_quantity"]) >= {"x", "y", "psi", "kappa", "vx", "ax", "coeff_a1"}
+    assert {"node_idx", "n_ties", "too_close", "nodes"} <= set(pd["integer_outputs_compared_bit_exact"])
+    assert list(bench.sample_indices(32768, 2048)[[0, -1]]) == [0, 32767]      # the sample spans the whole batch
 
     l = out["latency_us"]
     assert l["ticks"] == 4 and l["p50"] > 0 and l["device_us"] == pytest.approx(900.0)
@@ -170,11 +185,17 @@ def test_the_line_carries_the_drivers_contract(monkeypatch, capsys):
     cl = out["extra"]["closed_loop"]
     assert cl["planners"] == 256 and cl["planner_ticks_per_s"] > 0 and cl["keys_match_recording"] is True
     cd = out["extra"]["closed_loop_device"]
-    assert cd["planners"] == 3 and cd["ticks"] == 40 and cd["matches_recording"] is True and cd["planner_ticks_per_s"] == pytest.approx(3 * 40 / 0.06)
-    assert cd["live_inputs_planner_ticks_per_s"] > 0
+    assert cd["planners"] == 4 and cd["ticks"] == 40 and cd["matches_recording"] is True and cd["planner_ticks_per_s"] == pytest.approx(4 * 40 / 0.06)
+    assert cd["live_inputs_planner_ticks_per_s"] > 0 and "SAME" in cd["inputs"]
+    cm = out["extra"]["closed_loop_device_mixed"]
+    assert cm["planners"] == 4 and len(cm["groups"]) == 4 and cm["matches_recording"] is True and cm["planner_checks"] == 3 * 4 and len(cm["checked_at_ticks"]) == 3
+    c3 = out["extra"]["c3"]
+    assert c3["batch"] == 6 and c3["ticks_per_s"] > 0 and c3["parity_checked"] is True and 0 < c3["roofline_frac"] <= c3["roofline_frac_refline_per_position"]
+    c5 = out["extra"]["c5"]
+    assert c5["horizon_300m"]["ticks"] == 2 and c5["horizon_100m"]["p99_us"] >= c5["horizon_100m"]["p50_us"] > 0
     assert 1.0 <= out["paths_per_tick"] <= 4.0
     # order of the device calls: resident inputs before any run, and the sample re-uploaded for the device-only latency
-    assert hip.calls[0] == "batch_upload" and hip.calls.count("batch_upload") == 3
+    assert hip.calls[0] == "batch_upload" and hip.calls.count("batch_upload") == 4
 
 
 def test_traffic_is_reported_for_the_grid_it_was_measured_on(monkeypatch, capsys):

@@ -132,6 +132,9 @@ def exercise(name, lat):
         pos = lat.node_pos[g0]
         for s in range(n_pl):
             fl.set_start(s, pos, float(lat.node_psi[g0]), 0.0)
+        fl.set_start_range(0, n_pl, pos, float(lat.node_psi[g0]), 0.0)          # (the one-call form over the whole fleet)
+        if n_pl > 3:
+            fl.set_start_range(2, n_pl - 1, pos, float(lat.node_psi[g0]), 1.0)
         veh = [[(2.5, 10.0, p[:2]), (2.0, 3.0, p[2:3])] for _ in range(n_pl)]
         try:
             fl.calc_paths(["straight"] * n_pl, 0.0, veh, [[1, 2, 3]] * n_pl)

@@ -93,6 +93,11 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p)
 
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) std::memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) std::memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemcpy2D(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind)
+{
+    for (size_t r = 0; r < h; ++r) std::memcpy(static_cast<char*>(d) + r * dp, static_cast<const char*>(s) + r * sp, w);
+    return hipSuccess;
+}
 hipError_t hipMemset(void* d, int v, size_t n) { if (n) std::memset(d, v, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if (n) std::memset(d, v, n); return hipSuccess; }
 
