@@ -163,7 +163,9 @@ struct FPathsOut { const int* closest_obj_index; const int* n_actions; const int
                    const int* n_nodes; const int* n_pts; const int* nodes; const int* node_idx; const double* coeff; const double* pp; };
 // arguments of calc_vel_profile (ltpl_planner_vel_in)
 struct FVelIn { const double* pos_x; const double* pos_y; const double* vel_est; const double* vel_max; const double* gg_scale;
-                const double* gg_ax; const double* gg_ay; const double* safety_d; const int* incl_emerg; };
+                const double* gg_ax; const double* gg_ay; const double* safety_d; const int* incl_emerg;
+                // ABI v6: machine tables per planner (null: one table for the call): first row of every table, table of every planner
+                const int* ax_off; const int* ax_idx; };
 
 // seam (2): job table + pooled arrays (the layout k_vel_profile reads). Job slot j owns 4 R doubles of `pool` (kappa R | el R | gg 2 R)
 // and R doubles of `out`; an unused slot has n = 0.
@@ -171,7 +173,18 @@ struct VelJob {
     int mode, n, n_el, has_v_end;
     int off_kappa, off_el, off_gg, off_out;
     double v_start, v_end, v_ego, v_obj, safety_d, obj_dist, obj_x, obj_y;
+    // THE CAR of the job (ABI v6: a fleet of different cars): Graph_LTPL.calc_vel_profile's vel_max and ax_max_machines are arguments per
+    // call = per vehicle (Graph_LTPL.py:344-351). v_max <= 0 / n_axm == 0: the parameter set of the launch.
+    double v_max;
+    int axm_off, n_axm;             // the job's machine table: rows [axm_off, axm_off + n_axm) of the call's stacked tables
 };
+struct JobCar { double v_max; int axm_off, n_axm; };
+FLT_FN JobCar car_of(const FVelIn& vin, int p)
+{
+    JobCar c{vin.vel_max[p], 0, 0};
+    if (vin.ax_off && vin.ax_idx) { const int t = vin.ax_idx[p]; c.axm_off = vin.ax_off[t]; c.n_axm = vin.ax_off[t + 1] - vin.ax_off[t]; }
+    return c;
+}
 // Lane plane (device only, stage-A table): the forward-backward jobs of slots >= 1 are solved one LANE per job (k_fleet_fb_lanes), so their
 // operands go into a plane tiled by job and blocked by rows, (|kappa|, element length) as an fp32 pair (`ke`, layout = kep_base / kep_row of
 // the batch velocity stage); plane index q = p (per_planner - 1) + slot - 1. The results come back job-major in `out` like every other
@@ -576,10 +589,11 @@ FLT_FN void finalize_bp(const X& x, const FCfg& cfg, const double* s_arr, const 
 // job slot `slot` of planner p (slot 0 is reserved for the follow job of a tick: the device runs the follow jobs as their own launch)
 template <class X>
 FLT_FN int make_job(const X& x, const Dims& D, const FJobs& J, int p, int slot, int mode, const Rows& pv, double gax, double gay, int i0, int i1,
-                    int n_el, double v_start, bool has_end, double v_end)
+                    int n_el, double v_start, bool has_end, double v_end, const JobCar& car = JobCar{0.0, 0, 0})
 {
     const int j = p * J.per_planner + slot;
     VelJob jb{};
+    jb.v_max = car.v_max; jb.axm_off = car.axm_off; jb.n_axm = car.n_axm;
     jb.mode = mode; jb.n = i1 - i0; jb.n_el = n_el; jb.has_v_end = has_end ? 1 : 0; jb.v_start = v_start; jb.v_end = v_end;
     jb.off_kappa = j * 4 * D.R; jb.off_el = jb.off_kappa + D.R; jb.off_gg = jb.off_kappa + 2 * D.R; jb.off_out = j * D.R;
     double* kap = J.pool + jb.off_kappa; double* el = J.pool + jb.off_el; double* gg = J.pool + jb.off_gg;
@@ -612,6 +626,7 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
     if (!S.ref_done) ref_idx(x, cfg, B, S, vin.pos_x[p], vin.pos_y[p]);
     S.ref_done = 0;
     const double vel_max = vin.vel_max[p], gg_scale = vin.gg_scale[p], gax = vin.gg_ax[p], gay = vin.gg_ay[p];
+    const JobCar car = car_of(vin, p);
     S.traj_base_id += 10;
     if (!S.has_old_gg) { S.old_gg_scale = gg_scale; S.has_old_gg = 1; }
     S.n_bp = 0; S.has_bp = 1; S.n_ids = 0;
@@ -677,14 +692,14 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
                 obj_dist = s_obj - s_sta;
             }
             if (J.jobs[p * J.per_planner].n > 0) { fail(S, LTPL_ERR_CAPACITY, E_CAP_JOBS); return; }       // (two follow keys in one tick: not a thing)
-            const int j = make_job(x, D, J, p, 0, LTPL_VEL_FOLLOW_CONTROLLED, pv, sgx, sgy, pref, m, m - pref, W.vel_start, false, 0.0);
+            const int j = make_job(x, D, J, p, 0, LTPL_VEL_FOLLOW_CONTROLLED, pv, sgx, sgy, pref, m, m - pref, W.vel_start, false, 0.0, car);
             x.sync();
             if (x.lane() == 0) {
                 VelJob& jb = J.jobs[p * J.per_planner + j];
                 jb.v_ego = vin.vel_est[p]; jb.v_obj = v_obj; jb.safety_d = vin.safety_d[p]; jb.obj_dist = obj_dist; jb.obj_x = ox; jb.obj_y = oy;
             }
             W.job_follow = j;
-            W.job_free = make_job(x, D, J, p, n_jobs++, LTPL_VEL_FB, pv, sgx, sgy, pref, m, m - pref - 1, W.vel_start, false, 0.0);
+            W.job_free = make_job(x, D, J, p, n_jobs++, LTPL_VEL_FB, pv, sgx, sgy, pref, m, m - pref - 1, W.vel_start, false, 0.0, car);
         }
         if (T.id != LTPL_ACT_FOLLOW || T.red_len) {                                                 // :834-903
             W.generic = 1;
@@ -708,7 +723,7 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
                 v_idx = m;
             }
             W.v_idx = v_idx;
-            if (v_idx - pref > 1) { W.job_fb = make_job(x, D, J, p, n_jobs++, LTPL_VEL_FB, pv, sgx, sgy, pref, v_idx, v_idx - pref - 1, W.vel_start, true, v_end); W.has_fb = 1; }
+            if (v_idx - pref > 1) { W.job_fb = make_job(x, D, J, p, n_jobs++, LTPL_VEL_FB, pv, sgx, sgy, pref, v_idx, v_idx - pref - 1, W.vel_start, true, v_end, car); W.has_fb = 1; }
         }
     }
     x.sync();

@@ -59,6 +59,7 @@ __device__ __forceinline__ void fleet_load(const WaveX& x, const fleet::Block& B
     for (int i = x.lane(); i < (int)(sizeof(fleet::PlannerS) / 8); i += 64) dst[i] = src[i];
     x.sync();
 }
+#define FLEET_AXM_ROWS 512          // machine-table rows of one call, all tables together (the lane kernel keeps them in LDS)
 #define FLEET_ERR_SHIFT 13
 #define FLEET_ERR_MASK 0x1fff
 static_assert((fleet::E_CAP_VEL << 8 | 0xff) <= FLEET_ERR_MASK, "error word: site bits");
@@ -157,7 +158,7 @@ template <int EM, bool AXM1>
 __global__ __launch_bounds__(64) void k_fleet_fb_lanes(DevVelParams p, const DevVelJob* jobs, const double* pool, const ke_t* ke, int ke_rows,
                                                        double* outp, int cap, int n_planners, int per, double* out)
 {
-    __shared__ double axm_s[128];
+    __shared__ double axm_s[2 * FLEET_AXM_ROWS];              // ALL machine tables of the call (every lane indexes its own job's table)
     const int lane = threadIdx.x;
     for (int i = lane; i < 2 * p.n_axm; i += 64) axm_s[i] = p.axm[i];
     __syncthreads();
@@ -170,7 +171,12 @@ __global__ __launch_bounds__(64) void k_fleet_fb_lanes(DevVelParams p, const Dev
     LaneProf L; L.KE = ke + kep_base(q, ke_rows);
     double* D = outp + tile_base(q, cap);
     const double cax = pool[jp->off_gg], cay = pool[jp->off_gg + 1];
-    lane_fb_profile<EM, AXM1>(L, D, 0, n, cax, cay, p, axm_s, p.v_max, jp->v_start, jp->has_v_end != 0, jp->v_end);
+    // the car of the job: its own vel_max / machine table (fleet::VelJob, ABI v6), else the launch's
+    DevVelParams pj = p;
+    if (jp->v_max > 0.0) pj.v_max = jp->v_max;
+    const double* axm_j = axm_s;
+    if (jp->n_axm > 0) { pj.n_axm = jp->n_axm; axm_j = axm_s + 2 * jp->axm_off; }
+    lane_fb_profile<EM, AXM1>(L, D, 0, n, cax, cay, pj, axm_j, pj.v_max, jp->v_start, jp->has_v_end != 0, jp->v_end);
     // results job-major like every other job's (a lane writes its own row: scattered 8-byte stores, but this launch leaves half of the
     // SIMDs idle and runs next to the follow jobs -- the readers in k_fleet_vel_b then find coalesced rows)
     double* o = out + jp->off_out;
@@ -198,6 +204,7 @@ struct FleetTickIn {
     void* d_buf = nullptr; size_t cap = 0;
     fleet::FObj ob{}; const int* zone_off = nullptr; const int* zone_gid = nullptr;
     fleet::FVelIn vin{}; const double* axm = nullptr; int n_axm = 0; double vel_max = 0.0; int any_emerg = 0;
+    int n_axm_total = 0, multi_axm = 0;      // ABI v6: rows of all machine tables together; several tables (jobs carry their own): n_axm = rows of table 0
     bool has_paths = false, has_vel = false;
 };
 
@@ -455,15 +462,28 @@ static int fleet_pack_inputs(ltpl_fleet* f, FleetTickIn* t, const ltpl_planner_p
         o_ra = a.add(8 * (size_t)(nv + 1)); o_ve = a.add(8 * (size_t)(nv + 1)); o_px = a.add(8 * (size_t)(np_ + 1)); o_py = a.add(8 * (size_t)(np_ + 1));
         o_zo = a.add(4 * (size_t)(N + 1)); o_zg = a.add(4 * (size_t)(nz + 1));
     }
-    size_t o_v[8] = {0}, o_em = 0, o_axm = 0;
+    size_t o_v[8] = {0}, o_em = 0, o_axm = 0, o_axo = 0, o_axi = 0;
+    int n_tab = 0;
     if (vin) {
         if (!vin->pos_est_x || !vin->pos_est_y || !vin->vel_est || !vin->vel_max || !vin->gg_scale || !vin->gg_ax || !vin->gg_ay || !vin->safety_d ||
             !vin->ax_max_machines || vin->n_ax_max_machines < 1) { f->err = "fleet: null input"; return LTPL_ERR_INVALID_ARG; }
         if (vin->gg_row_off || vin->gg_rows) { f->err = fleet::err_text(0, LTPL_ERR_UNSUPPORTED | (fleet::E_GG_DICT << 8)); return LTPL_ERR_UNSUPPORTED; }
-        if (vin->n_ax_max_machines > 64) { f->err = "ax_max_machines with more than 64 rows"; return LTPL_ERR_CAPACITY; }
-        for (int s = 1; s < N; ++s) if (vin->vel_max[s] != vin->vel_max[0]) { f->err = "fleet: vel_max must be the same for all planners of a call"; return LTPL_ERR_UNSUPPORTED; }
+        // a fleet of different cars (ABI v6): vel_max per planner, machine tables per planner (ax_table_off / ax_table_idx)
+        n_tab = vin->n_ax_tables > 1 ? vin->n_ax_tables : 0;
+        if (n_tab) {
+            if (!vin->ax_table_off || !vin->ax_table_idx) { f->err = "fleet: n_ax_tables > 1 without ax_table_off / ax_table_idx"; return LTPL_ERR_INVALID_ARG; }
+            if (vin->ax_table_off[0] != 0 || vin->ax_table_off[n_tab] != vin->n_ax_max_machines) { f->err = "fleet: ax_table_off must run from 0 to n_ax_max_machines"; return LTPL_ERR_INVALID_ARG; }
+            for (int t_ = 0; t_ < n_tab; ++t_) {
+                const int rows = vin->ax_table_off[t_ + 1] - vin->ax_table_off[t_];
+                if (rows < 1 || rows > 64) { f->err = "fleet: a machine table needs 1 .. 64 rows"; return rows < 1 ? LTPL_ERR_INVALID_ARG : LTPL_ERR_CAPACITY; }
+            }
+            if (vin->n_ax_max_machines > FLEET_AXM_ROWS) { f->err = "fleet: more than 512 machine-table rows in one call"; return LTPL_ERR_CAPACITY; }
+            for (int s = 0; s < N; ++s) if (vin->ax_table_idx[s] < 0 || vin->ax_table_idx[s] >= n_tab) { f->err = "fleet: ax_table_idx out of range"; return LTPL_ERR_INVALID_ARG; }
+        } else if (vin->n_ax_max_machines > 64) { f->err = "ax_max_machines with more than 64 rows"; return LTPL_ERR_CAPACITY; }
+        for (int s = 0; s < N; ++s) if (!(vin->vel_max[s] > 0.0)) { f->err = "fleet: vel_max must be positive"; return LTPL_ERR_INVALID_ARG; }
         for (int k = 0; k < 8; ++k) o_v[k] = a.add(8 * (size_t)N);
         o_em = a.add(4 * (size_t)N); o_axm = a.add(16 * (size_t)vin->n_ax_max_machines);
+        if (n_tab) { o_axo = a.add(4 * (size_t)(n_tab + 1)); o_axi = a.add(4 * (size_t)N); }
     }
     int rc = fleet_stage(f, a.size);
     if (rc) return rc;
@@ -499,8 +519,12 @@ static int fleet_pack_inputs(ltpl_fleet* f, FleetTickIn* t, const ltpl_planner_p
         else memset(hb + o_em, 0, 4 * (size_t)N);
         memcpy(hb + o_axm, vin->ax_max_machines, 16 * (size_t)vin->n_ax_max_machines);
         auto dp = [&](int k) { return reinterpret_cast<const double*>(db + o_v[k]); };
-        t->vin = fleet::FVelIn{dp(0), dp(1), dp(2), dp(3), dp(4), dp(5), dp(6), dp(7), reinterpret_cast<const int*>(db + o_em)};
-        t->axm = reinterpret_cast<const double*>(db + o_axm); t->n_axm = vin->n_ax_max_machines; t->vel_max = vin->vel_max[0]; t->any_emerg = any;
+        if (n_tab) { memcpy(hb + o_axo, vin->ax_table_off, 4 * (size_t)(n_tab + 1)); memcpy(hb + o_axi, vin->ax_table_idx, 4 * (size_t)N); }
+        t->vin = fleet::FVelIn{dp(0), dp(1), dp(2), dp(3), dp(4), dp(5), dp(6), dp(7), reinterpret_cast<const int*>(db + o_em),
+                               n_tab ? reinterpret_cast<const int*>(db + o_axo) : nullptr, n_tab ? reinterpret_cast<const int*>(db + o_axi) : nullptr};
+        t->axm = reinterpret_cast<const double*>(db + o_axm); t->vel_max = vin->vel_max[0]; t->any_emerg = any;
+        t->n_axm_total = vin->n_ax_max_machines; t->multi_axm = n_tab ? 1 : 0;
+        t->n_axm = n_tab ? vin->ax_table_off[1] - vin->ax_table_off[0] : vin->n_ax_max_machines;
         t->has_vel = true;
     }
     if (a.size) FLEET_TRY(f, hipMemcpyAsync(t->d_buf, f->h_stage, a.size, hipMemcpyHostToDevice, f->h->stream));
@@ -534,13 +558,16 @@ static int fleet_launch_paths(ltpl_fleet* f, const FleetTickIn& t, bool pre, boo
 
 // one launch of the velocity kernel over a job table. sel 1: forward-backward / brake jobs of all slots ("lite" LDS scratch); sel 2: the
 // follow jobs (slot 0 of every planner)
-static int fleet_launch_vel_jobs(ltpl_fleet* f, const ltpl_vel_params& vp, const double* d_axm, const FleetJobsDev& J, int sel)
+// kernel variant of a launch: with several machine tables (a fleet of different cars) the interpolating form, whatever table 0 looks like
+static int fleet_variant(const ltpl_vel_params& vp, bool multi) { const int v = vel_variant(&vp); return multi ? (v & ~1) : v; }
+
+static int fleet_launch_vel_jobs(ltpl_fleet* f, const ltpl_vel_params& vp, const double* d_axm, const FleetJobsDev& J, int sel, bool multi = false)
 {
     ltpl_handle* h = f->h;
     DevVelParams p;
     int rc = make_vel_params(h, &vp, d_axm, &p);
     if (rc) { f->err = h->err; return rc; }
-    vel_kernel_t kern = sel == 1 ? vel_kernel_const_of<1>(vel_variant(&vp)) : vel_kernel_const_of<2>(vel_variant(&vp));
+    vel_kernel_t kern = sel == 1 ? vel_kernel_const_of<1>(fleet_variant(vp, multi)) : vel_kernel_const_of<2>(fleet_variant(vp, multi));
     const size_t lds = sel == 1 ? f->vel_lds_lite : f->vel_lds;
     if (lds > 48 * 1024) FLEET_TRY(f, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     DoneSignal done; done.host_flag = nullptr; done.dev_count = nullptr; done.seq = 0u;
@@ -583,20 +610,21 @@ static int fleet_launch_vel(ltpl_fleet* f, const FleetTickIn& t)
     {   // forward-backward jobs (slots >= 1), one lane per job, on the second stream: 512 long waves for 8 192 planners -- next to the follow jobs
         DevVelParams p;
         if ((rc = make_vel_params(h, &vp, t.axm, &p))) { f->err = h->err; return rc; }
+        p.n_axm = t.n_axm_total;           // (the lane kernel stages ALL tables of the call; a job without its own table reads the first p.n_axm... rows of table 0 only when there is one table)
         const unsigned waves = (unsigned)(((size_t)N * (fleet::JOBS_A - 1) + 63) / 64);
         FLEET_TRY(f, hipEventRecord(f->ev_a, st));
         FLEET_TRY(f, hipStreamWaitEvent(f->stream2, f->ev_a, 0));
-        hipLaunchKernelGGL(fleet_lanes_kernel_of(vel_variant(&vp)), dim3(waves), dim3(64), 0, f->stream2, p, reinterpret_cast<const DevVelJob*>(f->JA.jobs),
+        hipLaunchKernelGGL(fleet_lanes_kernel_of(fleet_variant(vp, t.multi_axm != 0)), dim3(waves), dim3(64), 0, f->stream2, p, reinterpret_cast<const DevVelJob*>(f->JA.jobs),
                            (const double*)f->JA.pool, reinterpret_cast<const ke_t*>(f->JA.ke), f->JA.ke_rows, f->JA.outp, f->D.RV, N, (int)fleet::JOBS_A,
                            f->JA.out);
         FLEET_TRY(f, hipGetLastError());
         FLEET_TRY(f, hipEventRecord(f->ev_b, f->stream2));
     }
-    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA, 2))) return rc;        // follow jobs (slot 0): one wave per job
+    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA, 2, t.multi_axm != 0))) return rc;        // follow jobs (slot 0): one wave per job
     FLEET_TRY(f, hipStreamWaitEvent(st, f->ev_b, 0));
     hipLaunchKernelGGL(k_fleet_vel_b, dim3(N), dim3(64), 0, st, f->args, f->JA.view(), f->JB.view());
     FLEET_TRY(f, hipGetLastError());
-    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JB, 1))) return rc;
+    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JB, 1, t.multi_axm != 0))) return rc;
     hipLaunchKernelGGL(k_fleet_vel_c, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JB.view(), f->JC.view());
     FLEET_TRY(f, hipGetLastError());
     if (t.any_emerg) {
@@ -686,6 +714,7 @@ try {
     FleetTickIn& v = f->curv;
     if ((rc = fleet_pack_inputs(f, &v, nullptr, in, false))) return rc;
     FleetTickIn t = f->cur; t.vin = v.vin; t.axm = v.axm; t.n_axm = v.n_axm; t.vel_max = v.vel_max; t.any_emerg = v.any_emerg;
+    t.n_axm_total = v.n_axm_total; t.multi_axm = v.multi_axm;
     if ((rc = fleet_launch_vel(f, t))) return rc;
     return fleet_check(f);
 } LTPL_ABI_CATCH(abi_err_of(f))

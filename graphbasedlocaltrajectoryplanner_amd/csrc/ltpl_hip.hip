@@ -785,6 +785,9 @@ struct DevVelJob {
     int mode, n, n_el, has_v_end;
     int off_kappa, off_el, off_gg, off_out;       // offsets (in doubles) into the pooled job arrays
     double v_start, v_end, v_ego, v_obj, safety_d, obj_dist, obj_x, obj_y;
+    // the car of the job (fleet::VelJob, ABI v6): v_max <= 0 / n_axm == 0 -> the launch's parameter set (seam 2, host planner)
+    double v_max;
+    int axm_off, n_axm;                           // rows [axm_off, axm_off + n_axm) of the launch's stacked machine tables
 };
 
 // `lite`: only what the forward-backward and brake profiles touch (w, kabs, el, machine table, run flags) -- no arc length, no follow scratch
@@ -821,7 +824,7 @@ static size_t vel_scratch_bytes(int cap, bool with_gg, bool with_xy, bool lite =
 // (SEL 1: three arrays, "lite" scratch) and the follow jobs (SEL 2: six arrays, job slot 0 of every planner) as two launches; a block
 // whose job belongs to the other launch returns at once. `job_stride`: block b works on job b * job_stride.
 template <int EM, bool AXM1, bool GG = true, int SEL = 0>
-__global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p, const DevVelJob* jobs,
+__global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p_, const DevVelJob* jobs,
                                                     const double* pool, double* out_pool, int* out_flags, int cap,
                                                     long long* dbg, DoneSignal done, int job_stride)
 {
@@ -831,6 +834,10 @@ __global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p, 
     const int j = blockIdx.x * job_stride;
     const DevVelJob jb = jobs[j];
     if (jb.n <= 0) { signal_done(done); return; }          // unused slot of a fleet's job table (fleet_dev.hpp); seam (2) itself rejects empty jobs
+    // the car of the job: its own vel_max / machine table (a fleet of different cars), else the launch's
+    DevVelParams p = p_;
+    if (jb.v_max > 0.0) p.v_max = jb.v_max;
+    if (jb.n_axm > 0) { p.n_axm = jb.n_axm; p.axm = p_.axm + 2 * jb.axm_off; }
     const bool follow = jb.mode == LTPL_VEL_FOLLOW || jb.mode == LTPL_VEL_FOLLOW_CONTROLLED;
     if constexpr (SEL == 1) { if (follow) return; }
     if constexpr (SEL == 2) { if (!follow) return; }

@@ -64,6 +64,8 @@ inline int api_calc_vel_profile(ltpl_planner* p, const ltpl_planner_vel_in* in)
     if (!in || !in->pos_est_x || !in->pos_est_y || !in->vel_est || !in->vel_max || !in->gg_scale || !in->gg_ax || !in->gg_ay ||
         !in->safety_d || !in->ax_max_machines || in->n_ax_max_machines < 1)
         return p->P.fail(LTPL_ERR_INVALID_ARG, "planner: null input");
+    if (in->n_ax_tables > 1 || in->ax_table_off || in->ax_table_idx)
+        return p->P.fail(LTPL_ERR_UNSUPPORTED, "planner: machine tables per planner (ABI v6) are a feature of ltpl_fleet_*; ltpl_planner_* takes one table per call");
     const int n = (int)p->P.sc.size();
     std::vector<VelReq> req((size_t)n);
     for (int s = 0; s < n; ++s) {

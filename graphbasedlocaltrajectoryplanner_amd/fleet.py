@@ -46,6 +46,23 @@ class Fleet(Planner):
         vi, keep2 = self._pack_vel_in(pos_est, vel_est, **vel_kwargs)
         self._check(self._fn("tape_append")(self.handle, C.byref(pi), C.byref(vi)))
 
+    @staticmethod
+    def _machine_tables(vi, tables, idx, keep):
+        """Machine limits per planner (ABI v6): ``tables`` = list of (rows, 2) arrays [v, ax], ``idx`` = table of every planner. One table:
+        the plain form (ax_max_machines / n_ax_max_machines); several: stacked back to back with row offsets and the per-planner index."""
+        f64, i32 = np.float64, np.int32
+        tabs = [np.ascontiguousarray(np.asarray(t, f64).reshape(-1, 2)) for t in tables]
+        stacked = np.ascontiguousarray(np.concatenate(tabs))
+        vi.ax_max_machines, vi.n_ax_max_machines = stacked.ctypes.data, stacked.shape[0]
+        keep.append(stacked)
+        if len(tabs) > 1:
+            off = np.ascontiguousarray(np.concatenate(([0], np.cumsum([t.shape[0] for t in tabs]))).astype(i32))
+            ti = np.ascontiguousarray(np.asarray(idx, i32).reshape(-1))
+            vi.n_ax_tables, vi.ax_table_off, vi.ax_table_idx = len(tabs), off.ctypes.data, ti.ctypes.data
+            keep += [off, ti]
+        else:
+            vi.n_ax_tables, vi.ax_table_off, vi.ax_table_idx = 0, None, None
+
     def pack_groups(self, groups, ax_max_machines=((100.0, 5.0),)):
         """Input structs of one tick for planners that come in GROUPS with identical inputs (vectorised: no Python loop over planners).
         ``groups``: list of (count, dict) in planner order; dict keys: prev_action (name), t_now, vehicles [(radius, vel, positions)],
@@ -95,21 +112,31 @@ class Fleet(Planner):
             setattr(pi, k, a.ctypes.data)
         v = [cat(c, f64, 0.0) for c in vcols]
         em = cat(emerg, i32, 0)
-        axm = np.ascontiguousarray(np.asarray(ax_max_machines, f64).reshape(-1, 2))
         vi = PlannerVelIn()
         for name, a in zip(("pos_est_x", "pos_est_y", "vel_est", "vel_max", "gg_scale", "gg_ax", "gg_ay", "safety_d"), v):
             setattr(vi, name, a.ctypes.data)
-        vi.incl_emerg_traj, vi.ax_max_machines, vi.n_ax_max_machines = em.ctypes.data, axm.ctypes.data, axm.shape[0]
+        vi.incl_emerg_traj = em.ctypes.data
         vi.gg_row_off, vi.gg_rows = None, None
-        return pi, vi, (arrs, v, em, axm)
+        # machine limits: the call's table, or -- a fleet of different cars -- a table per group (key "ax_max_machines" of the group)
+        tables, tab_idx, keep_t = [], [], []
+        for cnt, g in groups:
+            t = np.asarray(g.get("ax_max_machines", ax_max_machines), f64).reshape(-1, 2)
+            k = next((i for i, u in enumerate(tables) if u.shape == t.shape and np.array_equal(u, t)), None)
+            if k is None:
+                tables.append(t); k = len(tables) - 1
+            tab_idx.append(np.full(cnt, k, i32))
+        Fleet._machine_tables(vi, tables, np.concatenate(tab_idx), keep_t)
+        return pi, vi, (arrs, v, em, keep_t)
 
     def pack_arrays(self, prev_action, t_now, veh_off, pos_off, veh_radius, veh_vel, pos_x, pos_y, zone_off, zone_gid,
                     pos_est, vel_est, vel_max=100.0, gg_scale=1.0, local_gg=(5.0, 5.0), safety_d=30.0, incl_emerg_traj=False,
-                    ax_max_machines=((100.0, 5.0),)):
+                    ax_max_machines=((100.0, 5.0),), ax_tables=None, ax_table_idx=None):
         """Input structs of one tick from the caller's own arrays (a simulator that holds its vehicles as arrays): the layout of
         ``ltpl_planner_paths_in`` / ``ltpl_planner_vel_in`` (include/ltpl_hip.h) -- ``prev_action`` action ids (LTPL_ACT_*) per planner,
         CSR offsets ``veh_off`` [n + 1] / ``pos_off`` [n_veh + 1] / ``zone_off`` [n + 1], own position of a vehicle first. Scalars are
-        broadcast. Returns (paths struct, velocity struct, keep-alive) like ``pack_groups``."""
+        broadcast; ``vel_max`` may be an array (one value per planner). Different cars: ``ax_tables`` = list of machine tables and
+        ``ax_table_idx`` = the table of every planner (instead of the one table ``ax_max_machines``). Returns (paths struct, velocity struct,
+        keep-alive) like ``pack_groups``."""
         n, i32, f64 = self.n_scen, np.int32, np.float64
 
         def arr(a, dt, size=None, pad=None):
@@ -133,13 +160,19 @@ class Fleet(Planner):
         v = [np.ascontiguousarray(pe[:, 0]), np.ascontiguousarray(pe[:, 1]), arr(vel_est, f64, n), arr(vel_max, f64, n), arr(gg_scale, f64, n),
              arr(local_gg[0], f64, n), arr(local_gg[1], f64, n), arr(safety_d, f64, n)]
         em = arr(np.asarray(incl_emerg_traj).astype(i32), i32, n)
-        axm = np.ascontiguousarray(np.asarray(ax_max_machines, f64).reshape(-1, 2))
         vi = PlannerVelIn()
         for name, a in zip(("pos_est_x", "pos_est_y", "vel_est", "vel_max", "gg_scale", "gg_ax", "gg_ay", "safety_d"), v):
             setattr(vi, name, a.ctypes.data)
-        vi.incl_emerg_traj, vi.ax_max_machines, vi.n_ax_max_machines = em.ctypes.data, axm.ctypes.data, axm.shape[0]
+        vi.incl_emerg_traj = em.ctypes.data
         vi.gg_row_off, vi.gg_rows = None, None
-        return pi, vi, (arrs, v, em, axm)
+        keep_t = []
+        if ax_tables is not None:
+            if ax_table_idx is None or len(np.asarray(ax_table_idx).reshape(-1)) != n:
+                raise ValueError("pack_arrays: ax_table_idx needs one entry per planner")
+            Fleet._machine_tables(vi, list(ax_tables), ax_table_idx, keep_t)
+        else:
+            Fleet._machine_tables(vi, [ax_max_machines], None, keep_t)
+        return pi, vi, (arrs, v, em, keep_t)
 
     def calc_paths_packed(self, pi):
         """``calc_paths`` on an input struct of ``pack_groups`` (a caller that already holds its fleet's inputs as arrays pays no packing)."""

@@ -45,8 +45,9 @@ class PlannerPathsIn(C.Structure):
 class PlannerVelIn(C.Structure):
     _fields_ = [("pos_est_x", _vp), ("pos_est_y", _vp), ("vel_est", _vp), ("vel_max", _vp),
                 ("gg_scale", _vp), ("gg_ax", _vp), ("gg_ay", _vp), ("safety_d", _vp),
-                ("incl_emerg_traj", _vp), ("n_ax_max_machines", C.c_int32), ("reserved0", C.c_int32),
-                ("ax_max_machines", _vp), ("gg_row_off", _vp), ("gg_rows", _vp)]
+                ("incl_emerg_traj", _vp), ("n_ax_max_machines", C.c_int32), ("n_ax_tables", C.c_int32),
+                ("ax_max_machines", _vp), ("gg_row_off", _vp), ("gg_rows", _vp),
+                ("ax_table_off", _vp), ("ax_table_idx", _vp)]         # ABI v6: machine tables per planner (fleet)
 
 
 class _Staging(object):

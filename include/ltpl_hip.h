@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LTPL_ABI_VERSION 5
+#define LTPL_ABI_VERSION 6
 
 /* status codes */
 #define LTPL_OK               0
@@ -458,14 +458,14 @@ typedef struct {                    /* arguments of Graph_LTPL.calc_vel_profile 
     const double*  pos_est_x;       /* [n_scen]                                                                   */
     const double*  pos_est_y;
     const double*  vel_est;
-    const double*  vel_max;         /* [n_scen] (one value per call: all entries must agree)                      */
+    const double*  vel_max;         /* [n_scen] ltpl_planner_*: one value per call (all entries must agree); ltpl_fleet_*: per planner (ABI v6) */
     const double*  gg_scale;
     const double*  gg_ax;           /* [n_scen] constant local_gg tuple (ax, ay)                                  */
     const double*  gg_ay;
     const double*  safety_d;
     const int32_t* incl_emerg_traj; /* [n_scen]                                                                   */
-    int32_t n_ax_max_machines;
-    int32_t reserved0;
+    int32_t n_ax_max_machines;      /* rows of ax_max_machines (all tables together)                              */
+    int32_t n_ax_tables;            /* ABI v6: 0 or 1 = ONE machine table for every planner of the call (was reserved0)            */
     const double*  ax_max_machines; /* [n_ax_max_machines * 2] rows [v, ax]                                       */
     /* ABI v4 -- LOCATION DEPENDENT FRICTION, local_gg as a dict {action id: [rows x (ax, ay)]} (OnlineTrajectoryHandler.py:649-666;
      * Graph_LTPL.py:360-365). Both NULL: constant friction (gg_ax / gg_ay). Otherwise rows gg_row_off[s * LTPL_PLANNER_MAX_KEYS + k]
@@ -474,6 +474,12 @@ typedef struct {                    /* arguments of Graph_LTPL.calc_vel_profile 
      * a key with zero rows falls back to (gg_ax, gg_ay)                                                            */
     const int32_t* gg_row_off;      /* [n_scen * LTPL_PLANNER_MAX_KEYS + 1]                                       */
     const double*  gg_rows;         /* [total rows * 2] rows [ax, ay]                                             */
+    /* ABI v6 -- A FLEET OF DIFFERENT CARS (ltpl_fleet_* only; ltpl_planner_* returns LTPL_ERR_UNSUPPORTED): Graph_LTPL.calc_vel_profile
+     * takes vel_max and ax_max_machines per call, i.e. per vehicle (Graph_LTPL.py:344-351). n_ax_tables > 1: ax_max_machines holds that
+     * many tables back to back, table t = rows ax_table_off[t] .. ax_table_off[t + 1] (ax_table_off[n_ax_tables] = n_ax_max_machines),
+     * planner s uses table ax_table_idx[s]. Both NULL with n_ax_tables <= 1: one table for all.                                    */
+    const int32_t* ax_table_off;    /* [n_ax_tables + 1] first row of every table                                  */
+    const int32_t* ax_table_idx;    /* [n_scen] table of every planner                                              */
 } ltpl_planner_vel_in;
 
 /* Sizes a caller needs for the query buffers below: rows per (stitched) path / trajectory, nodes per path. */

@@ -62,8 +62,16 @@ int run_jobs(HostFleet* F, const ltpl_vel_params& vp, JobSet& J)
         jobs.push_back(jb); res.push_back(r); idx.push_back(j);
     }
     if (jobs.empty()) return LTPL_OK;
-    const int rc = oracle_vel_profile(F->d, &vp, (int)jobs.size(), jobs.data(), res.data());
-    if (rc) { F->err = "oracle_vel_profile failed"; return rc; }
+    // a fleet of different cars (ABI v6): a job may carry its own vel_max / machine table (fleet::VelJob) -- such jobs are solved one by one
+    // with their own parameter set, the others in one call with the launch's
+    for (size_t i = 0; i < idx.size(); ++i) {
+        const VelJob& v = J.jobs[idx[i]];
+        ltpl_vel_params pj = vp;
+        if (v.v_max > 0.0) pj.v_max = v.v_max;
+        if (v.n_axm > 0) { pj.n_ax_max_machines = v.n_axm; pj.ax_max_machines = vp.ax_max_machines + 2 * (size_t)v.axm_off; }
+        const int rc = oracle_vel_profile(F->d, &pj, 1, &jobs[i], &res[i]);
+        if (rc) { F->err = "oracle_vel_profile failed"; return rc; }
+    }
     for (size_t i = 0; i < idx.size(); ++i) { J.flags[2 * idx[i]] = res[i].too_close; J.flags[2 * idx[i] + 1] = res[i].vel_bound; }
     return LTPL_OK;
 }
@@ -173,12 +181,15 @@ int oracle_fleet_calc_vel_profile(oracle_fleet* f, const ltpl_planner_vel_in* in
     if (!f || !in) return LTPL_ERR_INVALID_ARG;
     HostFleet& F = f->F; const int n = F.D.N;
     if (in->gg_row_off || in->gg_rows) { F.err = err_text(0, LTPL_ERR_UNSUPPORTED | (E_GG_DICT << 8)); return LTPL_ERR_UNSUPPORTED; }
-    for (int s = 1; s < n; ++s) if (in->vel_max[s] != in->vel_max[0]) { F.err = "fleet: vel_max must be the same for all planners of a call"; return LTPL_ERR_UNSUPPORTED; }
+    const int n_tab = in->n_ax_tables > 1 ? in->n_ax_tables : 0;
+    if (n_tab && (!in->ax_table_off || !in->ax_table_idx)) { F.err = "fleet: n_ax_tables > 1 without ax_table_off / ax_table_idx"; return LTPL_ERR_INVALID_ARG; }
     ltpl_vel_params vp; std::memset(&vp, 0, sizeof(vp));
     vp.dyn_model_exp = F.pc.dyn_model_exp; vp.drag_coeff = F.pc.drag_coeff; vp.m_veh = F.pc.m_veh; vp.len_veh = F.lat.veh_length;
-    vp.n_ax_max_machines = in->n_ax_max_machines; vp.ax_max_machines = in->ax_max_machines; vp.follow_control_type = F.pc.follow_control_type;
+    vp.n_ax_max_machines = n_tab ? in->ax_table_off[1] - in->ax_table_off[0] : in->n_ax_max_machines; vp.ax_max_machines = in->ax_max_machines;
+    vp.follow_control_type = F.pc.follow_control_type;
     vp.c_p = F.pc.c_p; vp.k_p = F.pc.k_p; vp.k_d = F.pc.k_d; vp.tan_w = F.pc.tan_w; vp.v_max = in->vel_max[0];
-    FVelIn vin{in->pos_est_x, in->pos_est_y, in->vel_est, in->vel_max, in->gg_scale, in->gg_ax, in->gg_ay, in->safety_d, in->incl_emerg_traj};
+    FVelIn vin{in->pos_est_x, in->pos_est_y, in->vel_est, in->vel_max, in->gg_scale, in->gg_ax, in->gg_ay, in->safety_d, in->incl_emerg_traj,
+               n_tab ? in->ax_table_off : nullptr, n_tab ? in->ax_table_idx : nullptr};
     HostX x; int rc;
     FJobs JA = F.JA.view(), JB = F.JB.view(), JC = F.JC.view();
     for (int p = 0; p < n; ++p) { Block B = F.block(p); vel_a(x, F.flat, F.cfg, B, *B.S(), p, F.obj(), vin, JA); }

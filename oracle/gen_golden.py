@@ -148,6 +148,14 @@ def main_ticks(only=None):
     record_ticks("overtake", 600, lambda gl: [Dummy(gl)(dynamic=True, vel_scale=0.5, s0=120.0)], rs.ZONE_EXAMPLE,
                  vel_kwargs=lambda t: {'gg_scale': 1.0 if t < 200 else 0.5, 'incl_emerg_traj': (t % 3 == 0)},
                  action_pref=("left", "right", "straight", "follow"))
+    # a DIFFERENT CAR (round 4): vel_max 42 m/s and the machine limits of inputs/veh_dyn_info/ax_max_machines.csv (18 rows) instead of
+    # Graph_LTPL.calc_vel_profile's defaults (100 m/s, [[100, 5]]) -- with an opponent, so that follow and overtake profiles run under
+    # these limits too. Replayed by a fleet NEXT TO the default car of the c2 recording: per-planner vel_max / ax_max_machines.
+    axm_csv = np.loadtxt(os.path.join(rs.REF_ROOT if hasattr(rs, "REF_ROOT") else "/root/reference", "inputs", "veh_dyn_info", "ax_max_machines.csv"),
+                         delimiter=",", comments="#")
+    record_ticks("car2", 400, lambda gl: [Dummy(gl)(dynamic=True, vel_scale=0.4, s0=140.0)], rs.ZONE_EXAMPLE,
+                 vel_kwargs=lambda t: {'vel_max': 42.0, 'ax_max_machines': axm_csv, 'incl_emerg_traj': (t % 5 == 0)},
+                 action_pref=("left", "right", "straight", "follow"))
     # location dependent friction: local_gg as a dict of per-path rows (OTH.py:649-666), rows = friction_map(path coordinates); an
     # opponent ahead so that follow / overtake profiles and (with incl_emerg_traj) the emergency profile run on varying friction too
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -197,3 +197,47 @@ def test_array_inputs_equal_the_list_inputs(fleet_backend, monteblanco):
         assert list(ta[0].keys()) == list(tb[0].keys()) and ta[1] == tb[1]
         for key in ta[0]:
             assert np.array_equal(ta[0][key][0], tb[0][key][0]), (t['tick'], key)
+
+
+def two_cars_replay(fleet, lat, n_per_group, n_ticks, check_every=1):
+    """A fleet of DIFFERENT cars in one call per tick (ABI v6): group A replays the reference's c2 loop (vel_max 100 m/s, machine table
+    [[100, 5]] = Graph_LTPL.calc_vel_profile's defaults), group B the reference's car2 loop (vel_max 42 m/s, the 18-row table of
+    inputs/veh_dyn_info/ax_max_machines.csv) -- every planner must reproduce what the unmodified reference computed for ITS car."""
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    from graphbasedlocaltrajectoryplanner_amd.tick_replay import vehicles_of_tick, zone_gids_of_tick, check_trajectories
+    for name in ("pack_groups", "calc_paths_packed", "calc_vel_profile_packed"):      # (the CPU harness binds the Planner class)
+        if not hasattr(fleet, name):
+            setattr(fleet, name, getattr(Fleet, name).__get__(fleet))
+    recs = [pr.load_ticks("c2")[:n_ticks], pr.load_ticks("car2")[:n_ticks]]
+    assert recs[1][0]['vel_args']['vel_max'] == 42.0 and len(recs[1][0]['vel_args']['ax_max_machines']) == 18
+    n = n_per_group
+    for g, ticks in enumerate(recs):
+        st = ticks[0]['start']
+        for q in range(g * n, (g + 1) * n):
+            fleet.set_start(q, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+    seen = set()
+    for k in range(n_ticks):
+        groups = []
+        for ticks in recs:
+            t, va = ticks[k], ticks[k]['vel_args']
+            groups.append((n, dict(prev_action=t['action_id_sel'], t_now=t['t'], vehicles=vehicles_of_tick(t), zone_gids=zone_gids_of_tick(lat, t),
+                                   pos_est=t['pos_est'], vel_est=va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'],
+                                   local_gg=tuple(va['local_gg']), safety_d=va['safety_d'], incl_emerg_traj=va['incl_emerg_traj'],
+                                   ax_max_machines=va['ax_max_machines'])))
+        pi, vi, keep = fleet.pack_groups(groups)
+        fleet.calc_paths_packed(pi)
+        fleet.calc_vel_profile_packed(vi)
+        if k % check_every == 0 or k == n_ticks - 1:
+            for g, ticks in enumerate(recs):
+                for q in sorted(set((g * n, (g + 1) * n - 1))):
+                    traj, ids, ref = fleet.trajectories(q)
+                    check_trajectories(traj, ids, ref, ticks[k], "car %d planner %d tick %d" % (g, q, k))
+                    seen.update(traj.keys())
+    return seen
+
+
+def test_a_fleet_of_different_cars(fleet_backend, monteblanco):
+    """Per-planner vel_max and ax_max_machines (Graph_LTPL.calc_vel_profile takes them per call = per vehicle, Graph_LTPL.py:344-351)
+    through ONE fleet call per tick, pinned to two recordings of the unmodified reference made with different cars."""
+    seen = two_cars_replay(fleet_backend.planner(4), monteblanco, 2, 260)
+    assert {"follow", "right", "emergency"} <= seen

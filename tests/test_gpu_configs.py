@@ -6,6 +6,8 @@
   C5  high-resolution oval (0.5 m layer spacing, 21 lateral nodes) with a slow opponent ahead: the single-tick latency
       kernel incl. the follow-mode velocity profile on every tick
 All through the C ABI (libltpl_hip.so) against the oracle on identical packed inputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -15,6 +17,8 @@ from graphbasedlocaltrajectoryplanner_amd import _capi
 from graphbasedlocaltrajectoryplanner_amd.scenario_gen import c2_scenarios, raceline_state
 from graphbasedlocaltrajectoryplanner_amd.sharding import shard_bounds, RESULT_FIELDS, VEL_FIELDS
 from graphbasedlocaltrajectoryplanner_amd.synthetic_lattice import c3_lattice, c5_lattice, scattered_obstacle_scenarios
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -264,3 +268,26 @@ def test_object_ingestion_matches_reference_and_oracle(monteblanco, hip_backend,
     assert np.array_equal(a["on_track"], b["on_track"]) and 0.2 < a["on_track"].mean() < 0.8
     assert np.allclose(a["pred_x"], b["pred_x"], rtol=0, atol=1e-11) and np.allclose(a["pred_y"], b["pred_y"], rtol=0, atol=1e-11)
     assert np.array_equal(a["radius"], b["radius"])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """SURVEY section 8e readiness without an 8-GPU node: bench.py --gpus 2 spawns two ranks (LTPL_BENCH_SHARE_GPU=1: both on device 0, gloo
+    for the barrier / max / gather) -- the N > 1 code path of the driver's scaling run end to end on real kernels: one line from rank 0,
+    n_gpus = 2, the value counts both shards, per-rank times, the sharded fleet leg, parity of rank 0's shard."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, LTPL_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--batch", "4096",
+                        "--exact-steps", "--cpu-sample", "64", "--fleet-planners", "512", "--fleet-ticks", "40"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["parity_checked"] is True
+    assert len(out["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in out["per_rank_ms_per_step"]) and out["efficiency_vs_n1"] is None
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 2 * 4096) < 1e-3 * 2 * 4096
+    fs = out["extra"]["closed_loop_device_sharded"]
+    assert fs["planners_total"] == 512 and len(fs["per_rank_planner_ticks_per_s"]) == 2 and fs["matches_recording"] is True

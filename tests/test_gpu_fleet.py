@@ -147,3 +147,15 @@ def test_split_entry_points_equal_the_fused_ones(hip, monteblanco):
     seen = pr.replay(_SplitCalls(fleet), monteblanco, pr.load_ticks("zonewall"), scen=1)
     assert seen['full'] >= 15
     fleet.close()
+
+
+def test_a_fleet_of_different_cars_on_the_device(hip, monteblanco):
+    """ABI v6 on the MI355X: per-planner vel_max / machine tables in one ltpl_fleet_calc_vel_profile call per tick -- 2 x 33 planners replay
+    the reference's c2 (default car) and car2 (vel_max 42 m/s, 18-row machine table) recordings side by side; lane-per-job forward-backward
+    jobs and wave-per-job follow jobs both take the car from the job."""
+    from test_fleet_host_logic import two_cars_replay
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    fleet = Fleet(hip, 66)
+    seen = two_cars_replay(fleet, monteblanco, 33, 300, check_every=7)
+    fleet.close()
+    assert {"follow", "right", "emergency"} <= seen
