@@ -46,20 +46,18 @@ inline FCfg fcfg_of(const ltpl_planner_config* cfg)
     return c;
 }
 
-// OnlineTrajectoryHandler.set_initial_pose through the host planner's set_start, converted into a zeroed planner block image
+// OnlineTrajectoryHandler.set_initial_pose (planner_core.hpp) converted into a zeroed planner block image
 // (`prev`: the planner's scalars before the call or nullptr -- set_initial_pose only re-initialises the iterative memory, OTH.py:161-179)
 inline int start_block(const ltplp::HostLat& lat, const Dims& D, double x, double y, double heading, double vel, double mho,
                        int* in_track, int* cor_heading, unsigned char* image, const PlannerS* prev, std::string* why)
 {
-    ltplp::Planner P;
-    P.lat = lat; P.sc.resize(1);
-    int rc = P.set_start(0, x, y, heading, vel, mho, in_track, cor_heading);
-    if (rc) { *why = P.err; return rc; }
-    const ltplp::Scn& H = P.sc[0];
+    ltplp::StartPose H;
+    const int rc = ltplp::set_initial_pose(lat, x, y, heading, vel, mho, in_track, cor_heading, &H, why);
+    if (rc) return rc;
     PlannerS keep{}; const bool carry = prev != nullptr;
     if (carry) keep = *prev;
     std::memset(image, 0, D.stride);
-    Block B{image, D};
+    Block B{image, D, nullptr};
     PlannerS& S = *B.S();
     if (carry) {
         S.traj_base_id = keep.traj_base_id; S.n_calc = keep.n_calc; std::memcpy(S.calc_buffer, keep.calc_buffer, sizeof(S.calc_buffer));
@@ -70,8 +68,8 @@ inline int start_block(const ltplp::HostLat& lat, const Dims& D, double x, doubl
     S.sel_action = S.raw_action = LTPL_ACT_NONE;
     S.const_rows = -1; S.old_gg_scale = carry ? keep.old_gg_scale : 1.0;
     S.has_last = H.has_last ? 1 : 0;
-    if (H.has_last && !H.last.empty()) {
-        const ltplp::Traj& T = H.last[0];
+    if (H.has_last) {
+        const ltplp::Traj& T = H.last;
         if (T.rows() > D.R || T.n_nodes() > D.CN) { *why = "fleet: start spline exceeds the row capacity"; return LTPL_ERR_CAPACITY; }
         TrajM& M = S.tm[0][0];
         M.id = T.id; M.red_len = T.red_len ? 1 : 0; M.rows = T.rows(); M.nc = (int)(T.coeff.size() / 8); M.nn = T.n_nodes(); M.ni = (int)T.node_idx.size();
@@ -88,7 +86,7 @@ inline void caps_of(const Dims& D, ltpl_planner_caps* c) { c->cap_rows = D.R; c-
 
 inline int paths_view(const Dims& D, const unsigned char* image, ltpl_planner_paths_view* v)
 {
-    Block B{const_cast<unsigned char*>(image), D};
+    Block B{const_cast<unsigned char*>(image), D, nullptr};
     const PlannerS& S = *B.S();
     v->n_keys = 0;
     v->start_node[0] = S.has_start ? S.start_node[0] : -1; v->start_node[1] = S.has_start ? S.start_node[1] : -1;
@@ -107,7 +105,7 @@ inline int paths_view(const Dims& D, const unsigned char* image, ltpl_planner_pa
 
 inline int traj_view(const Dims& D, const unsigned char* image, ltpl_planner_traj_view* v)
 {
-    Block B{const_cast<unsigned char*>(image), D};
+    Block B{const_cast<unsigned char*>(image), D, nullptr};
     const PlannerS& S = *B.S();
     v->n_keys = 0;
     v->cut_index_pos = S.cut_index_pos; v->cut_layer = S.cut_layer; v->vel_plan = S.vel_plan; v->acc_plan = S.acc_plan;
@@ -132,7 +130,8 @@ inline std::string err_text(int planner, int err)
         "fewer than 6 rows (IndexError, OTH.py:923)", "cut_layer beyond the backup plan", "backup plan shorter than the cut index",
         "backup brake profile length mismatch", "emergency profile without any trajectory (IndexError, OTH.py:1029)", "calc_time_buffer_len above 16",
         "local_gg in its dict form is not supported by the fleet (use the host planner)", "more velocity jobs than slots", "start layer without a planning range (end of an open track)",
-        "velocity job longer than max_path_pts + 64 points"};
+        "velocity job longer than max_path_pts + 64 points",
+        "local_gg rows of a path do not match its coordinates (OTH.py:641-646)"};
     const int site = (err >> 8) & 0xff;
     return "fleet: planner " + std::to_string(planner) + ": " + (site > 0 && site < (int)(sizeof(sites) / sizeof(sites[0])) ? sites[site] : "error");
 }

@@ -12,8 +12,9 @@
 //   ref_idx     OnlineTrajectoryHandler.get_ref_idx                              OTH.py:518-601
 //   vel_a/b/c/d OnlineTrajectoryHandler.calc_vel_profile in four stages around the three launches of seam (2)   OTH.py:603-1040
 //
-// Restrictions against planner_core.hpp (reported, not emulated): local_gg in its constant form only (the dict form stays with the
-// host planner), fixed capacities (rows / nodes per stitched path, planner_caps), errors are per-planner codes instead of messages.
+// Restrictions (reported, not emulated): fixed capacities (rows / nodes per stitched path, planner_caps), errors are per-planner codes.
+// Round 4: location dependent friction (local_gg as a dict of per-path rows, OTH.py:649-666) is part of the state machine -- the host
+// planner (ltpl_planner_*) is the one-lane instantiation of THIS source (planner_host.hpp), not a second implementation.
 #pragma once
 
 #include <cmath>
@@ -40,7 +41,8 @@ FLT_FN double inf() { return HUGE_VAL; }
 
 // error sites (S.err = LTPL_ERR_* | site << 8)
 enum Site { E_BACKUP_KEY = 1, E_NO_START, E_CAP_ROWS, E_CAP_NODES, E_CUT_LAYER, E_BRAKE_PREFIX, E_FOLLOW_EMPTY, E_NO_NODES, E_END_NONE,
-            E_FOLLOW_SHORT, E_VX_SHORT, E_ROW5, E_BACKUP_CUT, E_BACKUP_SHORT, E_BACKUP_LEN, E_EMERG_EMPTY, E_CALC_BUF, E_GG_DICT, E_CAP_JOBS, E_NO_RANGE, E_CAP_VEL };
+            E_FOLLOW_SHORT, E_VX_SHORT, E_ROW5, E_BACKUP_CUT, E_BACKUP_SHORT, E_BACKUP_LEN, E_EMERG_EMPTY, E_CALC_BUF, E_GG_DICT, E_CAP_JOBS, E_NO_RANGE, E_CAP_VEL,
+            E_GG_ROWS };
 
 // ---------------------------------------------------------------------------------------------------------------------
 // plain-data state
@@ -51,13 +53,15 @@ struct TrajM {                      // one entry of __last_action_set_* (windows
     int c0, nc;                     // coeff rows of 8
     int n0, nn;                     // node pairs [layer, node]
     int i0, ni;                     // node indices
-    double gax, gay;                // __last_action_set_path_gg (constant rows)
+    double gax, gay;                // __last_action_set_path_gg: constant rows ...
+    int has_gg, pad_;               // ... or (location dependent friction) one row per path coordinate in the slot's gg array, same window as the rows
 };
 
 struct Work {                       // per key of the current tick, stages A -> C
     int n, c0, vel_idx, pref_idx, v_idx, cut_index_layer;
     int job_follow, job_free, job_fb, job_backup;
     int generic, has_fb, too_close, vel_bound, keep, drop, empty;
+    int gv_n, pad_;                 // rows of this key's friction rows from the cut on (0: constant friction), kept in Block::gv for stage C
     double vel_start;
 };
 
@@ -89,6 +93,10 @@ struct Dims {
     int RV;                         // points per velocity job (LDS-resident solver): cp + 64 <= R
     size_t stride;                  // bytes per planner block
     size_t o_traj, traj_bytes, o_bp, o_velc, o_sarr, o_vx, o_scr;
+    // Friction rows (local_gg as a dict) live in their OWN array, allocated when the first call carries rows: [ax, ay] per path row for the
+    // 2 x KEYS trajectory slots + KEYS windows "from the cut on" for stage C. Inside the planner block they made every fleet's state
+    // 57 % larger (Monteblanco: 235 -> 370 KB per planner) and the fleet tick 5 % slower whether rows were ever passed or not (r04h).
+    size_t gg_slot, gg_stride;
     FLT_FN size_t o_pp() const { return 0; }
     FLT_FN size_t o_coeff() const { return sizeof(double) * (size_t)R * 5; }
     FLT_FN size_t o_nodes() const { return o_coeff() + sizeof(double) * (size_t)CN * 8; }
@@ -103,7 +111,8 @@ inline Dims make_dims(int N, int max_path_nodes, int max_path_pts)
     D.N = N; D.cn = max_path_nodes; D.cp = max_path_pts;
     D.R = 2 * max_path_pts + 64; D.CN = 2 * max_path_nodes + 8;            // = ltpl_planner_caps
     D.RV = max_path_pts + 64;
-    D.traj_bytes = align256(sizeof(double) * (size_t)D.R * 5 + sizeof(double) * (size_t)D.CN * 8 + sizeof(int) * (size_t)D.CN * 3);
+    D.traj_bytes = align256(D.o_nidx() + sizeof(int) * (size_t)D.CN);
+    D.gg_slot = align256(sizeof(double) * (size_t)D.R * 2); D.gg_stride = D.gg_slot * 3 * KEYS;
     size_t o = align256(sizeof(PlannerS));
     D.o_traj = o; o += D.traj_bytes * 2 * KEYS;
     D.o_bp = o; o += align256(sizeof(double) * (size_t)D.R * 7) * BPS;
@@ -126,14 +135,16 @@ struct Rows {
     FLT_FN const double* col(int c) const { return p + (size_t)c * ld; }
 };
 
-struct Block {                      // one planner's memory
-    unsigned char* b; Dims D;
+struct Block {                      // one planner's memory (`g`: its friction rows, null until a call carries rows)
+    unsigned char* b; Dims D; unsigned char* g;
     FLT_FN PlannerS* S() const { return reinterpret_cast<PlannerS*>(b); }
     FLT_FN unsigned char* slot(int set, int k) const { return b + D.o_traj + D.traj_bytes * (size_t)(set * KEYS + k); }
     FLT_FN Rows pp(int set, int k) const { return Rows{reinterpret_cast<double*>(slot(set, k)), D.R}; }
     FLT_FN double* coeff(int set, int k) const { return reinterpret_cast<double*>(slot(set, k) + D.o_coeff()); }
     FLT_FN int* nodes(int set, int k) const { return reinterpret_cast<int*>(slot(set, k) + D.o_nodes()); }
     FLT_FN int* nidx(int set, int k) const { return reinterpret_cast<int*>(slot(set, k) + D.o_nidx()); }
+    FLT_FN Rows gg(int set, int k) const { return Rows{reinterpret_cast<double*>(g + D.gg_slot * (size_t)(set * KEYS + k)), D.R}; }
+    FLT_FN Rows gv(int k) const { return Rows{reinterpret_cast<double*>(g + D.gg_slot * (size_t)(2 * KEYS + k)), D.R}; }
     FLT_FN Rows bp(int k) const { return Rows{reinterpret_cast<double*>(b + D.o_bp + align256(sizeof(double) * (size_t)D.R * 7) * (size_t)k), D.R}; }
     FLT_FN double* velc() const { return reinterpret_cast<double*>(b + D.o_velc); }
     FLT_FN double* sarr(int k) const { return reinterpret_cast<double*>(b + D.o_sarr + align256(sizeof(double) * (size_t)D.R) * (size_t)k); }
@@ -165,7 +176,10 @@ struct FPathsOut { const int* closest_obj_index; const int* n_actions; const int
 struct FVelIn { const double* pos_x; const double* pos_y; const double* vel_est; const double* vel_max; const double* gg_scale;
                 const double* gg_ax; const double* gg_ay; const double* safety_d; const int* incl_emerg;
                 // ABI v6: machine tables per planner (null: one table for the call): first row of every table, table of every planner
-                const int* ax_off; const int* ax_idx; };
+                const int* ax_off; const int* ax_idx;
+                // location dependent friction (local_gg as a dict, OTH.py:649-666; null: the constant tuple): rows gg_off[p * MK + k] ..
+                // gg_off[p * MK + k + 1] of gg_rows ([ax, ay] per path coordinate) belong to planner p's k-th path key, MK = LTPL_PLANNER_MAX_KEYS
+                const int* gg_off; const double* gg_rows; };
 
 // seam (2): job table + pooled arrays (the layout k_vel_profile reads). Job slot j owns 4 R doubles of `pool` (kappa R | el R | gg 2 R)
 // and R doubles of `out`; an unused slot has n = 0.
@@ -177,8 +191,17 @@ struct VelJob {
     // call = per vehicle (Graph_LTPL.py:344-351). v_max <= 0 / n_axm == 0: the parameter set of the launch.
     double v_max;
     int axm_off, n_axm;             // the job's machine table: rows [axm_off, axm_off + n_axm) of the call's stacked tables
+    int gg_rows, pad_;              // 1: the friction limits differ from row to row (pool form, [ax, ay] per row); 0: gg[0], gg[1] for every row
 };
 struct JobCar { double v_max; int axm_off, n_axm; };
+// friction limits of a job's rows: constant (ax, ay) or rows of a [ax, ay] table (window `g`, first row `base`), times `scale`
+struct GgSrc {
+    Rows g; double ax, ay, scale;
+    FLT_FN bool rows() const { return g.p != nullptr; }
+    FLT_FN double at(int i, int c) const { return g.p ? g.at(i, c) * scale : (c ? ay : ax) * scale; }
+};
+FLT_FN GgSrc gg_const(double ax, double ay, double scale = 1.0) { return GgSrc{Rows{nullptr, 0}, ax, ay, scale}; }
+FLT_FN GgSrc gg_table(const Rows& g, double scale = 1.0) { return GgSrc{g, 0.0, 0.0, scale}; }
 FLT_FN JobCar car_of(const FVelIn& vin, int p)
 {
     JobCar c{vin.vel_max[p], 0, 0};
@@ -588,24 +611,24 @@ FLT_FN void finalize_bp(const X& x, const FCfg& cfg, const double* s_arr, const 
 
 // job slot `slot` of planner p (slot 0 is reserved for the follow job of a tick: the device runs the follow jobs as their own launch)
 template <class X>
-FLT_FN int make_job(const X& x, const Dims& D, const FJobs& J, int p, int slot, int mode, const Rows& pv, double gax, double gay, int i0, int i1,
+FLT_FN int make_job(const X& x, const Dims& D, const FJobs& J, int p, int slot, int mode, const Rows& pv, const GgSrc& gsrc, int i0, int i1,
                     int n_el, double v_start, bool has_end, double v_end, const JobCar& car = JobCar{0.0, 0, 0})
 {
     const int j = p * J.per_planner + slot;
     VelJob jb{};
-    jb.v_max = car.v_max; jb.axm_off = car.axm_off; jb.n_axm = car.n_axm;
+    jb.v_max = car.v_max; jb.axm_off = car.axm_off; jb.n_axm = car.n_axm; jb.gg_rows = gsrc.rows() ? 1 : 0;
     jb.mode = mode; jb.n = i1 - i0; jb.n_el = n_el; jb.has_v_end = has_end ? 1 : 0; jb.v_start = v_start; jb.v_end = v_end;
     jb.off_kappa = j * 4 * D.R; jb.off_el = jb.off_kappa + D.R; jb.off_gg = jb.off_kappa + 2 * D.R; jb.off_out = j * D.R;
     double* kap = J.pool + jb.off_kappa; double* el = J.pool + jb.off_el; double* gg = J.pool + jb.off_gg;
-    if (J.ke && mode == LTPL_VEL_FB && slot >= 1) {
+    if (J.ke && mode == LTPL_VEL_FB && slot >= 1 && !gsrc.rows()) {
         F2* ke = J.ke + kep_base_f(p * (J.per_planner - 1) + slot - 1, J.ke_rows);
         for (int i = x.lane(); i < i1 - i0; i += X::W) {
             F2 r; r.x = (ke_scalar_f)fabs(pv.at(i0 + i, 3)); r.y = i < n_el ? (ke_scalar_f)pv.at(i0 + i, 4) : (ke_scalar_f)0;
             ke[kep_row_f(i)] = r;
         }
-        if (x.lane() == 0) { gg[0] = gax; gg[1] = gay; }
+        if (x.lane() == 0) { gg[0] = gsrc.at(0, 0); gg[1] = gsrc.at(0, 1); }
     } else {
-        for (int i = x.lane(); i < i1 - i0; i += X::W) { kap[i] = pv.at(i0 + i, 3); gg[(size_t)i * 2] = gax; gg[(size_t)i * 2 + 1] = gay; }
+        for (int i = x.lane(); i < i1 - i0; i += X::W) { kap[i] = pv.at(i0 + i, 3); gg[(size_t)i * 2] = gsrc.at(i0 + i, 0); gg[(size_t)i * 2 + 1] = gsrc.at(i0 + i, 1); }
         for (int i = x.lane(); i < n_el; i += X::W) el[i] = pv.at(i0 + i, 4);
         if (n_el < 1 && x.lane() == 0) el[0] = 0.0;
     }
@@ -625,8 +648,7 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
     if (S.err) return;
     if (!S.ref_done) ref_idx(x, cfg, B, S, vin.pos_x[p], vin.pos_y[p]);
     S.ref_done = 0;
-    const double vel_max = vin.vel_max[p], gg_scale = vin.gg_scale[p], gax = vin.gg_ax[p], gay = vin.gg_ay[p];
-    const JobCar car = car_of(vin, p);
+    const double vel_max = vin.vel_max[p], gg_scale = vin.gg_scale[p];
     S.traj_base_id += 10;
     if (!S.has_old_gg) { S.old_gg_scale = gg_scale; S.has_old_gg = 1; }
     S.n_bp = 0; S.has_bp = 1; S.n_ids = 0;
@@ -634,6 +656,34 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
     const int set = S.cur_set;
     int n_jobs = 1;                                        // next free slot (0: the follow job)
     S.n_work = S.n_last;
+    // local gg of the stitched paths (:641-666): the caller's rows for a key ("each path coordinate must be represented by a row"), or the
+    // constant tuple. Rows are kept next to the path rows (same window: they are trimmed with them) and, from the cut on, in Block::gv(k)
+    // for stage C (the emergency profile uses the FIRST kept key's rows even when that key falls back to the backup plan). Its own loop
+    // in front of the job construction: calls without rows (the common case) pay one uniform branch.
+    if (vin.gg_off && vin.gg_rows && B.g) {
+        const int MK = LTPL_PLANNER_MAX_KEYS;
+        for (int k = 0; k < S.n_last; ++k) {
+            const int sl = S.last_slot[k];
+            TrajM& T = S.tm[set][sl];
+            const int rows = T.rows;
+            const int c0 = S.cut_index_pos < 0 ? 0 : (S.cut_index_pos < rows ? S.cut_index_pos : rows);
+            int g_n = 0; const double* g_src = vin.gg_rows;
+            if (k < MK) { const int o0 = vin.gg_off[p * MK + k]; g_n = vin.gg_off[p * MK + k + 1] - o0; g_src += (size_t)o0 * 2; }
+            if (g_n > 0 && g_n != rows) { fail(S, LTPL_ERR_INVALID_ARG, E_GG_ROWS); return; }
+            if (g_n > 0) {
+                const Rows G = B.gg(set, sl).from(T.r0), gv = B.gv(k);
+                for (int i = x.lane(); i < rows; i += X::W) {
+                    const double ax = g_src[(size_t)i * 2], ay = g_src[(size_t)i * 2 + 1];
+                    G.at(i, 0) = ax; G.at(i, 1) = ay;
+                    if (i >= c0) { gv.at(i - c0, 0) = ax; gv.at(i - c0, 1) = ay; }
+                }
+            }
+            T.has_gg = g_n > 0 ? 1 : 0;
+        }
+        x.sync();
+    } else {
+        for (int k = 0; k < S.n_last; ++k) S.tm[set][S.last_slot[k]].has_gg = 0;
+    }
     for (int k = 0; k < S.n_last; ++k) {
         const int sl = S.last_slot[k];
         TrajM& T = S.tm[set][sl];
@@ -648,6 +698,7 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
         W.cut_index_layer = cil;
         const Rows pv = B.pp(set, sl).from(T.r0 + c0);                           // action_set_path_param_vel: rows from cut_index_pos on
         W.c0 = T.r0 + c0;                                                        // (absolute row in the slot: the window below moves)
+        W.gv_n = T.has_gg ? m : 0;
         {   // trim the memory for the next iteration, aligned with the nodes (:714-731): the windows move, node indices are re-based
             int* ni = B.nidx(set, sl) + T.i0 + S.cut_layer;
             const int cnt = T.ni - S.cut_layer;
@@ -656,7 +707,7 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
             T.i0 += S.cut_layer; T.ni = cnt;
             const int c1 = cil < 0 ? 0 : (cil < rows ? cil : rows);
             T.r0 += c1; T.rows = rows - c1;
-            T.gax = gax; T.gay = gay;
+            T.gax = vin.gg_ax[p]; T.gay = vin.gg_ay[p];
             const int cc = S.cut_layer < T.nc ? S.cut_layer : T.nc;
             T.c0 += cc; T.nc -= cc;
             const int cnn = S.cut_layer < T.nn ? S.cut_layer : T.nn;
@@ -673,7 +724,9 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
         S.old_gg_scale = gg_scale;
         W.pref_idx = vel_idx; W.vel_start = S.vel_plan;
         const int pref = W.pref_idx;
-        const double sgx = gax * gg_scale, sgy = gay * gg_scale;
+        // friction limits of the rows of `pv`, times gg_scale (:944); built at the job (the closest-point searches of the follow branch in
+        // between are the register peak of the stage: nothing of this is kept alive across them)
+        auto gsrc_of = [&]() { return T.has_gg ? gg_table(B.gg(set, sl).from(W.c0), vin.gg_scale[p]) : gg_const(T.gax, T.gay, vin.gg_scale[p]); };
         if (n_jobs + (T.id == LTPL_ACT_FOLLOW ? 1 : 0) + ((T.id != LTPL_ACT_FOLLOW || T.red_len) ? 1 : 0) > J.per_planner) { fail(S, LTPL_ERR_CAPACITY, E_CAP_JOBS); return; }
         if (m > D.RV) { fail(S, LTPL_ERR_CAPACITY, E_CAP_VEL); return; }
         if (T.id == LTPL_ACT_FOLLOW) {                                                              // :763-830
@@ -692,14 +745,14 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
                 obj_dist = s_obj - s_sta;
             }
             if (J.jobs[p * J.per_planner].n > 0) { fail(S, LTPL_ERR_CAPACITY, E_CAP_JOBS); return; }       // (two follow keys in one tick: not a thing)
-            const int j = make_job(x, D, J, p, 0, LTPL_VEL_FOLLOW_CONTROLLED, pv, sgx, sgy, pref, m, m - pref, W.vel_start, false, 0.0, car);
+            const int j = make_job(x, D, J, p, 0, LTPL_VEL_FOLLOW_CONTROLLED, pv, gsrc_of(), pref, m, m - pref, W.vel_start, false, 0.0, car_of(vin, p));
             x.sync();
             if (x.lane() == 0) {
                 VelJob& jb = J.jobs[p * J.per_planner + j];
                 jb.v_ego = vin.vel_est[p]; jb.v_obj = v_obj; jb.safety_d = vin.safety_d[p]; jb.obj_dist = obj_dist; jb.obj_x = ox; jb.obj_y = oy;
             }
             W.job_follow = j;
-            W.job_free = make_job(x, D, J, p, n_jobs++, LTPL_VEL_FB, pv, sgx, sgy, pref, m, m - pref - 1, W.vel_start, false, 0.0, car);
+            W.job_free = make_job(x, D, J, p, n_jobs++, LTPL_VEL_FB, pv, gsrc_of(), pref, m, m - pref - 1, W.vel_start, false, 0.0, car_of(vin, p));
         }
         if (T.id != LTPL_ACT_FOLLOW || T.red_len) {                                                 // :834-903
             W.generic = 1;
@@ -723,7 +776,7 @@ FLT_FN void vel_a(const X& x, const FLat& lat, const FCfg& cfg, const Block& B, 
                 v_idx = m;
             }
             W.v_idx = v_idx;
-            if (v_idx - pref > 1) { W.job_fb = make_job(x, D, J, p, n_jobs++, LTPL_VEL_FB, pv, sgx, sgy, pref, v_idx, v_idx - pref - 1, W.vel_start, true, v_end, car); W.has_fb = 1; }
+            if (v_idx - pref > 1) { W.job_fb = make_job(x, D, J, p, n_jobs++, LTPL_VEL_FB, pv, gsrc_of(), pref, v_idx, v_idx - pref - 1, W.vel_start, true, v_end, car_of(vin, p)); W.has_fb = 1; }
         }
     }
     x.sync();
@@ -812,7 +865,9 @@ FLT_FN void vel_b(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int 
                 const Rows bpp = B.pp(bs, bk).from(Bm.r0);
                 if (br - i0 > D.RV) { fail(S, LTPL_ERR_CAPACITY, E_CAP_VEL); return; }
                 // brake job on the backup rows [i0, br): no gg_scale (:229-255)
-                W.job_backup = make_job(x, D, JB, p, n_backup++, LTPL_VEL_BRAKE, bpp, Bm.gax, Bm.gay, i0, br, br - i0 - 1, S.vel_plan, false, 0.0);
+                const Rows bgg = B.gg(bs, bk).from(Bm.r0);
+                W.job_backup = make_job(x, D, JB, p, n_backup++, LTPL_VEL_BRAKE, bpp, Bm.has_gg ? gg_table(bgg) : gg_const(Bm.gax, Bm.gay), i0, br, br - i0 - 1,
+                                        S.vel_plan, false, 0.0);
                 // the key's memory becomes the (trimmed) backup
                 const Rows tpp = B.pp(set, sl); double* tco = B.coeff(set, sl); int* tnd = B.nodes(set, sl); int* tni = B.nidx(set, sl);
                 const double* bco = B.coeff(bs, bk) + (size_t)Bm.c0 * 8; const int* bnd = B.nodes(bs, bk) + (size_t)Bm.n0 * 2; const int* bni = B.nidx(bs, bk) + Bm.i0;
@@ -820,9 +875,10 @@ FLT_FN void vel_b(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int 
                 N.r0 = 0; N.rows = br - c1; N.i0 = 0; N.ni = Bm.ni - cl;
                 const int cc = cl < Bm.nc ? cl : Bm.nc, cnn = cl < Bm.nn ? cl : Bm.nn;
                 N.c0 = 0; N.nc = Bm.nc - cc; N.n0 = 0; N.nn = Bm.nn - cnn;
-                N.gax = Bm.gax; N.gay = Bm.gay;
+                N.gax = Bm.gax; N.gay = Bm.gay; N.has_gg = Bm.has_gg;
                 x.sync();
                 for (int c = 0; c < 5; ++c) for (int i = x.lane(); i < N.rows; i += X::W) tpp.at(i, c) = bpp.at(c1 + i, c);
+                if (Bm.has_gg) { const Rows tgg = B.gg(set, sl); for (int c = 0; c < 2; ++c) for (int i = x.lane(); i < N.rows; i += X::W) tgg.at(i, c) = bgg.at(c1 + i, c); }
                 for (int i = x.lane(); i < N.ni; i += X::W) tni[i] = bni[cl + i] - cil;
                 for (int i = x.lane(); i < N.nc * 8; i += X::W) tco[i] = bco[(size_t)cc * 8 + i];
                 for (int i = x.lane(); i < N.nn * 2; i += X::W) tnd[i] = bnd[(size_t)cnn * 2 + i];
@@ -895,8 +951,11 @@ FLT_FN void vel_c(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int 
         jb.mode = LTPL_VEL_BRAKE; jb.n = m; jb.n_el = m - 1; jb.v_start = m > 0 ? base.at(0, 5) : 0.0;
         jb.off_kappa = j * 4 * D.R; jb.off_el = jb.off_kappa + D.R; jb.off_gg = jb.off_kappa + 2 * D.R; jb.off_out = j * D.R;
         double* kap = JC.pool + jb.off_kappa; double* el = JC.pool + jb.off_el; double* gg = JC.pool + jb.off_gg;
+        // local gg of the emergency profile: the first kept key's rows from the cut on (W.gv of stage A), the constant tuple behind them
         const double gax = vin.gg_ax[p], gay = vin.gg_ay[p];
-        for (int i = x.lane(); i < m; i += X::W) { kap[i] = base.at(i, 4); gg[(size_t)i * 2] = gax; gg[(size_t)i * 2 + 1] = gay; }
+        const int k0 = S.bp_slot[0]; const int gvn = S.w[k0].gv_n; const Rows gv = B.gv(k0);
+        jb.gg_rows = gvn > 0 ? 1 : 0;
+        for (int i = x.lane(); i < m; i += X::W) { kap[i] = base.at(i, 4); gg[(size_t)i * 2] = i < gvn ? gv.at(i, 0) : gax; gg[(size_t)i * 2 + 1] = i < gvn ? gv.at(i, 1) : gay; }
         for (int i = x.lane(); i + 1 < m; i += X::W) el[i] = base.at(i + 1, 0) - base.at(i, 0);
         if (m < 2 && x.lane() == 0) el[0] = 0.0;
         if (x.lane() == 0) JC.jobs[j] = jb;

@@ -46,7 +46,8 @@ struct WaveX {
 
 static_assert(sizeof(fleet::VelJob) == sizeof(DevVelJob) && offsetof(fleet::VelJob, obj_y) == offsetof(DevVelJob, obj_y), "job layouts must agree");
 
-struct FleetArgs { fleet::Dims D; fleet::FLat lat; fleet::FCfg cfg; unsigned char* state; int* err_word; const int* rng_end; };
+struct FleetArgs { fleet::Dims D; fleet::FLat lat; fleet::FCfg cfg; unsigned char* state; int* err_word; const int* rng_end;
+                   unsigned char* gg; };      // gg: friction rows of the planners (null until a call carries rows)
 
 // The planner's scalars (PlannerS, ~1 KB) live in LDS while a kernel works on them: every lane executes the scalar control flow on the SAME
 // copy (uniform reads are LDS broadcasts; all lanes store the same value to the same address, in lockstep), instead of 64 private copies in
@@ -62,7 +63,7 @@ __device__ __forceinline__ void fleet_load(const WaveX& x, const fleet::Block& B
 #define FLEET_AXM_ROWS 512          // machine-table rows of one call, all tables together (the lane kernel keeps them in LDS)
 #define FLEET_ERR_SHIFT 13
 #define FLEET_ERR_MASK 0x1fff
-static_assert((fleet::E_CAP_VEL << 8 | 0xff) <= FLEET_ERR_MASK, "error word: site bits");
+static_assert((fleet::E_GG_ROWS << 8 | 0xff) <= FLEET_ERR_MASK, "error word: site bits");
 __device__ __forceinline__ void fleet_store(const WaveX& x, const fleet::Block& B, const fleet::PlannerS* S, int p, int* err_word)
 {
     x.sync();
@@ -76,7 +77,7 @@ __device__ __forceinline__ void fleet_store(const WaveX& x, const fleet::Block& 
 __global__ __launch_bounds__(64) void k_fleet_paths_pre(FleetArgs F, fleet::FObj ob, fleet::FPathsIn pin)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
-    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D, F.gg ? F.gg + F.D.gg_stride * (size_t)p : nullptr};
     __shared__ fleet::PlannerS S;
     fleet_load(x, B, &S);
     if (!S.err) fleet::paths_pre(x, F.lat, F.cfg, B, S, p, ob, pin);
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(64) void k_fleet_paths_pre(FleetArgs F, fleet::FObj
 __global__ __launch_bounds__(64) void k_fleet_paths_post(FleetArgs F, fleet::FPathsOut po)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
-    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D, F.gg ? F.gg + F.D.gg_stride * (size_t)p : nullptr};
     __shared__ fleet::PlannerS S;
     fleet_load(x, B, &S);
     if (!S.err) fleet::paths_post(x, F.lat, B, S, p, po);
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(64) void k_fleet_paths_post(FleetArgs F, fleet::FPa
 __global__ __launch_bounds__(64) void k_fleet_ref_idx(FleetArgs F, const double* px, const double* py)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
-    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D, F.gg ? F.gg + F.D.gg_stride * (size_t)p : nullptr};
     __shared__ fleet::PlannerS S;
     fleet_load(x, B, &S);
     if (!S.err) { fleet::ref_idx(x, F.cfg, B, S, px[p], py[p]); S.ref_done = 1; }
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(64) void k_fleet_ref_idx(FleetArgs F, const double*
 __global__ __launch_bounds__(64, 4) void k_fleet_vel_a(FleetArgs F, fleet::FObj ob, fleet::FVelIn vin, fleet::FJobs JA)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
-    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D, F.gg ? F.gg + F.D.gg_stride * (size_t)p : nullptr};
     __shared__ fleet::PlannerS S;
     fleet_load(x, B, &S);
     fleet::vel_a(x, F.lat, F.cfg, B, S, p, ob, vin, JA);
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(64, 4) void k_fleet_vel_a(FleetArgs F, fleet::FObj 
 __global__ __launch_bounds__(64) void k_fleet_vel_b(FleetArgs F, fleet::FJobs JA, fleet::FJobs JB)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
-    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D, F.gg ? F.gg + F.D.gg_stride * (size_t)p : nullptr};
     __shared__ fleet::PlannerS S;
     fleet_load(x, B, &S);
     fleet::vel_b(x, F.cfg, B, S, p, JA, JB);
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(64) void k_fleet_vel_b(FleetArgs F, fleet::FJobs JA
 __global__ __launch_bounds__(64) void k_fleet_vel_c(FleetArgs F, fleet::FVelIn vin, fleet::FJobs JB, fleet::FJobs JC)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
-    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D, F.gg ? F.gg + F.D.gg_stride * (size_t)p : nullptr};
     __shared__ fleet::PlannerS S;
     fleet_load(x, B, &S);
     fleet::vel_c(x, F.cfg, B, S, p, vin, JB, JC);
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(64) void k_fleet_vel_c(FleetArgs F, fleet::FVelIn v
 __global__ __launch_bounds__(64) void k_fleet_vel_d(FleetArgs F, fleet::FVelIn vin, fleet::FJobs JC)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
-    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D, F.gg ? F.gg + F.D.gg_stride * (size_t)p : nullptr};
     __shared__ fleet::PlannerS S;
     fleet_load(x, B, &S);
     fleet::vel_d(x, B, S, p, vin, JC);
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(64) void k_fleet_fb_lanes(DevVelParams p, const Dev
     const int pl = q / (per - 1), slot = q % (per - 1) + 1;
     const DevVelJob* jp = jobs + (size_t)pl * per + slot;
     const int n = jp->n;
-    if (n <= 0 || jp->mode != LTPL_VEL_FB) return;
+    if (n <= 0 || jp->mode != LTPL_VEL_FB || jp->gg_rows) return;      // (jobs with friction ROWS: k_vel_profile<.., GG, SEL 3>, one wave per job)
     LaneProf L; L.KE = ke + kep_base(q, ke_rows);
     double* D = outp + tile_base(q, cap);
     const double cax = pool[jp->off_gg], cay = pool[jp->off_gg + 1];
@@ -204,6 +205,7 @@ struct FleetTickIn {
     void* d_buf = nullptr; size_t cap = 0;
     fleet::FObj ob{}; const int* zone_off = nullptr; const int* zone_gid = nullptr;
     fleet::FVelIn vin{}; const double* axm = nullptr; int n_axm = 0; double vel_max = 0.0; int any_emerg = 0;
+    int has_gg = 0;                          // the call carries friction rows (local_gg as a dict) for some planner
     int n_axm_total = 0, multi_axm = 0;      // ABI v6: rows of all machine tables together; several tables (jobs carry their own): n_axm = rows of table 0
     bool has_paths = false, has_vel = false;
 };
@@ -213,7 +215,7 @@ struct ltpl_fleet {
     std::string err;
     fleet::Dims D{}; fleet::FCfg cfg{}; ltpl_planner_config pc{};
     FleetArgs args{};
-    unsigned char* d_state = nullptr; int* d_err = nullptr; const double* d_w_last = nullptr; int n_w_last = 0;
+    unsigned char* d_state = nullptr; unsigned char* d_gg = nullptr; int* d_err = nullptr; const double* d_w_last = nullptr; int n_w_last = 0;
     std::vector<void*> allocs;
     // seam (1) arrays
     fleet::FPathsIn pin{}; DevPathsOut dout{}; void* d_out = nullptr;
@@ -224,7 +226,7 @@ struct ltpl_fleet {
     std::vector<FleetTickIn> tape;
     std::vector<unsigned char> image;                 // host image of one planner block (queries)
     bool began = false;
-    size_t vel_lds = 0, vel_lds_lite = 0;
+    size_t vel_lds = 0, vel_lds_lite = 0, vel_lds_gg = 0, vel_lds_lite_gg = 0;
     ~ltpl_fleet()
     {
         if (h) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); --h->n_planners; }
@@ -314,7 +316,7 @@ try {
     std::vector<double> wl(cfg->n_w_last > 0 ? cfg->w_last_edges : nullptr, cfg->n_w_last > 0 ? cfg->w_last_edges + cfg->n_w_last : nullptr);
     f->n_w_last = cfg->n_w_last; wl.push_back(0.0);
     if ((rc = fleet_upload(f.get(), wl, &f->d_w_last))) return bail(rc);
-    f->args.D = f->D; f->args.lat = fl; f->args.cfg = f->cfg; f->args.state = f->d_state; f->args.err_word = f->d_err; f->args.rng_end = h->lat.rng_end;
+    f->args.D = f->D; f->args.lat = fl; f->args.cfg = f->cfg; f->args.state = f->d_state; f->args.gg = nullptr; f->args.err_word = f->d_err; f->args.rng_end = h->lat.rng_end;
     // seam (1)
     if ((rc = fleet_alloc(f.get(), (size_t)N, &f->pin.start_layer))) return bail(rc);
     if ((rc = fleet_alloc(f.get(), (size_t)N, &f->pin.start_node))) return bail(rc);
@@ -343,6 +345,7 @@ try {
     if (hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&f->ev_a, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&f->ev_b, hipEventDisableTiming) != hipSuccess) return bail((f->err = "fleet: stream / event creation failed", LTPL_ERR_HIP));
     f->vel_lds = vel_scratch_bytes(f->D.RV, false, false); f->vel_lds_lite = vel_scratch_bytes(f->D.RV, false, false, true);
+    f->vel_lds_gg = vel_scratch_bytes(f->D.RV, true, false); f->vel_lds_lite_gg = vel_scratch_bytes(f->D.RV, true, false, true);
     if (f->vel_lds > 150 * 1024) return bail((f->err = "fleet: velocity profile too long for the LDS-resident solver", LTPL_ERR_CAPACITY));
     f->image.resize(f->D.stride);
     *out = f.release();
@@ -462,12 +465,26 @@ static int fleet_pack_inputs(ltpl_fleet* f, FleetTickIn* t, const ltpl_planner_p
         o_ra = a.add(8 * (size_t)(nv + 1)); o_ve = a.add(8 * (size_t)(nv + 1)); o_px = a.add(8 * (size_t)(np_ + 1)); o_py = a.add(8 * (size_t)(np_ + 1));
         o_zo = a.add(4 * (size_t)(N + 1)); o_zg = a.add(4 * (size_t)(nz + 1));
     }
-    size_t o_v[8] = {0}, o_em = 0, o_axm = 0, o_axo = 0, o_axi = 0;
-    int n_tab = 0;
+    size_t o_v[8] = {0}, o_em = 0, o_axm = 0, o_axo = 0, o_axi = 0, o_ggo = 0, o_ggr = 0;
+    int n_tab = 0, n_gg = 0;
     if (vin) {
         if (!vin->pos_est_x || !vin->pos_est_y || !vin->vel_est || !vin->vel_max || !vin->gg_scale || !vin->gg_ax || !vin->gg_ay || !vin->safety_d ||
             !vin->ax_max_machines || vin->n_ax_max_machines < 1) { f->err = "fleet: null input"; return LTPL_ERR_INVALID_ARG; }
-        if (vin->gg_row_off || vin->gg_rows) { f->err = fleet::err_text(0, LTPL_ERR_UNSUPPORTED | (fleet::E_GG_DICT << 8)); return LTPL_ERR_UNSUPPORTED; }
+        // location dependent friction (local_gg as a dict, OTH.py:649-666): rows per planner and path key
+        if ((vin->gg_row_off != nullptr) != (vin->gg_rows != nullptr)) { f->err = "fleet: gg_row_off and gg_rows come together"; return LTPL_ERR_INVALID_ARG; }
+        if (vin->gg_row_off) {
+            const int MK = LTPL_PLANNER_MAX_KEYS;
+            if (vin->gg_row_off[0] != 0) { f->err = "fleet: gg_row_off must start at 0"; return LTPL_ERR_INVALID_ARG; }
+            for (int i = 0; i < N * MK; ++i) if (vin->gg_row_off[i + 1] < vin->gg_row_off[i]) { f->err = "fleet: gg_row_off must be non-decreasing"; return LTPL_ERR_INVALID_ARG; }
+            n_gg = vin->gg_row_off[N * MK];
+            if (n_gg > 0 && f->vel_lds_gg > 150 * 1024) { f->err = "fleet: velocity profile with friction rows too long for the LDS-resident solver"; return LTPL_ERR_CAPACITY; }
+            if (n_gg > 0 && !f->d_gg) {        // the planners' friction rows: allocated by the first call that carries rows (no kernel of this fleet is in flight that could read the pointer)
+                FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
+                int rc_ = fleet_alloc(f, f->D.gg_stride * (size_t)N, &f->d_gg, false);
+                if (rc_) return rc_;
+                f->args.gg = f->d_gg;
+            }
+        }
         // a fleet of different cars (ABI v6): vel_max per planner, machine tables per planner (ax_table_off / ax_table_idx)
         n_tab = vin->n_ax_tables > 1 ? vin->n_ax_tables : 0;
         if (n_tab) {
@@ -484,6 +501,7 @@ static int fleet_pack_inputs(ltpl_fleet* f, FleetTickIn* t, const ltpl_planner_p
         for (int k = 0; k < 8; ++k) o_v[k] = a.add(8 * (size_t)N);
         o_em = a.add(4 * (size_t)N); o_axm = a.add(16 * (size_t)vin->n_ax_max_machines);
         if (n_tab) { o_axo = a.add(4 * (size_t)(n_tab + 1)); o_axi = a.add(4 * (size_t)N); }
+        if (n_gg > 0) { o_ggo = a.add(4 * ((size_t)N * LTPL_PLANNER_MAX_KEYS + 1)); o_ggr = a.add(16 * (size_t)n_gg); }
     }
     int rc = fleet_stage(f, a.size);
     if (rc) return rc;
@@ -521,7 +539,10 @@ static int fleet_pack_inputs(ltpl_fleet* f, FleetTickIn* t, const ltpl_planner_p
         auto dp = [&](int k) { return reinterpret_cast<const double*>(db + o_v[k]); };
         if (n_tab) { memcpy(hb + o_axo, vin->ax_table_off, 4 * (size_t)(n_tab + 1)); memcpy(hb + o_axi, vin->ax_table_idx, 4 * (size_t)N); }
         t->vin = fleet::FVelIn{dp(0), dp(1), dp(2), dp(3), dp(4), dp(5), dp(6), dp(7), reinterpret_cast<const int*>(db + o_em),
-                               n_tab ? reinterpret_cast<const int*>(db + o_axo) : nullptr, n_tab ? reinterpret_cast<const int*>(db + o_axi) : nullptr};
+                               n_tab ? reinterpret_cast<const int*>(db + o_axo) : nullptr, n_tab ? reinterpret_cast<const int*>(db + o_axi) : nullptr,
+                               n_gg > 0 ? reinterpret_cast<const int*>(db + o_ggo) : nullptr, n_gg > 0 ? reinterpret_cast<const double*>(db + o_ggr) : nullptr};
+        if (n_gg > 0) { memcpy(hb + o_ggo, vin->gg_row_off, 4 * ((size_t)N * LTPL_PLANNER_MAX_KEYS + 1)); memcpy(hb + o_ggr, vin->gg_rows, 16 * (size_t)n_gg); }
+        t->has_gg = n_gg > 0 ? 1 : 0;
         t->axm = reinterpret_cast<const double*>(db + o_axm); t->vel_max = vin->vel_max[0]; t->any_emerg = any;
         t->n_axm_total = vin->n_ax_max_machines; t->multi_axm = n_tab ? 1 : 0;
         t->n_axm = n_tab ? vin->ax_table_off[1] - vin->ax_table_off[0] : vin->n_ax_max_machines;
@@ -561,19 +582,23 @@ static int fleet_launch_paths(ltpl_fleet* f, const FleetTickIn& t, bool pre, boo
 // kernel variant of a launch: with several machine tables (a fleet of different cars) the interpolating form, whatever table 0 looks like
 static int fleet_variant(const ltpl_vel_params& vp, bool multi) { const int v = vel_variant(&vp); return multi ? (v & ~1) : v; }
 
-static int fleet_launch_vel_jobs(ltpl_fleet* f, const ltpl_vel_params& vp, const double* d_axm, const FleetJobsDev& J, int sel, bool multi = false)
+static int fleet_launch_vel_jobs(ltpl_fleet* f, const ltpl_vel_params& vp, const double* d_axm, const FleetJobsDev& J, int sel, bool multi = false, bool rows = false)
 {
     ltpl_handle* h = f->h;
     DevVelParams p;
     int rc = make_vel_params(h, &vp, d_axm, &p);
     if (rc) { f->err = h->err; return rc; }
-    vel_kernel_t kern = sel == 1 ? vel_kernel_const_of<1>(fleet_variant(vp, multi)) : vel_kernel_const_of<2>(fleet_variant(vp, multi));
-    const size_t lds = sel == 1 ? f->vel_lds_lite : f->vel_lds;
+    // `rows`: the call carries friction rows -- every pool-form job holds one [ax, ay] row per point (constants replicated), so the GG
+    // form of the kernel serves all of them; sel 3 then picks the forward-backward jobs the lane kernel left out
+    const int v = fleet_variant(vp, multi);
+    vel_kernel_t kern = rows ? (sel == 1 ? vel_kernel_rows_of<1>(v) : sel == 2 ? vel_kernel_rows_of<2>(v) : vel_kernel_rows_of<3>(v))
+                             : (sel == 1 ? vel_kernel_const_of<1>(v) : vel_kernel_const_of<2>(v));
+    const size_t lds = rows ? (sel == 2 ? f->vel_lds_gg : f->vel_lds_lite_gg) : (sel == 1 ? f->vel_lds_lite : f->vel_lds);
     if (lds > 48 * 1024) FLEET_TRY(f, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     DoneSignal done; done.host_flag = nullptr; done.dev_count = nullptr; done.seq = 0u;
-    const unsigned blocks = (unsigned)(sel == 1 ? f->D.N * J.per : f->D.N);
+    const unsigned blocks = (unsigned)(sel != 2 ? f->D.N * J.per : f->D.N);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, h->stream, h->lat, p, reinterpret_cast<const DevVelJob*>(J.jobs),
-                       J.pool, J.out, J.flags, f->D.RV, h->lp4.dbg, done, sel == 1 ? 1 : J.per);
+                       J.pool, J.out, J.flags, f->D.RV, h->lp4.dbg, done, sel != 2 ? 1 : J.per);
     FLEET_TRY(f, hipGetLastError());
 #ifdef LTPL_EXPERIMENT
     if (h->d_dbg && J.per > 1) {        // LTPL_DEBUG_TIMING=1 (experiment build): cycle stamps of the first 256 blocks of the launch, per slot index
@@ -620,16 +645,18 @@ static int fleet_launch_vel(ltpl_fleet* f, const FleetTickIn& t)
         FLEET_TRY(f, hipGetLastError());
         FLEET_TRY(f, hipEventRecord(f->ev_b, f->stream2));
     }
-    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA, 2, t.multi_axm != 0))) return rc;        // follow jobs (slot 0): one wave per job
+    const bool rows = t.has_gg != 0, multi = t.multi_axm != 0;
+    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA, 2, multi, rows))) return rc;            // follow jobs (slot 0): one wave per job
+    if (rows && (rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA, 3, multi, true))) return rc;    // forward-backward jobs with friction rows
     FLEET_TRY(f, hipStreamWaitEvent(st, f->ev_b, 0));
     hipLaunchKernelGGL(k_fleet_vel_b, dim3(N), dim3(64), 0, st, f->args, f->JA.view(), f->JB.view());
     FLEET_TRY(f, hipGetLastError());
-    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JB, 1, t.multi_axm != 0))) return rc;
+    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JB, 1, multi, rows))) return rc;
     hipLaunchKernelGGL(k_fleet_vel_c, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JB.view(), f->JC.view());
     FLEET_TRY(f, hipGetLastError());
     if (t.any_emerg) {
         ltpl_vel_params ve = vp; ve.dyn_model_exp = 1.0; ve.drag_coeff = 0.854; ve.m_veh = 1160.0;       // calc_brake_emergency.py:4-6,31-36
-        if ((rc = fleet_launch_vel_jobs(f, ve, t.axm, f->JC, 1))) return rc;
+        if ((rc = fleet_launch_vel_jobs(f, ve, t.axm, f->JC, 1, false, rows))) return rc;
         hipLaunchKernelGGL(k_fleet_vel_d, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JC.view());
         FLEET_TRY(f, hipGetLastError());
     }
@@ -714,7 +741,7 @@ try {
     FleetTickIn& v = f->curv;
     if ((rc = fleet_pack_inputs(f, &v, nullptr, in, false))) return rc;
     FleetTickIn t = f->cur; t.vin = v.vin; t.axm = v.axm; t.n_axm = v.n_axm; t.vel_max = v.vel_max; t.any_emerg = v.any_emerg;
-    t.n_axm_total = v.n_axm_total; t.multi_axm = v.multi_axm;
+    t.n_axm_total = v.n_axm_total; t.multi_axm = v.multi_axm; t.has_gg = v.has_gg;
     if ((rc = fleet_launch_vel(f, t))) return rc;
     return fleet_check(f);
 } LTPL_ABI_CATCH(abi_err_of(f))

@@ -14,12 +14,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <memory>
 #include <string>
 #include <type_traits>
 #include <vector>
 
 #include "../../include/ltpl_hip.h"
-#include "planner_api.hpp"
+#include "planner_host.hpp"
 #include "fleet_api.hpp"
 #include "capsule.hpp"
 
@@ -788,6 +790,7 @@ struct DevVelJob {
     // the car of the job (fleet::VelJob, ABI v6): v_max <= 0 / n_axm == 0 -> the launch's parameter set (seam 2, host planner)
     double v_max;
     int axm_off, n_axm;                           // rows [axm_off, axm_off + n_axm) of the launch's stacked machine tables
+    int gg_rows, pad_;                            // 1: off_gg holds n caller-supplied [ax, ay] rows (local_gg as a dict, OTH.py:649-666) instead of two constants
 };
 
 // `lite`: only what the forward-backward and brake profiles touch (w, kabs, el, machine table, run flags) -- no arc length, no follow scratch
@@ -822,7 +825,9 @@ static size_t vel_scratch_bytes(int cap, bool with_gg, bool with_xy, bool lite =
 // them) -- three LDS arrays less per wave and no per-point loads of the limits. SEL (fleet): the occupancy of these launches is bound by
 // the LDS a wave needs and the recurrences are latency chains (~200 cycles per point), so the fleet runs the forward-backward / brake jobs
 // (SEL 1: three arrays, "lite" scratch) and the follow jobs (SEL 2: six arrays, job slot 0 of every planner) as two launches; a block
-// whose job belongs to the other launch returns at once. `job_stride`: block b works on job b * job_stride.
+// whose job belongs to the other launch returns at once. SEL 3 (fleet, calls with location dependent friction): the forward-backward
+// jobs whose limits are ROWS (DevVelJob::gg_rows) -- the lane kernel that solves a tick's other forward-backward jobs takes constants only.
+// `job_stride`: block b works on job b * job_stride.
 template <int EM, bool AXM1, bool GG = true, int SEL = 0>
 __global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p_, const DevVelJob* jobs,
                                                     const double* pool, double* out_pool, int* out_flags, int cap,
@@ -841,7 +846,9 @@ __global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p_,
     const bool follow = jb.mode == LTPL_VEL_FOLLOW || jb.mode == LTPL_VEL_FOLLOW_CONTROLLED;
     if constexpr (SEL == 1) { if (follow) return; }
     if constexpr (SEL == 2) { if (!follow) return; }
-    VelScratch vs = carve_vel_scratch(smem, cap, GG, false, nullptr, nullptr, SEL == 1);
+    if constexpr (SEL == 3) { if (follow || !jb.gg_rows) return; }
+    constexpr bool LITE = SEL == 1 || SEL == 3;
+    VelScratch vs = carve_vel_scratch(smem, cap, GG, false, nullptr, nullptr, LITE);
     vs.dbg = dbg;
     const int n = jb.n;
     for (int i = lane; i < n; i += 64) {
@@ -862,7 +869,7 @@ __global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p_,
         fb_profile<EM, AXM1, GG>(n, vs, cax, cay, p, p.v_max, jb.v_start, jb.has_v_end != 0, jb.v_end, lane);
     } else if (jb.mode == LTPL_VEL_BRAKE) {
         brake_profile<EM, GG>(n, vs.w, vs, cax, cay, jb.v_start, p, lane);
-    } else if constexpr (SEL != 1) {
+    } else if constexpr (!LITE) {
         FollowIn fi; fi.v_start = jb.v_start; fi.v_ego = jb.v_ego; fi.v_obj = jb.v_obj; fi.safety_d = jb.safety_d;
         fi.obj_dist = jb.obj_dist; fi.obj_x = jb.obj_x; fi.obj_y = jb.obj_y;
         follow_profile<EM, AXM1, GG>(lat, n, jb.n_el, vs, cax, cay, p, fi, lane, &too_close, &vel_bound, false,
@@ -2859,6 +2866,14 @@ static vel_kernel_t vel_kernel_const_of(int v)          // constant friction lim
         case 0: return k_vel_profile<0, false, false, SEL>; case 1: return k_vel_profile<0, true, false, SEL>;
         case 2: return k_vel_profile<1, false, false, SEL>; case 3: return k_vel_profile<1, true, false, SEL>;
         case 4: return k_vel_profile<2, false, false, SEL>; default: return k_vel_profile<2, true, false, SEL>;
+    }
+}
+template <int SEL>
+static vel_kernel_t vel_kernel_rows_of(int v)           // friction limits as rows per job (fleet, local_gg as a dict): the interpolating machine-table form only
+{
+    switch (v >> 1) {
+        case 0: return k_vel_profile<0, false, true, SEL>; case 1: return k_vel_profile<1, false, true, SEL>;
+        default: return k_vel_profile<2, false, true, SEL>;
     }
 }
 static tick_kernel_t tick_kernel_of(int v, bool plan_a = false)

@@ -130,12 +130,14 @@ class Fleet(Planner):
 
     def pack_arrays(self, prev_action, t_now, veh_off, pos_off, veh_radius, veh_vel, pos_x, pos_y, zone_off, zone_gid,
                     pos_est, vel_est, vel_max=100.0, gg_scale=1.0, local_gg=(5.0, 5.0), safety_d=30.0, incl_emerg_traj=False,
-                    ax_max_machines=((100.0, 5.0),), ax_tables=None, ax_table_idx=None):
+                    ax_max_machines=((100.0, 5.0),), ax_tables=None, ax_table_idx=None, gg_row_off=None, gg_rows=None):
         """Input structs of one tick from the caller's own arrays (a simulator that holds its vehicles as arrays): the layout of
         ``ltpl_planner_paths_in`` / ``ltpl_planner_vel_in`` (include/ltpl_hip.h) -- ``prev_action`` action ids (LTPL_ACT_*) per planner,
         CSR offsets ``veh_off`` [n + 1] / ``pos_off`` [n_veh + 1] / ``zone_off`` [n + 1], own position of a vehicle first. Scalars are
         broadcast; ``vel_max`` may be an array (one value per planner). Different cars: ``ax_tables`` = list of machine tables and
-        ``ax_table_idx`` = the table of every planner (instead of the one table ``ax_max_machines``). Returns (paths struct, velocity struct,
+        ``ax_table_idx`` = the table of every planner (instead of the one table ``ax_max_machines``). Location dependent friction (local_gg as a
+        dict, OTH.py:649-666): ``gg_rows`` (rows, 2) = [ax, ay] per path coordinate and ``gg_row_off`` [n * 4 + 1] = the rows of planner p's
+        k-th path key are gg_row_off[4 p + k] .. gg_row_off[4 p + k + 1] (none: that key drives with the constant ``local_gg``). Returns (paths struct, velocity struct,
         keep-alive) like ``pack_groups``."""
         n, i32, f64 = self.n_scen, np.int32, np.float64
 
@@ -166,6 +168,15 @@ class Fleet(Planner):
         vi.incl_emerg_traj = em.ctypes.data
         vi.gg_row_off, vi.gg_rows = None, None
         keep_t = []
+        if gg_row_off is not None or gg_rows is not None:
+            go = np.ascontiguousarray(np.asarray(gg_row_off, i32).reshape(-1))
+            gr = np.ascontiguousarray(np.asarray(gg_rows, f64).reshape(-1, 2))
+            if go.size != n * _capi.PLANNER_MAX_KEYS + 1 or gr.shape[0] < int(go[-1]):
+                raise ValueError("pack_arrays: gg_row_off needs n * %d + 1 entries and gg_rows gg_row_off[-1] rows" % _capi.PLANNER_MAX_KEYS)
+            if gr.shape[0] == 0:
+                gr = np.zeros((1, 2))
+            vi.gg_row_off, vi.gg_rows = go.ctypes.data, gr.ctypes.data
+            keep_t += [go, gr]
         if ax_tables is not None:
             if ax_table_idx is None or len(np.asarray(ax_table_idx).reshape(-1)) != n:
                 raise ValueError("pack_arrays: ax_table_idx needs one entry per planner")

@@ -21,7 +21,7 @@ def build(force=False):
     csrc = os.path.join(os.path.dirname(HERE), "graphbasedlocaltrajectoryplanner_amd", "csrc")
     srcs = [os.path.join(HERE, "fleet_host_shim.cpp"), os.path.join(HERE, "ltpl_oracle.c"),
             os.path.join(os.path.dirname(HERE), "include", "ltpl_hip.h")]
-    srcs += [os.path.join(csrc, f) for f in ("planner_core.hpp", "fleet_core.hpp", "fleet_api.hpp")]
+    srcs += [os.path.join(csrc, f) for f in ("planner_core.hpp", "planner_host.hpp", "fleet_core.hpp", "fleet_api.hpp")] + [os.path.join(HERE, "oracle_compute.hpp")]
     if not force and os.path.isfile(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(s) for s in srcs):
         return LIB
     subprocess.check_call(["make", "-s", "-C", HERE, "-B", "libltpl_fleet_host.so"])

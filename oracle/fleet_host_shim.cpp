@@ -1,215 +1,41 @@
 // ORACLE / TEST INFRASTRUCTURE ONLY -- never linked into or loaded by the product path.
 //
-// The fleet state machine (graphbasedlocaltrajectoryplanner_amd/csrc/fleet_core.hpp: the planner's iterative memory as wave-uniform SPMD
-// code over plain-data state, run by libltpl_hip.so with one wave per planner on DEVICE-resident state) compiled with its one-lane host
-// policy and bound to the ORACLE's CPU arithmetic for seam (1) / seam (2). Purpose: the GPU-less build container replays the reference's
-// tick recordings through exactly the source the device runs (`-m "not gpu"`: "the host logic"). Exported names carry the prefix
-// oracle_fleet_ so that they can never be mistaken for the product's ltpl_fleet_* symbols.
-#include "../graphbasedlocaltrajectoryplanner_amd/csrc/fleet_api.hpp"
+// The fleet front end's semantics on the host: the planner state machine (graphbasedlocaltrajectoryplanner_amd/csrc/fleet_core.hpp, the
+// source libltpl_hip.so runs with one wave per planner on DEVICE-resident state) through the product's host instantiation
+// (csrc/planner_host.hpp) with the fleet's error behaviour -- every stage runs for every planner, a failing planner keeps its error word
+// and its state until it gets a new start pose (`sticky_errors`) -- bound to the ORACLE's CPU arithmetic (oracle_compute.hpp). Purpose: the
+// GPU-less build container replays the reference's tick recordings with the fleet's inputs (cars per planner, friction rows per planner)
+// and error semantics (`-m "not gpu"`: "the host logic"). Exported names carry the prefix oracle_fleet_ so that they can never be mistaken
+// for the product's ltpl_fleet_* symbols.
+#include "oracle_compute.hpp"
 
-extern "C" {
-int oracle_plan_paths(const ltpl_lattice_desc* d, const ltpl_paths_in* in, ltpl_paths_out* out);
-int oracle_vel_profile(const ltpl_lattice_desc* d, const ltpl_vel_params* params, int n_jobs, const ltpl_vel_job* jobs,
-                       ltpl_vel_result* results);
-}
+namespace { std::string g_err; }
 
-namespace {
-using namespace fleet;
-std::string g_err;
-
-struct JobSet {
-    int per = 0; std::vector<VelJob> jobs; std::vector<double> pool, out; std::vector<int> flags;
-    void init(int N, int per_planner, int R)
-    {
-        per = per_planner; jobs.assign((size_t)N * per, VelJob{}); pool.assign((size_t)N * per * 4 * R, 0.0); out.assign((size_t)N * per * R, 0.0);
-        flags.assign((size_t)N * per * 2, 0);
-    }
-    FJobs view() { return FJobs{jobs.data(), pool.data(), out.data(), flags.data(), per, nullptr, 0}; }
-};
-
-struct HostFleet {
-    const ltpl_lattice_desc* d = nullptr;
-    ltplp::HostLat lat; FLat flat; FCfg cfg; Dims D; ltpl_planner_config pc; std::vector<double> w_last;
-    std::vector<unsigned char> state;
-    std::string err;
-    // inputs of the tick
-    std::vector<int> prev_action, veh_off, pos_off; std::vector<double> t_now, radius, vel, px, py;
-    // seam (1)
-    std::vector<int> p_sl, p_sn, p_fl, p_la, p_cc, p_nl, p_ll, p_ln; std::vector<double> p_psi;
-    std::vector<int> o_end, o_coi, o_con, o_na, o_id, o_valid, o_red, o_goal, o_nn, o_np, o_nt, o_nodes, o_nidx; std::vector<double> o_co, o_pp;
-    JobSet JA, JB, JC;
-    bool began = false;
-    FObj obj() { return FObj{prev_action.data(), t_now.data(), veh_off.data(), pos_off.data(), radius.data(), vel.data(), px.data(), py.data()}; }
-    Block block(int p) { return Block{state.data() + D.stride * (size_t)p, D}; }
-    int first_error()
-    {
-        for (int p = 0; p < D.N; ++p) { const int e = block(p).S()->err; if (e) { err = err_text(p, e); return e & 0xff; } }
-        return LTPL_OK;
-    }
-};
-
-int run_jobs(HostFleet* F, const ltpl_vel_params& vp, JobSet& J)
-{
-    std::vector<ltpl_vel_job> jobs; std::vector<ltpl_vel_result> res; std::vector<size_t> idx;
-    for (size_t j = 0; j < J.jobs.size(); ++j) {
-        const VelJob& v = J.jobs[j];
-        if (v.n <= 0) continue;
-        ltpl_vel_job jb; std::memset(&jb, 0, sizeof(jb));
-        jb.mode = v.mode; jb.n = v.n; jb.n_el = v.n_el; jb.has_v_end = v.has_v_end; jb.v_start = v.v_start; jb.v_end = v.v_end; jb.v_ego = v.v_ego;
-        jb.v_obj = v.v_obj; jb.safety_d = v.safety_d; jb.obj_dist = v.obj_dist; jb.obj_x = v.obj_x; jb.obj_y = v.obj_y;
-        jb.kappa = J.pool.data() + v.off_kappa; jb.el_lengths = J.pool.data() + v.off_el; jb.loc_gg = J.pool.data() + v.off_gg;
-        ltpl_vel_result r; r.vx = J.out.data() + v.off_out; r.too_close = 0; r.vel_bound = 1;
-        jobs.push_back(jb); res.push_back(r); idx.push_back(j);
-    }
-    if (jobs.empty()) return LTPL_OK;
-    // a fleet of different cars (ABI v6): a job may carry its own vel_max / machine table (fleet::VelJob) -- such jobs are solved one by one
-    // with their own parameter set, the others in one call with the launch's
-    for (size_t i = 0; i < idx.size(); ++i) {
-        const VelJob& v = J.jobs[idx[i]];
-        ltpl_vel_params pj = vp;
-        if (v.v_max > 0.0) pj.v_max = v.v_max;
-        if (v.n_axm > 0) { pj.n_ax_max_machines = v.n_axm; pj.ax_max_machines = vp.ax_max_machines + 2 * (size_t)v.axm_off; }
-        const int rc = oracle_vel_profile(F->d, &pj, 1, &jobs[i], &res[i]);
-        if (rc) { F->err = "oracle_vel_profile failed"; return rc; }
-    }
-    for (size_t i = 0; i < idx.size(); ++i) { J.flags[2 * idx[i]] = res[i].too_close; J.flags[2 * idx[i] + 1] = res[i].vel_bound; }
-    return LTPL_OK;
-}
-}  // namespace
-
-struct oracle_fleet { HostFleet F; };
+struct oracle_fleet { ltpl_planner* p = nullptr; };
 
 extern "C" {
 int oracle_fleet_create(const ltpl_lattice_desc* d, int max_path_nodes, int max_path_pts, const ltpl_planner_config* cfg, oracle_fleet** out)
 {
-    int rc = check_config(cfg, &g_err);
+    ltplp::HostLat lat;
+    int rc = lat.init(d, max_path_nodes, max_path_pts, &g_err);
     if (rc) return rc;
-    oracle_fleet* f = new oracle_fleet();
-    HostFleet& F = f->F;
-    if ((rc = F.lat.init(d, max_path_nodes, max_path_pts, &g_err))) { delete f; return rc; }
-    F.d = d; F.flat = flat_of(F.lat); F.cfg = fcfg_of(cfg); F.pc = *cfg;
-    if (cfg->n_w_last > 0) F.w_last.assign(cfg->w_last_edges, cfg->w_last_edges + cfg->n_w_last);
-    F.D = make_dims(cfg->n_scen, max_path_nodes, max_path_pts);
-    if ((rc = check_dims(F.D, &g_err))) { delete f; return rc; }
-    F.state.assign(F.D.stride * (size_t)cfg->n_scen, 0);
-    for (int p = 0; p < cfg->n_scen; ++p) { PlannerS* S = F.block(p).S(); S->em_base_id = S->action_forced = S->sel_action = S->raw_action = LTPL_ACT_NONE; S->closest_obj_index = -1; S->const_rows = -1; S->old_gg_scale = 1.0; }
-    F.JA.init(F.D.N, JOBS_A, F.D.R); F.JB.init(F.D.N, 1, F.D.R); F.JC.init(F.D.N, 1, F.D.R);
-    *out = f;
+    ltpl_planner* p = nullptr;
+    if ((rc = ltplp::api_create(new OracleCompute(d), lat, cfg, &p, &g_err, /*sticky=*/true))) return rc;
+    *out = new oracle_fleet(); (*out)->p = p;
     return LTPL_OK;
 }
-int oracle_fleet_destroy(oracle_fleet* f) { delete f; return LTPL_OK; }
-int oracle_fleet_get_caps(const oracle_fleet* f, ltpl_planner_caps* c) { if (!f || !c) return LTPL_ERR_INVALID_ARG; caps_of(f->F.D, c); return LTPL_OK; }
-const char* oracle_fleet_last_error(const oracle_fleet* f) { return f ? f->F.err.c_str() : g_err.c_str(); }
+int oracle_fleet_destroy(oracle_fleet* f) { if (f) { delete f->p; delete f; } return LTPL_OK; }
+int oracle_fleet_get_caps(const oracle_fleet* f, ltpl_planner_caps* c) { return f ? ltplp::api_get_caps(f->p, c) : LTPL_ERR_INVALID_ARG; }
+const char* oracle_fleet_last_error(const oracle_fleet* f) { return f ? f->p->P.err.c_str() : g_err.c_str(); }
 int oracle_fleet_set_start(oracle_fleet* f, int32_t p, double x, double y, double heading, double vel, double mho, int32_t* in_track, int32_t* cor_heading)
 {
-    if (!f || p < 0 || p >= f->F.D.N) return LTPL_ERR_INVALID_ARG;
-    HostFleet& F = f->F;
-    std::vector<unsigned char> image(F.D.stride);
-    const PlannerS prev = *F.block(p).S();
-    const int rc = start_block(F.lat, F.D, x, y, heading, vel, mho, in_track, cor_heading, image.data(), &prev, &F.err);
-    if (rc) return rc;
-    std::memcpy(F.block(p).b, image.data(), F.D.stride);
-    return LTPL_OK;
+    return f ? f->p->P.set_start(p, x, y, heading, vel, mho, in_track, cor_heading) : LTPL_ERR_INVALID_ARG;
 }
-int oracle_fleet_calc_paths_begin(oracle_fleet* f, const ltpl_planner_paths_in* in)
-{
-    if (!f || !in) return LTPL_ERR_INVALID_ARG;
-    HostFleet& F = f->F; const int n = F.D.N;
-    const int nv = in->veh_off[n], np_ = in->pos_off[nv];
-    F.prev_action.assign(in->prev_action, in->prev_action + n); F.t_now.assign(in->t_now, in->t_now + n);
-    F.veh_off.assign(in->veh_off, in->veh_off + n + 1); F.pos_off.assign(in->pos_off, in->pos_off + nv + 1);
-    F.radius.assign(in->veh_radius, in->veh_radius + nv); F.px.assign(in->pos_x, in->pos_x + np_); F.py.assign(in->pos_y, in->pos_y + np_);
-    if (in->veh_vel) F.vel.assign(in->veh_vel, in->veh_vel + nv); else F.vel.assign((size_t)nv, 0.0);
-    F.radius.push_back(0.0); F.vel.push_back(0.0); F.px.push_back(0.0); F.py.push_back(0.0);
-    F.p_sl.assign(n, 0); F.p_sn.assign(n, 0); F.p_fl.assign(n, 0); F.p_la.assign(n, LTPL_ACT_NONE); F.p_cc.assign(n, -1); F.p_psi.assign(n, 0.0); F.p_nl.assign(n, 0);
-    F.p_ll.assign((size_t)n * LTPL_MAX_LAST_NODES, -1); F.p_ln.assign((size_t)n * LTPL_MAX_LAST_NODES, -1);
-    FPathsIn pin{F.p_sl.data(), F.p_sn.data(), F.p_fl.data(), F.p_la.data(), F.p_cc.data(), F.p_psi.data(), F.p_nl.data(), F.p_ll.data(), F.p_ln.data()};
-    HostX x;
-    for (int p = 0; p < n; ++p) {
-        Block B = F.block(p);
-        if (!B.S()->err) paths_pre(x, F.flat, F.cfg, B, *B.S(), p, F.obj(), pin);
-        if (B.S()->err) { F.p_sl[p] = 0; F.p_sn[p] = F.lat.rl_idx[0]; F.p_fl[p] = LTPL_FLAG_ACTION_SETS; F.p_la[p] = LTPL_ACT_NONE; F.p_cc[p] = -1; F.p_nl[p] = 0; }   // harmless scenario, result not looked at
-    }
-    F.began = true;
-    return F.first_error();
-}
-int oracle_fleet_calc_paths_finish(oracle_fleet* f, const int32_t* zone_off, const int32_t* zone_gid)
-{
-    if (!f || !zone_off || !f->F.began) return LTPL_ERR_INVALID_ARG;
-    HostFleet& F = f->F; const int n = F.D.N, A = LTPL_MAX_ACTIONS, cn = F.D.cn, cp = F.D.cp;
-    F.began = false;
-    ltpl_paths_in in; std::memset(&in, 0, sizeof(in));
-    static const double zero = 0.0;
-    in.n_scen = n; in.n_w_last = (int)F.w_last.size(); in.w_last_edges = F.w_last.empty() ? &zero : F.w_last.data();
-    in.start_layer = F.p_sl.data(); in.start_node = F.p_sn.data(); in.flags = F.p_fl.data(); in.last_action = F.p_la.data();
-    in.const_closest = F.p_cc.data(); in.psi_s = F.p_psi.data();
-    in.veh_off = F.veh_off.data(); in.pos_off = F.pos_off.data(); in.veh_radius = F.radius.data(); in.pos_x = F.px.data(); in.pos_y = F.py.data();
-    in.zone_off = zone_off; in.zone_gid = zone_gid;
-    in.n_last = F.p_nl.data(); in.last_layer = F.p_ll.data(); in.last_node = F.p_ln.data();
-    F.o_end.resize(n); F.o_coi.resize(n); F.o_con.resize((size_t)n * 2); F.o_na.resize(n);
-    for (auto* v : {&F.o_id, &F.o_valid, &F.o_red, &F.o_goal, &F.o_nn, &F.o_np, &F.o_nt}) v->resize((size_t)n * A);
-    F.o_nodes.resize((size_t)n * A * cn); F.o_nidx.resize((size_t)n * A * cn); F.o_co.resize((size_t)n * A * cn * 8); F.o_pp.resize((size_t)n * A * cp * 5);
-    ltpl_paths_out out; std::memset(&out, 0, sizeof(out));
-    out.cap_nodes = cn; out.cap_pts = cp; out.end_layer = F.o_end.data(); out.closest_obj_index = F.o_coi.data(); out.closest_obj_node = F.o_con.data();
-    out.n_actions = F.o_na.data(); out.action_id = F.o_id.data(); out.valid = F.o_valid.data(); out.reduced = F.o_red.data(); out.goal_layer = F.o_goal.data();
-    out.n_nodes = F.o_nn.data(); out.n_pts = F.o_np.data(); out.n_ties = F.o_nt.data(); out.nodes = F.o_nodes.data(); out.node_idx = F.o_nidx.data();
-    out.coeff = F.o_co.data(); out.path_param = F.o_pp.data();
-    const int rc = oracle_plan_paths(F.d, &in, &out);
-    if (rc) { F.err = "oracle_plan_paths failed"; return rc; }
-    FPathsOut po{F.o_coi.data(), F.o_na.data(), F.o_id.data(), F.o_valid.data(), F.o_red.data(), F.o_nn.data(), F.o_np.data(), F.o_nodes.data(),
-                 F.o_nidx.data(), F.o_co.data(), F.o_pp.data()};
-    HostX x;
-    for (int p = 0; p < n; ++p) { Block B = F.block(p); if (!B.S()->err) paths_post(x, F.flat, B, *B.S(), p, po); }
-    return F.first_error();
-}
-int oracle_fleet_calc_paths(oracle_fleet* f, const ltpl_planner_paths_in* in)
-{
-    // (as on the device: every stage runs for every planner, a failing planner is skipped by the later stages and reported at the end)
-    const int rc = oracle_fleet_calc_paths_begin(f, in);
-    if (rc && !f->F.began) return rc;
-    return oracle_fleet_calc_paths_finish(f, in->zone_off, in->zone_gid);
-}
-int oracle_fleet_get_ref_idx(oracle_fleet* f, const double* px, const double* py)
-{
-    if (!f || !px || !py) return LTPL_ERR_INVALID_ARG;
-    HostFleet& F = f->F; HostX x;
-    for (int p = 0; p < F.D.N; ++p) { Block B = F.block(p); ref_idx(x, F.cfg, B, *B.S(), px[p], py[p]); B.S()->ref_done = 1; }
-    return LTPL_OK;
-}
-int oracle_fleet_calc_vel_profile(oracle_fleet* f, const ltpl_planner_vel_in* in)
-{
-    if (!f || !in) return LTPL_ERR_INVALID_ARG;
-    HostFleet& F = f->F; const int n = F.D.N;
-    if (in->gg_row_off || in->gg_rows) { F.err = err_text(0, LTPL_ERR_UNSUPPORTED | (E_GG_DICT << 8)); return LTPL_ERR_UNSUPPORTED; }
-    const int n_tab = in->n_ax_tables > 1 ? in->n_ax_tables : 0;
-    if (n_tab && (!in->ax_table_off || !in->ax_table_idx)) { F.err = "fleet: n_ax_tables > 1 without ax_table_off / ax_table_idx"; return LTPL_ERR_INVALID_ARG; }
-    ltpl_vel_params vp; std::memset(&vp, 0, sizeof(vp));
-    vp.dyn_model_exp = F.pc.dyn_model_exp; vp.drag_coeff = F.pc.drag_coeff; vp.m_veh = F.pc.m_veh; vp.len_veh = F.lat.veh_length;
-    vp.n_ax_max_machines = n_tab ? in->ax_table_off[1] - in->ax_table_off[0] : in->n_ax_max_machines; vp.ax_max_machines = in->ax_max_machines;
-    vp.follow_control_type = F.pc.follow_control_type;
-    vp.c_p = F.pc.c_p; vp.k_p = F.pc.k_p; vp.k_d = F.pc.k_d; vp.tan_w = F.pc.tan_w; vp.v_max = in->vel_max[0];
-    FVelIn vin{in->pos_est_x, in->pos_est_y, in->vel_est, in->vel_max, in->gg_scale, in->gg_ax, in->gg_ay, in->safety_d, in->incl_emerg_traj,
-               n_tab ? in->ax_table_off : nullptr, n_tab ? in->ax_table_idx : nullptr};
-    HostX x; int rc;
-    FJobs JA = F.JA.view(), JB = F.JB.view(), JC = F.JC.view();
-    for (int p = 0; p < n; ++p) { Block B = F.block(p); vel_a(x, F.flat, F.cfg, B, *B.S(), p, F.obj(), vin, JA); }
-    if ((rc = run_jobs(&F, vp, F.JA))) return rc;
-    for (int p = 0; p < n; ++p) { Block B = F.block(p); vel_b(x, F.cfg, B, *B.S(), p, JA, JB); }
-    if ((rc = run_jobs(&F, vp, F.JB))) return rc;
-    for (int p = 0; p < n; ++p) { Block B = F.block(p); vel_c(x, F.cfg, B, *B.S(), p, vin, JB, JC); }
-    ltpl_vel_params ve = vp; ve.dyn_model_exp = 1.0; ve.drag_coeff = 0.854; ve.m_veh = 1160.0;     // calc_brake_emergency.py:4-6,31-36
-    if ((rc = run_jobs(&F, ve, F.JC))) return rc;
-    for (int p = 0; p < n; ++p) { Block B = F.block(p); vel_d(x, B, *B.S(), p, vin, JC); }
-    return F.first_error();
-}
-int oracle_fleet_get_paths(const oracle_fleet* f, int32_t p, ltpl_planner_paths_view* v)
-{
-    if (!f || !v || p < 0 || p >= f->F.D.N) return LTPL_ERR_INVALID_ARG;
-    return paths_view(f->F.D, f->F.state.data() + f->F.D.stride * (size_t)p, v);
-}
-int oracle_fleet_get_trajectories(const oracle_fleet* f, int32_t p, ltpl_planner_traj_view* v)
-{
-    if (!f || !v || p < 0 || p >= f->F.D.N) return LTPL_ERR_INVALID_ARG;
-    return traj_view(f->F.D, f->F.state.data() + f->F.D.stride * (size_t)p, v);
-}
+int oracle_fleet_calc_paths_begin(oracle_fleet* f, const ltpl_planner_paths_in* in) { return f ? ltplp::api_calc_paths_begin(f->p, in) : LTPL_ERR_INVALID_ARG; }
+int oracle_fleet_calc_paths_finish(oracle_fleet* f, const int32_t* zo, const int32_t* zg) { return f ? ltplp::api_calc_paths_finish(f->p, zo, zg) : LTPL_ERR_INVALID_ARG; }
+int oracle_fleet_calc_paths(oracle_fleet* f, const ltpl_planner_paths_in* in) { return f ? ltplp::api_calc_paths(f->p, in) : LTPL_ERR_INVALID_ARG; }
+int oracle_fleet_get_ref_idx(oracle_fleet* f, const double* px, const double* py) { return (f && px && py) ? f->p->P.get_ref_idx(px, py) : LTPL_ERR_INVALID_ARG; }
+int oracle_fleet_calc_vel_profile(oracle_fleet* f, const ltpl_planner_vel_in* in) { return f ? ltplp::api_calc_vel_profile(f->p, in) : LTPL_ERR_INVALID_ARG; }
+int oracle_fleet_get_paths(const oracle_fleet* f, int32_t p, ltpl_planner_paths_view* v) { return f ? ltplp::api_get_paths(f->p, p, v) : LTPL_ERR_INVALID_ARG; }
+int oracle_fleet_get_trajectories(const oracle_fleet* f, int32_t p, ltpl_planner_traj_view* v) { return f ? ltplp::api_get_trajectories(f->p, p, v) : LTPL_ERR_INVALID_ARG; }
 }

@@ -1,38 +1,14 @@
 // ORACLE / TEST INFRASTRUCTURE ONLY -- never linked into or loaded by the product path.
 //
-// The product's host state machine (graphbasedlocaltrajectoryplanner_amd/csrc/planner_core.hpp: the C++ restatement of the
-// reference's OnlineTrajectoryHandler) bound to the ORACLE's CPU arithmetic (oracle_plan_paths / oracle_vel_profile of
-// ltpl_oracle.c) instead of the HIP kernels. Purpose: the GPU-less build container can drive the host logic through the
+// The product's host planner (graphbasedlocaltrajectoryplanner_amd/csrc/planner_host.hpp: the planner state machine of fleet_core.hpp --
+// the C++ restatement of the reference's OnlineTrajectoryHandler -- on host memory) bound to the ORACLE's CPU arithmetic
+// (oracle_compute.hpp) instead of the HIP kernels. Purpose: the GPU-less build container can drive the host logic through the
 // recorded closed loops of tests/golden/*_ticks.npz (`-m "not gpu"` tests cover "the host logic"). On the GPU box the same
 // recordings run through libltpl_hip.so (`-m gpu`). The exported names carry the prefix oracle_planner_ so that they can
 // never be mistaken for the product's ltpl_planner_* symbols.
-#include "../graphbasedlocaltrajectoryplanner_amd/csrc/planner_api.hpp"
-
-extern "C" {
-int oracle_plan_paths(const ltpl_lattice_desc* d, const ltpl_paths_in* in, ltpl_paths_out* out);
-int oracle_vel_profile(const ltpl_lattice_desc* d, const ltpl_vel_params* params, int n_jobs, const ltpl_vel_job* jobs,
-                       ltpl_vel_result* results);
-}
+#include "oracle_compute.hpp"
 
 namespace {
-struct OracleCompute : ltplp::Compute {
-    const ltpl_lattice_desc* d;          // owned by the caller (Python keeps the arrays alive)
-    std::string err;
-    explicit OracleCompute(const ltpl_lattice_desc* desc) : d(desc) {}
-    int plan_paths(const ltpl_paths_in* in, ltpl_paths_out* out) override
-    {
-        const int rc = oracle_plan_paths(d, in, out);
-        if (rc) err = "oracle_plan_paths failed";
-        return rc;
-    }
-    int vel_profile(const ltpl_vel_params* p, int n, const ltpl_vel_job* jobs, ltpl_vel_result* res) override
-    {
-        const int rc = oracle_vel_profile(d, p, n, jobs, res);
-        if (rc) err = "oracle_vel_profile failed";
-        return rc;
-    }
-    const char* last_error() override { return err.c_str(); }
-};
 std::string g_err;
 }
 

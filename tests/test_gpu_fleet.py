@@ -24,6 +24,7 @@ def hip(monteblanco):
     ("zonewall", 3, {"straight", "follow", "right"}),
     ("ggdrop", 1, {"straight"}),                              # backup branch: second velocity launch
     ("overtake", 70, {"follow", "left", "right", "emergency"}),   # >= 64 planners: one-wave batch path kernel; emergency: third launch
+    ("ggmap", 2, {"follow", "emergency"}),                    # location dependent friction: rows per job (k_vel_profile GG, SEL 2 / 3 / 1)
 ])
 def test_closed_loop_replay_matches_reference_recordings(hip, monteblanco, name, n, must_see):
     from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
@@ -159,3 +160,34 @@ def test_a_fleet_of_different_cars_on_the_device(hip, monteblanco):
     seen = two_cars_replay(fleet, monteblanco, 33, 300, check_every=7)
     fleet.close()
     assert {"follow", "right", "emergency"} <= seen
+
+
+def test_friction_rows_next_to_constant_tuples_on_the_device(hip, monteblanco):
+    """local_gg per vehicle on the MI355X: 2 x 33 planners of one fleet, the first half with the friction MAP of the 'ggmap' recording
+    (rows per path coordinate, OTH.py:649-666), the second half with a constant tuple on 'c2' -- forward-backward jobs with rows go to the
+    wave-per-job kernel (SEL 3), those with constants stay on the lane kernel, in the same call."""
+    from test_fleet_host_logic import friction_rows_next_to_constants
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    fleet = Fleet(hip, 66)
+    keys = friction_rows_next_to_constants(fleet, monteblanco, n_ticks=200, reps=33)
+    fleet.close()
+    assert {"follow", "emergency", "right"} <= keys, keys
+
+
+def test_friction_rows_that_do_not_match_the_path_on_the_device(hip, monteblanco):
+    from graphbasedlocaltrajectoryplanner_amd._capi import BackendError
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    ticks = pr.load_ticks("c1")
+    fleet = Fleet(hip, 2)
+    st, t = ticks[0]['start'], ticks[0]
+    for p in (0, 1):
+        fleet.set_start(p, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+    veh, zg, va = pr.vehicles_of_tick(t), pr.zone_gids_of_tick(monteblanco, t), t['vel_args']
+    fleet.calc_paths([t['action_id_sel']] * 2, [t['t']] * 2, [veh] * 2, [zg] * 2)
+    short = {k: [np.full((v.shape[0] - 1, 2), 5.0)] for k, v in fleet.paths(0)['path_param'].items()}
+    with pytest.raises(BackendError, match="planner 0: local_gg rows"):
+        fleet.calc_vel_profile([t['pos_est']] * 2, va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'], local_gg=[short, tuple(va['local_gg'])],
+                               ax_max_machines=va['ax_max_machines'], safety_d=va['safety_d'], incl_emerg_traj=va['incl_emerg_traj'])
+    traj, ids, ref = fleet.trajectories(1)
+    pr.check_trajectories(traj, ids, ref, t, "the neighbour of the failing planner")
+    fleet.close()

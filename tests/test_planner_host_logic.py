@@ -142,24 +142,3 @@ def test_input_staging_grows_and_keeps_the_layout(host_backend):
     assert i32(i.zone_gid, 705).tolist() == list(range(700)) + list(range(5))
     acts = i32(i.prev_action, 2)
     assert acts[1] == -1 and acts[0] != -1
-
-
-def test_threaded_batch_equals_the_serial_batch(host_backend, monteblanco, monkeypatch):
-    """LTPL_PLANNER_THREADS (opt-in): the per-planner loops of a batch on worker threads -- contiguous ranges merged in order -- must give
-    what the serial loops give, planner by planner, and still follow the recording."""
-    import numpy as np
-    ticks = pr.load_ticks("c2")
-    serial = host_backend.planner(40)
-    pr.replay(serial, monteblanco, ticks, scen=39, n_ticks=120)
-    monkeypatch.setenv("LTPL_PLANNER_THREADS", "4")
-    monkeypatch.setenv("LTPL_PLANNER_SPIN_US", "50")
-    threaded = host_backend.planner(40)
-    pr.replay(threaded, monteblanco, ticks, scen=17, n_ticks=120)
-    for s in (0, 9, 10, 19, 20, 29, 30, 39):                          # both sides of every range boundary (4 ranges of 10)
-        a, b = serial.trajectories(s), threaded.trajectories(s)
-        assert list(a[0].keys()) == list(b[0].keys()) and a[1] == b[1] and a[2]["cut_index_pos"] == b[2]["cut_index_pos"]
-        for k in a[0]:
-            assert np.array_equal(a[0][k][0], b[0][k][0])
-        pa, pb = serial.paths(s), threaded.paths(s)
-        assert pa["keys"] == pb["keys"] and pa["nodes"] == pb["nodes"]
-        assert all(np.array_equal(pa["path_param"][k], pb["path_param"][k]) for k in pa["keys"])

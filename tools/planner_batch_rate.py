@@ -1,9 +1,9 @@
 """Closed-loop rate of a BATCH of planners (ltpl_planner_* entry points): N planners are driven with the recorded inputs of the C2 loop
-(every planner the same inputs; each carries its own state), wall time per tick and planner-ticks per second. Used to see what the
-opt-in host threads (LTPL_PLANNER_THREADS) buy on a given box:
+(every planner the same inputs; each carries its own state), wall time per tick and planner-ticks per second (the
+fleet, tools/fleet_rate.py, is the form meant for batches):
 
-    for T in 1 4 8; do LTPL_PLANNER_THREADS=$T python tools/planner_batch_rate.py --planners 256; done       # MI355X
-    LTPL_PLANNER_THREADS=8 python tools/planner_batch_rate.py --planners 64 --harness                         # no GPU (oracle arithmetic)
+    python tools/planner_batch_rate.py --planners 256             # MI355X
+    python tools/planner_batch_rate.py --planners 64 --harness    # no GPU (oracle arithmetic)
 """
 import argparse
 import os
@@ -53,8 +53,8 @@ def main():
     a0, a1 = pl.trajectories(0), pl.trajectories(n - 1)
     same = list(a0[0].keys()) == list(a1[0].keys()) and all(np.array_equal(a0[0][k][0], a1[0][k][0]) for k in a0[0])
     c, v = np.array(t_c[20:]), np.array(t_v[20:])
-    print("planners %d  threads %s  calc_paths %.3f ms  calc_vel_profile %.3f ms  tick %.3f ms  = %.0f planner-ticks/s  (Python packing of "
-          "the inputs included; first / last planner identical: %s)" % (n, os.environ.get("LTPL_PLANNER_THREADS", "1"), c.mean() * 1e3,
+    print("planners %d  calc_paths %.3f ms  calc_vel_profile %.3f ms  tick %.3f ms  = %.0f planner-ticks/s  (Python packing of "
+          "the inputs included; first / last planner identical: %s)" % (n, c.mean() * 1e3,
                                                                         v.mean() * 1e3, (c + v).mean() * 1e3, n / (c + v).mean(), same))
 
 
