@@ -698,12 +698,16 @@ def worker(args):
                          # what actually limits the kernel: instruction issue + dependent LDS round trips, not DRAM (the lattice is cache
                          # resident: traffic_frac ~ 0.1). `issue` = the bound that binds, from a PMC pass of this build
                          "limiter": "valu-issue / lds pipe (cache-resident working set)",
-                         "binding": {"bound": "valu-issue", "issue_frac": issue_frac, "lane_frac": lane_frac,
+                         "binding": {"bound": ("lds-pipe" if issue and issue.get("lds_util") and issue_frac is not None and issue["lds_util"] > issue_frac
+                                               else "valu-issue"),
+                                     "issue_frac": issue_frac, "lane_frac": lane_frac,
                                      "useful_lane_frac": (issue_frac * lane_frac) if issue else None,
                                      "lds_frac": issue["lds_util"] if issue else None,
                                      "what": "issue_frac = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x kernel time x 2.4 GHz); lane_frac = "
                                              "active lanes per vector instruction / 64; useful_lane_frac = their product = share of the chip's "
-                                             "lane throughput that does work; lds_frac = SQ_ACTIVE_INST_LDS x 4 / (256 CUs x kernel time x 2.4 GHz)"},
+                                             "lane throughput that does work; lds_frac = SQ_ACTIVE_INST_LDS x 4 / (256 CUs x kernel time x 2.4 GHz); bound = the larger of issue_frac and lds_frac. "
+                                             "Both are lower bounds: the clock under this load is below the 2.4 GHz peak (counted inside the waves' own "
+                                             "lifetime, wait_frac_of_wave_cycles aside, the LDS pipe of a CU is ~77 % busy)"},
                          "frac_refline_per_position": (ab_paths - ab["mask"] + ab["mask_refline_per_position"]) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "issue": issue,
                          "kernel": "k_paths<1>", "kernel_ms": dom_ms,

@@ -159,7 +159,8 @@ template <int EM, bool AXM1>
 __global__ __launch_bounds__(64) void k_fleet_fb_lanes(DevVelParams p, const DevVelJob* jobs, const double* pool, const ke_t* ke, int ke_rows,
                                                        double* outp, int cap, int n_planners, int per, double* out)
 {
-    __shared__ double axm_s[2 * FLEET_AXM_ROWS];              // ALL machine tables of the call (every lane indexes its own job's table)
+    extern __shared__ double axm_s[];                         // ALL machine tables of the call, 16 B per row (every lane indexes its own job's table);
+                                                              // sized by the launch: a fixed 8 KB took LDS from the follow jobs running next to this kernel (r04i)
     const int lane = threadIdx.x;
     for (int i = lane; i < 2 * p.n_axm; i += 64) axm_s[i] = p.axm[i];
     __syncthreads();
@@ -174,9 +175,11 @@ __global__ __launch_bounds__(64) void k_fleet_fb_lanes(DevVelParams p, const Dev
     const double cax = pool[jp->off_gg], cay = pool[jp->off_gg + 1];
     // the car of the job: its own vel_max / machine table (fleet::VelJob, ABI v6), else the launch's
     DevVelParams pj = p;
-    if (jp->v_max > 0.0) pj.v_max = jp->v_max;
     const double* axm_j = axm_s;
+#ifndef LTPL_LANES_UNIFORM_CAR
+    if (jp->v_max > 0.0) pj.v_max = jp->v_max;
     if (jp->n_axm > 0) { pj.n_axm = jp->n_axm; axm_j = axm_s + 2 * jp->axm_off; }
+#endif
     lane_fb_profile<EM, AXM1>(L, D, 0, n, cax, cay, pj, axm_j, pj.v_max, jp->v_start, jp->has_v_end != 0, jp->v_end);
     // results job-major like every other job's (a lane writes its own row: scattered 8-byte stores, but this launch leaves half of the
     // SIMDs idle and runs next to the follow jobs -- the readers in k_fleet_vel_b then find coalesced rows)
@@ -639,7 +642,7 @@ static int fleet_launch_vel(ltpl_fleet* f, const FleetTickIn& t)
         const unsigned waves = (unsigned)(((size_t)N * (fleet::JOBS_A - 1) + 63) / 64);
         FLEET_TRY(f, hipEventRecord(f->ev_a, st));
         FLEET_TRY(f, hipStreamWaitEvent(f->stream2, f->ev_a, 0));
-        hipLaunchKernelGGL(fleet_lanes_kernel_of(fleet_variant(vp, t.multi_axm != 0)), dim3(waves), dim3(64), 0, f->stream2, p, reinterpret_cast<const DevVelJob*>(f->JA.jobs),
+        hipLaunchKernelGGL(fleet_lanes_kernel_of(fleet_variant(vp, t.multi_axm != 0)), dim3(waves), dim3(64), 16 * (size_t)(t.n_axm_total > 0 ? t.n_axm_total : 1), f->stream2, p, reinterpret_cast<const DevVelJob*>(f->JA.jobs),
                            (const double*)f->JA.pool, reinterpret_cast<const ke_t*>(f->JA.ke), f->JA.ke_rows, f->JA.outp, f->D.RV, N, (int)fleet::JOBS_A,
                            f->JA.out);
         FLEET_TRY(f, hipGetLastError());

@@ -841,8 +841,10 @@ __global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p_,
     if (jb.n <= 0) { signal_done(done); return; }          // unused slot of a fleet's job table (fleet_dev.hpp); seam (2) itself rejects empty jobs
     // the car of the job: its own vel_max / machine table (a fleet of different cars), else the launch's
     DevVelParams p = p_;
+#ifndef LTPL_VELJOB_UNIFORM_CAR
     if (jb.v_max > 0.0) p.v_max = jb.v_max;
     if (jb.n_axm > 0) { p.n_axm = jb.n_axm; p.axm = p_.axm + 2 * jb.axm_off; }
+#endif
     const bool follow = jb.mode == LTPL_VEL_FOLLOW || jb.mode == LTPL_VEL_FOLLOW_CONTROLLED;
     if constexpr (SEL == 1) { if (follow) return; }
     if constexpr (SEL == 2) { if (!follow) return; }

@@ -26,7 +26,6 @@
  *   LTPL_POLL=1 (+ LTPL_POLL_SYNC_EVERY, LTPL_POLL_QUERY)   completion of small calls through a polled word instead of a stream sync
  *   LTPL_NO_SELFTEST=1          skip the create-time self-test (one-wave vs four-wave kernel on probe scenarios)
  *   LTPL_HOST_PROF=1            host-side timing table of the entry points on stderr at exit
- *   LTPL_PLANNER_THREADS=<n>, LTPL_PLANNER_SPIN_US=<us>   worker threads of the planner's per-planner host loops (default: serial)
  * Timing / fault-injection switches (LTPL_ABLATE, LTPL_EXP_SKIP, LTPL_LDS_POISON, LTPL_SCRATCH_POISON, LTPL_DEBUG_TIMING,
  * LTPL_DEBUG_OCC) skip work, overwrite memory or instrument kernels; they are compiled into the EXPERIMENT build only
  * (-DLTPL_EXPERIMENT -> libltpl_hip_exp.so, used by tools/ and one fault-injection test) and do not exist in libltpl_hip.so.
@@ -548,8 +547,8 @@ int ltpl_planner_get_trajectories(const ltpl_planner* planner, int32_t scen, ltp
  * (csrc/fleet_core.hpp) between the launches of the path kernel and the velocity kernel: no host work per planner, no host
  * synchronisation inside a tick. Entry points and structs are those of ltpl_planner_* (same argument meaning, same views), so a
  * caller switches by the prefix. Differences, all reported and none silent:
- *   - local_gg only in its constant form (gg_row_off / gg_rows must be NULL -> LTPL_ERR_UNSUPPORTED; the dict form stays with
- *     ltpl_planner_*);
+ *   - local_gg in both forms since ABI v6 (gg_row_off / gg_rows: friction rows per planner and path key; rows that do not match
+ *     the coordinates of the path are an error of that planner, OTH.py:641-646);
  *   - the conditions on which the reference raises (OTH.py:334, :712, :830, :919, :923, :1029, ...) are detected per planner on the
  *     device: the call returns the status of the FIRST failing planner ("fleet: planner N: ..."), that planner keeps its error
  *     state (its later ticks are skipped) until ltpl_fleet_set_start gives it a new pose; the other planners are not affected;

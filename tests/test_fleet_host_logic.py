@@ -54,7 +54,7 @@ def test_closed_loop_replay_on_an_open_track(open_lattice):
     assert {"straight", "follow", "right"} <= seen['keys'] and seen['full'] >= 15
 
 
-@pytest.mark.parametrize("track", ["millbrook", "berlin"])    # one-node layers with a range of almost a lap; 40 nodes per layer
+@pytest.mark.parametrize("track", ["millbrook", "berlin", "lvms", "modena", "zalazone"])    # all race line files of the reference (millbrook: one-node layers with a range of almost a lap; berlin: 40 nodes per layer)
 def test_closed_loop_replay_on_other_tracks(track):
     from oracle.fleet_host import HostFleetBackend
     from test_other_tracks import lattice_of

@@ -53,7 +53,7 @@ def test_open_track(open_lattice):
     fleet.close()
 
 
-@pytest.mark.parametrize("track", ["millbrook", "berlin"])
+@pytest.mark.parametrize("track", ["millbrook", "berlin", "lvms", "modena", "zalazone"])
 def test_other_tracks(track):
     from graphbasedlocaltrajectoryplanner_amd import _capi
     from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
