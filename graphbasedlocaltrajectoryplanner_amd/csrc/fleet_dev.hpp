@@ -74,12 +74,10 @@ __device__ __forceinline__ void fleet_store(const WaveX& x, const fleet::Block& 
     if (x.lane() == 0 && S->err) atomicCAS(err_word, 0, ((p + 1) << FLEET_ERR_SHIFT) | (S->err & FLEET_ERR_MASK));
 }
 
-__global__ __launch_bounds__(64) void k_fleet_paths_pre(FleetArgs F, fleet::FObj ob, fleet::FPathsIn pin)
+// OTH.calc_paths in front of seam (1) for planner p (scalars in LDS)
+__device__ __forceinline__ void fleet_pre_body(const WaveX& x, const FleetArgs& F, const fleet::Block& B, fleet::PlannerS& S, int p, const fleet::FObj& ob,
+                                               const fleet::FPathsIn& pin)
 {
-    const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
-    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D, F.gg ? F.gg + F.D.gg_stride * (size_t)p : nullptr};
-    __shared__ fleet::PlannerS S;
-    fleet_load(x, B, &S);
     if (!S.err) fleet::paths_pre(x, F.lat, F.cfg, B, S, p, ob, pin);
     if (!S.err && F.rng_end[S.start_node[0]] < 0) fleet::fail(S, LTPL_ERR_INVALID_ARG, fleet::E_NO_RANGE);
     if (S.err && x.lane() == 0) {
@@ -88,6 +86,15 @@ __global__ __launch_bounds__(64) void k_fleet_paths_pre(FleetArgs F, fleet::FObj
         pin.start_layer[p] = l0; pin.start_node[p] = F.lat.rl_idx[l0]; pin.flags[p] = LTPL_FLAG_ACTION_SETS; pin.last_action[p] = LTPL_ACT_NONE;
         pin.const_closest[p] = -1; pin.psi_s[p] = 0.0; pin.n_last[p] = 0;
     }
+}
+
+__global__ __launch_bounds__(64) void k_fleet_paths_pre(FleetArgs F, fleet::FObj ob, fleet::FPathsIn pin)
+{
+    const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D, F.gg ? F.gg + F.D.gg_stride * (size_t)p : nullptr};
+    __shared__ fleet::PlannerS S;
+    fleet_load(x, B, &S);
+    fleet_pre_body(x, F, B, S, p, ob, pin);
     fleet_store(x, B, &S, p, F.err_word);
 }
 
@@ -118,6 +125,35 @@ __global__ __launch_bounds__(64, 4) void k_fleet_vel_a(FleetArgs F, fleet::FObj 
     __shared__ fleet::PlannerS S;
     fleet_load(x, B, &S);
     fleet::vel_a(x, F.lat, F.cfg, B, S, p, ob, vin, JA);
+    fleet_store(x, B, &S, p, F.err_word);
+}
+
+// TAPE mode (both calls of a tick and the next tick's inputs are known): stages that follow each other without a seam in between run as
+// ONE kernel -- the scalars are loaded / stored once and a kernel boundary (drain + refill of 8 192 short waves) goes away:
+//   paths_post + vel_a            (behind seam (1))
+//   vel_c | vel_d + paths_pre     (behind the last velocity launch of tick t: the first kernel of tick t + 1)
+__global__ __launch_bounds__(64, 4) void k_fleet_post_vel_a(FleetArgs F, fleet::FPathsOut po, fleet::FObj ob, fleet::FVelIn vin, fleet::FJobs JA)
+{
+    const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D, F.gg ? F.gg + F.D.gg_stride * (size_t)p : nullptr};
+    __shared__ fleet::PlannerS S;
+    fleet_load(x, B, &S);
+    if (!S.err) fleet::paths_post(x, F.lat, B, S, p, po);
+    x.sync();
+    fleet::vel_a(x, F.lat, F.cfg, B, S, p, ob, vin, JA);
+    fleet_store(x, B, &S, p, F.err_word);
+}
+template <bool D>      // D: the tick had an emergency launch -> stage D in front of the next tick; else stage C
+__global__ __launch_bounds__(64) void k_fleet_tail_pre(FleetArgs F, fleet::FVelIn vin, fleet::FJobs J0, fleet::FJobs JC, fleet::FObj ob_next, fleet::FPathsIn pin)
+{
+    const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D, F.gg ? F.gg + F.D.gg_stride * (size_t)p : nullptr};
+    __shared__ fleet::PlannerS S;
+    fleet_load(x, B, &S);
+    if constexpr (D) fleet::vel_d(x, B, S, p, vin, JC);
+    else fleet::vel_c(x, F.cfg, B, S, p, vin, J0, JC);
+    x.sync();
+    fleet_pre_body(x, F, B, S, p, ob_next, pin);
     fleet_store(x, B, &S, p, F.err_word);
 }
 
@@ -230,6 +266,7 @@ struct ltpl_fleet {
     std::vector<unsigned char> image;                 // host image of one planner block (queries)
     bool began = false;
     size_t vel_lds = 0, vel_lds_lite = 0, vel_lds_gg = 0, vel_lds_lite_gg = 0;
+    bool tape_fuse = !(getenv("LTPL_FLEET_NO_FUSE") && atoi(getenv("LTPL_FLEET_NO_FUSE")) != 0);     // tape runs with fused stage kernels (results identical)
     ~ltpl_fleet()
     {
         if (h) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); --h->n_planners; }
@@ -555,7 +592,7 @@ static int fleet_pack_inputs(ltpl_fleet* f, FleetTickIn* t, const ltpl_planner_p
     return LTPL_OK;
 }
 
-static int fleet_launch_paths(ltpl_fleet* f, const FleetTickIn& t, bool pre, bool rest)
+static int fleet_launch_paths(ltpl_fleet* f, const FleetTickIn& t, bool pre, bool rest, bool post = true, fleet::FPathsOut* po_out = nullptr)
 {
     ltpl_handle* h = f->h; const int N = f->D.N; hipStream_t st = h->stream;
     if (pre) {
@@ -575,6 +612,8 @@ static int fleet_launch_paths(ltpl_fleet* f, const FleetTickIn& t, bool pre, boo
     if (rc) { f->err = h->err; return rc; }
     const fleet::FPathsOut po{f->dout.closest_obj_index, f->dout.n_actions, f->dout.action_id, f->dout.valid, f->dout.reduced, f->dout.n_nodes, f->dout.n_pts,
                               f->dout.nodes, f->dout.node_idx, f->dout.coeff, f->dout.path_param};
+    if (po_out) *po_out = po;
+    if (!post) return LTPL_OK;          // (tape mode: paths_post runs inside the first kernel of the velocity step)
     hipLaunchKernelGGL(k_fleet_paths_post, dim3(N), dim3(64), 0, st, f->args, po);
     FLEET_TRY(f, hipGetLastError());
     return LTPL_OK;
@@ -624,7 +663,9 @@ static int fleet_launch_vel_jobs(ltpl_fleet* f, const ltpl_vel_params& vp, const
     return LTPL_OK;
 }
 
-static int fleet_launch_vel(ltpl_fleet* f, const FleetTickIn& t)
+// `fused_post`: paths_post of this tick has not run yet (tape mode) -> first kernel = paths_post + vel_a; `next`: the tick that follows on the
+// tape -> its paths_pre runs inside the last state-machine kernel of this tick
+static int fleet_launch_vel(ltpl_fleet* f, const FleetTickIn& t, const fleet::FPathsOut* fused_post = nullptr, const FleetTickIn* next = nullptr)
 {
     ltpl_handle* h = f->h; const int N = f->D.N; hipStream_t st = h->stream;
     static const double one_row[2] = {0.0, 0.0};
@@ -633,7 +674,8 @@ static int fleet_launch_vel(ltpl_fleet* f, const FleetTickIn& t)
     vp.n_ax_max_machines = t.n_axm; vp.ax_max_machines = one_row;      // (the table itself is read on the device: t.axm)
     vp.follow_control_type = f->pc.follow_control_type; vp.c_p = f->pc.c_p; vp.k_p = f->pc.k_p; vp.k_d = f->pc.k_d; vp.tan_w = f->pc.tan_w; vp.v_max = t.vel_max;
     int rc;
-    hipLaunchKernelGGL(k_fleet_vel_a, dim3(N), dim3(64), 0, st, f->args, t.ob, t.vin, f->JA.view());
+    if (fused_post) hipLaunchKernelGGL(k_fleet_post_vel_a, dim3(N), dim3(64), 0, st, f->args, *fused_post, t.ob, t.vin, f->JA.view());
+    else hipLaunchKernelGGL(k_fleet_vel_a, dim3(N), dim3(64), 0, st, f->args, t.ob, t.vin, f->JA.view());
     FLEET_TRY(f, hipGetLastError());
     {   // forward-backward jobs (slots >= 1), one lane per job, on the second stream: 512 long waves for 8 192 planners -- next to the follow jobs
         DevVelParams p;
@@ -655,12 +697,14 @@ static int fleet_launch_vel(ltpl_fleet* f, const FleetTickIn& t)
     hipLaunchKernelGGL(k_fleet_vel_b, dim3(N), dim3(64), 0, st, f->args, f->JA.view(), f->JB.view());
     FLEET_TRY(f, hipGetLastError());
     if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JB, 1, multi, rows))) return rc;
-    hipLaunchKernelGGL(k_fleet_vel_c, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JB.view(), f->JC.view());
+    if (next && !t.any_emerg) hipLaunchKernelGGL(k_fleet_tail_pre<false>, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JB.view(), f->JC.view(), next->ob, f->pin);
+    else hipLaunchKernelGGL(k_fleet_vel_c, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JB.view(), f->JC.view());
     FLEET_TRY(f, hipGetLastError());
     if (t.any_emerg) {
         ltpl_vel_params ve = vp; ve.dyn_model_exp = 1.0; ve.drag_coeff = 0.854; ve.m_veh = 1160.0;       // calc_brake_emergency.py:4-6,31-36
         if ((rc = fleet_launch_vel_jobs(f, ve, t.axm, f->JC, 1, false, rows))) return rc;
-        hipLaunchKernelGGL(k_fleet_vel_d, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JC.view());
+        if (next) hipLaunchKernelGGL(k_fleet_tail_pre<true>, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JB.view(), f->JC.view(), next->ob, f->pin);
+        else hipLaunchKernelGGL(k_fleet_vel_d, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JC.view());
         FLEET_TRY(f, hipGetLastError());
     }
     return LTPL_OK;
@@ -803,10 +847,18 @@ try {
     FLEET_TRY(f, hipEventCreate(&e0)); FLEET_TRY(f, hipEventCreate(&e1));
     FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
     FLEET_TRY(f, hipEventRecord(e0, f->h->stream));
+    const bool fuse = f->tape_fuse;
     for (int i = first; i < first + count; ++i) {
         const FleetTickIn& t = f->tape[(size_t)i];
-        if ((rc = fleet_launch_paths(f, t, true, true))) return rc;
-        if ((rc = fleet_launch_vel(f, t))) return rc;
+        if (!fuse) {
+            if ((rc = fleet_launch_paths(f, t, true, true))) return rc;
+            if ((rc = fleet_launch_vel(f, t))) return rc;
+            continue;
+        }
+        // fused stages: paths_pre of tick i ran inside the last kernel of tick i - 1 (except for the first tick of the run)
+        fleet::FPathsOut po{};
+        if ((rc = fleet_launch_paths(f, t, i == first, true, false, &po))) return rc;
+        if ((rc = fleet_launch_vel(f, t, &po, i + 1 < first + count ? &f->tape[(size_t)i + 1] : nullptr))) return rc;
     }
     FLEET_TRY(f, hipEventRecord(e1, f->h->stream));
     FLEET_TRY(f, hipEventSynchronize(e1));

@@ -26,6 +26,7 @@
  *   LTPL_POLL=1 (+ LTPL_POLL_SYNC_EVERY, LTPL_POLL_QUERY)   completion of small calls through a polled word instead of a stream sync
  *   LTPL_NO_SELFTEST=1          skip the create-time self-test (one-wave vs four-wave kernel on probe scenarios)
  *   LTPL_HOST_PROF=1            host-side timing table of the entry points on stderr at exit
+ *   LTPL_FLEET_NO_FUSE=1        fleet tape runs with one kernel per stage instead of the fused stage kernels (read by ltpl_fleet_create)
  * Timing / fault-injection switches (LTPL_ABLATE, LTPL_EXP_SKIP, LTPL_LDS_POISON, LTPL_SCRATCH_POISON, LTPL_DEBUG_TIMING,
  * LTPL_DEBUG_OCC) skip work, overwrite memory or instrument kernels; they are compiled into the EXPERIMENT build only
  * (-DLTPL_EXPERIMENT -> libltpl_hip_exp.so, used by tools/ and one fault-injection test) and do not exist in libltpl_hip.so.

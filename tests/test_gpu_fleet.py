@@ -191,3 +191,38 @@ def test_friction_rows_that_do_not_match_the_path_on_the_device(hip, monteblanco
     traj, ids, ref = fleet.trajectories(1)
     pr.check_trajectories(traj, ids, ref, t, "the neighbour of the failing planner")
     fleet.close()
+
+
+def test_fused_tape_kernels_equal_the_separate_ones(hip, monteblanco, monkeypatch):
+    """Tape runs execute paths_post + vel_a and vel_c | vel_d + the next tick's paths_pre as one kernel each (round 4). Same stages, same
+    order per planner: the state after 151 ticks of four recordings (with and without emergency launches, i.e. both tail variants) must
+    be IDENTICAL, array for array, to the run with one kernel per stage (LTPL_FLEET_NO_FUSE=1, read when the fleet is created), also when
+    the tape is run in several segments."""
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    names, per, T = ("c2", "overtake", "zonewall", "ggdrop"), 8, 151     # (the overtake recording asks for the emergency profile every third tick: 150 is one)
+    recs = [pr.load_ticks(nm) for nm in names]
+
+    def run(segments):
+        fleet = Fleet(hip, per * len(names))
+        for g, ticks in enumerate(recs):
+            st = ticks[0]['start']
+            fleet.set_start_range(g * per, (g + 1) * per, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+        for k in range(T):
+            fleet.tape_append_groups([(per, group_inputs(monteblanco, ticks[k])) for ticks in recs], ax_max_machines=recs[0][k]['vel_args']['ax_max_machines'])
+        for a, b in segments:
+            fleet.tape_run(a, b - a)
+        out = [(fleet.trajectories(p), fleet.paths(p)) for p in (0, per, 2 * per + 3, 4 * per - 1)]
+        fleet.close()
+        return out
+    fused = run([(0, T)])
+    fused_seg = run([(0, 1), (1, 70), (70, T)])
+    monkeypatch.setenv("LTPL_FLEET_NO_FUSE", "1")
+    plain = run([(0, T)])
+    for other in (fused_seg, plain):
+        for (ta, pa), (tb, pb) in zip(fused, other):
+            assert list(ta[0].keys()) == list(tb[0].keys()) and ta[1] == tb[1] and ta[2]['cut_index_pos'] == tb[2]['cut_index_pos']
+            for k in ta[0]:
+                assert np.array_equal(ta[0][k][0], tb[0][k][0]), k
+            assert pa['keys'] == pb['keys'] and pa['nodes'] == pb['nodes']
+            assert all(np.array_equal(pa['path_param'][k], pb['path_param'][k]) for k in pa['keys'])
+    assert "emergency" in fused[1][0][0]                       # the overtake group ran with the emergency launch (tail variant D)
