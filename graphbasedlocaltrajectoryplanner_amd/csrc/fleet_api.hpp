@@ -35,7 +35,7 @@ inline int check_config(const ltpl_planner_config* cfg, std::string* why)
 // scratch rows of a planner block hold two coordinate lists of a path's nodes (paths_pre) and the job tables address rows with ints
 inline int check_dims(const Dims& D, std::string* why)
 {
-    if (2 * D.CN > D.R || D.RV > D.R) { *why = "fleet: lattice with more path nodes than the block's scratch rows hold (2 (2 max_path_nodes + 8) > 2 max_path_pts + 64)"; return LTPL_ERR_CAPACITY; }
+    if (2 * D.CN > D.SR || D.RV > D.R || D.R > D.SR) { *why = "planner: inconsistent block dimensions"; return LTPL_ERR_CAPACITY; }      // (holds by construction, make_dims)
     return LTPL_OK;
 }
 

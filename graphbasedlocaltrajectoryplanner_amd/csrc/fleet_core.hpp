@@ -91,6 +91,7 @@ struct PlannerS {
 struct Dims {
     int N, R, CN, cn, cp;
     int RV;                         // points per velocity job (LDS-resident solver): cp + 64 <= R
+    int SR;                         // doubles per scratch row: max(R, 2 CN) -- paths_pre keeps the node coordinates of a path (x | y) in one
     size_t stride;                  // bytes per planner block
     size_t o_traj, traj_bytes, o_bp, o_velc, o_sarr, o_vx, o_scr;
     // Friction rows (local_gg as a dict) live in their OWN array, allocated when the first call carries rows: [ax, ay] per path row for the
@@ -111,6 +112,7 @@ inline Dims make_dims(int N, int max_path_nodes, int max_path_pts)
     D.N = N; D.cn = max_path_nodes; D.cp = max_path_pts;
     D.R = 2 * max_path_pts + 64; D.CN = 2 * max_path_nodes + 8;            // = ltpl_planner_caps
     D.RV = max_path_pts + 64;
+    D.SR = D.R > 2 * D.CN ? D.R : 2 * D.CN;
     D.traj_bytes = align256(D.o_nidx() + sizeof(int) * (size_t)D.CN);
     D.gg_slot = align256(sizeof(double) * (size_t)D.R * 2); D.gg_stride = D.gg_slot * 3 * KEYS;
     size_t o = align256(sizeof(PlannerS));
@@ -119,7 +121,7 @@ inline Dims make_dims(int N, int max_path_nodes, int max_path_pts)
     D.o_velc = o; o += align256(sizeof(double) * (size_t)D.R);
     D.o_sarr = o; o += align256(sizeof(double) * (size_t)D.R) * KEYS;
     D.o_vx = o; o += align256(sizeof(double) * (size_t)D.R) * 2;
-    D.o_scr = o; o += align256(sizeof(double) * (size_t)D.R) * 2;
+    D.o_scr = o; o += align256(sizeof(double) * (size_t)D.SR) * 2;
     D.stride = o;
     return D;
 }
@@ -149,7 +151,7 @@ struct Block {                      // one planner's memory (`g`: its friction r
     FLT_FN double* velc() const { return reinterpret_cast<double*>(b + D.o_velc); }
     FLT_FN double* sarr(int k) const { return reinterpret_cast<double*>(b + D.o_sarr + align256(sizeof(double) * (size_t)D.R) * (size_t)k); }
     FLT_FN double* vx(int k) const { return reinterpret_cast<double*>(b + D.o_vx + align256(sizeof(double) * (size_t)D.R) * (size_t)k); }
-    FLT_FN double* scr(int k) const { return reinterpret_cast<double*>(b + D.o_scr + align256(sizeof(double) * (size_t)D.R) * (size_t)k); }
+    FLT_FN double* scr(int k) const { return reinterpret_cast<double*>(b + D.o_scr + align256(sizeof(double) * (size_t)D.SR) * (size_t)k); }
 };
 
 // lattice tables the state machine reads (device pointers on the device, host vectors in the harness)

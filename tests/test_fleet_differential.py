@@ -57,3 +57,37 @@ def test_fleet_and_host_planner_agree_on_other_tracks(track):
     for seed in (2, 3):
         st = drive(lat, HostPlannerBackend(lat).planner(1), HostFleetBackend(lat).planner(1), seed, 300, exact=True)
         assert st['ticks'] >= 200, st
+
+
+@pytest.mark.parametrize("horizon", [100.0, 300.0])
+def test_high_resolution_lattice_with_a_long_horizon(horizon):
+    """C5: 0.5 m layer spacing, 202 / 602 layers of planning range -- more path NODES (2 x 602 + 8) than a block has trajectory rows per
+    scratch array; the scratch rows of a planner block are sized for both since round 4 (fleet::Dims::SR; before, such lattices were
+    refused at create time)."""
+    from graphbasedlocaltrajectoryplanner_amd.synthetic_lattice import c5_lattice
+    from oracle.fleet_host import HostFleetBackend
+    from oracle.planner_host import HostPlannerBackend
+    lat = c5_lattice(horizon=horizon)
+    keys = set()
+    for seed in (2, 3, 5):
+        st = drive(lat, HostPlannerBackend(lat).planner(1), HostFleetBackend(lat).planner(2), seed, 60, exact=True, scen_b=1)
+        assert st['ticks'] >= 40, st
+        keys |= st['keys']
+    assert "straight" in keys, keys
+
+
+@pytest.mark.gpu
+def test_long_horizon_fleet_on_the_device():
+    """C5 as BASELINE specifies it (600 layers of planning range: long-horizon mode of the path kernel, parent tables in global memory) as
+    a FLEET: ltpl_fleet_* against ltpl_planner_* on the same handle, closed loop."""
+    from graphbasedlocaltrajectoryplanner_amd import _capi
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    from graphbasedlocaltrajectoryplanner_amd.planner import Planner
+    from graphbasedlocaltrajectoryplanner_amd.synthetic_lattice import c5_lattice
+    lat = c5_lattice(horizon=300.0)
+    hip = _capi.HipBackend(lat)
+    for seed in (2, 3):
+        A, B = Planner(hip, 1), Fleet(hip, 3)
+        st = drive(lat, A, B, seed, 60, exact=False, scen_b=2)
+        assert st['ticks'] >= 40, st
+        A.close(); B.close()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Host-side memory / UB check (no GPU needed): builds the oracle and the host-logic harness -- i.e. the product's planner state machine
-# csrc/planner_core.hpp + csrc/planner_api.hpp behind the oracle's arithmetic -- with AddressSanitizer + UndefinedBehaviorSanitizer,
+# csrc/fleet_core.hpp through csrc/planner_host.hpp (+ csrc/planner_core.hpp) behind the oracle's arithmetic -- with AddressSanitizer + UndefinedBehaviorSanitizer,
 # runs the CPU test suite through them (closed-loop replays of every recording, all tracks), and restores the normal builds.
 # Found in round 2: a reference into a vector kept across push_back (emergency trajectory), memcpy from an empty vector's null data().
 #   tools/sanitize_host.sh [pytest args]            default: the whole CPU suite
