@@ -131,7 +131,9 @@ inline std::string err_text(int planner, int err)
         "backup brake profile length mismatch", "emergency profile without any trajectory (IndexError, OTH.py:1029)", "calc_time_buffer_len above 16",
         "local_gg in its dict form is not supported by the fleet (use the host planner)", "more velocity jobs than slots", "start layer without a planning range (end of an open track)",
         "velocity job longer than max_path_pts + 64 points",
-        "local_gg rows of a path do not match its coordinates (OTH.py:641-646)"};
+        "local_gg rows of a path do not match its coordinates (OTH.py:641-646)",
+        "emergency profile: the friction rows of the first path do not match the first trajectory (a backup plan): the reference raises "
+        "RuntimeError 'Length of loc_gg and kappa must be equal!' (OTH.py:1031, calc_brake_emergency.py:31)"};
     const int site = (err >> 8) & 0xff;
     return "fleet: planner " + std::to_string(planner) + ": " + (site > 0 && site < (int)(sizeof(sites) / sizeof(sites[0])) ? sites[site] : "error");
 }

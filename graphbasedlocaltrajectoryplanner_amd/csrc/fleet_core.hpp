@@ -42,7 +42,7 @@ FLT_FN double inf() { return HUGE_VAL; }
 // error sites (S.err = LTPL_ERR_* | site << 8)
 enum Site { E_BACKUP_KEY = 1, E_NO_START, E_CAP_ROWS, E_CAP_NODES, E_CUT_LAYER, E_BRAKE_PREFIX, E_FOLLOW_EMPTY, E_NO_NODES, E_END_NONE,
             E_FOLLOW_SHORT, E_VX_SHORT, E_ROW5, E_BACKUP_CUT, E_BACKUP_SHORT, E_BACKUP_LEN, E_EMERG_EMPTY, E_CALC_BUF, E_GG_DICT, E_CAP_JOBS, E_NO_RANGE, E_CAP_VEL,
-            E_GG_ROWS };
+            E_GG_ROWS, E_EMERG_GG };
 
 // ---------------------------------------------------------------------------------------------------------------------
 // plain-data state
@@ -956,8 +956,12 @@ FLT_FN void vel_c(const X& x, const FCfg& cfg, const Block& B, PlannerS& S, int 
         // local gg of the emergency profile: the first kept key's rows from the cut on (W.gv of stage A), the constant tuple behind them
         const double gax = vin.gg_ax[p], gay = vin.gg_ay[p];
         const int k0 = S.bp_slot[0]; const int gvn = S.w[k0].gv_n; const Rows gv = B.gv(k0);
+        // With rows, the reference hands the rows of the first key's CURRENT path to the brake solver next to the kappa of the first
+        // TRAJECTORY (OTH.py:1029-1036): when that trajectory is the backup plan (other length) tph raises "Length of loc_gg and kappa
+        // must be equal!" (reproduced with the unmodified reference, oracle/gen_golden.py 'ggmapdrop' notes). Reported, not papered over.
+        if (gvn > 0 && gvn != m) { fail(S, LTPL_ERR_INVALID_ARG, E_EMERG_GG); return; }
         jb.gg_rows = gvn > 0 ? 1 : 0;
-        for (int i = x.lane(); i < m; i += X::W) { kap[i] = base.at(i, 4); gg[(size_t)i * 2] = i < gvn ? gv.at(i, 0) : gax; gg[(size_t)i * 2 + 1] = i < gvn ? gv.at(i, 1) : gay; }
+        for (int i = x.lane(); i < m; i += X::W) { kap[i] = base.at(i, 4); gg[(size_t)i * 2] = gvn > 0 ? gv.at(i, 0) : gax; gg[(size_t)i * 2 + 1] = gvn > 0 ? gv.at(i, 1) : gay; }
         for (int i = x.lane(); i + 1 < m; i += X::W) el[i] = base.at(i + 1, 0) - base.at(i, 0);
         if (m < 2 && x.lane() == 0) el[0] = 0.0;
         if (x.lane() == 0) JC.jobs[j] = jb;

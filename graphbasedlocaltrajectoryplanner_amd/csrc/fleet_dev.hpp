@@ -63,7 +63,7 @@ __device__ __forceinline__ void fleet_load(const WaveX& x, const fleet::Block& B
 #define FLEET_AXM_ROWS 512          // machine-table rows of one call, all tables together (the lane kernel keeps them in LDS)
 #define FLEET_ERR_SHIFT 13
 #define FLEET_ERR_MASK 0x1fff
-static_assert((fleet::E_GG_ROWS << 8 | 0xff) <= FLEET_ERR_MASK, "error word: site bits");
+static_assert((fleet::E_EMERG_GG << 8 | 0xff) <= FLEET_ERR_MASK, "error word: site bits");
 __device__ __forceinline__ void fleet_store(const WaveX& x, const fleet::Block& B, const fleet::PlannerS* S, int p, int* err_word)
 {
     x.sync();

@@ -164,6 +164,15 @@ def main_ticks(only=None):
                  vel_kwargs=lambda t, paths: {'local_gg': {k: [friction_map(v[0][:, 0:2])] for k, v in paths.items()},
                                               'gg_scale': 1.0 if t < 350 else 0.8, 'incl_emerg_traj': (t % 4 == 0)},
                  action_pref=("left", "right", "straight", "follow"))
+    # the same friction map LOSING GRIP at tick 200 (x 0.36): the recursive-infeasibility backup branch (OTH.py:947-1006) with the dict form --
+    # the brake profile of the backup plan runs on the backup path's OWN rows (__backup_path_gg) -- and emergency profiles on rows
+    # (free track like 'ggdrop': with an opponent ahead the follow profile brakes anyway and the branch is not reached. NOTE: with the
+    #  emergency profile requested on a tick whose first trajectory is the backup plan the UNMODIFIED reference raises -- OTH.py:1031 hands
+    #  the rows of the current path to tph.calc_vel_profile_brake next to the kappa of the backup trajectory: RuntimeError "Length of loc_gg
+    #  and kappa must be equal!" -- so the recording asks for it only while the grip is intact; the product reports that case as an error)
+    record_ticks("ggmapdrop", 400, lambda gl: None, None,
+                 vel_kwargs=lambda t, paths: {'local_gg': {k: [friction_map(v[0][:, 0:2]) * (1.0 if t < 280 else 0.3)] for k, v in paths.items()},
+                                              'incl_emerg_traj': (t % 4 == 0 and t < 270)})
     # LATTICE.virt_goal_n = False (stock: True): no virtual goal vertices, GraphBase.search_graph_layer tries the end layer's nodes one
     # by one (GraphBase.py:896-927). Nodes, edges and costs of the lattice are those of the stock build (asserted); only the goal rule
     # differs, which the product expresses as goal costs (lattice.goal_order_cost).

@@ -33,7 +33,11 @@ def local_gg_of_tick(t, path_param):
     va = t['vel_args']
     if va.get('local_gg') is not None:
         return tuple(va['local_gg'])
-    return {k: [friction_map(pp[:, 0:2])] for k, pp in path_param.items()}
+    # (recordings whose map changes over time -- 'ggmapdrop' -- scale the whole map: the factor is read off the recorded first row)
+    first = next(iter(path_param.values()))
+    fac = float(va['local_gg_first'][0, 0]) / float(friction_map(first[:1, 0:2])[0, 0]) if 'local_gg_first' in va and len(first) else 1.0
+    fac = 1.0 if abs(fac - 1.0) < 1e-9 else fac
+    return {k: [friction_map(pp[:, 0:2]) * fac] for k, pp in path_param.items()}
 
 
 def replay(planner, lat, ticks, scen=0, n_ticks=None, others=None):

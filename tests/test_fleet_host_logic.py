@@ -25,13 +25,14 @@ def fleet_backend(monteblanco):
     ("ggdrop", {"straight"}),                                 # recursive-infeasibility backup branch (OTH.py:947-1006)
     ("overtake", {"follow", "left", "right", "emergency"}),   # dropped overtakes (OTH.py:1007-1015), emergency profile
     ("ggmap", {"follow", "emergency"}),                       # location dependent friction: local_gg as a dict of per-path rows
+    ("ggmapdrop", {"straight", "emergency"}),                 # ... losing grip: 83 ticks of the backup branch on the backup path's own rows
 ])
 def test_closed_loop_replay_matches_reference_recordings(fleet_backend, monteblanco, name, must_see):
     ticks = pr.load_ticks(name)
     seen = pr.replay(fleet_backend.planner(1), monteblanco, ticks)
     assert must_see <= seen['keys'], seen
     assert seen['full'] >= 15
-    if name == "ggmap":
+    if name in ("ggmap", "ggmapdrop"):
         assert seen.get('ggmap', 0) == len(ticks)             # every tick ran with the dict form (OTH.py:649-666)
     if name == "overtake":
         assert seen['dropped'] > 50 and seen['emergency'] > 100
@@ -288,3 +289,24 @@ def test_a_fleet_of_different_cars(fleet_backend, monteblanco):
     through ONE fleet call per tick, pinned to two recordings of the unmodified reference made with different cars."""
     seen = two_cars_replay(fleet_backend.planner(4), monteblanco, 2, 260)
     assert {"follow", "right", "emergency"} <= seen
+
+
+@pytest.mark.parametrize("front_end", ["fleet", "planner"])
+def test_emergency_profile_on_a_backup_plan_with_friction_rows_raises_like_the_reference(fleet_backend, monteblanco, front_end):
+    """OTH.py:1029-1036 with local_gg as a dict: the emergency profile takes the kappa of the FIRST trajectory and the friction rows of the
+    first key's CURRENT path. When the first trajectory is the backup plan (recursive infeasibility, OTH.py:947-1006) the two differ in
+    length and tph.calc_vel_profile_brake raises "Length of loc_gg and kappa must be equal!" -- observed with the unmodified reference while
+    recording 'ggmapdrop' (oracle/gen_golden.py), which therefore asks for the emergency profile only while the grip is intact. The
+    product reports the same situation as an error instead of inventing rows."""
+    from graphbasedlocaltrajectoryplanner_amd._capi import BackendError
+    from oracle.planner_host import HostPlannerBackend
+    ticks = pr.load_ticks("ggmapdrop")
+    pl = (fleet_backend if front_end == "fleet" else HostPlannerBackend(monteblanco)).planner(1)
+    pr.replay(pl, monteblanco, ticks, n_ticks=300)                    # 20 ticks into the loss of grip: the backup branch is active
+    t = ticks[300]
+    va = t['vel_args']
+    pl.calc_paths([t['action_id_sel']], [t['t']], [pr.vehicles_of_tick(t)], [pr.zone_gids_of_tick(monteblanco, t)])
+    lgg = pr.local_gg_of_tick(t, pl.paths(0)['path_param'])
+    with pytest.raises(BackendError, match="Length of loc_gg and kappa must be equal"):
+        pl.calc_vel_profile([t['pos_est']], va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'], local_gg=[lgg],
+                            ax_max_machines=va['ax_max_machines'], safety_d=va['safety_d'], incl_emerg_traj=True)

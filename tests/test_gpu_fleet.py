@@ -25,6 +25,7 @@ def hip(monteblanco):
     ("ggdrop", 1, {"straight"}),                              # backup branch: second velocity launch
     ("overtake", 70, {"follow", "left", "right", "emergency"}),   # >= 64 planners: one-wave batch path kernel; emergency: third launch
     ("ggmap", 2, {"follow", "emergency"}),                    # location dependent friction: rows per job (k_vel_profile GG, SEL 2 / 3 / 1)
+    ("ggmapdrop", 2, {"straight", "emergency"}),              # ... losing grip: backup brake jobs on the backup path's own rows (JB with rows)
 ])
 def test_closed_loop_replay_matches_reference_recordings(hip, monteblanco, name, n, must_see):
     from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
@@ -226,3 +227,23 @@ def test_fused_tape_kernels_equal_the_separate_ones(hip, monteblanco, monkeypatc
             assert pa['keys'] == pb['keys'] and pa['nodes'] == pb['nodes']
             assert all(np.array_equal(pa['path_param'][k], pb['path_param'][k]) for k in pa['keys'])
     assert "emergency" in fused[1][0][0]                       # the overtake group ran with the emergency launch (tail variant D)
+
+
+def test_emergency_profile_on_a_backup_plan_with_friction_rows_on_the_device(hip, monteblanco):
+    """The device's detection of the situation in which the reference raises "Length of loc_gg and kappa must be equal!" (see
+    tests/test_fleet_host_logic.py); the neighbour planner, which does not ask for the emergency profile, is served."""
+    from graphbasedlocaltrajectoryplanner_amd._capi import BackendError
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    ticks = pr.load_ticks("ggmapdrop")
+    fleet = Fleet(hip, 2)
+    pr.replay(fleet, monteblanco, ticks, n_ticks=300, scen=1)
+    t = ticks[300]
+    va = t['vel_args']
+    fleet.calc_paths([t['action_id_sel']] * 2, [t['t']] * 2, [pr.vehicles_of_tick(t)] * 2, [pr.zone_gids_of_tick(monteblanco, t)] * 2)
+    lgg = pr.local_gg_of_tick(t, fleet.paths(0)['path_param'])
+    with pytest.raises(BackendError, match="planner 0: emergency profile.*Length of loc_gg and kappa must be equal"):
+        fleet.calc_vel_profile([t['pos_est']] * 2, va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'], local_gg=[lgg, lgg],
+                               ax_max_machines=va['ax_max_machines'], safety_d=va['safety_d'], incl_emerg_traj=[True, False])
+    traj, ids, ref = fleet.trajectories(1)
+    pr.check_trajectories(traj, ids, ref, t, "the neighbour of the failing planner")
+    fleet.close()
