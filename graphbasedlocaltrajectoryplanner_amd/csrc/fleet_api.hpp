@@ -25,10 +25,10 @@ inline FLat flat_of(const ltplp::HostLat& h)
 
 inline int check_config(const ltpl_planner_config* cfg, std::string* why)
 {
-    if (!cfg || cfg->n_scen < 1) { *why = "fleet: null argument or n_scen < 1"; return LTPL_ERR_INVALID_ARG; }
-    if (cfg->n_w_last < 0 || cfg->n_w_last > LTPL_MAX_LAST_NODES - 1) { *why = "fleet: n_w_last out of range"; return LTPL_ERR_INVALID_ARG; }
-    if (cfg->calc_time_buffer_len < 1 || cfg->calc_time_buffer_len > CALC_BUF) { *why = "fleet: calc_time_buffer_len must be 1 .. 16"; return LTPL_ERR_CAPACITY; }
-    if (cfg->filt_window_width < 1 || cfg->filt_window_width % 2 != 1) { *why = "fleet: Window width of moving average filter must be odd! (tph.conv_filt)"; return LTPL_ERR_INVALID_ARG; }
+    if (!cfg || cfg->n_scen < 1) { *why = "planner config: null argument or n_scen < 1"; return LTPL_ERR_INVALID_ARG; }
+    if (cfg->n_w_last < 0 || cfg->n_w_last > LTPL_MAX_LAST_NODES - 1) { *why = "planner config: n_w_last out of range"; return LTPL_ERR_INVALID_ARG; }
+    if (cfg->calc_time_buffer_len < 1 || cfg->calc_time_buffer_len > CALC_BUF) { *why = "planner config: calc_time_buffer_len must be 1 .. 16"; return LTPL_ERR_CAPACITY; }
+    if (cfg->filt_window_width < 1 || cfg->filt_window_width % 2 != 1) { *why = "planner config: Window width of moving average filter must be odd! (tph.conv_filt)"; return LTPL_ERR_INVALID_ARG; }
     return LTPL_OK;
 }
 

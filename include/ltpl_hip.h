@@ -432,7 +432,7 @@ typedef struct {
     double  v_max_offset;           /* ACTIONSET.v_max_offset            OTH.py:102                               */
     double  delaycomp;              /* DELAY.delaycomp                   OTH.py:117                               */
     double  calc_time_safety;       /* CALC_TIME.calc_time_safety        OTH.py:121                               */
-    int32_t calc_time_buffer_len;   /* CALC_TIME.calc_time_buffer_len    OTH.py:122                               */
+    int32_t calc_time_buffer_len;   /* CALC_TIME.calc_time_buffer_len    OTH.py:122   (1 .. 16; reference default 5)  */
     int32_t filt_window_width;      /* SMOOTHING.filt_window_width       OTH.py:107 (only 1 is supported)         */
     double  dyn_model_exp, drag_coeff, m_veh;          /* OTH.__init__ arguments -> VpForwardBackward (OTH.py:137-144) */
     int32_t follow_control_type;    /* 0 = 'PD', 1 = 'PDtan'             OTH.py:112-114                           */
