@@ -799,6 +799,14 @@ struct SweepK {
 // 16 bits) in the low bits. (Round 3: one atomic add on a counter and one atomic min on the key word per chunk, two arrays to reset and to
 // read back; the LDS pipe of a CU is ~78 % busy in this kernel, profiles/r04b_pmc_karg_reload.txt.) With two or more winners the low bits hold
 // the SUM of their keys (< 2^23 for 127 in-edges) and are not used: the exact tie-break below elects into `widx`.
+#ifndef LTPL_MQ
+#define LTPL_MQ 2             // obstacle positions tested per pass over a transition's edges in the mask phase
+#endif
+#ifndef LTPL_CH_ALWAYS
+#define LTPL_CH_ALWAYS 1      // edge chunks of a transition that are processed unconditionally (sentinel edges in unused lanes); later chunks are skipped when
+                              // empty. Round 3 kept two: 44 % of Monteblanco's transitions have at most 64 edges, one is 2 % fewer vector and 5 % fewer LDS
+                              // instructions (+0.9 % ticks/s, profiles/r04l_*); three costs a spilled register
+#endif
 #define CW_SHIFT 24
 #define CW_ONE (1u << CW_SHIFT)
 struct LayerArgs {
@@ -842,19 +850,19 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
     // +inf: inf + cost = inf never wins the atomic min and never matches a finite minimum, so the rounds need no
     // per-lane bookkeeping and no divergent control flow.
     // Lanes beyond the transition hold the SENTINEL edge (cost +inf, lattice edge id E: prefetch), so every lane of a loaded chunk runs
-    // the same code: all LDS reads of a round are issued before the first wait and no lane needs an "is this an edge" select. Only chunks
-    // from the third on are skipped when empty (uniform; 111 edges per transition on average).
+    // the same code: all LDS reads of a round are issued before the first wait and no lane needs an "is this an edge" select. Chunks
+    // from the second on (LTPL_CH_ALWAYS) are skipped when empty (uniform; 111 edges per transition on average).
     double cand[CH][NA];
 #pragma unroll
     for (int ci = 0; ci < CH; ++ci) {
-        if (ci >= 2 && (ci * NW) * 64 >= A.ne) continue;            // uniform: no edges in this chunk
+        if (ci >= LTPL_CH_ALWAYS && (ci * NW) * 64 >= A.ne) continue;            // uniform: no edges in this chunk
         const int src = sw_src(er[ci].meta);
 #pragma unroll
         for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) cand[ci][SL[f]] = dist[poff[f] + src];
     }
 #pragma unroll
     for (int ci = 0; ci < CH; ++ci) {
-        if (ci >= 2 && (ci * NW) * 64 >= A.ne) continue;
+        if (ci >= LTPL_CH_ALWAYS && (ci * NW) * 64 >= A.ne) continue;
         const int dst = sw_dst(er[ci].meta);
         const double c_pr = er[ci].c;                                                  // planning_range: every edge
         // other filters: unblocked edges (bit ci of `blk`: this lane's edge of chunk ci is blocked)
@@ -906,14 +914,14 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
         double got[CH][NA];
 #pragma unroll
         for (int ci = 0; ci < CH; ++ci) {
-            if (ci >= 2 && (ci * NW) * 64 >= A.ne) continue;
+            if (ci >= LTPL_CH_ALWAYS && (ci * NW) * 64 >= A.ne) continue;
             const int dst = sw_dst(er[ci].meta);
 #pragma unroll
             for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) got[ci][SL[f]] = dist[coff[f] + dst];
         }
 #pragma unroll
         for (int ci = 0; ci < CH; ++ci) {
-            if (ci >= 2 && (ci * NW) * 64 >= A.ne) continue;
+            if (ci >= LTPL_CH_ALWAYS && (ci * NW) * 64 >= A.ne) continue;
             const int dst = sw_dst(er[ci].meta);
             const unsigned key = elect_key(er[ci].meta);
 #pragma unroll
@@ -955,7 +963,7 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
             for (int round = 0; round < 2; ++round) {
 #pragma unroll
                 for (int ci = 0; ci < CH; ++ci) {
-                    if (ci >= 2 && (ci * NW) * 64 >= A.ne) continue;
+                    if (ci >= LTPL_CH_ALWAYS && (ci * NW) * 64 >= A.ne) continue;
                     const int src = sw_src(er[ci].meta), dst = sw_dst(er[ci].meta);
                     const unsigned key = elect_key(er[ci].meta);
 #pragma unroll
@@ -1236,7 +1244,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
             const int eb = ly.z, ee = ly.w;
             while (m) {
                 // up to MQ matching positions per round, broadcast into uniform registers
-                constexpr int MQ = 2;
+                constexpr int MQ = LTPL_MQ;
                 double qx[MQ], qy[MQ], qr[MQ];
                 int qlane[MQ];                                 // lane that holds the query's position (exact test: flush_shell)
                 float qxf[MQ], qyf[MQ], qlm[MQ], qlh[MQ];      // fp32 query, thresholds of the two-sided cull (without the edge's own terms)
@@ -1434,7 +1442,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
 #pragma unroll
             for (int ci = 0; ci < CH; ++ci) {
                 bw[ci] = 0u; sh[ci] = 32;
-                if (ci >= 2 && ly.z + ci * SNT >= ly.w) continue;   // uniform: chunks 0 and 1 are always loaded, the rest on demand
+                if (ci >= LTPL_CH_ALWAYS && ly.z + ci * SNT >= ly.w) continue;   // uniform: chunk 0 is always loaded, the rest on demand
                 const int e = ly.z + (ci * SWN + swave) * 64 + lane;
                 // lanes beyond the transition load the SENTINEL edge (index E: cost +inf, source = destination = node 0): a fixed
                 // number of loads in flight lets the compiler wait precisely, and the sweep needs no "is this lane an edge" select
