@@ -974,6 +974,12 @@ __device__ __forceinline__ void tick_vel_stage(const DevLat& lat, const DevPaths
     if (lane == 0) { vout.vel_bound[slot] = vel_bound; vout.too_close[slot] = too_close; }
 }
 
+// the arguments of k_tick as they lie in the kernarg segment
+struct TickKArgs { PathsKArgs pk; DevVelParams p; DevTickVelIn vin; DevTickVelOut vout; int vel_off, vel_stride, vel_cap; };
+static_assert(sizeof(DevVelParams) % 8 == 0 && sizeof(DevTickVelIn) % 8 == 0 && sizeof(DevTickVelOut) % 8 == 0 && alignof(DevVelParams) == 8 &&
+              alignof(DevTickVelIn) == 8 && alignof(DevTickVelOut) == 8, "TickKArgs must mirror the kernarg layout of k_tick");
+static constexpr size_t KOFF_TP = offsetof(TickKArgs, p), KOFF_TVIN = offsetof(TickKArgs, vin), KOFF_TVOUT = offsetof(TickKArgs, vout);
+
 // body of k_tick. RL = true: every argument struct is a reference INTO THE KERNARG SEGMENT, re-read per stage (karg_reload, paths_team.hpp)
 template <int EM, bool AXM1, class P, bool RL>
 __device__ __forceinline__ void tick_body(const DevLat& lat_, const DevPathsIn& in_, const DevPathsOut& out_, const TeamLds& lp_,
@@ -985,11 +991,12 @@ __device__ __forceinline__ void tick_body(const DevLat& lat_, const DevPathsIn& 
     if (wave < LTPL_MAX_ACTIONS) vs = carve_vel_scratch(smem + vel_off + (size_t)wave * vel_stride, vel_cap, false, true, &px, &py);
     WavePath wp = team_paths_body<NUM_WAVES, P, RL>(lat_, in_, out_, lp_, smem, ts, wave < LTPL_MAX_ACTIONS ? vs.kabs : nullptr,
                                                  wave < LTPL_MAX_ACTIONS ? vs.el : nullptr, px, py);
-    const DevLat& lat = *karg_reload<RL>(&lat_); const DevPathsIn& in = *karg_reload<RL>(&in_); const DevPathsOut& out = *karg_reload<RL>(&out_);
-    const TeamLds& lp = *karg_reload<RL>(&lp_);
+    // (re-derived from the kernarg segment pointer, not carried across the path search: karg_at, paths_team.hpp)
+    const DevLat& lat = *LTPL_KARG_LAT(&lat_); const DevPathsIn& in = *LTPL_KARG_IN(&in_); const DevPathsOut& out = *LTPL_KARG_OUT(&out_);
+    const TeamLds& lp = *LTPL_KARG_LP(&lp_);
     // (the small parameter structs of the velocity stage by value: its recurrences must not depend on argument loads)
-    const DevVelParams p = *karg_reload<RL>(&p_);
-    const DevTickVelIn vin = *karg_reload<RL>(&vin_); const DevTickVelOut vout = *karg_reload<RL>(&vout_);
+    const DevVelParams p = *karg_at<RL, DevVelParams, KOFF_TP>(&p_);
+    const DevTickVelIn vin = *karg_at<RL, DevTickVelIn, KOFF_TVIN>(&vin_); const DevTickVelOut vout = *karg_at<RL, DevTickVelOut, KOFF_TVOUT>(&vout_);
     const int s = blockIdx.x;
     // The fourth wave has no primitive of its own: it computes the unconstrained profile of the 'follow' slot
     // (calc_vel_profile_follow.py:297-307, independent of the controlled part) while wave 0 runs the brake / segment part.
@@ -1017,13 +1024,9 @@ __device__ __forceinline__ void tick_body(const DevLat& lat_, const DevPathsIn& 
         }
         __syncthreads();
     }
-    signal_done(karg_reload<RL>(&out)->done);
+    signal_done(LTPL_KARG_OUT(&out)->done);
 }
 
-// the arguments of k_tick as they lie in the kernarg segment
-struct TickKArgs { PathsKArgs pk; DevVelParams p; DevTickVelIn vin; DevTickVelOut vout; int vel_off, vel_stride, vel_cap; };
-static_assert(sizeof(DevVelParams) % 8 == 0 && sizeof(DevTickVelIn) % 8 == 0 && sizeof(DevTickVelOut) % 8 == 0 && alignof(DevVelParams) == 8 &&
-              alignof(DevTickVelIn) == 8 && alignof(DevTickVelOut) == 8, "TickKArgs must mirror the kernarg layout of k_tick");
 
 template <int EM, bool AXM1, class P>
 __global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, DevPathsOut out, TeamLds lp,

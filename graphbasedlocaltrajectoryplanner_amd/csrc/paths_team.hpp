@@ -148,6 +148,31 @@ __device__ __forceinline__ const PathsKArgs* paths_kargs()
     return (const PathsKArgs*)(const PathsKArgs LTPL_AS4*)__builtin_amdgcn_kernarg_segment_ptr();
 }
 
+// One of the four structs, RE-DERIVED from the kernarg segment pointer (RL = true only: the body is then known to run on the leading
+// arguments of k_paths / k_tick). karg_reload launders a pointer that has to stay alive between the phases -- four pointers = eight
+// scalar registers that the compiler parked in vector lanes around every phase (52 of the kernel's lane moves were attributed to that
+// asm statement, -gline-tables-only build); the segment pointer itself is a kernel input the hardware provides.
+template <bool RL, class T, size_t OFF>
+__device__ __forceinline__ const T* karg_at(const T* p)
+{
+    if constexpr (RL) {
+#ifdef LTPL_KARG_CARRY
+        return karg_reload<RL>(p);
+#else
+        unsigned long long v = (unsigned long long)(const char LTPL_AS4*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(v));
+        return (const T*)(const T LTPL_AS4*)(v + OFF);
+#endif
+    } else return p;
+}
+// (constants, not offsetof in the macros: the kernel bodies #define lat / in / out / lp)
+static constexpr size_t KOFF_LAT = offsetof(PathsKArgs, lat), KOFF_IN = offsetof(PathsKArgs, in), KOFF_OUT = offsetof(PathsKArgs, out),
+                        KOFF_LP = offsetof(PathsKArgs, lp);
+#define LTPL_KARG_LAT(p) karg_at<RL, DevLat, KOFF_LAT>(p)
+#define LTPL_KARG_IN(p) karg_at<RL, DevPathsIn, KOFF_IN>(p)
+#define LTPL_KARG_OUT(p) karg_at<RL, DevPathsOut, KOFF_OUT>(p)
+#define LTPL_KARG_LP(p) karg_at<RL, TeamLds, KOFF_LP>(p)
+
 // Parent tables: `default` and `overtake_left` are never both needed beyond the object layer (the templates either use
 // `default` itself or branch left / right off its prefix), so they share one table; three tables serve four filters.
 #define NPAR 3
@@ -518,11 +543,11 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
                                                   bool skip_pp, double* vel_kappa, double* vel_len, double* vel_x, double* vel_y, int vtile)
 {
     // (RL: argument structs in the kernarg segment, re-read at every stage of the assembly -- see karg_reload)
-    const DevLat* latp = karg_reload<RL>(&lat_); const DevPathsIn* inp = karg_reload<RL>(&in_); const DevPathsOut* outp = karg_reload<RL>(&out_);
+    const DevLat* latp = LTPL_KARG_LAT(&lat_); const DevPathsIn* inp = LTPL_KARG_IN(&in_); const DevPathsOut* outp = LTPL_KARG_OUT(&out_);
 #define lat (*latp)
 #define in (*inp)
 #define out (*outp)
-#define LTPL_KARGS() do { latp = karg_reload<RL>(latp); inp = karg_reload<RL>(inp); outp = karg_reload<RL>(outp); } while (0)
+#define LTPL_KARGS() do { latp = LTPL_KARG_LAT(latp); inp = LTPL_KARG_IN(inp); outp = LTPL_KARG_OUT(outp); } while (0)
     const int L = lat.L;
     double* kx = reinterpret_cast<double*>(pw);
     double* ky = kx + hm; double* el = ky + hm; double* mx = el + hm; double* my = mx + hm;
@@ -1014,14 +1039,14 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
                                                     const TeamLds& lp_, unsigned char* smem, TeamShared& ts,
                                                     double* vel_kappa, double* vel_len, double* vel_x, double* vel_y)
 {
-    const DevLat* latp = karg_reload<RL>(&lat_); const DevPathsIn* inp = karg_reload<RL>(&in_);
-    const DevPathsOut* outp = karg_reload<RL>(&out_); const TeamLds* lpp = karg_reload<RL>(&lp_);
+    const DevLat* latp = LTPL_KARG_LAT(&lat_); const DevPathsIn* inp = LTPL_KARG_IN(&in_);
+    const DevPathsOut* outp = LTPL_KARG_OUT(&out_); const TeamLds* lpp = LTPL_KARG_LP(&lp_);
     // (the body keeps its names: `lat`, `in`, `out`, `lp` are the CURRENT views; LTPL_KARGS() re-reads them at a phase boundary)
 #define lat (*latp)
 #define in (*inp)
 #define out (*outp)
 #define lp (*lpp)
-#define LTPL_KARGS() do { latp = karg_reload<RL>(latp); inp = karg_reload<RL>(inp); outp = karg_reload<RL>(outp); lpp = karg_reload<RL>(lpp); } while (0)
+#define LTPL_KARGS() do { latp = LTPL_KARG_LAT(latp); inp = LTPL_KARG_IN(inp); outp = LTPL_KARG_OUT(outp); lpp = LTPL_KARG_LP(lpp); } while (0)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int L = lat.L;
     constexpr int NT = NW * 64;
