@@ -174,6 +174,21 @@ __device__ __forceinline__ void vl_stamp(long long*, int, int) {}
 // ---------------------------------------------------------------------------------------------------------------------
 // wave helpers (wave64)
 // ---------------------------------------------------------------------------------------------------------------------
+// minimum of a double over the wave (no NaN among the keys): 12 cross-lane moves against the 30 of the three-key form -- the first key
+// decides nearly always, so the callers reduce it alone and fall back to wave_min3 only when it is attained more than once (the
+// cross-lane moves are ds_bpermute, i.e. LDS-pipe instructions in a kernel whose LDS pipe is a co-limiter)
+__device__ __forceinline__ double wave_min_f64(double k)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const double o = __shfl_xor(k, m); k = o < k ? o : k; }
+    return k;
+}
+__device__ __forceinline__ int wave_min_i32(int k)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(k, m); k = o < k ? o : k; }
+    return k;
+}
 __device__ __forceinline__ void wave_min3(double& k1, double& k2, int& idx)
 {
 #pragma unroll
@@ -733,8 +748,7 @@ __device__ __forceinline__ void follow_profile(const DevLat& lat, int n, int n_e
             const double wctl = v_control * v_control;
             int first = 0x7fffffff;
             for (int i = lane; i < n; i += 64) if (vs.wb[i] <= wctl) { first = i; break; }
-            double d1 = (double)first, d2 = 0.0; int di = first;
-            wave_min3(d1, d2, di);
+            const int di = wave_min_i32(first);                                           // (first index over the lanes: an integer minimum)
             idx_c = (di == 0x7fffffff) ? 0 : di;                                          // np.argmax of an all-False mask
             if (idx_c > stop_idx) idx_c = stop_idx;
             if (idx_c == 0) idx_c = stop_idx;
@@ -936,8 +950,7 @@ __device__ __forceinline__ void tick_vel_stage(const DevLat& lat, const DevPaths
             const double spl_len = vs.s[n - 1];
             int first = 0x7fffffff;
             for (int i = lane; i < n - 1; i += 64) if (!(vs.s[i + 1] < (spl_len - 5.0))) { first = i; break; }
-            double d1 = (double)first, d2 = 0.0; int di = first;
-            wave_min3(d1, d2, di);
+            const int di = wave_min_i32(first);
             v_idx = ((di == 0x7fffffff) ? 0 : di) + 1;
             if (v_idx == 1 && n > 1) v_idx = n;
         } else {

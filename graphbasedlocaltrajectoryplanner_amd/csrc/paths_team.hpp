@@ -317,10 +317,14 @@ __device__ __forceinline__ int team_goal(const DevLat& lat, const double* dcur, 
             if (tot < g1 || (tot == g1 && (bestc < g2 || (bestc == g2 && n < gn)))) { g1 = tot; g2 = bestc; gn = n; }
         }
     }
+    // the total alone first: a unique minimum (the normal case) needs no tie-break and carries no tie flag
+    const double mt = wave_min_f64(g1);
+    if (!(mt < INFINITY)) return -1;
+    const unsigned long long eq = __ballot(g1 == mt);
+    if ((eq & (eq - 1ull)) == 0ull) return __builtin_amdgcn_readlane(gn, __ffsll((long long)eq) - 1);
     double m1 = g1, m2 = g2; int mn = gn;
     wave_min3(m1, m2, mn);
-    const int ntie = __popcll(__ballot(g1 == m1 && g1 < INFINITY));
-    return (m1 < INFINITY) ? (mn | (ntie > 1 ? (1 << 30) : 0)) : -1;
+    return mn | (1 << 30);                                     // (two or more lanes attain the total: the flag of the round-3 form)
 }
 
 // Serial form of one sweep layer for filter f (lane = destination node, private loop over its in-edges in CSC order):
@@ -1365,7 +1369,12 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
                 const double d2 = dx * dx + dy * dy;
                 if (d2 < bd) { bd = d2; bn = n; }
             }
-            wave_min3(bd, dummy, bn);
+            {   // closest node: the squared distance alone first (a tie falls back to the (distance, node) reduction)
+                const double mb = wave_min_f64(bd);
+                const unsigned long long eq = __ballot(bd == mb);
+                if ((eq & (eq - 1ull)) == 0ull && eq != 0ull) bn = __builtin_amdgcn_readlane(bn, __ffsll((long long)eq) - 1);
+                else wave_min3(bd, dummy, bn);
+            }
             cn = bn;
         }
         if (lane == 0) { ts.closest_idx = ci; ts.cl = cl; ts.cn = cn; ts.have_cn = have; }
