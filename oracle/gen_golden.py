@@ -173,6 +173,15 @@ def main_ticks(only=None):
     record_ticks("ggmapdrop", 400, lambda gl: None, None,
                  vel_kwargs=lambda t, paths: {'local_gg': {k: [friction_map(v[0][:, 0:2]) * (1.0 if t < 280 else 0.3)] for k, v in paths.items()},
                                               'incl_emerg_traj': (t % 4 == 0 and t < 270)})
+    # the OTHER CAR on the friction map (round 4): per-vehicle machine table / vel_max and per-path friction rows in the same calls -- with an
+    # opponent (follow, overtakes, emergency profiles under both) and, on a free track, through the loss of grip (backup branch)
+    record_ticks("car2ggmap", 360, lambda gl: [Dummy(gl)(dynamic=True, vel_scale=0.4, s0=150.0)], rs.ZONE_EXAMPLE,
+                 vel_kwargs=lambda t, paths: {'local_gg': {k: [friction_map(v[0][:, 0:2])] for k, v in paths.items()}, 'vel_max': 42.0,
+                                              'ax_max_machines': axm_csv, 'gg_scale': 1.0 if t < 250 else 0.85, 'incl_emerg_traj': (t % 4 == 0)},
+                 action_pref=("left", "right", "straight", "follow"))
+    record_ticks("car2ggdrop", 380, lambda gl: None, None,
+                 vel_kwargs=lambda t, paths: {'local_gg': {k: [friction_map(v[0][:, 0:2]) * (1.0 if t < 260 else 0.3)] for k, v in paths.items()},
+                                              'vel_max': 42.0, 'ax_max_machines': axm_csv, 'incl_emerg_traj': (t % 4 == 0 and t < 250)})
     # LATTICE.virt_goal_n = False (stock: True): no virtual goal vertices, GraphBase.search_graph_layer tries the end layer's nodes one
     # by one (GraphBase.py:896-927). Nodes, edges and costs of the lattice are those of the stock build (asserted); only the goal rule
     # differs, which the product expresses as goal costs (lattice.goal_order_cost).

@@ -26,13 +26,15 @@ def fleet_backend(monteblanco):
     ("overtake", {"follow", "left", "right", "emergency"}),   # dropped overtakes (OTH.py:1007-1015), emergency profile
     ("ggmap", {"follow", "emergency"}),                       # location dependent friction: local_gg as a dict of per-path rows
     ("ggmapdrop", {"straight", "emergency"}),                 # ... losing grip: 83 ticks of the backup branch on the backup path's own rows
+    ("car2ggmap", {"follow", "right", "emergency"}),          # the other car (vel_max 42, 18-row machine table) on the friction map
+    ("car2ggdrop", {"straight", "emergency"}),                # ... through the loss of grip: 119 backup ticks
 ])
 def test_closed_loop_replay_matches_reference_recordings(fleet_backend, monteblanco, name, must_see):
     ticks = pr.load_ticks(name)
     seen = pr.replay(fleet_backend.planner(1), monteblanco, ticks)
     assert must_see <= seen['keys'], seen
     assert seen['full'] >= 15
-    if name in ("ggmap", "ggmapdrop"):
+    if name in ("ggmap", "ggmapdrop", "car2ggmap", "car2ggdrop"):
         assert seen.get('ggmap', 0) == len(ticks)             # every tick ran with the dict form (OTH.py:649-666)
     if name == "overtake":
         assert seen['dropped'] > 50 and seen['emergency'] > 100
@@ -310,3 +312,64 @@ def test_emergency_profile_on_a_backup_plan_with_friction_rows_raises_like_the_r
     with pytest.raises(BackendError, match="Length of loc_gg and kappa must be equal"):
         pl.calc_vel_profile([t['pos_est']], va['vel_est'], vel_max=va['vel_max'], gg_scale=va['gg_scale'], local_gg=[lgg],
                             ax_max_machines=va['ax_max_machines'], safety_d=va['safety_d'], incl_emerg_traj=True)
+
+
+def cars_and_rows_replay(fleet, lat, reps, n_ticks, check_every=1):
+    """Machine tables per planner AND friction rows per planner in the same calls: planners [0, reps) replay 'car2ggmap' (the other car on
+    the friction map: vel_max 42 m/s, 18-row table, local_gg as a dict), planners [reps, 2 reps) 'c2' (default car, constant tuple), through
+    ``pack_arrays`` -- the caller's own arrays with ax_tables / ax_table_idx and gg_row_off / gg_rows. Returns the keys seen."""
+    from graphbasedlocaltrajectoryplanner_amd import _capi
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    from graphbasedlocaltrajectoryplanner_amd.planner import KEY_IDS
+    from graphbasedlocaltrajectoryplanner_amd.tick_replay import vehicles_of_tick, zone_gids_of_tick, check_trajectories
+    for name in ("pack_arrays", "calc_paths_packed", "calc_vel_profile_packed"):      # (the CPU harness binds the Planner class)
+        if not hasattr(fleet, name):
+            setattr(fleet, name, getattr(Fleet, name).__get__(fleet))
+    recs = [pr.load_ticks("car2ggmap")[:n_ticks], pr.load_ticks("c2")[:n_ticks]]
+    n, MK = 2 * reps, _capi.PLANNER_MAX_KEYS
+    for g, ticks in enumerate(recs):
+        st = ticks[0]['start']
+        for q in range(g * reps, (g + 1) * reps):
+            fleet.set_start(q, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+    tables = [np.asarray(recs[0][0]['vel_args']['ax_max_machines'], float).reshape(-1, 2), np.asarray(recs[1][0]['vel_args']['ax_max_machines'], float).reshape(-1, 2)]
+    assert tables[0].shape[0] == 18 and tables[1].shape[0] == 1
+    seen = set()
+    for k in range(n_ticks):
+        per = [recs[0][k]] * reps + [recs[1][k]] * reps
+        veh = [vehicles_of_tick(t) for t in per]
+        veh_off = np.concatenate(([0], np.cumsum([len(v) for v in veh])))
+        flat = [v for vs in veh for v in vs]
+        pos_off = np.concatenate(([0], np.cumsum([len(v[2]) for v in flat]))) if flat else np.zeros(1, int)
+        pos = np.concatenate([np.asarray(v[2], float).reshape(-1, 2) for v in flat]) if flat else np.zeros((0, 2))
+        zones = [sorted(set(int(z) for z in zone_gids_of_tick(lat, t))) for t in per]
+        zone_off = np.concatenate(([0], np.cumsum([len(z) for z in zones])))
+        va = [t['vel_args'] for t in per]
+        common = dict(prev_action=[KEY_IDS.get(t['action_id_sel'], _capi.ACT_NONE) if isinstance(t['action_id_sel'], str) else _capi.ACT_NONE for t in per],
+                      t_now=[t['t'] for t in per], veh_off=veh_off, pos_off=pos_off, veh_radius=[v[0] for v in flat], veh_vel=[v[1] for v in flat],
+                      pos_x=pos[:, 0], pos_y=pos[:, 1], zone_off=zone_off, zone_gid=[z for zs in zones for z in zs],
+                      pos_est=[t['pos_est'] for t in per], vel_est=[a['vel_est'] for a in va], vel_max=[a['vel_max'] for a in va],
+                      gg_scale=[a['gg_scale'] for a in va],
+                      local_gg=([5.0] * reps + [float(a['local_gg'][0]) for a in va[reps:]], [5.0] * reps + [float(a['local_gg'][1]) for a in va[reps:]]),
+                      safety_d=[a['safety_d'] for a in va], incl_emerg_traj=[bool(a['incl_emerg_traj']) for a in va],
+                      ax_tables=tables, ax_table_idx=[0] * reps + [1] * reps)
+        pi, _vi, keep0 = fleet.pack_arrays(**common)
+        fleet.calc_paths_packed(pi)
+        paths = fleet.paths(0)                                           # (all planners of the first group are in the same state)
+        lgg = pr.local_gg_of_tick(recs[0][k], paths['path_param'])
+        rows = [np.asarray(lgg[key][0], float) for key in paths['keys']]
+        one = [r.shape[0] for r in rows] + [0] * (MK - len(rows))
+        off = np.concatenate(([0], np.cumsum(one * reps + [0] * (MK * reps))))
+        _pi, vi, keep1 = fleet.pack_arrays(gg_row_off=off, gg_rows=np.concatenate(rows * reps), **common)
+        fleet.calc_vel_profile_packed(vi)
+        if k % check_every == 0 or k == n_ticks - 1:
+            for q in sorted({0, reps - 1, reps, n - 1}):
+                t = per[q]
+                traj, ids, ref = fleet.trajectories(q)
+                check_trajectories(traj, ids, ref, t, "planner %d tick %d" % (q, k))
+                seen.update(traj.keys())
+    return seen
+
+
+def test_machine_tables_and_friction_rows_per_planner_in_the_same_calls(fleet_backend, monteblanco):
+    seen = cars_and_rows_replay(fleet_backend.planner(4), monteblanco, 2, 300)
+    assert {"follow", "right", "emergency"} <= seen, seen

@@ -26,6 +26,8 @@ def hip(monteblanco):
     ("overtake", 70, {"follow", "left", "right", "emergency"}),   # >= 64 planners: one-wave batch path kernel; emergency: third launch
     ("ggmap", 2, {"follow", "emergency"}),                    # location dependent friction: rows per job (k_vel_profile GG, SEL 2 / 3 / 1)
     ("ggmapdrop", 2, {"straight", "emergency"}),              # ... losing grip: backup brake jobs on the backup path's own rows (JB with rows)
+    ("car2ggmap", 2, {"follow", "right", "emergency"}),       # the other car on the friction map
+    ("car2ggdrop", 1, {"straight", "emergency"}),
 ])
 def test_closed_loop_replay_matches_reference_recordings(hip, monteblanco, name, n, must_see):
     from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
@@ -247,3 +249,15 @@ def test_emergency_profile_on_a_backup_plan_with_friction_rows_on_the_device(hip
     traj, ids, ref = fleet.trajectories(1)
     pr.check_trajectories(traj, ids, ref, t, "the neighbour of the failing planner")
     fleet.close()
+
+
+def test_machine_tables_and_friction_rows_per_planner_on_the_device(hip, monteblanco):
+    """2 x 33 planners: the other car on the friction map (machine table 0, rows) next to the default car with a constant tuple (table 1) in
+    the same ltpl_fleet_calc_vel_profile calls -- the wave-per-job kernels in their rows form take the job's own table, the lane kernel
+    stages both tables and leaves the jobs with rows to them."""
+    from test_fleet_host_logic import cars_and_rows_replay
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    fleet = Fleet(hip, 66)
+    seen = cars_and_rows_replay(fleet, monteblanco, 33, 160, check_every=5)
+    fleet.close()
+    assert {"follow", "right", "emergency"} <= seen, seen

@@ -12,7 +12,7 @@ import planner_replay as pr
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["c2", "c1", "zonewall", "ggdrop", "overtake", "ggmap", "ggmapdrop"])
+@pytest.mark.parametrize("name", ["c2", "c1", "zonewall", "ggdrop", "overtake", "ggmap", "ggmapdrop", "car2ggmap", "car2ggdrop"])
 def test_planner_closed_loop_matches_reference_recordings(hip_backend, monteblanco, name):
     from graphbasedlocaltrajectoryplanner_amd.planner import Planner
     ticks = pr.load_ticks(name)

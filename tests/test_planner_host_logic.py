@@ -25,6 +25,8 @@ def host_backend(monteblanco):
     ("overtake", {"follow", "left", "right", "emergency"}),   # dropped overtakes (OTH.py:1007-1015), emergency profile
     ("ggmap", {"follow", "emergency"}),                       # location dependent friction: local_gg as a dict of per-path rows
     ("ggmapdrop", {"straight", "emergency"}),                 # ... losing grip: 83 ticks of the backup branch on the backup path's own rows
+    ("car2ggmap", {"follow", "right", "emergency"}),          # the other car (vel_max 42, 18-row machine table) on the friction map
+    ("car2ggdrop", {"straight", "emergency"}),                # ... through the loss of grip: 119 backup ticks
 ])
 def test_closed_loop_replay_matches_reference_recordings(host_backend, monteblanco, name, must_see):
     ticks = pr.load_ticks(name)
@@ -36,7 +38,7 @@ def test_closed_loop_replay_matches_reference_recordings(host_backend, monteblan
         assert seen['dropped'] > 50 and seen['emergency'] > 100
     if name == "ggdrop":
         assert sum(1 for t in ticks if t['backup_available'] and t['tick'] > 300) > 50
-    if name in ("ggmap", "ggmapdrop"):
+    if name in ("ggmap", "ggmapdrop", "car2ggmap", "car2ggdrop"):
         assert seen.get('ggmap', 0) == len(ticks)             # every tick ran with the dict form (OTH.py:649-666)
 
 
