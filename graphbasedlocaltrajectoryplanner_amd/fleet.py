@@ -197,6 +197,10 @@ class Fleet(Planner):
         pi, vi, keep = self.pack_groups(groups, ax_max_machines)
         self._check(self._fn("tape_append")(self.handle, C.byref(pi), C.byref(vi)))
 
+    def tape_append_packed(self, pi, vi):
+        """Append the input structs of ``pack_groups`` / ``pack_arrays`` (both calls of one tick) to the tape."""
+        self._check(self._fn("tape_append")(self.handle, C.byref(pi), C.byref(vi)))
+
     def tape_run(self, first, count):
         """Advance all planners through ticks [first, first + count) of the tape; returns the device time in ms."""
         ms = C.c_float(0.0)

@@ -314,10 +314,11 @@ def test_emergency_profile_on_a_backup_plan_with_friction_rows_raises_like_the_r
                             ax_max_machines=va['ax_max_machines'], safety_d=va['safety_d'], incl_emerg_traj=True)
 
 
-def cars_and_rows_replay(fleet, lat, reps, n_ticks, check_every=1):
+def cars_and_rows_replay(fleet, lat, reps, n_ticks, check_every=1, collect=None):
     """Machine tables per planner AND friction rows per planner in the same calls: planners [0, reps) replay 'car2ggmap' (the other car on
     the friction map: vel_max 42 m/s, 18-row table, local_gg as a dict), planners [reps, 2 reps) 'c2' (default car, constant tuple), through
-    ``pack_arrays`` -- the caller's own arrays with ax_tables / ax_table_idx and gg_row_off / gg_rows. Returns the keys seen."""
+    ``pack_arrays`` -- the caller's own arrays with ax_tables / ax_table_idx and gg_row_off / gg_rows. Returns the keys seen; ``collect``: list
+    that receives the packed input structs of every tick."""
     from graphbasedlocaltrajectoryplanner_amd import _capi
     from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
     from graphbasedlocaltrajectoryplanner_amd.planner import KEY_IDS
@@ -361,6 +362,8 @@ def cars_and_rows_replay(fleet, lat, reps, n_ticks, check_every=1):
         off = np.concatenate(([0], np.cumsum(one * reps + [0] * (MK * reps))))
         _pi, vi, keep1 = fleet.pack_arrays(gg_row_off=off, gg_rows=np.concatenate(rows * reps), **common)
         fleet.calc_vel_profile_packed(vi)
+        if collect is not None:
+            collect.append((pi, vi, keep0, keep1))                       # (the structs of the tick, for a tape)
         if k % check_every == 0 or k == n_ticks - 1:
             for q in sorted({0, reps - 1, reps, n - 1}):
                 t = per[q]

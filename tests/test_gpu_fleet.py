@@ -261,3 +261,28 @@ def test_machine_tables_and_friction_rows_per_planner_on_the_device(hip, montebl
     seen = cars_and_rows_replay(fleet, monteblanco, 33, 160, check_every=5)
     fleet.close()
     assert {"follow", "right", "emergency"} <= seen, seen
+
+
+def test_a_tape_with_machine_tables_and_friction_rows(hip, monteblanco):
+    """The TAPE with per-planner tables and friction rows (fused stage kernels, rows form of the velocity launches): the packed inputs of a
+    per-call run of 120 ticks are appended to the tape of a second fleet, which must end in the identical state."""
+    from test_fleet_host_logic import cars_and_rows_replay
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    T, reps = 120, 3
+    a, b = Fleet(hip, 2 * reps), Fleet(hip, 2 * reps)
+    ticks = []
+    cars_and_rows_replay(a, monteblanco, reps, T, check_every=20, collect=ticks)
+    recs = [pr.load_ticks("car2ggmap"), pr.load_ticks("c2")]
+    for g, rec in enumerate(recs):
+        st = rec[0]['start']
+        b.set_start_range(g * reps, (g + 1) * reps, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+    for pi, vi, _k0, _k1 in ticks:
+        b.tape_append_packed(pi, vi)
+    assert b.tape_run(0, T) > 0.0
+    for q in (0, reps - 1, reps, 2 * reps - 1):
+        (ta, ia, ra), (tb, ib, rb) = a.trajectories(q), b.trajectories(q)
+        assert list(ta.keys()) == list(tb.keys()) and ia == ib and ra['cut_index_pos'] == rb['cut_index_pos']
+        for k in ta:
+            assert np.array_equal(ta[k][0], tb[k][0]), (q, k)
+        pr.check_trajectories(tb, ib, rb, recs[0 if q < reps else 1][T - 1], "tape planner %d" % q)
+    a.close(); b.close()
