@@ -50,6 +50,7 @@ struct DevLat {
     const double* node_x; const double* node_y; const double* vgoal;
     const int* in_ptr; const int* edge_src; const double* edge_cost; const double* edge_len; const int* samp_ptr;
     const double* sx; const double* sy; const double* spsi; const double* slen;
+    const double* ssc;                // [S][2] (sin, cos) of spsi, tabulated at ltpl_create: the spline end slopes of a path need no sincos per path
     const double* glob_rl;
     const double* grx; const double* gry;   // x / y columns of glob_rl as contiguous arrays (coalesced scans)
     // derived at ltpl_create
@@ -2284,6 +2285,11 @@ try {
     UP(edge_len, d->edge_len, L.E); UP(samp_ptr, d->samp_ptr, L.E + 1);
     UP(sx, d->samp_x, L.S); UP(sy, d->samp_y, L.S); UP(spsi, d->samp_psi, L.S); UP(slen, d->samp_len, L.S);
     UP(glob_rl, d->glob_rl, (size_t)L.G * 5);
+    {
+        std::vector<double> sc(2 * (size_t)L.S + 2, 0.0);
+        for (int k = 0; k < L.S; ++k) { sc[2 * (size_t)k] = sin(d->samp_psi[k]); sc[2 * (size_t)k + 1] = cos(d->samp_psi[k]); }
+        UP(ssc, sc.data(), 2 * (size_t)L.S + 2);
+    }
     {
         std::vector<double> gx((size_t)L.G), gy((size_t)L.G);
         for (int k = 0; k < L.G; ++k) { gx[(size_t)k] = d->glob_rl[(size_t)k * 5 + 1]; gy[(size_t)k] = d->glob_rl[(size_t)k * 5 + 2]; }

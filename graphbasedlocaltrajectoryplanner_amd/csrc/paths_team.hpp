@@ -252,6 +252,7 @@ struct TeamShared {
     int fac_j[LTPL_MAX_LAST_NODES], fac_src[LTPL_MAX_LAST_NODES], fac_dst[LTPL_MAX_LAST_NODES];
     double fac[LTPL_MAX_LAST_NODES];
     int fac_jmax;
+    double psi_sc[2];                          // (sin, cos) of the scenario's start heading psi_s (LTPL_FLAG_HAS_PSI_S), phase 0
 };
 
 // uniform per-scenario state, computed redundantly by every wave (scalar registers)
@@ -544,7 +545,8 @@ __device__ __forceinline__ void team_backtrack(const DevPathsOut& out, const Tea
 template <bool RL = false>
 __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevPathsIn& in_, const DevPathsOut& out_, int s, int sl, int flags,
                                                   int hm, bool by_rank, int slot, int N, int lane, unsigned char* pw, long long* adbg,
-                                                  bool skip_pp, double* vel_kappa, double* vel_len, double* vel_x, double* vel_y, int vtile)
+                                                  bool skip_pp, double* vel_kappa, double* vel_len, double* vel_x, double* vel_y, int vtile,
+                                                  const double* ts_psi)
 {
     // (RL: argument structs in the kernarg segment, re-read at every stage of the assembly -- see karg_reload)
     const DevLat* latp = LTPL_KARG_LAT(&lat_); const DevPathsIn* inp = LTPL_KARG_IN(&in_); const DevPathsOut* outp = LTPL_KARG_OUT(&out_);
@@ -606,8 +608,11 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
             pidx[i] = run + off;
             kx[i] = at(lat.sx, k0); ky[i] = at(lat.sy, k0); el[i] = at(lat.edge_len, e);
             pedge[i] = k0;                                   // from here on: first sample of the segment's edge
-            if (i == 0) el[N] = at(lat.spsi, k0);               // heading of the first / last gathered sample (spline end slopes)
-            if (i == N - 1) { kx[N] = at(lat.sx, k1 - 1); ky[N] = at(lat.sy, k1 - 1); pidx[N] = run + off + take - 1; cpy[0] = at(lat.spsi, k1 - 1); }
+            // (sin, cos) of the heading of the first / last gathered sample (spline end slopes) from the lattice's table, parked in rows 0 and
+            // N of the right-hand sides (unused until the solve)
+            if (i == 0) { mx[0] = at(lat.ssc, 2 * k0); my[0] = at(lat.ssc, 2 * k0 + 1); }
+            if (i == N - 1) { kx[N] = at(lat.sx, k1 - 1); ky[N] = at(lat.sy, k1 - 1); pidx[N] = run + off + take - 1;
+                              mx[N] = at(lat.ssc, 2 * (k1 - 1)); my[N] = at(lat.ssc, 2 * (k1 - 1) + 1); }
         }
         run += tot;
     }
@@ -626,12 +631,12 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
     // on the elimination order is prepared by all lanes (reciprocal segment lengths, diagonal, right-hand sides of x and
     // y); the sequential elimination (lane 0 -> x, lane 1 -> y) is one reciprocal and four fused multiply-adds per row.
     {
-        // end slopes: tangent = (cos(psi + pi/2), sin(psi + pi/2)) = (-sin psi, cos psi); lane 0 <- psi_s, lane 1 <- psi_e
-        double ang = 0.0;
-        if (lane == 0) ang = (flags & LTPL_FLAG_HAS_PSI_S) ? in.psi_s[s] : el[N];
-        if (lane == 1) ang = cpy[0];
-        double sn, cs;
-        sincos(ang, &sn, &cs);
+        // end slopes: tangent = (cos(psi + pi/2), sin(psi + pi/2)) = (-sin psi, cos psi). Round 4: no sincos per path (165 vector
+        // instructions on 64 lanes for two angles) -- the headings of the samples are lattice constants (DevLat::ssc), the start heading of
+        // a scenario with a constant path segment is one sincos per SCENARIO (phase 0, TeamShared::psi_sc)
+        double sn = 0.0, cs = 1.0;
+        if (lane == 0) { if (flags & LTPL_FLAG_HAS_PSI_S) { sn = ts_psi[0]; cs = ts_psi[1]; } else { sn = mx[0]; cs = my[0]; } }
+        if (lane == 1) { sn = mx[N]; cs = my[N]; }
         const double sx0 = -readlane_f64(sn, 0), sy0 = readlane_f64(cs, 0), sxN = -readlane_f64(sn, 1), syN = readlane_f64(cs, 1);
         // rows i = 1 .. N-1: a_i = 1/h_{i-1}, c_i = 1/h_i, b_i = 2 (a_i + c_i); stored: cpx <- a_i, cpy <- b_i (scratch),
         // mx / my <- right-hand sides d_i (x / y)
@@ -777,7 +782,7 @@ template <class P, bool RL = false>
 __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const Scen& sc,
                                   const TeamLds& lp, unsigned char* smem, int a, int f, int J, int name, int reduced,
                                   int jcl, bool share_prefix, int lane, unsigned char* pw,
-                                  double* vel_kappa, double* vel_len, double* vel_x, double* vel_y, int vtile_in)
+                                  double* vel_kappa, double* vel_len, double* vel_x, double* vel_y, int vtile_in, const double* ts_psi)
 {
     const int hm = P::hmax(lp), s = sc.s;
     const int slot = s * LTPL_MAX_ACTIONS + a;
@@ -799,7 +804,7 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
     team_backtrack<P>(out, lp, smem, slot, f, J, jcl, share_prefix, lane, pw);
     const int end_node = reinterpret_cast<const int*>(reinterpret_cast<double*>(pw) + 7 * hm)[hm + 1 + J];      // pidx[J]
     const int n_pts = team_assemble_rest<RL>(lat, in, out, s, sc.sl, sc.flags, hm, P::par_entry == 2, slot, J, lane, pw, adbg,
-                                         LTPL_ABLATED(lp, 16), vel_kappa, vel_len, vel_x, vel_y, vtile);
+                                         LTPL_ABLATED(lp, 16), vel_kappa, vel_len, vel_x, vel_y, vtile, ts_psi);
     const int L = lat.L;
     wp.n_pts = n_pts; wp.n_nodes = J + 1;
     { int gl = sc.sl + J; if (gl >= L) gl -= L; wp.goal_layer = gl; }
@@ -1112,6 +1117,11 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
 #pragma unroll
         for (int m = 1; m < LTPL_MAX_LAST_NODES; m <<= 1) { const int o = __shfl_xor(mx, m); mx = o > mx ? o : mx; }
         if (tid == 0) ts.fac_jmax = mx;
+    }
+    if (wave == 0 && (sc.flags & LTPL_FLAG_HAS_PSI_S)) {        // start heading of the constant path segment: one sincos per scenario, not per path
+        double sn, cs;
+        sincos(in.psi_s[sc.s], &sn, &cs);
+        if (lane == 0) { ts.psi_sc[0] = sn; ts.psi_sc[1] = cs; }
     }
     // vehicle of every position (radius lookup in phase 2)
     for (int k = tid; k < sc.n_veh; k += NT) {
@@ -1759,7 +1769,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
             }
         }
         wp = team_assemble<P, RL>(lat, in, out, sc, lp, smem, a, filt[a], slot_j(a), slot_name(a), slot_red(a), jcl, sp, lane, pw,
-                               vel_kappa, vel_len, vel_x, vel_y, vtile_in);
+                               vel_kappa, vel_len, vel_x, vel_y, vtile_in, ts.psi_sc);
     }
     dbg_stamp(lp.dbg, 7);
     return wp;
