@@ -158,34 +158,89 @@ def parity_check(res, vres, ref, idx):
                           "psi: pi; vx: floor 1 m/s; ax: max(v^2 / 2, 5 m/s^2)"}
 
 
-def read_traffic(batch, workload):
-    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC summary (profiles/pmc_traffic.json), if it
-    was collected for this workload and batch size (grid = 64 threads x batch); otherwise null."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.isfile(p):
-        try:
-            with open(p) as fh:
-                d = json.load(fh)
-            if d.get("workload", "c2") == workload and int(d.get("grid_size", 0)) == 64 * batch:
-                return d.get("hbm_bytes_per_launch")
-        except Exception:
-            return None
-    return None
+def library_stamp(hip):
+    """Resolved path + hashes of the library this run drives (LTPL_HIP_LIB may redirect it) and the digest of the batch path kernel's
+    instruction stream (__graft_entry__.build_stamp): what the committed counter passes under profiles/ are matched against."""
+    import __graft_entry__ as ge
+    sym = hip.paths_kernel_symbol(1)
+    try:
+        st = ge.build_stamp(hip.lib_path, sym) if sym else {"lib_sha256": ge.file_sha256(hip.lib_path)}
+    except Exception as e:                                   # (llvm-objdump missing, ...: reported, not fatal)
+        st = {"error": "%s: %s" % (type(e).__name__, e)}
+    st["path"] = hip.lib_path
+    return st
 
 
-def read_issue(batch, workload):
-    """VALU instruction count and lane utilisation of the dominant kernel from a committed rocprofv3 PMC pass of this build
-    (profiles/pmc_issue.json, written by tools/lanes_summarise.py), if it was collected for this workload and batch size."""
-    p = os.path.join(ROOT, "profiles", "pmc_issue.json")
-    if os.path.isfile(p):
-        try:
-            with open(p) as fh:
-                d = json.load(fh)
-            if d.get("workload", "c2") == workload and int(d.get("grid_size", 0)) == 64 * batch:
-                return d
-        except Exception:
-            return None
-    return None
+PROFILES_DIR = None      # (tests point this at a scratch directory)
+
+
+def _read_pmc(name, batch, workload, stamp):
+    """A committed rocprofv3 PMC summary profiles/<name> if it was collected for this workload and batch size (grid = 64 threads x batch);
+    `build_matches`: the digest of the profiled library's path kernel (written by tools/pmc_ab.sh / tools/profile_summarise.py) equals
+    the one of the library this run drives -- false flags a stale file, null a file without a stamp (collected before round 5)."""
+    p = os.path.join(PROFILES_DIR or os.path.join(ROOT, "profiles"), name)
+    if not os.path.isfile(p):
+        return None
+    try:
+        with open(p) as fh:
+            d = json.load(fh)
+    except Exception:
+        return None
+    if d.get("workload", "c2") != workload or int(d.get("grid_size", 0)) != 64 * batch:
+        return None
+    prof = (d.get("build") or {}).get("isa_sha256")
+    mine = (stamp or {}).get("isa_sha256")
+    d["build_matches"] = (prof == mine) if (prof and mine) else None
+    return d
+
+
+def read_traffic(batch, workload, stamp=None):
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC summary (profiles/pmc_traffic.json, C3:
+    pmc_traffic_c3.json), or None."""
+    return _read_pmc("pmc_traffic.json" if workload == "c2" else "pmc_traffic_%s.json" % workload, batch, workload, stamp)
+
+
+def read_issue(batch, workload, stamp=None):
+    """VALU / SALU / LDS instruction counts, lane utilisation and wait cycles of the dominant kernel from a committed rocprofv3 PMC pass
+    (profiles/pmc_issue.json, C3: pmc_issue_c3.json; written by tools/pmc_ab.sh), or None."""
+    return _read_pmc("pmc_issue.json" if workload == "c2" else "pmc_issue_%s.json" % workload, batch, workload, stamp)
+
+
+def issue_summary(issue_pmc, batch, dom_ms):
+    """The binding-pipe figures of a counter pass (see the `binding` block of the line) at the kernel's live duration dom_ms."""
+    if not issue_pmc:
+        return None
+    simd_cycles = N_SIMD * dom_ms * 1e-3 * CLOCK_HZ
+    return {"valu_insts": issue_pmc["valu_insts_per_launch"], "lanes_active": issue_pmc["lanes_active_per_valu_inst"],
+            # SQ_ACTIVE_INST_VALU (quad-cycles with a VALU instruction in flight, summed over the SIMDs) over the SIMD-cycles of the
+            # launch at its live duration; without that counter: instructions x 4 cycles (fp64 / transcendental rate; fp32 and
+            # integer wave64 instructions issue in 2 on CDNA4's SIMD-32, so this is an upper bound then)
+            "valu_util": (issue_pmc.get("valu_active_quad_cycles_per_launch") or issue_pmc["valu_insts_per_launch"])
+            * VALU_CYCLES_PER_INST / simd_cycles,
+            "salu_insts": issue_pmc.get("salu_insts_per_launch"), "lds_insts": issue_pmc.get("lds_insts_per_launch"),
+            "valu_insts_per_scenario": issue_pmc["valu_insts_per_launch"] / batch,
+            "salu_insts_per_scenario": (issue_pmc.get("salu_insts_per_launch") or 0.0) / batch,
+            "lds_insts_per_scenario": (issue_pmc.get("lds_insts_per_launch") or 0.0) / batch,
+            # the LDS pipe: one per CU, shared by its 16 resident scenarios (SQ_ACTIVE_INST_LDS, quad-cycles)
+            "lds_util": (issue_pmc["lds_active_quad_cycles_per_launch"] * VALU_CYCLES_PER_INST / (N_CU * dom_ms * 1e-3 * CLOCK_HZ))
+            if issue_pmc.get("lds_active_quad_cycles_per_launch") else None,
+            "wait_frac_of_wave_cycles": (issue_pmc["wait_any_quad_cycles_per_launch"] / issue_pmc["wave_quad_cycles_per_launch"])
+            if issue_pmc.get("wait_any_quad_cycles_per_launch") and issue_pmc.get("wave_quad_cycles_per_launch") else None,
+            "build_matches": issue_pmc.get("build_matches"),
+            "profiled_build": issue_pmc.get("build"),
+            "source": "profiles/%s (tag %s): PMC pass collected with tools/pmc_ab.sh, not in this run; build_matches = the digest of the "
+                      "profiled path kernel equals this run's" % ("pmc_issue.json" if issue_pmc.get("workload", "c2") == "c2"
+                                                                    else "pmc_issue_%s.json" % issue_pmc.get("workload"), issue_pmc.get("tag"))}
+
+
+def binding_of(issue):
+    issue_frac = issue["valu_util"] if issue else None
+    lane_frac = issue["lanes_active"] / 64.0 if issue else None
+    return {"bound": ("lds-pipe" if issue and issue.get("lds_util") and issue_frac is not None and issue["lds_util"] > issue_frac else "valu-issue"),
+            "issue_frac": issue_frac, "lane_frac": lane_frac,
+            "useful_lane_frac": (issue_frac * lane_frac) if issue else None,
+            "lds_frac": issue["lds_util"] if issue else None,
+            "wait_frac_of_wave_cycles": issue.get("wait_frac_of_wave_cycles") if issue else None}
 
 
 N_SIMD, N_CU, CLOCK_HZ, VALU_CYCLES_PER_INST = 1024, 256, 2.4e9, 4      # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz max clock; SQ counters tick in quad-cycles
@@ -428,7 +483,7 @@ def c5_latency(horizon_m, n_ticks, device=0):
     return out
 
 
-def c3_throughput(n_batch, device=0, min_s=1.5, n_parity=96):
+def c3_throughput(n_batch, device=0, min_s=1.5, n_parity=256):
     """BASELINE config C3 (the "HBM roofline run"): synthetic oval, 400 layers x 25 nodes, ~98 k edges, 32 static obstacles (64 obstacle
     positions) per scenario; resident tick pipeline like the headline, its own roofline figures and a parity check against the oracle."""
     from graphbasedlocaltrajectoryplanner_amd.synthetic_lattice import c3_lattice
@@ -454,6 +509,17 @@ def c3_throughput(n_batch, device=0, min_s=1.5, n_parity=96):
            "algorithmic_bytes_per_tick": ab["total"] / n_batch, "split_per_tick": {k: ab[k] / n_batch for k in ("mask", "sweep", "path", "vel")},
            "workload": "C3: synthetic oval lattice (%d layers / %d nodes / %d edges), 4 action primitives, 32 static obstacles (64 obstacle "
                        "positions); %d scenarios per step" % (lat.num_layers, lat.num_nodes, lat.num_edges, n_batch)}
+    # what binds C3 (BASELINE's "HBM roofline run"): the same counter passes as the headline, collected on the C3 batch
+    # (PMC_WORKLOAD=c3 tools/pmc_ab.sh -> profiles/pmc_issue_c3.json, tools/profile_summarise.py <tag> ... c3 -> profiles/pmc_traffic_c3.json)
+    stamp = library_stamp(hip)
+    issue = issue_summary(read_issue(n_batch, "c3", stamp), n_batch, dom_ms)
+    tr = read_traffic(n_batch, "c3", stamp)
+    out["library_kernel"] = {k: stamp.get(k) for k in ("kernel_symbol", "isa_sha256", "resources")}
+    out["binding"] = binding_of(issue) if issue else None
+    out["issue"] = issue
+    out["traffic"] = tr.get("hbm_bytes_per_launch") if tr else None
+    out["traffic_frac"] = (tr["hbm_bytes_per_launch"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if tr and tr.get("hbm_bytes_per_launch") else None
+    out["traffic_build_matches"] = tr.get("build_matches") if tr else None
     idx = sample_indices(n_batch, n_parity)
     _, ref = cpu_baseline(lat, scen, batch, vel, idx) if n_parity > 0 else (None, None)
     if ref is not None:
@@ -641,31 +707,14 @@ def worker(args):
                            "horizon_100m": c5_latency(100, args.c5_ticks, device=dev_index),
                            "what": "single-scenario synchronous ltpl_tick_batch calls on the high-resolution oval (0.5 m layer spacing), host wall "
                                    "time incl. marshalling and PCIe; 300 m = 600 layers (long-horizon mode), 100 m = the fused LDS-resident kernel"}
-        traffic = read_traffic(args.batch, args.workload)            # measured HBM bytes per launch of the dominant kernel (PMC), or None
-        issue_pmc = read_issue(args.batch, args.workload)
-        issue = None
-        if issue_pmc:
-            simd_cycles = N_SIMD * dom_ms * 1e-3 * CLOCK_HZ
-            issue = {"valu_insts": issue_pmc["valu_insts_per_launch"], "lanes_active": issue_pmc["lanes_active_per_valu_inst"],
-                     # SQ_ACTIVE_INST_VALU (quad-cycles with a VALU instruction in flight, summed over the SIMDs) over the SIMD-cycles of the
-                     # launch at its live duration; without that counter: instructions x 4 cycles (fp64 / transcendental rate; fp32 and
-                     # integer wave64 instructions issue in 2 on CDNA4's SIMD-32, so this is an upper bound then)
-                     "valu_util": (issue_pmc.get("valu_active_quad_cycles_per_launch") or issue_pmc["valu_insts_per_launch"])
-                     * VALU_CYCLES_PER_INST / simd_cycles,
-                     "salu_insts": issue_pmc.get("salu_insts_per_launch"), "lds_insts": issue_pmc.get("lds_insts_per_launch"),
-                     "valu_insts_per_scenario": issue_pmc["valu_insts_per_launch"] / args.batch,
-                     "salu_insts_per_scenario": (issue_pmc.get("salu_insts_per_launch") or 0.0) / args.batch,
-                     "lds_insts_per_scenario": (issue_pmc.get("lds_insts_per_launch") or 0.0) / args.batch,
-                     # the LDS pipe: one per CU, shared by its 16 resident scenarios (SQ_ACTIVE_INST_LDS, quad-cycles)
-                     "lds_util": (issue_pmc["lds_active_quad_cycles_per_launch"] * VALU_CYCLES_PER_INST / (N_CU * dom_ms * 1e-3 * CLOCK_HZ))
-                     if issue_pmc.get("lds_active_quad_cycles_per_launch") else None,
-                     "wait_frac_of_wave_cycles": (issue_pmc["wait_any_quad_cycles_per_launch"] / issue_pmc["wave_quad_cycles_per_launch"])
-                     if issue_pmc.get("wait_any_quad_cycles_per_launch") and issue_pmc.get("wave_quad_cycles_per_launch") else None,
-                     "source": "profiles/pmc_issue.json (tag %s): PMC pass of this build, not collected in this run" % issue_pmc.get("tag")}
+        stamp = library_stamp(hip)
+        traffic_pmc = read_traffic(args.batch, args.workload, stamp)   # measured HBM bytes per launch of the dominant kernel (PMC), or None
+        traffic = traffic_pmc.get("hbm_bytes_per_launch") if traffic_pmc else None
+        issue_pmc = read_issue(args.batch, args.workload, stamp)
+        issue = issue_summary(issue_pmc, args.batch, dom_ms)
         # the roofline that BINDS: vector-instruction issue (useful lane-operations / peak lane-operations of the launch) next to the
         # contract's HBM figure
-        issue_frac = issue["valu_util"] if issue else None
-        lane_frac = issue["lanes_active"] / 64.0 if issue else None
+        binding = binding_of(issue)
         out = {
             "metric": "planning ticks/s (all action primitives), " + ("Monteblanco lattice" if args.workload == "c2" else "synthetic C3 lattice"),
             "value": world * args.batch * timed_steps / elapsed,
@@ -692,22 +741,20 @@ def worker(args):
                                      "obstacles (64 obstacle positions)") % (lat.num_layers, lat.num_nodes, lat.num_edges))
                                    + "; %d independent scenarios per GPU per step, tick pipeline (paths + velocity)" % args.batch,
                        "batch_per_gpu": args.batch, "parallelism": "scenario-sharded x%d (no collective)" % world},
+            # the library this line was measured on (LTPL_HIP_LIB can redirect it) and the digest the counter passes are matched against
+            "library": stamp,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          # what actually limits the kernel: instruction issue + dependent LDS round trips, not DRAM (the lattice is cache
                          # resident: traffic_frac ~ 0.1). `issue` = the bound that binds, from a PMC pass of this build
                          "limiter": "valu-issue / lds pipe (cache-resident working set)",
-                         "binding": {"bound": ("lds-pipe" if issue and issue.get("lds_util") and issue_frac is not None and issue["lds_util"] > issue_frac
-                                               else "valu-issue"),
-                                     "issue_frac": issue_frac, "lane_frac": lane_frac,
-                                     "useful_lane_frac": (issue_frac * lane_frac) if issue else None,
-                                     "lds_frac": issue["lds_util"] if issue else None,
-                                     "what": "issue_frac = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x kernel time x 2.4 GHz); lane_frac = "
-                                             "active lanes per vector instruction / 64; useful_lane_frac = their product = share of the chip's "
-                                             "lane throughput that does work; lds_frac = SQ_ACTIVE_INST_LDS x 4 / (256 CUs x kernel time x 2.4 GHz); bound = the larger of issue_frac and lds_frac. "
-                                             "Both are lower bounds: the clock under this load is below the 2.4 GHz peak (counted inside the waves' own "
-                                             "lifetime, wait_frac_of_wave_cycles aside, the LDS pipe of a CU is ~77 % busy)"},
+                         "traffic_build_matches": traffic_pmc.get("build_matches") if traffic_pmc else None,
+                         "binding": dict(binding,
+                                     what="issue_frac = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x kernel time x 2.4 GHz); lane_frac = "
+                                          "active lanes per vector instruction / 64; useful_lane_frac = their product = share of the chip's "
+                                          "lane throughput that does work; lds_frac = SQ_ACTIVE_INST_LDS x 4 / (256 CUs x kernel time x 2.4 GHz); bound = the larger of issue_frac and lds_frac. "
+                                          "Both are lower bounds: the clock under this load is below the 2.4 GHz peak"),
                          "frac_refline_per_position": (ab_paths - ab["mask"] + ab["mask_refline_per_position"]) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "issue": issue,
                          "kernel": "k_paths<1>", "kernel_ms": dom_ms,

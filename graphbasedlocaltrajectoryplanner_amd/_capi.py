@@ -548,6 +548,7 @@ class HipBackend(object):
             raise BackendError("libltpl_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
                                "g.build()'`; there is no CPU fallback" % path)
         self.lib = C.CDLL(path)
+        self.lib_path = os.path.abspath(path)          # (LTPL_HIP_LIB redirects the product library: bench.py prints the resolved path + hashes)
         self._declare()
         self.binding = LatticeBinding(lattice)
         self.lattice = lattice
@@ -583,6 +584,14 @@ class HipBackend(object):
         L.ltpl_raceline_s.argtypes = [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_double)]
         L.ltpl_const_segment_test.argtypes = [C.c_void_p, _pf64, C.c_int32, _pf64, C.c_int32, _pf64, _pf64, _pf64,
                                               _pi32, _pi32]
+
+    def paths_kernel_symbol(self, team_waves=1):
+        """Mangled-name prefix of the path kernel this handle launches (batch form: team_waves = 1); '' for a library that predates it."""
+        if not hasattr(self.lib, "ltpl_paths_kernel_symbol"):
+            return ""
+        f = self.lib.ltpl_paths_kernel_symbol
+        f.argtypes, f.restype = [C.c_void_p, C.c_int32], C.c_char_p
+        return (f(self.handle, int(team_waves)) or b"").decode()
 
     def _check(self, rc):
         if rc != 0:

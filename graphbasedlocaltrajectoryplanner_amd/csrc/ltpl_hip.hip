@@ -175,9 +175,159 @@ __device__ __forceinline__ void vl_stamp(long long*, int, int) {}
 // ---------------------------------------------------------------------------------------------------------------------
 // wave helpers (wave64)
 // ---------------------------------------------------------------------------------------------------------------------
-// minimum of a double over the wave (no NaN among the keys): 12 cross-lane moves against the 30 of the three-key form -- the first key
-// decides nearly always, so the callers reduce it alone and fall back to wave_min3 only when it is attained more than once (the
-// cross-lane moves are ds_bpermute, i.e. LDS-pipe instructions in a kernel whose LDS pipe is a co-limiter)
+// CROSS-LANE MOVES ON THE VECTOR ALU (round 5). `__shfl_xor` / `__shfl_up` compile to ds_bpermute_b32: an LDS-pipe instruction with an LDS
+// round trip of latency per step, in kernels whose LDS pipe is a co-limiter and whose waves spend ~46 % of their cycles in s_waitcnt
+// (275 of the 907 static LDS-pipe instructions of the round-4 batch path kernel were ds_bpermute). The reductions and scans below exchange
+// through DPP row operations (partner at distance 1, 2, 4, 8 inside a row of 16 lanes) and the gfx950 row / half swaps
+// (v_permlane16_swap, v_permlane32_swap: distance 16 and 32) instead: no LDS instruction, no lgkmcnt wait.
+// ALL 64 LANES MUST BE ACTIVE at the call (wave-uniform control flow): a DPP move from an inactive lane delivers no data.
+// -DLTPL_SHFL_REDUCE restores the round-4 shuffle forms (same-box A/B, tools/ab_bench.sh).
+#ifndef LTPL_SHFL_REDUCE
+#define DPP_XOR1 0xB1                   // quad_perm:[1,0,3,2]
+#define DPP_XOR2 0x4E                   // quad_perm:[2,3,0,1]
+#define DPP_HALF_MIRROR 0x141           // lane i <-> 7 - i  of every 8: the partner at distance 4 once the quads are uniform
+#define DPP_MIRROR 0x140                // lane i <-> 15 - i of every 16: the partner at distance 8 once the halves of 8 are uniform
+#define DPP_ROR8 0x128                  // row_ror:8 = lane i ^ 8
+#define DPP_SHL4 0x104                  // row_shl:4 (lane i <- lane i + 4)
+#define DPP_SHR(n) (0x110 + (n))        // row_shr:n (lane i <- lane i - n inside the row)
+#define DPP_BCAST15 0x142               // lane 15 of every row -> the next row
+#define DPP_BCAST31 0x143               // lane 31 -> rows 2 and 3
+typedef unsigned lane_pair_t __attribute__((ext_vector_type(2)));
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
+{
+    return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+// the value of lane (i ^ M), M = 1, 2, 4, 8, for ANY lane contents (the mirror forms above need uniform sub-groups)
+template <int M> __device__ __forceinline__ int xor_i32(int v)
+{
+    if constexpr (M == 1) return dpp_i32<DPP_XOR1>(v);
+    else if constexpr (M == 2) return dpp_i32<DPP_XOR2>(v);
+    else if constexpr (M == 4) {           // banks (= quads of a row) 0, 2 take the quad above, banks 1, 3 the quad below
+        const int up = __builtin_amdgcn_update_dpp(v, v, DPP_SHL4, 0xf, 0x5, false);
+        return __builtin_amdgcn_update_dpp(up, v, DPP_SHR(4), 0xf, 0xa, false);
+    } else { static_assert(M == 8, "distance inside a row"); return dpp_i32<DPP_ROR8>(v); }
+}
+template <int M> __device__ __forceinline__ double xor_f64(double v) { return __hiloint2double(xor_i32<M>(__double2hiint(v)), xor_i32<M>(__double2loint(v))); }
+// distance 16 / 32: with both operands = v the swap returns, in every lane i, the pair {v[i], v[i ^ M]} (in an order that depends on the
+// lane's half) -- symmetric combinations (min, lexicographic min) need not know which is which
+template <int M> __device__ __forceinline__ lane_pair_t swap_pair(unsigned v)
+{
+    if constexpr (M == 16) return __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    else { static_assert(M == 32, "row / half swap"); return __builtin_amdgcn_permlane32_swap(v, v, false, false); }
+}
+template <int M> __device__ __forceinline__ void swap_pair_f64(double v, double& a, double& b)
+{
+    const lane_pair_t lo = swap_pair<M>((unsigned)__double2loint(v)), hi = swap_pair<M>((unsigned)__double2hiint(v));
+    a = __hiloint2double((int)hi.x, (int)lo.x); b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+
+// minimum of a double over the wave (no NaN among the keys), in every lane. The first key decides nearly always, so the callers reduce it
+// alone and fall back to wave_min3 only when it is attained more than once.
+__device__ __forceinline__ double wave_min_f64(double k)
+{
+    k = __builtin_fmin(k, dpp_f64<DPP_XOR1>(k));
+    k = __builtin_fmin(k, dpp_f64<DPP_XOR2>(k));
+    k = __builtin_fmin(k, dpp_f64<DPP_HALF_MIRROR>(k));
+    k = __builtin_fmin(k, dpp_f64<DPP_MIRROR>(k));
+    double a, b;
+    swap_pair_f64<16>(k, a, b); k = __builtin_fmin(a, b);
+    swap_pair_f64<32>(k, a, b); k = __builtin_fmin(a, b);
+    return k;
+}
+__device__ __forceinline__ int wave_min_i32(int k)
+{
+    k = min(k, dpp_i32<DPP_XOR1>(k));
+    k = min(k, dpp_i32<DPP_XOR2>(k));
+    k = min(k, dpp_i32<DPP_HALF_MIRROR>(k));
+    k = min(k, dpp_i32<DPP_MIRROR>(k));
+    lane_pair_t r = swap_pair<16>((unsigned)k); k = min((int)r.x, (int)r.y);
+    r = swap_pair<32>((unsigned)k); k = min((int)r.x, (int)r.y);
+    return k;
+}
+__device__ __forceinline__ int wave_max_i32(int k)
+{
+    k = max(k, dpp_i32<DPP_XOR1>(k));
+    k = max(k, dpp_i32<DPP_XOR2>(k));
+    k = max(k, dpp_i32<DPP_HALF_MIRROR>(k));
+    k = max(k, dpp_i32<DPP_MIRROR>(k));
+    lane_pair_t r = swap_pair<16>((unsigned)k); k = max((int)r.x, (int)r.y);
+    r = swap_pair<32>((unsigned)k); k = max((int)r.x, (int)r.y);
+    return k;
+}
+// maximum over every group of eight lanes (lanes 8 k .. 8 k + 7), in each of its lanes
+__device__ __forceinline__ int oct_max_i32(int k)
+{
+    k = max(k, dpp_i32<DPP_XOR1>(k));
+    k = max(k, dpp_i32<DPP_XOR2>(k));
+    return max(k, dpp_i32<DPP_HALF_MIRROR>(k));
+}
+// lexicographic minimum over (k1, k2, idx) / (k, idx): one exchange step at distance M (true partner: the keys differ from lane to lane)
+template <int M> __device__ __forceinline__ void min3_step(double& k1, double& k2, int& idx)
+{
+    if constexpr (M < 16) {
+        const double o1 = xor_f64<M>(k1), o2 = xor_f64<M>(k2); const int oi = xor_i32<M>(idx);
+        const bool take = (o1 < k1) || (o1 == k1 && ((o2 < k2) || (o2 == k2 && oi < idx)));
+        if (take) { k1 = o1; k2 = o2; idx = oi; }
+    } else {
+        double a1, b1, a2, b2; swap_pair_f64<M>(k1, a1, b1); swap_pair_f64<M>(k2, a2, b2);
+        const lane_pair_t ri = swap_pair<M>((unsigned)idx);
+        const int ai = (int)ri.x, bi = (int)ri.y;
+        const bool take_b = (b1 < a1) || (b1 == a1 && ((b2 < a2) || (b2 == a2 && bi < ai)));
+        k1 = take_b ? b1 : a1; k2 = take_b ? b2 : a2; idx = take_b ? bi : ai;
+    }
+}
+template <int M> __device__ __forceinline__ void min2_step(double& k, int& idx)
+{
+    if constexpr (M < 16) {
+        const double o = xor_f64<M>(k); const int oi = xor_i32<M>(idx);
+        const bool take = (o < k) || (o == k && oi < idx);
+        if (take) { k = o; idx = oi; }
+    } else {
+        double a, b; swap_pair_f64<M>(k, a, b);
+        const lane_pair_t ri = swap_pair<M>((unsigned)idx);
+        const int ai = (int)ri.x, bi = (int)ri.y;
+        const bool take_b = (b < a) || (b == a && bi < ai);
+        k = take_b ? b : a; idx = take_b ? bi : ai;
+    }
+}
+__device__ __forceinline__ void wave_min3(double& k1, double& k2, int& idx)
+{
+    min3_step<1>(k1, k2, idx); min3_step<2>(k1, k2, idx); min3_step<4>(k1, k2, idx); min3_step<8>(k1, k2, idx);
+    min3_step<16>(k1, k2, idx); min3_step<32>(k1, k2, idx);
+}
+// the same for (key, index) pairs: the closest-point searches carry no second key
+__device__ __forceinline__ void wave_min2(double& k, int& idx)
+{
+    min2_step<1>(k, idx); min2_step<2>(k, idx); min2_step<4>(k, idx); min2_step<8>(k, idx); min2_step<16>(k, idx); min2_step<32>(k, idx);
+}
+// ... over the lanes that agree in their low bits (lane & (np2 - 1)): the steps at distance >= np2 only (np2 a power of two, uniform)
+__device__ __forceinline__ void wave_min2_from(double& k, int& idx, int np2)
+{
+    if (np2 <= 1) min2_step<1>(k, idx);
+    if (np2 <= 2) min2_step<2>(k, idx);
+    if (np2 <= 4) min2_step<4>(k, idx);
+    if (np2 <= 8) min2_step<8>(k, idx);
+    if (np2 <= 16) min2_step<16>(k, idx);
+    if (np2 <= 32) min2_step<32>(k, idx);
+}
+
+// exclusive prefix sum of an int over the wave (+ the total): Hillis-Steele inside the rows (row_shr, lanes without a source add 0), then
+// the row totals through the two broadcast forms
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total)
+{
+    (void)lane;
+    int x = v;
+    x += __builtin_amdgcn_update_dpp(0, x, DPP_SHR(1), 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, DPP_SHR(2), 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, DPP_SHR(4), 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, DPP_SHR(8), 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, DPP_BCAST15, 0xa, 0xf, false);      // rows 1 and 3 += total of the row below
+    x += __builtin_amdgcn_update_dpp(0, x, DPP_BCAST31, 0xc, 0xf, false);      // rows 2 and 3 += total of rows 0 and 1
+    total = __builtin_amdgcn_readlane(x, 63);
+    return x - v;
+}
+#else       // ---- round-4 forms: every exchange is a ds_bpermute ---------------------------------------------------------------------
 __device__ __forceinline__ double wave_min_f64(double k)
 {
 #pragma unroll
@@ -190,6 +340,18 @@ __device__ __forceinline__ int wave_min_i32(int k)
     for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(k, m); k = o < k ? o : k; }
     return k;
 }
+__device__ __forceinline__ int wave_max_i32(int k)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(k, m); k = o > k ? o : k; }
+    return k;
+}
+__device__ __forceinline__ int oct_max_i32(int k)
+{
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) { const int o = __shfl_xor(k, m); k = o > k ? o : k; }
+    return k;
+}
 __device__ __forceinline__ void wave_min3(double& k1, double& k2, int& idx)
 {
 #pragma unroll
@@ -200,8 +362,6 @@ __device__ __forceinline__ void wave_min3(double& k1, double& k2, int& idx)
         if (take) { k1 = o1; k2 = o2; idx = oi; }
     }
 }
-
-// the same for (key, index) pairs: the closest-point searches carry no second key (half the shuffles of wave_min3)
 __device__ __forceinline__ void wave_min2(double& k, int& idx)
 {
 #pragma unroll
@@ -212,7 +372,13 @@ __device__ __forceinline__ void wave_min2(double& k, int& idx)
         if (take) { k = o; idx = oi; }
     }
 }
-
+__device__ __forceinline__ void wave_min2_from(double& k, int& idx, int np2)
+{
+    for (int m = np2; m < 64; m <<= 1) {
+        const double o = __shfl_xor(k, m); const int oi = __shfl_xor(idx, m);
+        if (o < k || (o == k && oi < idx)) { k = o; idx = oi; }
+    }
+}
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total)
 {
     int x = v;
@@ -224,6 +390,50 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total)
     total = __shfl(x, 63);
     return x - v;
 }
+#endif
+
+#ifdef LTPL_EXPERIMENT
+// Self-check of the cross-lane helpers above (experiment build only; tests/test_gpu_wave_ops.py through ltpl_exp_wave_ops_check):
+// every helper against a plain loop over the wave's values in LDS. err[0] = number of lanes that disagree.
+__global__ __launch_bounds__(64) void k_exp_wave_ops(const double* vals, const int* ivals, int rounds, int* err)
+{
+    __shared__ double sd[64], sd2[64];
+    __shared__ int si[64];
+    const int lane = threadIdx.x;
+    int bad = 0;
+    for (int r = 0; r < rounds; ++r) {
+        const double d = vals[(size_t)r * 128 + lane], d2 = vals[(size_t)r * 128 + 64 + lane];
+        const int iv = ivals[(size_t)r * 64 + lane];
+        sd[lane] = d; sd2[lane] = d2; si[lane] = iv;
+        __syncthreads();
+        double rmin = INFINITY; int imin = 0x7fffffff, imax = -0x7fffffff - 1, isum = 0, ipre = 0, omax = -0x7fffffff - 1;
+        double a1 = INFINITY, a2 = INFINITY; int ai = 0x7fffffff;          // lexicographic minimum over (d, d2, iv)
+        double b1 = INFINITY; int bi = 0x7fffffff;                          // ... over (d, iv)
+        for (int l = 0; l < 64; ++l) {
+            rmin = sd[l] < rmin ? sd[l] : rmin; imin = si[l] < imin ? si[l] : imin; imax = si[l] > imax ? si[l] : imax;
+            isum += si[l] & 0xff; if (l < lane) ipre += si[l] & 0xff;
+            if ((l >> 3) == (lane >> 3)) omax = si[l] > omax ? si[l] : omax;
+            if (sd[l] < a1 || (sd[l] == a1 && (sd2[l] < a2 || (sd2[l] == a2 && si[l] < ai)))) { a1 = sd[l]; a2 = sd2[l]; ai = si[l]; }
+            if (sd[l] < b1 || (sd[l] == b1 && si[l] < bi)) { b1 = sd[l]; bi = si[l]; }
+        }
+        if (wave_min_f64(d) != rmin) ++bad;
+        if (wave_min_i32(iv) != imin) ++bad;
+        if (wave_max_i32(iv) != imax) ++bad;
+        if (oct_max_i32(iv) != omax) ++bad;
+        { int tot; const int ex = wave_excl_scan(iv & 0xff, lane, tot); if (ex != ipre || tot != isum) ++bad; }
+        { double k1 = d, k2 = d2; int ix = iv; wave_min3(k1, k2, ix); if (k1 != a1 || k2 != a2 || ix != ai) ++bad; }
+        { double k = d; int ix = iv; wave_min2(k, ix); if (k != b1 || ix != bi) ++bad; }
+        for (int np2 = 1; np2 <= 64; np2 <<= 1) {                            // segment merge of phase 1: lanes with equal (lane & (np2 - 1))
+            double k = d; int ix = iv; wave_min2_from(k, ix, np2);
+            double c1 = INFINITY; int ci = 0x7fffffff;
+            for (int l = lane & (np2 - 1); l < 64; l += np2) if (sd[l] < c1 || (sd[l] == c1 && si[l] < ci)) { c1 = sd[l]; ci = si[l]; }
+            if (k != c1 || ix != ci) ++bad;
+        }
+        __syncthreads();
+    }
+    if (bad) atomicAdd(err, 1);
+}
+#endif
 
 // LDS hand-over between the lanes of ONE wave: DS operations of a wave execute in order, so only the compiler has to be
 // kept from reordering (wavefront-scope fences emit no s_waitcnt vmcnt and do not serialise outstanding global loads)
@@ -1423,7 +1633,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
         // longest profile of the launch (k_vel_final skips row chunks beyond it): one atomic per wave
         int nmax = js.y;
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(nmax, m); nmax = o > nmax ? o : nmax; }
+        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(nmax, m); nmax = o > nmax ? o : nmax; }   // (lanes beyond the job count have left: no DPP form here)
         if (lane == 0) atomicMax(&out.job_cnt[2], nmax);
     }
     const int s = slot / LTPL_MAX_ACTIONS;
@@ -1769,7 +1979,7 @@ __global__ __launch_bounds__(64) void k_follow_prep(DevLat lat, DevPathsIn in, D
         const ke_t* KE = vp.KE + kep_base(out.n_slots_pad + j, vp.plane_rows);
         int nmax = n;
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(nmax, m); nmax = o > nmax ? o : nmax; }
+        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(nmax, m); nmax = o > nmax ? o : nmax; }   // (lanes beyond the job count have left: no DPP form here)
         // one pass: closest path point of the object (o) and of the ego position (e), arc length in front of it and the element before
         double bo = INFINITY, be = INFINITY, so = 0.0, se = 0.0, po = 0.0, pe = 0.0, run = 0.0, e_prev = 0.0;
         int no = 0, ne = 0;
@@ -1997,6 +2207,13 @@ struct ltpl_handle {
     std::vector<int> rng_end_host;   // planning range end per start layer, -1 = no planning range (end of an open track)
     std::vector<int> sw2csc_host;    // CSC edge id of every sweep position (DevLat::sw2csc)
     int n_planners = 0;              // live ltpl_planner objects that compute through this handle (ltpl_destroy refuses while > 0)
+    // LTPL_TICK_GRAPH=1 (round 5, measurement switch, off by default): the single fused tick -- H2D copy of the packed inputs -> k_tick
+    // [-> D2H copy of the outputs] -- submitted as ONE hipGraph launch instead of two or three stream calls. The executable graph is
+    // built at the first tick and re-parameterised per tick (the pointers into the staging buffers move with the tick's counts).
+    int tick_graph = 0;
+    hipGraph_t tg_graph = nullptr; hipGraphExec_t tg_exec = nullptr;
+    hipGraphNode_t tg_n_in = nullptr, tg_n_k = nullptr, tg_n_out = nullptr;
+    const void* tg_func = nullptr; int tg_has_out = 0;
 };
 
 #define HIP_TRY(h, call)                                                                                              \
@@ -2022,6 +2239,26 @@ static const void* paths_kernel_of(const ltpl_handle* h, int nw)
     if (h->long_horizon) return reinterpret_cast<const void*>(k_paths<NUM_WAVES, PlanRtG>);
     return h->plan_class4 == 1 ? reinterpret_cast<const void*>(k_paths<NUM_WAVES, PlanA4>)
                                : reinterpret_cast<const void*>(k_paths<NUM_WAVES, PlanRt>);
+}
+
+// (mangled) symbol prefix of that kernel in the code object: what a profile is matched against (ltpl_paths_kernel_symbol)
+static const char* paths_kernel_symbol_of(const ltpl_handle* h, int nw)
+{
+    if (nw == 1) {
+        if (h->long_horizon) return "_Z7k_pathsILi1E7PlanRtGE";
+        switch (h->plan_class) {
+            case 1: return "_Z7k_pathsILi1E6PlanFxILi32ELi32ELi1EEE";
+            case 2: return "_Z7k_pathsILi1E6PlanFxILi32ELi40ELi1EEE";
+            case 3: return "_Z7k_pathsILi1E6PlanFxILi48ELi32ELi1EEE";
+            default: return "_Z7k_pathsILi1E6PlanRtE";
+        }
+    }
+    if (h->long_horizon) return "_Z7k_pathsILi4E7PlanRtGE";
+    return h->plan_class4 == 1 ? "_Z7k_pathsILi4E6PlanFxILi32ELi32ELi4EEE" : "_Z7k_pathsILi4E6PlanRtE";
+}
+extern "C" const char* ltpl_paths_kernel_symbol(const ltpl_handle* h, int32_t team_waves)
+{
+    return h ? paths_kernel_symbol_of(h, team_waves == 4 ? NUM_WAVES : 1) : "";
 }
 
 // the path kernel with `nw` waves per scenario in the LDS plan class chosen for the lattice at ltpl_create
@@ -2238,6 +2475,8 @@ extern "C" int ltpl_destroy(ltpl_handle* h)
     if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->h_flag) (void)hipHostFree(h->h_flag);
     if (h->d_done_cnt) (void)hipFree(h->d_done_cnt);
+    if (h->tg_exec) (void)hipGraphExecDestroy(h->tg_exec);
+    if (h->tg_graph) (void)hipGraphDestroy(h->tg_graph);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     free_resident(h->resident);
     delete h;
@@ -2448,6 +2687,7 @@ try {
     if (const char* e = getenv("LTPL_ZC_OUT")) h->zc_out = atoi(e);
     if (const char* e = getenv("LTPL_ZC_IN")) h->zc_in = atoi(e);
     if (const char* e = getenv("LTPL_POLL")) h->poll = atoi(e);
+    if (const char* e = getenv("LTPL_TICK_GRAPH")) h->tick_graph = atoi(e);
     if (const char* e = getenv("LTPL_POLL_SYNC_EVERY")) h->poll_sync_every = atoi(e);
     if (const char* e = getenv("LTPL_POLL_QUERY")) h->poll_query = atoi(e);
     if (h->poll) {
@@ -3220,6 +3460,39 @@ static int tick_set_lds_limit(ltpl_handle* h, size_t lds, int variant)
     return LTPL_OK;
 }
 
+// The fused single tick as one hipGraph launch (LTPL_TICK_GRAPH=1): copy node (packed inputs, H2D) -> kernel node (k_tick) -> copy node
+// (outputs, D2H; absent with zero-copy outputs). Built once; every tick re-parameterises the nodes of the executable graph (sizes and the
+// pointers into the staging buffers follow the tick's counts) and launches it. A change of topology or kernel rebuilds the graph.
+static int tick_launch_graph(ltpl_handle* h, TickLayout& t, bool zc)
+{
+    const void* func = reinterpret_cast<const void*>(tick_kernel_of(t.variant, h->plan_class4 == 1));
+    int vel_off = t.vel_off, vel_stride = t.vel_stride, vel_cap = t.vel_cap;
+    void* kargs[] = {&h->lat, &t.di, &t.dout, &h->lp4, &t.p, &t.dvin, &t.dvout, &vel_off, &vel_stride, &vel_cap};
+    hipKernelNodeParams kp{};
+    kp.func = const_cast<void*>(func); kp.gridDim = dim3(t.n_scen); kp.blockDim = dim3(WG_THREADS); kp.sharedMemBytes = (unsigned)t.lds;
+    kp.kernelParams = kargs; kp.extra = nullptr;
+    const int has_out = zc ? 0 : 1;
+    bool ok = h->tg_exec && h->tg_func == func && h->tg_has_out == has_out;
+    if (ok) {
+        ok = hipGraphExecMemcpyNodeSetParams1D(h->tg_exec, h->tg_n_in, h->d_in, h->h_in, t.in_total, hipMemcpyHostToDevice) == hipSuccess &&
+             hipGraphExecKernelNodeSetParams(h->tg_exec, h->tg_n_k, &kp) == hipSuccess &&
+             (!has_out || hipGraphExecMemcpyNodeSetParams1D(h->tg_exec, h->tg_n_out, h->h_out, h->d_out, t.out_total, hipMemcpyDeviceToHost) == hipSuccess);
+        if (!ok) (void)hipGetLastError();
+    }
+    if (!ok) {
+        if (h->tg_exec) { (void)hipGraphExecDestroy(h->tg_exec); h->tg_exec = nullptr; }
+        if (h->tg_graph) { (void)hipGraphDestroy(h->tg_graph); h->tg_graph = nullptr; }
+        HIP_TRY(h, hipGraphCreate(&h->tg_graph, 0));
+        HIP_TRY(h, hipGraphAddMemcpyNode1D(&h->tg_n_in, h->tg_graph, nullptr, 0, h->d_in, h->h_in, t.in_total, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipGraphAddKernelNode(&h->tg_n_k, h->tg_graph, &h->tg_n_in, 1, &kp));
+        if (has_out) HIP_TRY(h, hipGraphAddMemcpyNode1D(&h->tg_n_out, h->tg_graph, &h->tg_n_k, 1, h->h_out, h->d_out, t.out_total, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipGraphInstantiate(&h->tg_exec, h->tg_graph, nullptr, nullptr, 0));
+        h->tg_func = func; h->tg_has_out = has_out;
+    }
+    HIP_TRY(h, hipGraphLaunch(h->tg_exec, h->stream));
+    return LTPL_OK;
+}
+
 extern "C" int ltpl_tick_batch(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin, ltpl_paths_out* out,
                                ltpl_tick_vel_out* vout)
 try {
@@ -3239,9 +3512,13 @@ try {
                         static_cast<unsigned char*>(zc ? h->h_out : h->d_out)))) return rc;
     if (polled) t.dout.done = next_done_signal(h);
     if ((rc = tick_set_lds_limit(h, t.lds, t.variant))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, t.in_total, hipMemcpyHostToDevice, h->stream));
-    if ((rc = tick_launch(h, t))) return rc;
-    if (!zc) HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, t.out_total, hipMemcpyDeviceToHost, h->stream));
+    if (h->tick_graph && !t.pipeline) {
+        if ((rc = tick_launch_graph(h, t, zc))) return rc;
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(h->d_in, h->h_in, t.in_total, hipMemcpyHostToDevice, h->stream));
+        if ((rc = tick_launch(h, t))) return rc;
+        if (!zc) HIP_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, t.out_total, hipMemcpyDeviceToHost, h->stream));
+    }
     if (polled) { if ((rc = wait_done(h, t.dout.done.seq))) return rc; }
     else HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (t.pipeline) dbg_report_lanes(h); else dbg_report(h, "k_tick", in->n_scen);
@@ -3719,6 +3996,29 @@ extern "C" int ltpl_planner_get_ref_idx(ltpl_planner* p, const double* px, const
 extern "C" int ltpl_planner_calc_vel_profile(ltpl_planner* p, const ltpl_planner_vel_in* in) try { return ltplp::api_calc_vel_profile(p, in); } LTPL_ABI_CATCH(abi_err_of(p))
 extern "C" int ltpl_planner_get_paths(const ltpl_planner* p, int32_t scen, ltpl_planner_paths_view* v) try { return ltplp::api_get_paths(p, scen, v); } LTPL_ABI_CATCH(abi_err_of(p))
 extern "C" int ltpl_planner_get_trajectories(const ltpl_planner* p, int32_t scen, ltpl_planner_traj_view* v) try { return ltplp::api_get_trajectories(p, scen, v); } LTPL_ABI_CATCH(abi_err_of(p))
+
+#ifdef LTPL_EXPERIMENT
+// experiment build only: the cross-lane helpers against plain loops on `rounds` waves of caller-provided values (vals: rounds x 128
+// doubles, ivals: rounds x 64 ints, host memory); *n_bad = lanes that disagreed in some round
+extern "C" int ltpl_exp_wave_ops_check(int32_t device, const double* vals, const int32_t* ivals, int32_t rounds, int32_t* n_bad)
+try {
+    if (!vals || !ivals || !n_bad || rounds <= 0) return LTPL_ERR_INVALID_ARG;
+    if (hipSetDevice(device) != hipSuccess) return LTPL_ERR_HIP;
+    double* dv = nullptr; int* di = nullptr; int* de = nullptr;
+    int rc = LTPL_OK, zero = 0;
+    if (hipMalloc(&dv, sizeof(double) * 128 * (size_t)rounds) != hipSuccess || hipMalloc(&di, sizeof(int) * 64 * (size_t)rounds) != hipSuccess ||
+        hipMalloc(&de, sizeof(int)) != hipSuccess) rc = LTPL_ERR_HIP;
+    if (!rc && (hipMemcpy(dv, vals, sizeof(double) * 128 * (size_t)rounds, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(di, ivals, sizeof(int) * 64 * (size_t)rounds, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(de, &zero, sizeof(int), hipMemcpyHostToDevice) != hipSuccess)) rc = LTPL_ERR_HIP;
+    if (!rc) {
+        hipLaunchKernelGGL(k_exp_wave_ops, dim3(1), dim3(64), 0, 0, dv, di, rounds, de);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(n_bad, de, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = LTPL_ERR_HIP;
+    }
+    (void)hipFree(dv); (void)hipFree(di); (void)hipFree(de);
+    return rc;
+} LTPL_ABI_CATCH(nullptr)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // fleet (ABI v5): planners with device-resident state

@@ -1101,10 +1101,10 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
         const int v0 = at(lat.layer_off, b);
         lay[j] = make_int4(v0, (at(lat.layer_off, b + 1) - v0) | (at(lat.layer_degmax, b) << 16), at(lat.layer_ebase, b), at(lat.layer_ebase, b + 1));
     }
-    if (tid < LTPL_MAX_LAST_NODES) {
+    {
         // pair tid of the previous solution: which transition of the planning range does it span?
         int fj = -1, fs = -1, fd = -1; double fac = 1.0;
-        if (tid < sc.n_fac) {
+        if (tid < sc.n_fac && tid < LTPL_MAX_LAST_NODES) {
             const int* ll = in.last_layer + (size_t)sc.s * LTPL_MAX_LAST_NODES;
             const int* ln = in.last_node + (size_t)sc.s * LTPL_MAX_LAST_NODES;
             const int la = ll[tid], lb = ll[tid + 1];
@@ -1112,11 +1112,12 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
             int jj = lb - sc.sl; if (jj < 0) jj += L;
             if (la >= 0 && la < L && lb == nx && jj >= 1 && jj <= sc.H) { fj = jj; fs = ln[tid]; fd = ln[tid + 1]; fac = in.w_last[tid]; }
         }
-        ts.fac_j[tid] = fj; ts.fac_src[tid] = fs; ts.fac_dst[tid] = fd; ts.fac[tid] = fac;
-        int mx = fj;
-#pragma unroll
-        for (int m = 1; m < LTPL_MAX_LAST_NODES; m <<= 1) { const int o = __shfl_xor(mx, m); mx = o > mx ? o : mx; }
-        if (tid == 0) ts.fac_jmax = mx;
+        if (tid < LTPL_MAX_LAST_NODES) { ts.fac_j[tid] = fj; ts.fac_src[tid] = fs; ts.fac_dst[tid] = fd; ts.fac[tid] = fac; }
+        if (wave == 0) {                                   // (every lane of the wave takes part: fj = -1 beyond the list)
+            static_assert(LTPL_MAX_LAST_NODES <= 8, "the list lies in the first eight lanes");
+            const int mx = oct_max_i32(fj);
+            if (tid == 0) ts.fac_jmax = mx;
+        }
     }
     if (wave == 0 && (sc.flags & LTPL_FLAG_HAS_PSI_S)) {        // start heading of the constant path segment: one sincos per scenario, not per path
         double sn, cs;
@@ -1181,10 +1182,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
                 if (d2 < bd) { bd = d2; bl = l; }
             }
         }
-        for (int m = np2; m < 64; m <<= 1) {
-            const double od = __shfl_xor(bd, m); const int ol = __shfl_xor(bl, m);
-            if (od < bd || (od == bd && ol < bl)) { bd = od; bl = ol; }
-        }
+        wave_min2_from(bd, bl, np2);
         if (qv && seg == 0) {
             const int ol = bl, sl = sc.sl, el = sc.el;
             const bool gate = (sl - 1 <= ol && ol <= el + 1) || (sl > el && (sl - 1 <= ol || ol <= el + 1));
@@ -1362,8 +1360,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
                 if (ld <= H) { const int kk = ld * 256 + k; if (kk < key) key = kk; }
             }
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(key, m); key = o < key ? o : key; }
+        key = wave_min_i32(key);
         int ci = -1, cl = -1, have = 0, cn = -1;
         if (key != 0x7fffffff) {
             ci = key & 255; have = 1;

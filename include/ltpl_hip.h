@@ -293,6 +293,10 @@ int ltpl_destroy(ltpl_handle* handle);
 int ltpl_get_caps(const ltpl_handle* handle, ltpl_caps* caps);
 const char* ltpl_last_error(const ltpl_handle* handle);   /* NULL handle -> last create() error */
 int ltpl_version(void);
+/* diagnostics: symbol-name prefix (Itanium mangling) of the path kernel this handle launches for batches (team_waves = 1) or single
+ * ticks (team_waves = 4) -- the LDS plan class is chosen per lattice at ltpl_create. Profiles under profiles/ carry a digest of that
+ * kernel's instruction stream; bench.py uses this to check that a committed counter pass describes the library it runs. */
+const char* ltpl_paths_kernel_symbol(const ltpl_handle* handle, int32_t team_waves);
 
 /* --- seam (1): main_online_path_gen.py:11 ------------------------------------------------------------------------- */
 int ltpl_plan_paths(ltpl_handle* handle, const ltpl_paths_in* in, ltpl_paths_out* out);

@@ -77,6 +77,11 @@ class StandInBackend(object):
         self.caps = self.orc.caps
         self.calls = []
         self._resident = None
+        import __graft_entry__ as ge
+        self.lib_path = ge.HIP_LIB              # (the line reports the library's hashes and the digest of its batch path kernel)
+
+    def paths_kernel_symbol(self, team_waves=1):
+        return "_Z7k_pathsILi1E6PlanFxILi32ELi32ELi1EEE"
 
     def new_paths_result(self, n_scen):
         return self.orc.new_paths_result(n_scen)
@@ -203,8 +208,34 @@ def test_traffic_is_reported_for_the_grid_it_was_measured_on(monkeypatch, capsys
     with open(os.path.join(bench.ROOT, "profiles", "pmc_traffic.json")) as fh:
         pmc = json.load(fh)
     n = int(pmc["grid_size"]) // 64
-    assert bench.read_traffic(n, pmc.get("workload", "c2")) == pmc["hbm_bytes_per_launch"]
+    assert bench.read_traffic(n, pmc.get("workload", "c2"))["hbm_bytes_per_launch"] == pmc["hbm_bytes_per_launch"]
     assert bench.read_traffic(n // 2, "c2") is None and bench.read_traffic(n, "c3") is None
+
+
+def test_counter_passes_are_tied_to_the_build(monkeypatch, capsys, tmp_path):
+    """profiles/pmc_*.json carry the digest of the profiled library's path kernel (__graft_entry__.build_stamp); the line says whether it
+    is the digest of the library the run drives: a stale file is flagged, not attached silently."""
+    import __graft_entry__ as ge
+    ge.build_hip()
+    stamp = ge.build_stamp(ge.HIP_LIB, "_Z7k_pathsILi1E6PlanFxILi32ELi32ELi1EEE")
+    assert stamp["isa_sha256"] and stamp["resources"]["vgpr_count"] <= 128 and stamp["isa_instructions"] > 1000
+    monkeypatch.setattr(bench, "PROFILES_DIR", str(tmp_path))
+    issue = {"kernel": "k_paths<1, PlanFx<32, 32, 1> >", "tag": "test", "workload": "c2", "grid_size": 64 * 64,
+             "valu_insts_per_launch": 5.0e5, "salu_insts_per_launch": 3.0e5, "lds_insts_per_launch": 7.0e4,
+             "valu_active_quad_cycles_per_launch": 5.2e5, "lanes_active_per_valu_inst": 45.0, "lds_active_quad_cycles_per_launch": 1.4e5,
+             "wave_quad_cycles_per_launch": 3.0e6, "wait_any_quad_cycles_per_launch": 1.2e6}
+    traffic = {"kernel": issue["kernel"], "tag": "test", "workload": "c2", "grid_size": 64 * 64, "hbm_bytes_per_launch": 1.4e6}
+    for build, expect in ((dict(stamp, isa_sha256="0" * 64), False), (stamp, True), (None, None)):
+        for name, d in (("pmc_issue.json", issue), ("pmc_traffic.json", traffic)):
+            with open(tmp_path / name, "w") as fh:
+                json.dump(dict(d, build=build) if build else d, fh)
+        out, _ = run_worker(monkeypatch, capsys, no_cpu=True, no_extra=True, latency_ticks=0)
+        r = out["roofline"]
+        assert r["issue"]["build_matches"] is expect and r["traffic_build_matches"] is expect
+        assert r["traffic"] == 1.4e6 and r["issue"]["valu_insts_per_scenario"] == pytest.approx(5.0e5 / 64)
+        assert r["binding"]["wait_frac_of_wave_cycles"] == pytest.approx(0.4)
+        lib = out["library"]
+        assert lib["path"] == ge.HIP_LIB and lib["isa_sha256"] == stamp["isa_sha256"] and lib["lib_sha256"] == ge.file_sha256(ge.HIP_LIB)
 
 
 def test_flags_that_drop_legs(monkeypatch, capsys):
