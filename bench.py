@@ -92,11 +92,28 @@ def cpu_baseline(lat, scen_batch, batch, vel, idx):
         el = time.perf_counter() - t0
         if el > 10.0 or reps >= 200:
             break
-    return {"value": len(scen) * reps / el, "unit": "ticks/s", "cores": 1, "kind": "port",
-            "sample": "%d scenarios spread evenly over the batch of the timed region x %d passes through oracle_tick_batch (plain C, "
-                      "-O2, single thread, timed in this run on the GPU box's host; the reference's own Python over the dependency shims "
-                      "was measured once in the build container: ~32 ticks/s on 1 core, /root/reference is absent here)"
-                      % (len(scen), reps)}, ref
+    out = {"value": len(scen) * reps / el, "unit": "ticks/s", "cores": 1, "kind": "port",
+           "sample": "%d scenarios spread evenly over the batch of the timed region x %d passes through oracle_tick_batch (plain C, "
+                     "-O2, single thread, timed in this run on the GPU box's host). The reference's own Python cannot run here "
+                     "(/root/reference is absent on the GPU box): its measured rate is the committed artefact cited in `reference_python`"
+                     % (len(scen), reps)}
+    # the unmodified reference over the dependency shims, C2 closed loop, timed in the build container by tools/ref_python_rate.py
+    # (BASELINE.md section 4 / SURVEY.md section 8d: >= 2 000 ticks after 100 warm-up, perf_counter around calc_paths + calc_vel_profile)
+    p = os.path.join(ROOT, "profiles", "r05_ref_python_cpu.json")
+    if os.path.isfile(p):
+        try:
+            with open(p) as fh:
+                d = json.load(fh)
+            out["reference_python"] = {"ticks_per_s": d["ticks_per_s"], "mean_ms": d["tick"]["mean_ms"], "p50_ms": d["tick"]["p50_ms"],
+                                       "p99_ms": d["tick"]["p99_ms"], "ticks": d["ticks"], "warmup_ticks": d["warmup_ticks"], "cores": d["cores"],
+                                       "cpu_model": d["cpu_model"], "label": "reference-Python-over-shim", "where": d["where"],
+                                       "source": "profiles/r05_ref_python_cpu.json (tools/ref_python_rate.py); not measured in this run"}
+        except Exception:
+            pass
+    return out, ref
+
+
+ELEM_TOL_VX = 1e-4      # element-wise bound on vx where |vx| >= 1 m/s (the array-level bound is 1e-5 of the array's largest speed)
 
 
 def parity_check(res, vres, ref, idx):
@@ -108,9 +125,18 @@ def parity_check(res, vres, ref, idx):
                            "n_nodes", "n_pts", "n_ties", "nodes", "node_idx", "vel_bound", "too_close", "el_length_column")}
     worst = {k: 0.0 for k in ("x", "y", "psi", "kappa", "coeff_a0", "coeff_a1", "coeff_a2", "coeff_a3", "vx", "ax")}
     n_paths = 0
+    # ELEMENT-WISE relative errors |a - d| / |d| over the samples whose reference magnitude lies above a floor (the per-array max-norm
+    # tolerances above are the assertions of the parity suite; these show what they allow element by element, e.g. on the slow tail of a
+    # profile that brakes to standstill): vx where |vx| >= 1 m/s, ax where |ax| >= 0.5 m/s^2, kappa where |kappa| >= 1e-3 1/m
+    ELEM_FLOOR = {"vx": 1.0, "ax": 0.5, "kappa": 1e-3}
+    elem = {k: [] for k in ELEM_FLOOR}
 
     def rel(name, a, b, scale):
         worst[name] = max(worst[name], float(np.max(np.abs(a - b))) / scale if a.size else 0.0)
+        if name in elem and a.size:
+            m = np.abs(b) >= ELEM_FLOOR[name]
+            if m.any():
+                elem[name].append(np.abs(a[m] - b[m]) / np.abs(b[m]))
 
     for k, s in enumerate(idx):
         s = int(s)
@@ -150,9 +176,20 @@ def parity_check(res, vres, ref, idx):
             rel("ax", vres.ax[s, a, :npts], ovres.ax[k, a, :npts], max(float(np.max(np.abs(ovx))) ** 2 / 2.0, 5.0))   # ax differentiates v^2
     bad_ints = {k: v for k, v in ints.items() if v}
     max_rel = max(worst.values()) if worst else 0.0
-    ok = not bad_ints and max_rel <= 1e-5
+    elementwise = {}
+    for k, parts in elem.items():
+        e = np.concatenate(parts) if parts else np.zeros(0)
+        elementwise[k] = {"samples": int(e.size), "floor": ELEM_FLOOR[k],
+                          "p50": float(np.percentile(e, 50)) if e.size else None, "p99": float(np.percentile(e, 99)) if e.size else None,
+                          "max": float(e.max()) if e.size else None}
+    # north_star: "velocity profiles within 1e-5 relative" is asserted per array against the array's scale; element by element the
+    # velocity must stay within ELEM_TOL_VX wherever the car moves at all (|vx| >= 1 m/s)
+    vx_elem_ok = elementwise["vx"]["max"] is None or elementwise["vx"]["max"] <= ELEM_TOL_VX
+    ok = not bad_ints and max_rel <= 1e-5 and vx_elem_ok
     return ok, {"scenarios": int(len(idx)), "paths": n_paths, "sample": "evenly spread over the %d scenarios of the timed batch" % res.n_scen,
                 "max_rel_err": max_rel, "max_rel_err_by_quantity": worst,
+                "elementwise_rel_err": dict(elementwise, what="|gpu - oracle| / |oracle| per sample above the floor (vx >= 1 m/s, ax >= 0.5 m/s^2, "
+                                                              "kappa >= 1e-3 1/m): p50 / p99 / max; asserted: max(vx) <= %.0e" % ELEM_TOL_VX),
                 "integer_outputs_compared_bit_exact": sorted(ints.keys()), "integer_mismatches": bad_ints,
                 "scales": "x, y, coeff_a0: extent of the path; coeff_a1..a3: largest magnitude of that order; kappa: floor 1e-4 1/m; "
                           "psi: pi; vx: floor 1 m/s; ax: max(v^2 / 2, 5 m/s^2)"}
@@ -525,7 +562,7 @@ def c3_throughput(n_batch, device=0, min_s=1.5, n_parity=256):
     if ref is not None:
         ok, detail = parity_check(res, vres, ref, idx)
         out["parity_checked"] = bool(ok)
-        out["parity_detail"] = {k: detail[k] for k in ("scenarios", "paths", "max_rel_err", "integer_mismatches")}
+        out["parity_detail"] = {k: detail[k] for k in ("scenarios", "paths", "max_rel_err", "integer_mismatches", "elementwise_rel_err")}
     hip.close()
     return out
 

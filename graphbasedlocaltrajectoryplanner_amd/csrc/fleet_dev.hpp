@@ -274,6 +274,12 @@ struct ltpl_fleet {
     std::vector<FleetTickIn> tape;
     std::vector<unsigned char> image;                 // host image of one planner block (queries)
     bool began = false;
+    // some call of this fleet carried friction rows (local_gg as a dict): from then on a planner's MEMORY may hold a backup plan with rows of
+    // its own (PlannerS / Block::gg), and vel_b builds the backup brake job from them whatever the current call carries (OTH.py:963-968) --
+    // the brake / emergency job launches (JB, JC) keep the rows form of the kernel. (Every pool-form job holds one [ax, ay] row per point,
+    // constants replicated, so the rows form serves jobs without rows as well.) Round 4 chose by the current call alone: a backup plan with
+    // rows was then solved with its FIRST row's limits in a tick that passed none (advisor finding).
+    bool seen_gg = false;
     size_t vel_lds = 0, vel_lds_lite = 0, vel_lds_gg = 0, vel_lds_lite_gg = 0;
     bool tape_fuse = !(getenv("LTPL_FLEET_NO_FUSE") && atoi(getenv("LTPL_FLEET_NO_FUSE")) != 0);     // tape runs with fused stage kernels (results identical)
     ~ltpl_fleet()
@@ -442,18 +448,16 @@ extern "C" int ltpl_fleet_set_start_range(ltpl_fleet* f, int32_t p0, int32_t p1,
 try {
     if (!f || !in_track || !cor_heading) return LTPL_ERR_INVALID_ARG;
     if (p0 < 0 || p1 > f->D.N || p0 >= p1) { f->err = "fleet: planner range out of bounds"; return LTPL_ERR_INVALID_ARG; }
+    // the start pose first: it only needs the host's lattice tables, and a pose off the track (or a heading the track does not allow) must
+    // cost neither a device synchronisation nor a read-back, and must leave the planners' memory untouched
+    const int rc = fleet::start_block(f->h->hostlat, f->D, x, y, heading, vel, mho, in_track, cor_heading, f->image.data(), nullptr, &f->err);
+    if (rc) return rc;
     FLEET_TRY(f, hipSetDevice(f->h->device));
     FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
     const size_t cnt = (size_t)(p1 - p0), hs = sizeof(fleet::PlannerS);
     std::vector<fleet::PlannerS> prev(cnt);
     unsigned char* blk0 = f->d_state + f->D.stride * (size_t)p0;
     FLEET_TRY(f, hipMemcpy2D(prev.data(), hs, blk0, f->D.stride, hs, cnt, hipMemcpyDeviceToHost));
-    const int rc = fleet::start_block(f->h->hostlat, f->D, x, y, heading, vel, mho, in_track, cor_heading, f->image.data(), nullptr, &f->err);
-    if (rc) return rc;
-    // the image once, then device-to-device into every block of the range (the first block receives it from the host)
-    FLEET_TRY(f, hipMemcpy(blk0, f->image.data(), f->D.stride, hipMemcpyHostToDevice));
-    for (size_t q = 1; q < cnt; ++q)
-        FLEET_TRY(f, hipMemcpyAsync(blk0 + f->D.stride * q, blk0, f->D.stride, hipMemcpyDeviceToDevice, f->h->stream));
     // per-planner scalars: the image's header with the fields start_block carries over from the planner's state before the call
     const fleet::PlannerS base = *reinterpret_cast<const fleet::PlannerS*>(f->image.data());
     std::vector<fleet::PlannerS> hdr(cnt, base);
@@ -463,6 +467,13 @@ try {
         S.has_old_gg = keep.has_old_gg; S.cut_index_pos = keep.cut_index_pos; S.cut_layer = keep.cut_layer; S.vel_plan = keep.vel_plan; S.acc_plan = keep.acc_plan;
         S.em_base_id = keep.em_base_id; S.closest_obj_index = keep.closest_obj_index; S.old_gg_scale = keep.old_gg_scale;
     }
+    // From here on the range is being rewritten: a HIP failure below (the device is gone -- every later call fails as well) leaves the blocks
+    // of the range UNDEFINED; the error is returned and the fleet is to be destroyed. The image goes to the device once, with the first
+    // planner's own header already in place, then device-to-device into every other block of the range, then the other planners' headers.
+    std::memcpy(f->image.data(), &hdr[0], hs);
+    FLEET_TRY(f, hipMemcpy(blk0, f->image.data(), f->D.stride, hipMemcpyHostToDevice));
+    for (size_t q = 1; q < cnt; ++q)
+        FLEET_TRY(f, hipMemcpyAsync(blk0 + f->D.stride * q, blk0, f->D.stride, hipMemcpyDeviceToDevice, f->h->stream));
     FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
     FLEET_TRY(f, hipMemcpy2D(blk0, f->D.stride, hdr.data(), hs, hs, cnt, hipMemcpyHostToDevice));
     return LTPL_OK;
@@ -700,18 +711,20 @@ static int fleet_launch_vel(ltpl_fleet* f, const FleetTickIn& t, const fleet::FP
         FLEET_TRY(f, hipEventRecord(f->ev_b, f->stream2));
     }
     const bool rows = t.has_gg != 0, multi = t.multi_axm != 0;
+    if (rows) f->seen_gg = true;
+    const bool rows_mem = rows || f->seen_gg;          // jobs built from the planners' memory (backup plans) may carry rows of an earlier tick
     if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA, 2, multi, rows))) return rc;            // follow jobs (slot 0): one wave per job
     if (rows && (rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA, 3, multi, true))) return rc;    // forward-backward jobs with friction rows
     FLEET_TRY(f, hipStreamWaitEvent(st, f->ev_b, 0));
     hipLaunchKernelGGL(k_fleet_vel_b, dim3(N), dim3(64), 0, st, f->args, f->JA.view(), f->JB.view());
     FLEET_TRY(f, hipGetLastError());
-    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JB, 1, multi, rows))) return rc;
+    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JB, 1, multi, rows_mem))) return rc;
     if (next && !t.any_emerg) hipLaunchKernelGGL(k_fleet_tail_pre<false>, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JB.view(), f->JC.view(), next->ob, f->pin);
     else hipLaunchKernelGGL(k_fleet_vel_c, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JB.view(), f->JC.view());
     FLEET_TRY(f, hipGetLastError());
     if (t.any_emerg) {
         ltpl_vel_params ve = vp; ve.dyn_model_exp = 1.0; ve.drag_coeff = 0.854; ve.m_veh = 1160.0;       // calc_brake_emergency.py:4-6,31-36
-        if ((rc = fleet_launch_vel_jobs(f, ve, t.axm, f->JC, 1, false, rows))) return rc;
+        if ((rc = fleet_launch_vel_jobs(f, ve, t.axm, f->JC, 1, false, rows_mem))) return rc;
         if (next) hipLaunchKernelGGL(k_fleet_tail_pre<true>, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JB.view(), f->JC.view(), next->ob, f->pin);
         else hipLaunchKernelGGL(k_fleet_vel_d, dim3(N), dim3(64), 0, st, f->args, t.vin, f->JC.view());
         FLEET_TRY(f, hipGetLastError());

@@ -24,6 +24,7 @@
 #include "planner_host.hpp"
 #include "fleet_api.hpp"
 #include "capsule.hpp"
+#include "layer_grid.hpp"
 
 #define WG_THREADS 256
 #define PIPELINE_MIN_SCEN 64   // batches from this size on use the one-wave-per-scenario pipeline
@@ -77,6 +78,9 @@ struct DevLat {
                                       //     sample, largest sample distance from it, squared half of the largest gap between consecutive sample
                                       //     projections -- two-sided conservative cull of the obstacle mask, the exact test is fp64
     float cull_slack;                 // bound on the fp32 rounding of the cull's distance (positions, chord, arithmetic)
+    // closest-layer grid (layer_grid.hpp): per cell the <= 2 intervals of reference-line layers that can be closest to a point of the cell
+    // (first layer, length, first layer, length; length -1 = scan all layers); null: phase 1 scans all layers (LTPL_NO_LAYER_GRID=1)
+    const int4* lgrid; double lg_x0, lg_y0, lg_inv; int lg_nx, lg_ny;
 };
 
 struct DevPathsIn {
@@ -2596,6 +2600,15 @@ try {
             cap_sw[2 * (size_t)p] = cap[2 * e]; cap_sw[2 * (size_t)p + 1] = cap[2 * e + 1];
         }
         UP(edge_cap, cap_sw.data(), (size_t)L.E * 2);
+        // closest-layer grid of phase 1 (layer_grid.hpp: construction and conservativeness argument; tests/test_layer_grid.py)
+        L.lgrid = nullptr; L.lg_x0 = L.lg_y0 = L.lg_inv = 0.0; L.lg_nx = L.lg_ny = 0;
+        if (!getenv("LTPL_NO_LAYER_GRID")) {
+            const ltplgrid::Grid g = ltplgrid::build(L.L, d->refline_x, d->refline_y);
+            if (g.nx > 0 && g.ny > 0) {
+                UP(lgrid, reinterpret_cast<const int4*>(g.cells.data()), (size_t)g.nx * g.ny);
+                L.lg_x0 = g.x0; L.lg_y0 = g.y0; L.lg_inv = g.inv_cell; L.lg_nx = g.nx; L.lg_ny = g.ny;
+            }
+        }
     }
 #undef UP
 
@@ -3962,6 +3975,20 @@ extern "C" int ltpl_edge_capsules(int32_t n_edges, const int32_t* samp_ptr, cons
 try {
     if (n_edges < 0 || !samp_ptr || !samp_x || !samp_y || !capsules_out || !slack_out) return LTPL_ERR_INVALID_ARG;
     *slack_out = ltplcap::build(n_edges, samp_ptr, samp_x, samp_y, n_samples, capsules_out);
+    return LTPL_OK;
+} LTPL_ABI_CATCH(nullptr)
+
+extern "C" int ltpl_layer_grid(int32_t n_layers, const double* ref_x, const double* ref_y, double* origin_cell, int32_t* dims, int32_t* cells,
+                               int32_t cap_cells)
+try {
+    if (n_layers < 1 || !ref_x || !ref_y || !origin_cell || !dims) return LTPL_ERR_INVALID_ARG;
+    const ltplgrid::Grid g = ltplgrid::build(n_layers, ref_x, ref_y);
+    origin_cell[0] = g.x0; origin_cell[1] = g.y0; origin_cell[2] = g.inv_cell;
+    dims[0] = g.nx; dims[1] = g.ny;
+    if (cells) {
+        if ((size_t)cap_cells < (size_t)g.nx * g.ny) return LTPL_ERR_CAPACITY;
+        memcpy(cells, g.cells.data(), sizeof(int32_t) * g.cells.size());
+    }
     return LTPL_OK;
 } LTPL_ABI_CATCH(nullptr)
 

@@ -253,6 +253,7 @@ struct TeamShared {
     double fac[LTPL_MAX_LAST_NODES];
     int fac_jmax;
     double psi_sc[2];                          // (sin, cos) of the scenario's start heading psi_s (LTPL_FLAG_HAS_PSI_S), phase 0
+    int grid_miss[4];                          // phase 1, per wave: some position of the wave lies outside the closest-layer grid / in a full-scan cell
 };
 
 // uniform per-scenario state, computed redundantly by every wave (scalar registers)
@@ -1130,8 +1131,10 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
         for (int p = p0; p < p1; ++p) pos_veh[p] = (unsigned char)k;
     }
     // reference line -> LDS (aliases the parent table, which is not live before phase 4)
+    // (with the closest-layer grid the line is only read by the rare full scan of phase 1, which then takes it from global memory)
     double* refl = reinterpret_cast<double*>(smem + P::off_par(lp));
-    if (lp.ref_lds)
+    const bool ref_staged = lp.ref_lds && lat.lgrid == nullptr;
+    if (ref_staged)
         for (int l = tid; l < L; l += NT) { refl[2 * l] = at(lat.ref_x, l); refl[2 * l + 1] = at(lat.ref_y, l); }
     team_sync<NW>();
     {
@@ -1153,9 +1156,57 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
     dbg_stamp(lp.dbg, 1);
     LTPL_KARGS();
     // ---- phase 1: closest reference-line layer per obstacle position (get_intersec_edges.py:40-51) -----------------
-    // lane = (layer segment, position): every lane scans its segment of the reference line for its position (strict '<'
-    // keeps the first minimum), the segments of a position are then combined by log2(#segments) shuffle steps.
-    for (int pp0 = 0; pp0 < sc.n_pos; pp0 += 64) {
+    // Round 5: the closest-layer GRID (layer_grid.hpp, built at ltpl_create) names, for the cell a position lies in, the at most two
+    // intervals of layers that can be the argmin for any point of that cell; lane = position evaluates the reference's fp64 distances on
+    // those layers only, in ascending order with the full scan's strict '<' (same first minimum). Only when some position of the scenario
+    // lies outside the grid or in a "full scan" cell does the scan over ALL layers below run (for every position: it overwrites).
+    bool full_scan = true;
+    if (lat.lgrid != nullptr) {
+        const int4* const g_cells = pin_sgpr(lat.lgrid); const double* const g_rx = pin_sgpr(lat.ref_x); const double* const g_ry = pin_sgpr(lat.ref_y);
+        const double gx0 = lat.lg_x0, gy0 = lat.lg_y0, ginv = lat.lg_inv; const int gnx = lat.lg_nx, gny = lat.lg_ny;
+        bool miss = false;
+        for (int p0 = 0; p0 < sc.n_pos; p0 += NT) {
+            const int p = p0 + tid;
+            const bool pv = p < sc.n_pos;
+            double px = 0.0, py = 0.0; int4 c = make_int4(0, 0, 0, 0);
+            if (pv) {
+                px = in.pos_x[sc.pos0 + p]; py = in.pos_y[sc.pos0 + p];
+                const double fx = (px - gx0) * ginv, fy = (py - gy0) * ginv;
+                // (the comparison form also rejects NaN coordinates: they take the full scan like any position off the grid)
+                if (fx >= 0.0 && fy >= 0.0 && fx < (double)gnx && fy < (double)gny) c = g_cells[(int)fy * gnx + (int)fx];
+                else c.y = -1;
+                if (c.y < 0) { miss = true; c.y = 0; c.w = 0; }
+            }
+            const int tot = c.y + c.w;
+            double bd = INFINITY; int bl = 0x7fffffff;
+            for (int k = 0; __ballot(k < tot) != 0ull; ++k) {
+                if (k < tot) {
+                    const int l = k < c.y ? c.x + k : c.z + (k - c.y);
+                    const double dx = at(g_rx, l) - px, dy = at(g_ry, l) - py;
+                    const double d2 = dx * dx + dy * dy;
+                    if (d2 < bd) { bd = d2; bl = l; }          // (interval 1 lies below interval 2: ascending layers, first minimum)
+                }
+            }
+            if (pv) {
+                const int ol = bl, sl = sc.sl, el = sc.el;
+                const bool gate = (sl - 1 <= ol && ol <= el + 1) || (sl > el && (sl - 1 <= ol || ol <= el + 1));
+                pos_layer[p] = (short)(gate ? ol : -1);
+            }
+        }
+        const bool wave_miss = __ballot(miss) != 0ull;
+        if constexpr (NW == 1) full_scan = wave_miss;
+        else {
+            if (lane == 0) ts.grid_miss[wave] = wave_miss ? 1 : 0;
+            team_sync<NW>();
+            full_scan = false;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) full_scan = full_scan || ts.grid_miss[w] != 0;
+            if (full_scan) team_sync<NW>();            // (every wave has read the flags before the scan below rewrites pos_layer)
+        }
+    }
+    // The scan over all layers: lane = (layer segment, position), every lane scans its segment of the reference line for its position
+    // (strict '<' keeps the first minimum), the segments of a position are then combined by log2(#segments) exchange steps.
+    for (int pp0 = 0; pp0 < sc.n_pos && full_scan; pp0 += 64) {
         const int cnt = min(64, sc.n_pos - pp0);
         const int cntw = (cnt - wave + NW - 1) / NW;                 // positions of this wave: q = wave + NW * i
         if (cntw <= 0) continue;
@@ -1168,7 +1219,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
         if (qv) { px = in.pos_x[sc.pos0 + pp0 + q]; py = in.pos_y[sc.pos0 + pp0 + q]; }
         double bd = INFINITY; int bl = 0x7fffffff;
         const int l0 = seg * chunk, l1 = min(L, l0 + chunk);
-        if (lp.ref_lds) {
+        if (ref_staged) {
             for (int l = l0; l < l1; ++l) {
                 const double dx = refl[2 * l] - px, dy = refl[2 * l + 1] - py;
                 const double d2 = dx * dx + dy * dy;
@@ -1299,9 +1350,15 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
                         qlh[q] = t * 0.999999f - m_slack;                            // HIT   if dist^2 + (gap / 2)^2 <= (qlh - dev)^2
                     } else { qlane[q] = 0; qx[q] = 0.0; qy[q] = 0.0; qr[q] = -1.0; qxf[q] = 0.0f; qyf[q] = 0.0f; qlm[q] = -1.0e30f; qlh[q] = -1.0e30f; }   // always MISS
                 }
+                // the capsule records of the NEXT chunk of 64 edges are requested before the current chunk is evaluated (round 5: a wide
+                // transition -- 245 edges on the C3 oval -- was four dependent load -> evaluate steps per pass)
+                float4 nx0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nx1 = nx0;
+                if (eb + wave * 64 < ee) { const int en_ = min(eb + wave * 64 + lane, ee - 1); nx0 = at(m_cap, 2 * en_); nx1 = at(m_cap, 2 * en_ + 1); }
                 for (int e0 = eb + wave * 64; e0 < ee; e0 += NT) {
                     // (predicated, not branched: the list bookkeeping below is wave-uniform)
                     const int e = min(e0 + lane, ee - 1);
+                    const float4 c0 = nx0, c1 = nx1;                                  // (Ax, Ay, ABx, ABy), (1 / |AB|^2, dev, hg2, samples)
+                    if (e0 + NT < ee) { const int en_ = min(e0 + NT + lane, ee - 1); nx0 = at(m_cap, 2 * en_); nx1 = at(m_cap, 2 * en_ + 1); }
                     int el_ = e - sc.e_base; if (el_ < 0) el_ += m_E;
                     // lanes beyond the transition and edges already blocked by another object take no part
                     const bool live = e0 + lane < ee && !((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u);
@@ -1312,7 +1369,6 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
                     //   some sample is at most sqrt(d^2 + hg2) + dev away -> HIT without touching the samples if that <= threshold
                     // and only the thin shell in between runs the reference's exact fp64 sample test. (Round 2: with a bounding
                     // CIRCLE nearly every edge of a window was "near" and loaded its samples -- 0.44 ms of a 1.05 ms launch.)
-                    const float4 c0 = at(m_cap, 2 * e), c1 = at(m_cap, 2 * e + 1);   // (Ax, Ay, ABx, ABy), (1 / |AB|^2, dev, hg2, samples)
                     bool sure = false;
                     bool unsure_q[MQ];
 #pragma unroll

@@ -230,6 +230,13 @@ struct HostPlanner {
             for (int t = 0; t < n_tab; ++t) if (in->ax_table_off[t + 1] - in->ax_table_off[t] < 1) return fail(LTPL_ERR_INVALID_ARG, "planner: empty machine table");
             for (int s = 0; s < n; ++s) if (in->ax_table_idx[s] < 0 || in->ax_table_idx[s] >= n_tab) return fail(LTPL_ERR_INVALID_ARG, "planner: ax_table_idx out of range");
         }
+        // capacity of the velocity stage's machine tables (64 rows per table) and the per-planner speed limits: checked HERE, in front of
+        // the first stage -- the backend's own check would only fire after stage A has trimmed every planner's memory
+        for (int t = 0; t < (n_tab ? n_tab : 1); ++t) {
+            const int rows_t = n_tab ? in->ax_table_off[t + 1] - in->ax_table_off[t] : in->n_ax_max_machines;
+            if (rows_t < 1 || rows_t > 64) return fail(LTPL_ERR_CAPACITY, "planner: a machine table holds 1 .. 64 rows");
+        }
+        for (int s = 0; s < n; ++s) if (!(in->vel_max[s] > 0.0)) return fail(LTPL_ERR_INVALID_ARG, "planner: vel_max must be positive");
         const bool rows = in->gg_row_off && in->gg_rows;
         if (rows && gg.empty()) gg.assign(D.gg_stride * (size_t)n, 0);
         if (rows) for (int i = 0; i < n * MK; ++i) if (in->gg_row_off[i] < 0 || in->gg_row_off[i + 1] < in->gg_row_off[i]) return fail(LTPL_ERR_INVALID_ARG, "planner: gg_row_off must be non-decreasing");
@@ -241,9 +248,17 @@ struct HostPlanner {
                           n_tab ? in->ax_table_off : nullptr, n_tab ? in->ax_table_idx : nullptr, rows ? in->gg_row_off : nullptr, rows ? in->gg_rows : nullptr};
         fleet::HostX x; int rc;
         if (!sticky_errors) {
-            // Everything that can make the call fail is checked for ALL planners before any planner's memory is touched: an error of one
-            // planner of a batch (the reference's ValueError / IndexError for that vehicle) must not leave the others half-trimmed. The
-            // reference index itself (OTH.get_ref_idx) cuts nothing; a failing call forgets it again.
+            // The failures that depend on the ARGUMENTS and the stored trajectories alone (cut layer beyond a path, friction rows of the
+            // wrong length, a brake prefix, an empty follow window: E_CUT_LAYER, E_GG_ROWS, E_BRAKE_PREFIX, E_FOLLOW_EMPTY) are checked for
+            // ALL planners before any planner's memory is touched: such an error of one planner of a batch (the reference's ValueError /
+            // IndexError for that vehicle) must not leave the others half-trimmed. The reference index itself (OTH.get_ref_idx) cuts
+            // nothing; a failing call forgets it again.
+            // NOT covered: failures that only show while the stages run (job / row capacities E_CAP_JOBS, E_CAP_VEL, a velocity course
+            // shorter than the cut E_VX_SHORT, E_ROW5, the emergency profile on friction rows E_EMERG_GG, a backend error inside run_jobs).
+            // Those return after stage A has trimmed the planners' memories and advanced traj_base_id, and first_error() clears the
+            // planner's error word: the failing planner is then in the state the REFERENCE object is in after the same exception (its
+            // calc_vel_profile raises half way through as well, OTH.py:700-1040) -- callers re-initialise it with set_start, as the
+            // reference's callers must. (The fleet entry points keep the error sticky per planner instead: ltpl_fleet_*.)
             auto fail_pre = [&](int p, int code, int site) {
                 for (int q = 0; q < n; ++q) block(q).S()->ref_done = 0;
                 return fail(code, fleet::err_text(p, code | (site << 8)));

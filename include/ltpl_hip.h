@@ -330,6 +330,15 @@ int ltpl_raceline_s(const ltpl_handle* handle, double x, double y, double* s_out
 int ltpl_edge_capsules(int32_t n_edges, const int32_t* samp_ptr, const double* samp_x, const double* samp_y, int32_t n_samples,
                        float* capsules_out, float* slack_out);
 
+/* --- diagnostics (host only, no device needed): the closest-layer grid ltpl_create derives for the path kernel's first phase (closest
+ *     reference-line layer of an obstacle position = np.argmin over all layers, get_intersec_edges.py:40-51). Per grid cell the at most two
+ *     intervals of layers that can be closest to any point of the cell; the kernel evaluates the reference's exact distances on those and on
+ *     all layers for positions outside the grid / in cells marked "full scan". origin_cell: x0, y0, 1 / cell size; dims: nx, ny; cells (may
+ *     be NULL to query the dimensions first): 4 ints per cell, row-major in y: first layer and length of interval 1 and 2, length -1 = full
+ *     scan. tests/test_layer_grid.py checks against the brute-force argmin that the true answer is always among the candidates. --------- */
+int ltpl_layer_grid(int32_t n_layers, const double* ref_x, const double* ref_y, double* origin_cell, int32_t* dims, int32_t* cells,
+                    int32_t cap_cells);
+
 /* --- object ingestion: ObjectListInterface.py:75-153, check_inside_bounds.py:7-59 --------------------------------- */
 int ltpl_process_objects(ltpl_handle* handle, const ltpl_objects_in* in, ltpl_objects_out* out);
 
@@ -462,7 +471,7 @@ typedef struct {                    /* arguments of Graph_LTPL.calc_vel_profile 
     const double*  pos_est_x;       /* [n_scen]                                                                   */
     const double*  pos_est_y;
     const double*  vel_est;
-    const double*  vel_max;         /* [n_scen] ltpl_planner_*: one value per call (all entries must agree); ltpl_fleet_*: per planner (ABI v6) */
+    const double*  vel_max;         /* [n_scen] one value per planner (ABI v6; ltpl_planner_* groups its velocity jobs per car), > 0                 */
     const double*  gg_scale;
     const double*  gg_ax;           /* [n_scen] constant local_gg tuple (ax, ay)                                  */
     const double*  gg_ay;
@@ -478,7 +487,9 @@ typedef struct {                    /* arguments of Graph_LTPL.calc_vel_profile 
      * a key with zero rows falls back to (gg_ax, gg_ay)                                                            */
     const int32_t* gg_row_off;      /* [n_scen * LTPL_PLANNER_MAX_KEYS + 1]                                       */
     const double*  gg_rows;         /* [total rows * 2] rows [ax, ay]                                             */
-    /* ABI v6 -- A FLEET OF DIFFERENT CARS (ltpl_fleet_* only; ltpl_planner_* returns LTPL_ERR_UNSUPPORTED): Graph_LTPL.calc_vel_profile
+    /* ABI v6 -- A FLEET OF DIFFERENT CARS (ltpl_fleet_*, and since the round-4 merge of the two state machines ltpl_planner_* as well:
+     * the host planner groups its jobs per car; every table 1 .. 64 rows, every vel_max > 0, checked before any memory is cut):
+     * Graph_LTPL.calc_vel_profile
      * takes vel_max and ax_max_machines per call, i.e. per vehicle (Graph_LTPL.py:344-351). n_ax_tables > 1: ax_max_machines holds that
      * many tables back to back, table t = rows ax_table_off[t] .. ax_table_off[t + 1] (ax_table_off[n_ax_tables] = n_ax_max_machines),
      * planner s uses table ax_table_idx[s]. Both NULL with n_ax_tables <= 1: one table for all.                                    */

@@ -49,8 +49,11 @@ def same_trajectories(a, b, exact=True, what=""):
             assert np.all(err <= 2e-5 * sc), (what, k, err / sc)
 
 
-def drive(lat, A, B, seed, n_ticks, exact=True, scen_a=0, scen_b=0):
-    """A, B: planners with n_scen planners each (the inputs are replicated); compares planner scen_a of A with scen_b of B."""
+def drive(lat, A, B, seed, n_ticks, exact=True, scen_a=0, scen_b=0, gg_phases=False):
+    """A, B: planners with n_scen planners each (the inputs are replicated); compares planner scen_a of A with scen_b of B.
+    ``gg_phases``: phases of 25 ticks alternate between location dependent friction (``local_gg`` as a dict of [ax, ay] rows per path
+    coordinate, OTH.py:649-666) and a constant tuple at HALF the friction -- the car loses grip exactly when the rows stop coming, so the
+    backup brake plan of the tick after is solved on the PREVIOUS tick's rows (OTH.py:963-968) in a call that carries none."""
     rng = np.random.default_rng(seed)
     track = float(lat.glob_rl[-1, 0])
     stats = {'ticks': 0, 'restarts': 0, 'errors': 0, 'keys': set(), 'emergency_prev': 0, 'dropped': 0, 'red_len': 0, 'no_paths': 0}
@@ -115,7 +118,16 @@ def drive(lat, A, B, seed, n_ticks, exact=True, scen_a=0, scen_b=0):
         stats['red_len'] += int(any(res[0]['red_len'].values()))
         stats['no_paths'] += int(not res[0]['keys'])
         emerg = bool(rng.random() < 0.5)
-        kw = dict(vel_max=float(rng.choice([100.0, 60.0])), gg_scale=float(rng.choice([1.0, 1.0, 0.8])), local_gg=gg,
+        lgg = gg
+        if gg_phases:
+            if (tick // 25) % 2 == 0:
+                def fmap(xy):
+                    return np.column_stack((gg[0] * (1.0 + 0.25 * np.sin(0.03 * xy[:, 0])), gg[1] * (1.0 + 0.25 * np.cos(0.03 * xy[:, 1]))))
+                lgg = {k: [fmap(np.asarray(res[0]['path_param'][k])[:, 0:2])] for k in paths_keys}
+                stats['gg_row_ticks'] = stats.get('gg_row_ticks', 0) + 1
+            else:
+                lgg = (0.5 * gg[0], 0.5 * gg[1])
+        kw = dict(vel_max=float(rng.choice([100.0, 60.0])), gg_scale=float(rng.choice([1.0, 1.0, 0.8])), local_gg=lgg,
                   ax_max_machines=((0.0, 7.0), (40.0, 5.0), (100.0, 2.0)) if seed % 2 else ((100.0, 5.0),), safety_d=float(rng.choice([30.0, 15.0])),
                   incl_emerg_traj=emerg)
         if rng.random() < 0.01:

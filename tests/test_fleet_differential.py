@@ -46,6 +46,33 @@ def test_fleet_and_host_planner_agree_on_the_device(monteblanco, seed):
     A.close(); B.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_friction_rows_then_constants_with_a_loss_of_grip(monteblanco, seed):
+    """Ticks with friction rows, then ticks without, the car losing grip at the switch: the backup brake plan is solved on the rows the
+    PREVIOUS tick stored (OTH.py:963-968) in a call that carries none. Host state machines against each other (exact)."""
+    from oracle.fleet_host import HostFleetBackend
+    from oracle.planner_host import HostPlannerBackend
+    A, B = HostPlannerBackend(monteblanco).planner(1), HostFleetBackend(monteblanco).planner(2)
+    st = drive(monteblanco, A, B, seed, 260, exact=True, scen_b=1, gg_phases=True)
+    assert st['ticks'] >= 150 and st.get('gg_row_ticks', 0) >= 60, st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2])
+def test_friction_rows_then_constants_on_the_device(monteblanco, seed):
+    """The same on the MI355X: round 4 chose the friction-row form of the brake-job kernel by whether the CURRENT call carried rows, so a
+    backup plan with stored rows was solved with its first row's limits once the rows stopped coming (advisor finding, round 4); the fleet
+    now launches the rows form for backup / emergency jobs from the first call with rows on (fleet_dev.hpp, `seen_gg`)."""
+    from graphbasedlocaltrajectoryplanner_amd import _capi
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    from graphbasedlocaltrajectoryplanner_amd.planner import Planner
+    hip = _capi.HipBackend(monteblanco)
+    A, B = Planner(hip, 1), Fleet(hip, 70)
+    st = drive(monteblanco, A, B, seed, 260, exact=False, scen_b=69, gg_phases=True)
+    assert st['ticks'] >= 150 and st.get('gg_row_ticks', 0) >= 60, st
+    A.close(); B.close()
+
+
 @pytest.mark.parametrize("track", ["zalazone", "millbrook", "lvms"])
 def test_fleet_and_host_planner_agree_on_other_tracks(track):
     """The same differential loop on lattices of other plan classes (runtime LDS plan, one-node layers, a long oval)."""

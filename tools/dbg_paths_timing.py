@@ -13,10 +13,15 @@ import bench                                                                  # 
 from graphbasedlocaltrajectoryplanner_amd import _capi                        # noqa: E402
 from graphbasedlocaltrajectoryplanner_amd.lattice import Lattice              # noqa: E402
 
-lat = Lattice.load(os.path.join(ROOT, "tests", "golden", "monteblanco_lattice.npz"))
+workload = sys.argv[2] if len(sys.argv) > 2 else "c2"
+if workload == "c3":
+    from graphbasedlocaltrajectoryplanner_amd.synthetic_lattice import c3_lattice
+    lat = c3_lattice()
+else:
+    lat = Lattice.load(os.path.join(ROOT, "tests", "golden", "monteblanco_lattice.npz"))
 hip = _capi.HipBackend(lat)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
-scen, batch, vel = bench.make_batch(lat, n, seed=1, workload=sys.argv[2] if len(sys.argv) > 2 else "c2")
+scen, batch, vel = bench.make_batch(lat, n, seed=1, workload=workload)
 res = hip.new_paths_result(n)
 for i in range(2):
     hip.plan_paths(batch, res)
