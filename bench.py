@@ -453,11 +453,25 @@ def closed_loop_device_mixed(hip, lat, n_planners, n_ticks, names=("c2", "overta
         st = ticks[0]['start']
         fleet.set_start_range(p, p + sz, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
         p += sz
+    from graphbasedlocaltrajectoryplanner_amd.planner import KEY_IDS
     stops = sorted(set([max(1, n_ticks // 3), max(1, 2 * n_ticks // 3), n_ticks]))
-    ms, ok, checked, t_prev = 0.0, True, 0, 0
+    ms, ok, checked, t_prev, digested = 0.0, True, 0, 0, 0
     for t_stop in stops:
         ms += fleet.tape_run(t_prev, t_stop - t_prev)
         t_prev = t_stop
+        # EVERY planner of the fleet against the recording of its group, digested on the device (ltpl_fleet_digest: cut indices, velocity
+        # plan, keys, ids, rows, s_end, vx[0], vx[-1], sum of vx per trajectory) ...
+        if hasattr(fleet, "digest") and hasattr(fleet.lib, "ltpl_fleet_digest"):
+            dig = fleet.digest()
+            p = 0
+            for sz, ticks, nm in zip(sizes, recs, names):
+                try:
+                    digested += pr.check_digests(dig[p:p + sz], ticks[t_stop - 1], KEY_IDS, "%s tick %d (first planner of the group: %d)" % (nm, t_stop - 1, p))
+                except AssertionError as e:
+                    sys.stderr.write("closed_loop_device_mixed: %s\n" % e)
+                    ok = False
+                p += sz
+        # ... and full trajectories (where the recording holds them) of the first, the middle and the last planner of every group
         p = 0
         for sz, ticks, nm in zip(sizes, recs, names):
             for q in sorted(set((p, p + sz // 2, p + sz - 1))):
@@ -472,10 +486,10 @@ def closed_loop_device_mixed(hip, lat, n_planners, n_ticks, names=("c2", "overta
     fleet.close()
     return {"planner_ticks_per_s": n_planners * n_ticks / (ms * 1e-3), "planners": n_planners, "ticks": n_ticks,
             "ms_per_fleet_tick": ms / n_ticks, "groups": list(names), "matches_recording": ok, "planner_checks": checked,
-            "checked_at_ticks": [t - 1 for t in stops],
+            "planners_digested_on_device": digested, "checked_at_ticks": [t - 1 for t in stops],
             "what": "ltpl_fleet_* on a mixed tape: %d groups of planners replay different recordings of the reference side by side (device "
-                    "time of the tape segments, HIP events); first / middle / last planner of every group compared with the reference's "
-                    "recording at three ticks" % len(names)}
+                    "time of the tape segments, HIP events); at three ticks EVERY planner's digest (computed on the device) and the full "
+                    "trajectories of the first / middle / last planner of every group are compared with the reference's recording" % len(names)}
 
 
 def c5_latency(horizon_m, n_ticks, device=0):
@@ -859,7 +873,7 @@ def main():
     ap.add_argument("--dropin-ticks", type=int, default=2500)
     ap.add_argument("--fleet-planners", type=int, default=8192, help="extra.closed_loop_device: planners of the fleet")
     ap.add_argument("--fleet-ticks", type=int, default=200, help="extra.closed_loop_device: consecutive ticks")
-    ap.add_argument("--c3-batch", type=int, default=8192, help="extra.c3: scenarios per step")
+    ap.add_argument("--c3-batch", type=int, default=32768, help="extra.c3: scenarios per step (one size for builder and driver since round 5: the headline's)")
     ap.add_argument("--c5-ticks", type=int, default=400, help="extra.c5: ticks per horizon")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")

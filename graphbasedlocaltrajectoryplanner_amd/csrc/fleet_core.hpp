@@ -193,7 +193,8 @@ struct VelJob {
     // call = per vehicle (Graph_LTPL.py:344-351). v_max <= 0 / n_axm == 0: the parameter set of the launch.
     double v_max;
     int axm_off, n_axm;             // the job's machine table: rows [axm_off, axm_off + n_axm) of the call's stacked tables
-    int gg_rows, pad_;              // 1: the friction limits differ from row to row (pool form, [ax, ay] per row); 0: gg[0], gg[1] for every row
+    int gg_rows, lane_form;         // gg_rows 1: the friction limits differ from row to row (pool form, [ax, ay] per row); 0: gg[0], gg[1] for every row.
+                                    // lane_form 1: the operands lie in the lane plane (FJobs::ke), not in the pool: the job belongs to a lane kernel
 };
 struct JobCar { double v_max; int axm_off, n_axm; };
 // friction limits of a job's rows: constant (ax, ay) or rows of a [ax, ay] table (window `g`, first row `base`), times `scale`
@@ -220,7 +221,8 @@ typedef double ke_scalar_f;         // (operand records of the lane kernels as f
 typedef float ke_scalar_f;
 #endif
 struct F2 { ke_scalar_f x, y; };
-struct FJobs { VelJob* jobs; double* pool; const double* out; const int* flags; int per_planner; F2* ke; int ke_rows; };
+struct FJobs { VelJob* jobs; double* pool; const double* out; const int* flags; int per_planner; F2* ke; int ke_rows;
+               int ke_follow; };    // >= 0: the follow jobs (slot 0) without friction rows go to the lane plane as well, job index ke_follow + p (round 5)
 FLT_FN unsigned kep_base_f(int job, int plane_rows) { return ((unsigned)(job >> 6) * (unsigned)(plane_rows >> 3) * 64u + (unsigned)(job & 63)) * 8u; }
 FLT_FN unsigned kep_row_f(int r) { return ((unsigned)(r >> 3) << 9) + (unsigned)(r & 7); }
 // result i of the job in `slot` of planner p
@@ -622,8 +624,11 @@ FLT_FN int make_job(const X& x, const Dims& D, const FJobs& J, int p, int slot, 
     jb.mode = mode; jb.n = i1 - i0; jb.n_el = n_el; jb.has_v_end = has_end ? 1 : 0; jb.v_start = v_start; jb.v_end = v_end;
     jb.off_kappa = j * 4 * D.R; jb.off_el = jb.off_kappa + D.R; jb.off_gg = jb.off_kappa + 2 * D.R; jb.off_out = j * D.R;
     double* kap = J.pool + jb.off_kappa; double* el = J.pool + jb.off_el; double* gg = J.pool + jb.off_gg;
-    if (J.ke && mode == LTPL_VEL_FB && slot >= 1 && !gsrc.rows()) {
-        F2* ke = J.ke + kep_base_f(p * (J.per_planner - 1) + slot - 1, J.ke_rows);
+    jb.lane_form = (J.ke && !gsrc.rows() && ((mode == LTPL_VEL_FB && slot >= 1) || (J.ke_follow >= 0 && mode == LTPL_VEL_FOLLOW_CONTROLLED && slot == 0))) ? 1 : 0;
+    const bool lane_fb = J.ke && mode == LTPL_VEL_FB && slot >= 1 && !gsrc.rows();
+    const bool lane_follow = J.ke && J.ke_follow >= 0 && mode == LTPL_VEL_FOLLOW_CONTROLLED && slot == 0 && !gsrc.rows();
+    if (lane_fb || lane_follow) {
+        F2* ke = J.ke + kep_base_f(lane_fb ? p * (J.per_planner - 1) + slot - 1 : J.ke_follow + p, J.ke_rows);
         for (int i = x.lane(); i < i1 - i0; i += X::W) {
             F2 r; r.x = (ke_scalar_f)fabs(pv.at(i0 + i, 3)); r.y = i < n_el ? (ke_scalar_f)pv.at(i0 + i, 4) : (ke_scalar_f)0;
             ke[kep_row_f(i)] = r;

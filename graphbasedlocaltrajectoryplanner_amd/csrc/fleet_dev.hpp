@@ -127,6 +127,43 @@ __global__ __launch_bounds__(64) void k_fleet_ref_idx(FleetArgs F, const double*
     fleet_store(x, B, &S, p, F.err_word);
 }
 
+// DIGEST of every planner's result of the last tick (round 5: a check of the WHOLE fleet against a recording instead of copying sampled
+// planner blocks to the host): per planner LTPL_FLEET_DIGEST doubles --
+//   [0] error word, [1] cut_index_pos, [2] cut_layer, [3] keys of the trajectory set, [4] ids, [5] vel_plan, [6] n_vel_course, [7] acc_plan,
+//   per key k (LTPL_PLANNER_MAX_KEYS): [8 + 7 k ..] key id, trajectory id, rows, s of the last row, vx of the first / last row, sum of vx
+//   per id k: [8 + 7 K + 2 k ..] key id, id value
+// -- the quantities the tick recordings hold for every tick (tick_replay.check_trajectories). One wave per planner, read only.
+#define LTPL_FLEET_DIGEST (8 + 9 * LTPL_PLANNER_MAX_KEYS)
+__global__ __launch_bounds__(64) void k_fleet_digest(FleetArgs F, double* out)
+{
+    const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
+    const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D, F.gg ? F.gg + F.D.gg_stride * (size_t)p : nullptr};
+    __shared__ fleet::PlannerS S;
+    fleet_load(x, B, &S);
+    double* o = out + (size_t)p * LTPL_FLEET_DIGEST;
+    constexpr int K = LTPL_PLANNER_MAX_KEYS;
+    for (int i = x.lane(); i < LTPL_FLEET_DIGEST; i += 64) o[i] = 0.0;
+    x.sync();
+    if (x.lane() == 0) {
+        o[0] = (double)S.err; o[1] = (double)S.cut_index_pos; o[2] = (double)S.cut_layer; o[3] = (double)S.n_bp; o[4] = (double)S.n_ids;
+        o[5] = S.vel_plan; o[6] = (double)S.n_vel_course; o[7] = S.acc_plan;
+        for (int i = 0; i < S.n_ids && i < K; ++i) { o[8 + 7 * K + 2 * i] = (double)S.id_key[i]; o[8 + 7 * K + 2 * i + 1] = (double)S.id_val[i]; }
+    }
+    for (int i = 0; i < S.n_bp && i < K; ++i) {
+        const fleet::Rows r = B.bp(S.bp_slot[i]);
+        const int n = S.bp_rows[i];
+        double acc = 0.0;
+        for (int q = x.lane(); q < n; q += 64) acc += r.at(q, 5);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+        if (x.lane() == 0) {
+            double* k = o + 8 + 7 * i;
+            k[0] = (double)S.bp_id[i]; k[1] = (double)S.bp_traj_id[i]; k[2] = (double)n;
+            k[3] = n > 0 ? r.at(n - 1, 0) : 0.0; k[4] = n > 0 ? r.at(0, 5) : 0.0; k[5] = n > 0 ? r.at(n - 1, 5) : 0.0; k[6] = acc;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64, 4) void k_fleet_vel_a(FleetArgs F, fleet::FObj ob, fleet::FVelIn vin, fleet::FJobs JA)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
@@ -231,6 +268,56 @@ __global__ __launch_bounds__(64) void k_fleet_fb_lanes(DevVelParams p, const Dev
     double* o = out + jp->off_out;
     for (int i = 0; i < n; ++i) o[i] = sqrt(D[(size_t)i * 64]);
 }
+// The follow jobs of a tick (slot 0 of the stage-A table, LTPL_VEL_FOLLOW_CONTROLLED without friction rows), one LANE per job (round 5): the
+// controlled part of calc_vel_profile_follow.py:78-294 exactly as the batch velocity stage runs it (lane_follow_controlled, k_vel_lanes) on
+// the job's scalars. The wave-per-job form (k_vel_profile<.., 2>: every step of the recurrences on 64 lanes for one useful result, 14 jobs
+// resident per CU) was the longest kernel of a fleet tick -- 180 us for 8 192 planners, more than the path search; this form needs
+// n_planners / 64 waves. The unconstrained profile of a follow key is a forward-backward job of its own (k_fleet_fb_lanes) and the
+// intersection is stage B's, as before.
+template <int EM, bool AXM1>
+__global__ __launch_bounds__(64) void k_fleet_follow_lanes(DevLat lat, DevVelParams p, const DevVelJob* jobs, const double* pool, const ke_t* ke, int ke_rows,
+                                                           int ke_follow, double* P2, double* P3, int cap, int n_planners, int per, double* out, int* flags)
+{
+    extern __shared__ double axm_s[];                         // ALL machine tables of the call (every lane indexes its own job's table)
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 2 * p.n_axm; i += 64) axm_s[i] = p.axm[i];
+    __syncthreads();
+    const int q0 = blockIdx.x * 64 + lane;
+    const int q = q0 < n_planners ? q0 : n_planners - 1;      // (idle lanes repeat the last planner: the race line scan below runs on all 64 lanes)
+    const DevVelJob* jp = jobs + (size_t)q * per;
+    const int n = jp->n;
+    const bool mine = q0 < n_planners && n > 0 && jp->mode == LTPL_VEL_FOLLOW_CONTROLLED && !jp->gg_rows;   // (jobs with friction ROWS: k_vel_profile<.., GG, SEL 2>)
+    if (__ballot(mine) == 0ull) return;
+    const int idx_s_opp = lane_globrl_index(lat, jp->obj_x, jp->obj_y);
+    if (!mine) return;
+    LaneProf L; L.KE = ke + kep_base(ke_follow + q, ke_rows);
+    double* D2 = P2 + tile_base(q, cap); double* D3 = P3 + tile_base(q, cap);
+    const double cax = pool[jp->off_gg], cay = pool[jp->off_gg + 1];
+    DevVelParams pj = p;
+    const double* axm_j = axm_s;
+    if (jp->v_max > 0.0) pj.v_max = jp->v_max;
+    if (jp->n_axm > 0) { pj.n_axm = jp->n_axm; axm_j = axm_s + 2 * jp->axm_off; }
+    const LaneFollowOut fo = lane_follow_controlled<EM, AXM1>(lat, L, D2, D3, n, cax, cay, pj, axm_j, jp->v_start, jp->v_ego, jp->v_obj, jp->obj_dist,
+                                                              jp->safety_d, idx_s_opp, nullptr, -1);
+    // "vx_profile" (:289 / :294): brake profile in front of row n_decel - 1 (everywhere without a second segment), segment profile up to
+    // the stop index, zeros behind; results job-major like every other job's
+    double* o = out + jp->off_out;
+    for (int i = 0; i < n; ++i) {
+        const bool from_b = !fo.two_seg || i < fo.n_decel - 1;
+        const double w = from_b ? D2[(size_t)i * 64] : (i > fo.stop_idx ? 0.0 : D3[(size_t)i * 64]);
+        o[i] = sqrt(w);
+    }
+    flags[2 * ((size_t)q * per)] = fo.too_close; flags[2 * ((size_t)q * per) + 1] = fo.vel_bound;
+}
+typedef void (*fleet_follow_kernel_t)(DevLat, DevVelParams, const DevVelJob*, const double*, const ke_t*, int, int, double*, double*, int, int, int, double*, int*);
+static fleet_follow_kernel_t fleet_follow_kernel_of(int v)
+{
+    switch (v) {
+        case 0: return k_fleet_follow_lanes<0, false>; case 1: return k_fleet_follow_lanes<0, true>;
+        case 2: return k_fleet_follow_lanes<1, false>; case 3: return k_fleet_follow_lanes<1, true>;
+        case 4: return k_fleet_follow_lanes<2, false>; default: return k_fleet_follow_lanes<2, true>;
+    }
+}
 typedef void (*fleet_lanes_kernel_t)(DevVelParams, const DevVelJob*, const double*, const ke_t*, int, double*, int, int, int, double*);
 static fleet_lanes_kernel_t fleet_lanes_kernel_of(int v)
 {
@@ -246,7 +333,8 @@ static fleet_lanes_kernel_t fleet_lanes_kernel_of(int v)
 // ---------------------------------------------------------------------------------------------------------------------
 struct FleetJobsDev { fleet::VelJob* jobs = nullptr; double* pool = nullptr; double* out = nullptr; int* flags = nullptr; int per = 0;
                       fleet::F2* ke = nullptr; int ke_rows = 0; double* outp = nullptr;          // lane planes (stage-A table only): operands, profile state
-                      fleet::FJobs view() const { return fleet::FJobs{jobs, pool, out, flags, per, ke, ke_rows}; } };
+                      int ke_follow = -1; double* fp2 = nullptr; double* fp3 = nullptr;          // follow jobs in the lane plane: first job index; brake / segment profile planes
+                      fleet::FJobs view() const { return fleet::FJobs{jobs, pool, out, flags, per, ke, ke_rows, ke_follow}; } };
 
 // the inputs of one tick in device memory (one arena per tick of a tape, or the fleet's own for the per-call entry points)
 struct FleetTickIn {
@@ -389,11 +477,18 @@ try {
         bind_out(d, lo, f->D.cn, f->D.cp, &f->dout);
     }
     if ((rc = fleet_jobs_alloc(f.get(), &f->JA, fleet::JOBS_A))) return bail(rc);
-    {   // lane planes of the forward-backward jobs (slots 1 .. JOBS_A - 1), tiles of 64 jobs
-        const size_t tiles = ((size_t)N * (fleet::JOBS_A - 1) + 63) / 64;
+    {   // lane planes of the forward-backward jobs (slots 1 .. JOBS_A - 1), tiles of 64 jobs; round 5: behind them the tiles of the follow
+        // jobs (slot 0), which run one LANE per job as well (k_fleet_follow_lanes; LTPL_FLEET_FOLLOW_WAVES=1 keeps the wave-per-job form)
+        const size_t tiles = ((size_t)N * (fleet::JOBS_A - 1) + 63) / 64, ftiles = ((size_t)N + 63) / 64;
+        const bool follow_lanes = !(getenv("LTPL_FLEET_FOLLOW_WAVES") && atoi(getenv("LTPL_FLEET_FOLLOW_WAVES")) != 0);
         f->JA.ke_rows = (f->D.RV + 7) / 8 * 8;
-        if ((rc = fleet_alloc(f.get(), tiles * 64 * (size_t)f->JA.ke_rows, &f->JA.ke))) return bail(rc);
+        if ((rc = fleet_alloc(f.get(), (tiles + (follow_lanes ? ftiles : 0)) * 64 * (size_t)f->JA.ke_rows, &f->JA.ke))) return bail(rc);
         if ((rc = fleet_alloc(f.get(), tiles * 64 * (size_t)f->D.RV, &f->JA.outp))) return bail(rc);
+        if (follow_lanes) {
+            f->JA.ke_follow = (int)(tiles * 64);
+            if ((rc = fleet_alloc(f.get(), ftiles * 64 * (size_t)f->D.RV, &f->JA.fp2))) return bail(rc);
+            if ((rc = fleet_alloc(f.get(), ftiles * 64 * (size_t)f->D.RV, &f->JA.fp3))) return bail(rc);
+        }
     }
     if ((rc = fleet_jobs_alloc(f.get(), &f->JB, 1))) return bail(rc);
     if ((rc = fleet_jobs_alloc(f.get(), &f->JC, 1))) return bail(rc);
@@ -713,7 +808,16 @@ static int fleet_launch_vel(ltpl_fleet* f, const FleetTickIn& t, const fleet::FP
     const bool rows = t.has_gg != 0, multi = t.multi_axm != 0;
     if (rows) f->seen_gg = true;
     const bool rows_mem = rows || f->seen_gg;          // jobs built from the planners' memory (backup plans) may carry rows of an earlier tick
-    if ((rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA, 2, multi, rows))) return rc;            // follow jobs (slot 0): one wave per job
+    if (f->JA.ke_follow >= 0) {                                                                  // follow jobs (slot 0) without friction rows: one LANE per job (round 5)
+        DevVelParams p;
+        if ((rc = make_vel_params(h, &vp, t.axm, &p))) { f->err = h->err; return rc; }
+        p.n_axm = t.n_axm_total;
+        hipLaunchKernelGGL(fleet_follow_kernel_of(fleet_variant(vp, multi)), dim3((unsigned)((N + 63) / 64)), dim3(64), 16 * (size_t)(t.n_axm_total > 0 ? t.n_axm_total : 1), st,
+                           h->lat, p, reinterpret_cast<const DevVelJob*>(f->JA.jobs), (const double*)f->JA.pool, reinterpret_cast<const ke_t*>(f->JA.ke), f->JA.ke_rows,
+                           f->JA.ke_follow, f->JA.fp2, f->JA.fp3, f->D.RV, N, (int)fleet::JOBS_A, f->JA.out, f->JA.flags);
+        FLEET_TRY(f, hipGetLastError());
+    }
+    if ((rows || f->JA.ke_follow < 0) && (rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA, 2, multi, rows))) return rc;   // ... with friction rows (or LTPL_FLEET_FOLLOW_WAVES=1): one wave per job
     if (rows && (rc = fleet_launch_vel_jobs(f, vp, t.axm, f->JA, 3, multi, true))) return rc;    // forward-backward jobs with friction rows
     FLEET_TRY(f, hipStreamWaitEvent(st, f->ev_b, 0));
     hipLaunchKernelGGL(k_fleet_vel_b, dim3(N), dim3(64), 0, st, f->args, f->JA.view(), f->JB.view());
@@ -813,6 +917,22 @@ try {
     t.n_axm_total = v.n_axm_total; t.multi_axm = v.multi_axm; t.has_gg = v.has_gg;
     if ((rc = fleet_launch_vel(f, t))) return rc;
     return fleet_check(f);
+} LTPL_ABI_CATCH(abi_err_of(f))
+
+extern "C" int ltpl_fleet_digest(ltpl_fleet* f, double* out, int32_t cap_doubles_per_planner)
+try {
+    if (!f || !out) return LTPL_ERR_INVALID_ARG;
+    if (cap_doubles_per_planner != LTPL_FLEET_DIGEST) { f->err = "fleet: digest record size mismatch"; return LTPL_ERR_INVALID_ARG; }
+    FLEET_TRY(f, hipSetDevice(f->h->device));
+    const size_t n = (size_t)f->D.N * LTPL_FLEET_DIGEST;
+    double* d = nullptr;
+    struct Guard { void* a = nullptr; ~Guard() { if (a) (void)hipFree(a); } } g;
+    FLEET_TRY(f, hipMalloc(reinterpret_cast<void**>(&d), sizeof(double) * n)); g.a = d;
+    hipLaunchKernelGGL(k_fleet_digest, dim3(f->D.N), dim3(64), 0, f->h->stream, f->args, d);
+    FLEET_TRY(f, hipGetLastError());
+    FLEET_TRY(f, hipMemcpyAsync(out, d, sizeof(double) * n, hipMemcpyDeviceToHost, f->h->stream));
+    FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
+    return LTPL_OK;
 } LTPL_ABI_CATCH(abi_err_of(f))
 
 static int fleet_fetch(ltpl_fleet* f, int p)

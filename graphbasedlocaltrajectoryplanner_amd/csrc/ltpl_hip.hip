@@ -861,6 +861,24 @@ __device__ __forceinline__ int globrl_index_dev(const DevLat& lat, double px, do
     return ord >= 0 ? i1 : nb;
 }
 
+// Index pair start of the global race line segment ONE LANE's object is projected on (calc_vel_profile_follow.py:172-176; the wave form is
+// globrl_index_dev): closest race line point (first minimum, like np.argmin; the points are read with uniform indices, every lane compares
+// with its own object), then the neighbour test of get_s_coord (closed = True). Every lane of the wave must call it.
+__device__ __forceinline__ int lane_globrl_index(const DevLat& lat, double ox, double oy)
+{
+    const int G = lat.G - 1;
+    double bd = INFINITY; int nb = 0;
+#pragma unroll 8
+    for (int i = 0; i < G; ++i) {
+        const double dx = lat.grx[i] - ox, dy = lat.gry[i] - oy, d2 = dx * dx + dy * dy;
+        if (d2 < bd) { bd = d2; nb = i; }
+    }
+    int i1 = nb - 1; if (i1 < 0) i1 += G;
+    int i2 = nb + 1; if (i2 > G - 1) i2 = 0;
+    const int ord = angle_order_dev(at(lat.grx, nb), at(lat.gry, nb), ox, oy, at(lat.grx, i1), at(lat.gry, i1), at(lat.grx, i2), at(lat.gry, i2));
+    return ord >= 0 ? i1 : nb;
+}
+
 struct FollowIn { double v_start, v_ego, v_obj, safety_d, obj_dist, obj_x, obj_y; };
 
 // calc_vel_profile_follow.py:78-313. Inputs: vs.kabs[n], vs.el[n_el >= n] (tailing zero), gg; result vs.w (v^2).
@@ -1019,7 +1037,8 @@ struct DevVelJob {
     // the car of the job (fleet::VelJob, ABI v6): v_max <= 0 / n_axm == 0 -> the launch's parameter set (seam 2, host planner)
     double v_max;
     int axm_off, n_axm;                           // rows [axm_off, axm_off + n_axm) of the launch's stacked machine tables
-    int gg_rows, pad_;                            // 1: off_gg holds n caller-supplied [ax, ay] rows (local_gg as a dict, OTH.py:649-666) instead of two constants
+    int gg_rows, lane_form;                       // gg_rows 1: off_gg holds n caller-supplied [ax, ay] rows (local_gg as a dict, OTH.py:649-666) instead of two
+                                                  // constants; lane_form 1 (fleet): operands in the lane plane, the job belongs to a lane kernel
 };
 
 // `lite`: only what the forward-backward and brake profiles touch (w, kabs, el, machine table, run flags) -- no arc length, no follow scratch
@@ -1076,7 +1095,7 @@ __global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p_,
 #endif
     const bool follow = jb.mode == LTPL_VEL_FOLLOW || jb.mode == LTPL_VEL_FOLLOW_CONTROLLED;
     if constexpr (SEL == 1) { if (follow) return; }
-    if constexpr (SEL == 2) { if (!follow) return; }
+    if constexpr (SEL == 2) { if (!follow || jb.lane_form) return; }      // (fleet: follow jobs without friction rows run one lane per job, k_fleet_follow_lanes)
     if constexpr (SEL == 3) { if (follow || !jb.gg_rows) return; }
     constexpr bool LITE = SEL == 1 || SEL == 3;
     VelScratch vs = carve_vel_scratch(smem, cap, GG, false, nullptr, nullptr, LITE);
@@ -1565,6 +1584,153 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #define VF_BOUND_GENERIC 8
 #define VF_COMPOSE 16
 
+// The CONTROLLED part of calc_vel_profile_follow.py:78-294 for one lane (= one follow job): ego brake profile -> plane P2, opponent stop
+// distance on the global race line from index idx_s_opp, characteristic indices, segment profile -> plane P3. "vx_profile" (:289 / :294)
+// is then: P2 in front of row n_decel - 1 (all rows when !two_seg), P3 up to stop_idx, zeros behind -- composed by the caller. Shared by the
+// batch velocity stage (k_vel_lanes) and the fleet's lane kernel of the follow jobs (k_fleet_follow_lanes, round 5).
+struct LaneFollowOut { int vel_bound, too_close, two_seg, n_decel, stop_idx; };
+template <int EM, bool AXM1>
+__device__ __forceinline__ LaneFollowOut lane_follow_controlled(const DevLat& lat, const LaneProf& L, double* P2, double* P3, int n, double cax, double cay,
+                                                                const DevVelParams& p, const double* axm_tab, double v_start, double v_ego, double v_obj,
+                                                                double obj_dist, double safety_d_in, int idx_s_opp, long long* dbg, int drow)
+{
+    const double icay = 1.0 / cay;
+    int vel_bound = 1;
+    const double control_d = p.c_p * safety_d_in + p.len_veh, safety_d = safety_d_in + p.len_veh;
+    const int too_close = (obj_dist - safety_d) < 0.0 ? 1 : 0;
+    const double v_max = p.v_max;
+    double v_control;
+    if (p.ctrl == 0) v_control = (v_obj - p.k_p * (control_d - obj_dist) + p.k_d * (v_obj - v_ego));
+    else {
+        double a = (control_d - obj_dist) * D_PI / 2 * 1 / p.tan_w;
+        const double lo = -D_PI / 2 + 1e-5, hi = D_PI / 2 - 1e-5;
+        a = a < lo ? lo : (a > hi ? hi : a);
+        v_control = (v_obj - tan(a) * p.k_p + p.k_d * (v_obj - v_ego));
+    }
+    if (v_control < 0.0) v_control = 0.0;
+    if (v_control > v_max) v_control = v_max;
+    const double wctl = v_control * v_control;
+
+    // opponent brake distance on the global race line (:169-199); rows are gathered in chunks
+    const int G = lat.G - 1;
+    const double* grl = lat.glob_rl;
+    const double vel0 = grl[(size_t)idx_s_opp * 5 + 4];
+    double wopp = fmin(v_obj, vel0); wopp *= wopp;
+    double opp_stop = 0.0;
+    for (int base = 0; base < G && wopp > 0.01; base += LCH) {
+        double kr[LCH], lr[LCH];
+#pragma unroll
+        for (int c = 0; c < LCH; ++c) {
+            int j = base + c + idx_s_opp; j = j % G;
+            kr[c] = fabs(grl[(size_t)j * 5 + 3]); lr[c] = grl[(size_t)(j + 1) * 5] - grl[(size_t)j * 5];
+        }
+#pragma unroll
+        for (int c = 0; c < LCH; ++c) {
+            const int k = base + c;
+            if (k < G && wopp > 0.01) {
+                opp_stop += lr[c];
+                if (k + 1 >= G) wopp = 0.0;
+                else {
+                    const double a = ax_poss_w<EM, true, VMODE_DECEL_FORW>(wopp, kr[c] * (1.0 / 14.0), 14.0, p, axm_tab, 0.0);
+                    const double r = wopp + 2.0 * a * lr[c];
+                    wopp = r < 0.0 ? 0.0 : r;
+                }
+            }
+        }
+    }
+    vl_stamp(dbg, drow, 1);
+    // one pass over the path rows: ego brake profile -> P2 (:152-159), ego stop distance (:162-166), first index at
+    // or below the control speed (:254), arc length and stop index (:203-209)
+    const double s_stop = obj_dist - safety_d + opp_stop;                            // :206
+    double ego_stop = 0.0, s_run = 0.0, s_last = 0.0; int first_le = -1, stop_idx = 0;
+    {
+        double w = v_start * v_start; bool braking = true, counting = true, searching = true;
+        double kr[LCH], er[LCH], kn[LCH], en[LCH];
+        auto load_rows = [&](int base, double (&k)[LCH], double (&e)[LCH]) {
+#pragma unroll
+            for (int c = 0; c < LCH; ++c) {
+                const int r = base + c < n ? base + c : n - 1;
+                const ke_t ke = L.KE[kep_row(r)]; k[c] = (double)ke.x; e[c] = (double)ke.y;
+            }
+        };
+        load_rows(0, kr, er);
+        for (int base = 0; base < n; base += LCH) {
+            if (base + LCH < n) load_rows(base + LCH, kn, en);         // next chunk in flight during this chunk's steps
+#pragma unroll
+            for (int c = 0; c < LCH; ++c) {
+                const int i = base + c;
+                if (i < n) {
+                    const double wv = braking ? w : 0.0;
+                    P2[(size_t)i * 64] = wv;
+                    if (first_le < 0 && wv <= wctl) first_le = i;
+                    if (counting) { if (wv > 0.01) ego_stop += er[c]; else counting = false; }
+                    if (searching) { if (i < n - 1 && s_run < s_stop) stop_idx = i + 1; else searching = false; }
+                    if (i == n - 1) s_last = s_run; // s[n - 1]
+                    s_run += er[c];                 // s[i + 1]
+                    if (braking && i + 1 < n) {
+                        const double kq = kr[c] * icay, e = er[c];
+                        double r;
+                        if constexpr (EM == 1) {
+                            const double te = 2.0 * e, axa = fabs(cax);
+                            const double A0 = 1.0 - te * p.drag_m, A1 = A0 + te * (axa * kq);
+                            r = fmin(fma(A1, w, -te * axa), A0 * w);
+                        } else {
+                            r = w + 2.0 * ax_poss_w<EM, true, VMODE_DECEL_FORW>(w, kq, cax, p, axm_tab, 0.0) * e;
+                        }
+                        if (r < 0.0) braking = false; else w = r;
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < LCH; ++c) { kr[c] = kn[c]; er[c] = en[c]; }
+        }
+    }
+    vl_stamp(dbg, drow, 2);
+    double v_end = 0.0;
+    if (s_stop > s_last) {                                                           // :212-221
+        // the stop point lies beyond the path: end velocity = race-line velocity where the opponent's remaining brake
+        // distance is used up; the element lengths are fetched LCH at a time (one round trip per chunk, not per step)
+        const double s_ends = opp_stop - (s_stop - s_last);
+        int idx = 0; double summed = 0.0; bool run = summed < s_ends;
+        while (run) {
+            double dl[LCH];
+#pragma unroll
+            for (int c = 0; c < LCH; ++c) {
+                int j = idx + c + idx_s_opp; j = j % G;
+                dl[c] = grl[(size_t)(j + 1) * 5] - grl[(size_t)j * 5];
+            }
+#pragma unroll
+            for (int c = 0; c < LCH; ++c)
+                if (run) { if (summed < s_ends && idx < G) { summed += dl[c]; ++idx; } else run = false; }
+            if (run && !(summed < s_ends && idx < G)) run = false;
+        }
+        int j = (idx % G) + idx_s_opp; if (j >= G) j -= G;
+        v_end = grl[(size_t)j * 5 + 4];
+    }
+    vl_stamp(dbg, drow, 3);
+    int idx_c = 0, n_decel = 0; const bool two_seg = ego_stop < s_stop;
+    if (two_seg) {                                                                   // :247-292
+        double vcs = v_start;
+        if (v_start > v_control && stop_idx >= 2) {
+            idx_c = first_le < 0 ? 0 : first_le;
+            if (idx_c > stop_idx) idx_c = stop_idx;
+            if (idx_c == 0) idx_c = stop_idx;
+            n_decel = idx_c + 1 < n ? idx_c + 1 : n;
+            vcs = sqrt(P2[(size_t)(n_decel - 1) * 64]);
+        } else if (!(stop_idx >= 2)) vel_bound = 0;
+        const int m = (stop_idx + 1 < n ? stop_idx + 1 : n) - idx_c;
+        if (stop_idx - idx_c > 0) {
+            lane_fb_profile<EM, AXM1>(L, P3, idx_c, m, cax, cay, p, axm_tab, v_control, vcs, true, v_end);
+            if (fabs(sqrt(P3[(size_t)idx_c * 64]) - vcs) > 1.0) vel_bound = 0;
+        } else if (stop_idx - idx_c == 0) P3[(size_t)idx_c * 64] = vcs * vcs;
+        const double first_v = (n_decel - 1 > 0) ? sqrt(P2[0]) : sqrt(P3[0]);
+        if (fabs(first_v - v_start) > 1.0) vel_bound = 0;
+    }
+    vl_stamp(dbg, drow, 4);
+    LaneFollowOut o; o.vel_bound = vel_bound; o.too_close = too_close; o.two_seg = two_seg ? 1 : 0; o.n_decel = n_decel; o.stop_idx = stop_idx;
+    return o;
+}
+
 // the generic forward-backward profile of a slot (OTH.py:834-903) into plane D; returns its vel_bound flag
 template <int EM, bool AXM1>
 __device__ int lane_generic_profile(const DevLat& lat, const DevPathsOut& out, const LaneProf& L, double* D, int slot, int n,
@@ -1613,7 +1779,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
     __syncthreads();
     const int drow = b < nbG ? (b < 64 ? b : -1) : (b < nbG + nbF ? (b - nbG < 64 ? 64 + b - nbG : -1) : (b - nbG - nbF < 64 ? 128 + b - nbG - nbF : -1));
     vl_stamp(dbg, drow, 0);
-    const double cax = vin.gg_ax, cay = vin.gg_ay, icay = 1.0 / cay;
+    const double cax = vin.gg_ax, cay = vin.gg_ay;
     const int fbase = out.n_slots_pad;
     if (b >= nbG + nbF) {
         // ---- follow jobs, unconstrained profile (calc_vel_profile_follow.py:297-307) -------------------------------------
@@ -1652,140 +1818,11 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
 
     if (name == LTPL_ACT_FOLLOW) {                                                       // OTH.py:763-830
         // calc_vel_profile_follow.py:78-294 for this lane
-        int vel_bound = 1;
-        const double v_start = vel_plan, v_ego = vin.vel_est[s], v_obj = prep.v_obj[slot], obj_dist = prep.obj_dist[slot];
-        const double control_d = p.c_p * vin.safety_d + p.len_veh, safety_d = vin.safety_d + p.len_veh;
-        if ((obj_dist - safety_d) < 0.0) flags |= VF_TOO_CLOSE;
-        const double v_max = p.v_max;
-        double v_control;
-        if (p.ctrl == 0) v_control = (v_obj - p.k_p * (control_d - obj_dist) + p.k_d * (v_obj - v_ego));
-        else {
-            double a = (control_d - obj_dist) * D_PI / 2 * 1 / p.tan_w;
-            const double lo = -D_PI / 2 + 1e-5, hi = D_PI / 2 - 1e-5;
-            a = a < lo ? lo : (a > hi ? hi : a);
-            v_control = (v_obj - tan(a) * p.k_p + p.k_d * (v_obj - v_ego));
-        }
-        if (v_control < 0.0) v_control = 0.0;
-        if (v_control > v_max) v_control = v_max;
-        const double wctl = v_control * v_control;
-
-        // opponent brake distance on the global race line (:169-199); rows are gathered in chunks
-        const int G = lat.G - 1;
-        const double* grl = lat.glob_rl;
-        const int idx_s_opp = prep.idx_s_opp[slot];
-        const double vel0 = grl[(size_t)idx_s_opp * 5 + 4];
-        double wopp = fmin(v_obj, vel0); wopp *= wopp;
-        double opp_stop = 0.0;
-        for (int base = 0; base < G && wopp > 0.01; base += LCH) {
-            double kr[LCH], lr[LCH];
-#pragma unroll
-            for (int c = 0; c < LCH; ++c) {
-                int j = base + c + idx_s_opp; j = j % G;
-                kr[c] = fabs(grl[(size_t)j * 5 + 3]); lr[c] = grl[(size_t)(j + 1) * 5] - grl[(size_t)j * 5];
-            }
-#pragma unroll
-            for (int c = 0; c < LCH; ++c) {
-                const int k = base + c;
-                if (k < G && wopp > 0.01) {
-                    opp_stop += lr[c];
-                    if (k + 1 >= G) wopp = 0.0;
-                    else {
-                        const double a = ax_poss_w<EM, true, VMODE_DECEL_FORW>(wopp, kr[c] * (1.0 / 14.0), 14.0, p, axm_tab, 0.0);
-                        const double r = wopp + 2.0 * a * lr[c];
-                        wopp = r < 0.0 ? 0.0 : r;
-                    }
-                }
-            }
-        }
-        vl_stamp(dbg, drow, 1);
-        // one pass over the path rows: ego brake profile -> P2 (:152-159), ego stop distance (:162-166), first index at
-        // or below the control speed (:254), arc length and stop index (:203-209)
-        const double s_stop = obj_dist - safety_d + opp_stop;                            // :206
-        double ego_stop = 0.0, s_run = 0.0, s_last = 0.0; int first_le = -1, stop_idx = 0;
-        {
-            double w = v_start * v_start; bool braking = true, counting = true, searching = true;
-            double kr[LCH], er[LCH], kn[LCH], en[LCH];
-            auto load_rows = [&](int base, double (&k)[LCH], double (&e)[LCH]) {
-#pragma unroll
-                for (int c = 0; c < LCH; ++c) {
-                    const int r = base + c < n ? base + c : n - 1;
-                    const ke_t ke = L.KE[kep_row(r)]; k[c] = (double)ke.x; e[c] = (double)ke.y;
-                }
-            };
-            load_rows(0, kr, er);
-            for (int base = 0; base < n; base += LCH) {
-                if (base + LCH < n) load_rows(base + LCH, kn, en);         // next chunk in flight during this chunk's steps
-#pragma unroll
-                for (int c = 0; c < LCH; ++c) {
-                    const int i = base + c;
-                    if (i < n) {
-                        const double wv = braking ? w : 0.0;
-                        P2[(size_t)i * 64] = wv;
-                        if (first_le < 0 && wv <= wctl) first_le = i;
-                        if (counting) { if (wv > 0.01) ego_stop += er[c]; else counting = false; }
-                        if (searching) { if (i < n - 1 && s_run < s_stop) stop_idx = i + 1; else searching = false; }
-                        if (i == n - 1) s_last = s_run; // s[n - 1]
-                        s_run += er[c];                 // s[i + 1]
-                        if (braking && i + 1 < n) {
-                            const double kq = kr[c] * icay, e = er[c];
-                            double r;
-                            if constexpr (EM == 1) {
-                                const double te = 2.0 * e, axa = fabs(cax);
-                                const double A0 = 1.0 - te * p.drag_m, A1 = A0 + te * (axa * kq);
-                                r = fmin(fma(A1, w, -te * axa), A0 * w);
-                            } else {
-                                r = w + 2.0 * ax_poss_w<EM, true, VMODE_DECEL_FORW>(w, kq, cax, p, axm_tab, 0.0) * e;
-                            }
-                            if (r < 0.0) braking = false; else w = r;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < LCH; ++c) { kr[c] = kn[c]; er[c] = en[c]; }
-            }
-        }
-        vl_stamp(dbg, drow, 2);
-        double v_end = 0.0;
-        if (s_stop > s_last) {                                                           // :212-221
-            // the stop point lies beyond the path: end velocity = race-line velocity where the opponent's remaining brake
-            // distance is used up; the element lengths are fetched LCH at a time (one round trip per chunk, not per step)
-            const double s_ends = opp_stop - (s_stop - s_last);
-            int idx = 0; double summed = 0.0; bool run = summed < s_ends;
-            while (run) {
-                double dl[LCH];
-#pragma unroll
-                for (int c = 0; c < LCH; ++c) {
-                    int j = idx + c + idx_s_opp; j = j % G;
-                    dl[c] = grl[(size_t)(j + 1) * 5] - grl[(size_t)j * 5];
-                }
-#pragma unroll
-                for (int c = 0; c < LCH; ++c)
-                    if (run) { if (summed < s_ends && idx < G) { summed += dl[c]; ++idx; } else run = false; }
-                if (run && !(summed < s_ends && idx < G)) run = false;
-            }
-            int j = (idx % G) + idx_s_opp; if (j >= G) j -= G;
-            v_end = grl[(size_t)j * 5 + 4];
-        }
-        vl_stamp(dbg, drow, 3);
-        int idx_c = 0, n_decel = 0; const bool two_seg = ego_stop < s_stop;
-        if (two_seg) {                                                                   // :247-292
-            double vcs = v_start;
-            if (v_start > v_control && stop_idx >= 2) {
-                idx_c = first_le < 0 ? 0 : first_le;
-                if (idx_c > stop_idx) idx_c = stop_idx;
-                if (idx_c == 0) idx_c = stop_idx;
-                n_decel = idx_c + 1 < n ? idx_c + 1 : n;
-                vcs = sqrt(P2[(size_t)(n_decel - 1) * 64]);
-            } else if (!(stop_idx >= 2)) vel_bound = 0;
-            const int m = (stop_idx + 1 < n ? stop_idx + 1 : n) - idx_c;
-            if (stop_idx - idx_c > 0) {
-                lane_fb_profile<EM, AXM1>(L, P3, idx_c, m, cax, cay, p, axm_tab, v_control, vcs, true, v_end);
-                if (fabs(sqrt(P3[(size_t)idx_c * 64]) - vcs) > 1.0) vel_bound = 0;
-            } else if (stop_idx - idx_c == 0) P3[(size_t)idx_c * 64] = vcs * vcs;
-            const double first_v = (n_decel - 1 > 0) ? sqrt(P2[0]) : sqrt(P3[0]);
-            if (fabs(first_v - v_start) > 1.0) vel_bound = 0;
-        }
-        vl_stamp(dbg, drow, 4);
+        const LaneFollowOut fo = lane_follow_controlled<EM, AXM1>(lat, L, P2, P3, n, cax, cay, p, axm_tab, vel_plan, vin.vel_est[s], prep.v_obj[slot],
+                                                                  prep.obj_dist[slot], vin.safety_d, prep.idx_s_opp[slot], dbg, drow);
+        if (fo.too_close) flags |= VF_TOO_CLOSE;
+        int vel_bound = fo.vel_bound;
+        const bool two_seg = fo.two_seg != 0; const int n_decel = fo.n_decel, stop_idx = fo.stop_idx;
         // "vx_profile" (:289 / :294) = brake profile in front, segment profile up to the stop index, zeros behind. Normally only
         // described (two indices) and composed by the row-parallel final kernel; a reduced-horizon follow job needs P3 for its
         // generic profile, so there the composition is materialised in P0 here.
@@ -1962,21 +1999,7 @@ __global__ __launch_bounds__(64) void k_follow_prep(DevLat lat, DevPathsIn in, D
     double ox = ex, oy = ey, vobj = 0.0, odist = 0.0;
     if (have) { const int q = in.pos_off[v0 + ci]; ox = in.pos_x[q]; oy = in.pos_y[q]; vobj = vin.veh_vel[v0 + ci]; }
     vl_stamp(dbg, drow, 1);
-    // ---- closest race line point (first minimum, like np.argmin), then the neighbour test of get_s_coord (closed = True) ----
-    int idx;
-    {
-        const int G = lat.G - 1;
-        double bd = INFINITY; int nb = 0;
-#pragma unroll 8
-        for (int i = 0; i < G; ++i) {
-            const double dx = lat.grx[i] - ox, dy = lat.gry[i] - oy, d2 = dx * dx + dy * dy;
-            if (d2 < bd) { bd = d2; nb = i; }
-        }
-        int i1 = nb - 1; if (i1 < 0) i1 += G;
-        int i2 = nb + 1; if (i2 > G - 1) i2 = 0;
-        const int ord = angle_order_dev(at(lat.grx, nb), at(lat.gry, nb), ox, oy, at(lat.grx, i1), at(lat.gry, i1), at(lat.grx, i2), at(lat.gry, i2));
-        idx = ord >= 0 ? i1 : nb;
-    }
+    const int idx = lane_globrl_index(lat, ox, oy);
     vl_stamp(dbg, drow, 2);
     if (__ballot(have) != 0ull) {
         const double* xy = vp.XY + 2 * kep_base(j, vp.plane_rows);         // pairs: row r of this lane's job at xy + 2 * kep_row(r)

@@ -189,6 +189,7 @@ struct PlanRt {
     static constexpr bool par_global = false;     // parent tables in LDS
     static constexpr int par_entry = 2;           // bytes per parent entry
     static constexpr int ch1 = 4;                 // register chunks of 64 edges per layer transition (one-wave team)
+    static constexpr bool tail_pf = false;        // (see PlanFx)
 #define LTPL_PLAN_FIELD(name) static __device__ __forceinline__ int name(const TeamLds& lp) { return lp.name; }
     LTPL_PLAN_FIELD(kpad) LTPL_PLAN_FIELD(hmax) LTPL_PLAN_FIELD(off_dist) LTPL_PLAN_FIELD(off_cnt) LTPL_PLAN_FIELD(off_widx)
     LTPL_PLAN_FIELD(off_dumin) LTPL_PLAN_FIELD(off_best) LTPL_PLAN_FIELD(off_par) LTPL_PLAN_FIELD(off_lay)
@@ -201,6 +202,15 @@ struct PlanFx {
     static constexpr bool par_global = false;
     static constexpr int par_entry = 1;           // KPAD <= 127: the source node and the tie bit share one byte
     static constexpr int ch1 = 3;                 // 192 edges in registers: fits 128 VGPRs without spills (4 waves per SIMD)
+    // The edges of a transition beyond the register image (`tail_edges`) are read from global memory inside the layer step. Plan class B
+    // (HM = 40: the C3 oval with 245 edges per transition, lvms up to 330) meets them on EVERY layer: there the first 64 tail edges are
+    // requested at the top of the layer step and arrive while the register chunks are processed (round 5; C3: two dependent global round
+    // trips per layer less). Class A / C lattices (Monteblanco: 42 % of the transitions have a tail) keep their register budget.
+#ifdef LTPL_NO_TAIL_PF
+    static constexpr bool tail_pf = false;
+#else
+    static constexpr bool tail_pf = HM > 32 && NW == 1;
+#endif
     static constexpr int c_kpad = KPAD, c_hmax = HM;
     static constexpr int c_n_path_bufs = NW < LTPL_MAX_ACTIONS ? NW : LTPL_MAX_ACTIONS;
     static constexpr int c_off_dist = 0;
@@ -878,6 +888,12 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
             if ((ACT >> f) & 1u) { dist[coff[f] + n] = INFINITY; cnt_all[f * kpad + n] = 0u; }
     }
     team_sync<NW>();
+    // the first tail edges of the transition, requested now (P::tail_pf), consumed by tail_edges below
+    const bool has_tail = A.ne > CH * NT;
+    EdgeRegs tl; tl.c = INFINITY; tl.meta = 0u;
+    if constexpr (P::tail_pf) {
+        if (has_tail) { const int ei = CH * NT + tid; const int e = ei < A.ne ? A.eb + ei : K.E; tl.c = at(K.sw_cost, e); tl.meta = at(K.sw_meta, e); }
+    }
     // candidate sums are kept for the active filters only (compile-time compaction keeps the register image small)
     constexpr int NA = ((ACT >> 0) & 1) + ((ACT >> 1) & 1) + ((ACT >> 2) & 1) + ((ACT >> 3) & 1);
     constexpr int SL[NFILT] = {0, (int)((ACT >> 0) & 1), (int)(((ACT >> 0) & 1) + ((ACT >> 1) & 1)), (int)(((ACT >> 0) & 1) + ((ACT >> 1) & 1) + ((ACT >> 2) & 1))};
@@ -918,8 +934,10 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
         double* dumin = reinterpret_cast<double*>(smem + P::off_dumin(lp));
         for (int ei = CH * NT + tid; ei < A.ne; ei += NT) {
             const int e = A.eb + ei;
-            double c = at(K.sw_cost, e);
-            const unsigned meta = at(K.sw_meta, e);
+            double c; unsigned meta;
+            if (P::tail_pf && ROUND == 0 && ei < (CH + 1) * NT) { c = tl.c; meta = tl.meta; }   // (the prefetched first 64 tail edges; the later rounds
+                                                                                                //  re-read them -- cache hits now -- instead of holding three registers across the election)
+            else { c = at(K.sw_cost, e); meta = at(K.sw_meta, e); }
             const int src = sw_src(meta), dst = sw_dst(meta);
             int el_ = e - sc.e_base; if (el_ < 0) el_ += K.E;
             const bool unbl = !((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u);
@@ -942,7 +960,6 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
             }
         }
     };
-    const bool has_tail = A.ne > CH * NT;
     if (has_tail) tail_edges(0);
     team_sync<NW>();
     {

@@ -33,7 +33,7 @@ struct HostJobSet {
         per = per_planner; jobs.assign((size_t)N * per, fleet::VelJob{}); pool.assign((size_t)N * per * 4 * R, 0.0); out.assign((size_t)N * per * R, 0.0);
         flags.assign((size_t)N * per * 2, 0);
     }
-    fleet::FJobs view() { return fleet::FJobs{jobs.data(), pool.data(), out.data(), flags.data(), per, nullptr, 0}; }
+    fleet::FJobs view() { return fleet::FJobs{jobs.data(), pool.data(), out.data(), flags.data(), per, nullptr, 0, -1}; }
 };
 
 struct HostPlanner {

@@ -28,6 +28,8 @@ class Fleet(Planner):
         f("tape_clear").argtypes = [C.c_void_p]
         f("tape_append").argtypes = [C.c_void_p, C.POINTER(PlannerPathsIn), C.POINTER(PlannerVelIn)]
         f("tape_run").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
+        if hasattr(self.lib, "ltpl_fleet_digest"):
+            f("digest").argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int32]
 
     def set_start_range(self, first, past_last, pos, heading, vel=0.0, max_heading_offset=math.pi / 4):
         """``set_start`` with the same pose for the planners [first, past_last) in one call (ltpl_fleet_set_start_range)."""
@@ -200,6 +202,17 @@ class Fleet(Planner):
     def tape_append_packed(self, pi, vi):
         """Append the input structs of ``pack_groups`` / ``pack_arrays`` (both calls of one tick) to the tape."""
         self._check(self._fn("tape_append")(self.handle, C.byref(pi), C.byref(vi)))
+
+    DIGEST_DOUBLES = 8 + 9 * _capi.PLANNER_MAX_KEYS
+
+    def digest(self):
+        """Digest of EVERY planner's last tick, computed on the device (ltpl_fleet_digest): array [n_planners, DIGEST_DOUBLES] --
+        [0] error word, [1] cut_index_pos, [2] cut_layer, [3] n_keys, [4] n_ids, [5] vel_plan, [6] n_vel_course, [7] acc_plan, per key k:
+        [8 + 7 k ..] key id, trajectory id, rows, s_end, vx[0], vx[-1], sum(vx); per id k: [8 + 7 K + 2 k ..] key id, id value.
+        ``tick_replay.check_digests`` compares it with a tick of a recording for all planners at once."""
+        out = np.zeros((self.n_scen, self.DIGEST_DOUBLES), np.float64)
+        self._check(self._fn("digest")(self.handle, out.ctypes.data_as(C.POINTER(C.c_double)), int(self.DIGEST_DOUBLES)))
+        return out
 
     def tape_run(self, first, count):
         """Advance all planners through ticks [first, first + count) of the tape; returns the device time in ms."""

@@ -129,3 +129,45 @@ def check_trajectories(traj, ids, ref, t, what):
     if full is not None:
         for k in ev['keys']:
             check_traj(traj[k][0], full['traj'][k], "%s/%s" % (what, k))
+
+
+
+def check_digests(dig, t, key_id_of, what=""):
+    """Rows of ``Fleet.digest()`` (one per planner, all of which replayed the SAME recording) against tick ``t`` of that recording: what
+    ``check_trajectories`` checks on every tick (cut indices, velocity plan, keys / trajectory ids / path ids, rows, s_end, vx[0], vx[-1],
+    sum of vx: indices exact, floats 1e-5 relative), for all planners at once. ``key_id_of``: action name -> key id of the ABI
+    (planner.KEY_NAMES inverted). Returns the number of planners checked; raises AssertionError naming the first planner that differs."""
+    dig = np.asarray(dig, dtype=float)
+    if dig.shape[0] == 0:
+        return 0
+    K = (dig.shape[1] - 8) // 9
+    er, ev = t['ref_idx'], t['vel']
+
+    def bad(mask, msg):
+        if np.any(mask):
+            q = int(np.argmax(mask))
+            raise AssertionError("%s planner row %d: %s (digest %s)" % (what, q, msg, dig[q, :8 + 7 * K].tolist()))
+
+    bad(dig[:, 0] != 0, "error word set")
+    bad((dig[:, 1] != er['cut_index_pos']) | (dig[:, 2] != er['cut_layer']), "cut (%d, %d)" % (er['cut_index_pos'], er['cut_layer']))
+    bad(np.abs(dig[:, 5] - er['vel_plan']) > REL_TOL * max(abs(er['vel_plan']), 1.0), "vel_plan %g" % er['vel_plan'])
+    bad(np.abs(dig[:, 7] - er['acc_plan']) > REL_TOL * max(abs(er['acc_plan']), 5.0), "acc_plan %g" % er['acc_plan'])
+    bad(dig[:, 6] != er['vel_course'].shape[0], "vel_course length %d" % er['vel_course'].shape[0])
+    keys = list(ev['keys'])
+    bad(dig[:, 3] != len(keys), "trajectory keys %s" % keys)
+    for k, name in enumerate(keys):
+        d = dig[:, 8 + 7 * k: 8 + 7 * k + 7]
+        dg = ev['digest'][name]
+        bad(d[:, 0] != key_id_of[name], "key %d is not %s" % (k, name))
+        bad(d[:, 2] != dg[0], "%s: rows %d" % (name, dg[0]))
+        vs = max(abs(dg[4]) / max(dg[0], 1), 1.0)
+        bad(np.abs(d[:, 3] - dg[1]) > REL_TOL * max(abs(dg[1]), 1.0), "%s: s_end %g" % (name, dg[1]))
+        bad(np.abs(d[:, 4] - dg[2]) > REL_TOL * max(vs, abs(dg[2])), "%s: vx[0] %g" % (name, dg[2]))
+        bad(np.abs(d[:, 5] - dg[3]) > REL_TOL * max(vs, abs(dg[3])), "%s: vx[-1] %g" % (name, dg[3]))
+        bad(np.abs(d[:, 6] - dg[4]) > REL_TOL * max(abs(dg[4]), 1.0), "%s: sum vx %g" % (name, dg[4]))
+    # action_set_path_id (OTH.py:696-697,1034): one id per key of the tick INCLUDING dropped keys, in the dict's order
+    ids = list(ev['traj_id'].items())
+    bad(dig[:, 4] != len(ids), "path ids %s" % ids)
+    for k, (name, val) in enumerate(ids[:K]):
+        bad((dig[:, 8 + 7 * K + 2 * k] != key_id_of[name]) | (dig[:, 8 + 7 * K + 2 * k + 1] != val), "id %d is not %s: %s" % (k, name, val))
+    return int(dig.shape[0])

@@ -27,6 +27,9 @@
  *   LTPL_NO_SELFTEST=1          skip the create-time self-test (one-wave vs four-wave kernel on probe scenarios)
  *   LTPL_HOST_PROF=1            host-side timing table of the entry points on stderr at exit
  *   LTPL_FLEET_NO_FUSE=1        fleet tape runs with one kernel per stage instead of the fused stage kernels (read by ltpl_fleet_create)
+ *   LTPL_FLEET_FOLLOW_WAVES=1   fleet follow jobs one WAVE per job (the form before round 5) instead of one lane per job (ltpl_fleet_create)
+ *   LTPL_NO_LAYER_GRID=1        closest reference-line layer of an obstacle position by the scan over all layers, no create-time grid
+ *   LTPL_TICK_GRAPH=1           the single fused tick (copy in -> kernel [-> copy out]) as ONE hipGraph launch (measured: slower; off)
  * Timing / fault-injection switches (LTPL_ABLATE, LTPL_EXP_SKIP, LTPL_LDS_POISON, LTPL_SCRATCH_POISON, LTPL_DEBUG_TIMING,
  * LTPL_DEBUG_OCC) skip work, overwrite memory or instrument kernels; they are compiled into the EXPERIMENT build only
  * (-DLTPL_EXPERIMENT -> libltpl_hip_exp.so, used by tools/ and one fault-injection test) and do not exist in libltpl_hip.so.
@@ -594,6 +597,13 @@ int ltpl_fleet_calc_vel_profile(ltpl_fleet* fleet, const ltpl_planner_vel_in* in
 /* copy-out of one planner's state (a device-to-host copy of its block, then as ltpl_planner_get_*) */
 int ltpl_fleet_get_paths(ltpl_fleet* fleet, int32_t planner, ltpl_planner_paths_view* view);
 int ltpl_fleet_get_trajectories(ltpl_fleet* fleet, int32_t planner, ltpl_planner_traj_view* view);
+/* digest of EVERY planner's result of the last tick, computed on the device (one wave per planner, read only): per planner
+ * LTPL_FLEET_DIGEST_DOUBLES doubles -- [0] error word, [1] cut_index_pos, [2] cut_layer, [3] n_keys, [4] n_ids, [5] vel_plan,
+ * [6] n_vel_course, [7] acc_plan; per key k: [8 + 7 k ..] key id, trajectory id, rows, s of the last row, vx of the first and the last row,
+ * sum of vx; per id k: [8 + 7 K + 2 k ..] key id, id value (K = LTPL_PLANNER_MAX_KEYS). What the reference's tick recordings hold for every
+ * tick: a whole fleet is checked against a recording without copying planner blocks (bench.py extra.closed_loop_device_mixed). */
+#define LTPL_FLEET_DIGEST_DOUBLES (8 + 9 * LTPL_PLANNER_MAX_KEYS)
+int ltpl_fleet_digest(ltpl_fleet* fleet, double* out /* [n_planners * LTPL_FLEET_DIGEST_DOUBLES] */, int32_t doubles_per_planner);
 int ltpl_fleet_tape_clear(ltpl_fleet* fleet);
 int ltpl_fleet_tape_append(ltpl_fleet* fleet, const ltpl_planner_paths_in* paths_in, const ltpl_planner_vel_in* vel_in);
 int ltpl_fleet_tape_run(ltpl_fleet* fleet, int32_t first, int32_t count, float* ms_total /* may be NULL */);

@@ -23,7 +23,13 @@ def build(force=False):
     if (not force and os.path.isfile(LIB)
             and os.path.getmtime(LIB) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
         return LIB
-    subprocess.check_call(["make", "-s", "-C", HERE, "-B", "libltpl_oracle.so"])
+    # (two processes -- the ranks of a gloo test, pytest-xdist workers -- may find the library stale at the same time: one builds, the
+    #  other waits on the lock and finds it fresh)
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if force or not (os.path.isfile(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            subprocess.check_call(["make", "-s", "-C", HERE, "-B", "libltpl_oracle.so"])
     return LIB
 
 

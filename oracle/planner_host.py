@@ -24,7 +24,13 @@ def build(force=False):
     srcs += [os.path.join(csrc, f) for f in ("planner_core.hpp", "planner_host.hpp", "fleet_core.hpp", "fleet_api.hpp")] + [os.path.join(HERE, "oracle_compute.hpp")]
     if not force and os.path.isfile(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(s) for s in srcs):
         return LIB
-    subprocess.check_call(["make", "-s", "-C", HERE, "-B", "libltpl_planner_host.so"])
+    # (two processes -- the ranks of a gloo test, pytest-xdist workers -- may find the library stale at the same time: one builds, the
+    #  other waits on the lock and finds it fresh)
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if force or not (os.path.isfile(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(s) for s in srcs)):
+            subprocess.check_call(["make", "-s", "-C", HERE, "-B", "libltpl_planner_host.so"])
     return LIB
 
 

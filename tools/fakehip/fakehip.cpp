@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <set>
+#include <vector>
 #include <map>
 #include <random>
 #include <mutex>
@@ -156,6 +157,33 @@ hipError_t hipLaunchKernel(const void*, dim3 grid, dim3 block, void**, size_t sh
         for (auto& a : g_dev) if (a.second <= ((size_t)64 << 20)) scribble(a.first, a.second);
         for (auto& a : g_host) if (a.second <= ((size_t)64 << 20)) scribble(a.first, a.second);
     }
+    return hipSuccess;
+}
+// hipGraph (the LTPL_TICK_GRAPH form of the single tick): an executable graph is a list of recorded copies that hipGraphLaunch replays
+// (kernel nodes do nothing here, like launches)
+struct FakeNode { int kind; void* d; const void* s; size_t n; };
+struct FakeGraph { std::vector<FakeNode*> nodes; };
+hipError_t hipGraphCreate(hipGraph_t* g, unsigned) { *g = reinterpret_cast<hipGraph_t>(new FakeGraph()); return hipSuccess; }
+hipError_t hipGraphDestroy(hipGraph_t g) { FakeGraph* fg = reinterpret_cast<FakeGraph*>(g); for (FakeNode* n : fg->nodes) delete n; delete fg; return hipSuccess; }
+hipError_t hipGraphAddMemcpyNode1D(hipGraphNode_t* node, hipGraph_t g, const hipGraphNode_t*, size_t, void* d, const void* s, size_t n, hipMemcpyKind)
+{
+    FakeNode* fn = new FakeNode{0, d, s, n}; reinterpret_cast<FakeGraph*>(g)->nodes.push_back(fn); *node = reinterpret_cast<hipGraphNode_t>(fn); return hipSuccess;
+}
+hipError_t hipGraphAddKernelNode(hipGraphNode_t* node, hipGraph_t g, const hipGraphNode_t*, size_t, const hipKernelNodeParams* kp)
+{
+    if (!kp || !kp->func || kp->gridDim.x == 0 || kp->blockDim.x == 0 || kp->sharedMemBytes > 160 * 1024) return hipErrorInvalidValue;
+    FakeNode* fn = new FakeNode{1, nullptr, nullptr, 0}; reinterpret_cast<FakeGraph*>(g)->nodes.push_back(fn); *node = reinterpret_cast<hipGraphNode_t>(fn); return hipSuccess;
+}
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, hipGraphNode_t*, char*, size_t) { *e = reinterpret_cast<hipGraphExec_t>(g); return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+hipError_t hipGraphExecMemcpyNodeSetParams1D(hipGraphExec_t, hipGraphNode_t node, void* d, const void* s, size_t n, hipMemcpyKind)
+{
+    FakeNode* fn = reinterpret_cast<FakeNode*>(node); fn->d = d; fn->s = s; fn->n = n; return hipSuccess;
+}
+hipError_t hipGraphExecKernelNodeSetParams(hipGraphExec_t, hipGraphNode_t, const hipKernelNodeParams* kp) { return kp && kp->func ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t)
+{
+    for (FakeNode* n : reinterpret_cast<FakeGraph*>(e)->nodes) { if (n->kind == 0 && n->n) std::memcpy(n->d, n->s, n->n); else if (n->kind == 1) ++g_launches; }
     return hipSuccess;
 }
 void** __hipRegisterFatBinary(const void*) { static void* dummy = nullptr; return &dummy; }
