@@ -461,7 +461,7 @@ def closed_loop_device_mixed(hip, lat, n_planners, n_ticks, names=("c2", "overta
         t_prev = t_stop
         # EVERY planner of the fleet against the recording of its group, digested on the device (ltpl_fleet_digest: cut indices, velocity
         # plan, keys, ids, rows, s_end, vx[0], vx[-1], sum of vx per trajectory) ...
-        if hasattr(fleet, "digest") and hasattr(fleet.lib, "ltpl_fleet_digest"):
+        if hasattr(fleet, "digest") and hasattr(getattr(fleet, "lib", None), "ltpl_fleet_digest"):
             dig = fleet.digest()
             p = 0
             for sz, ticks, nm in zip(sizes, recs, names):
@@ -657,12 +657,12 @@ def worker(args):
     fleet_sharded = None
     if world > 1 and args.workload == "c2" and not args.no_extra:
         from graphbasedlocaltrajectoryplanner_amd.sharding import fleet_shard
-        lo, hi = fleet_shard(getattr(args, 'fleet_planners', 8192), rank, world)
+        lo, hi = fleet_shard(getattr(args, 'fleet_planners', 32768), rank, world)
         rate, ms_tick, ok_f, _ = closed_loop_device_rate(hip, lat, hi - lo, min(getattr(args, 'fleet_ticks', 200), 60), live=False)
         rates = gather_over_ranks(rate)
         oks = gather_over_ranks(1.0 if ok_f else 0.0)
         fleet_sharded = {"planner_ticks_per_s": float(sum(rates)), "per_rank_planner_ticks_per_s": rates,
-                         "planners_total": getattr(args, 'fleet_planners', 8192), "matches_recording": bool(min(oks) > 0.5),
+                         "planners_total": getattr(args, 'fleet_planners', 32768), "matches_recording": bool(min(oks) > 0.5),
                          "what": "one fleet per rank on its block of the vehicles (sharding.fleet_shard), no collective on the data path"}
         hip.batch_upload(batch, vel)
 
@@ -734,9 +734,13 @@ def worker(args):
                                     "what": "256 planners x 60 consecutive ticks through ltpl_planner_calc_paths / _calc_vel_profile, every "
                                             "planner carrying its own iterative memory; host-inclusive (packing, PCIe, host state machine)"}
             # the same closed loop with the planners' state in device memory (fleet): no host work per planner
-            n_fp, n_ft = getattr(args, 'fleet_planners', 8192), getattr(args, 'fleet_ticks', 200)
+            n_fp, n_ft = getattr(args, 'fleet_planners', 32768), getattr(args, 'fleet_ticks', 200)
             cdr, cd_ms, cdok, cd_live = closed_loop_device_rate(hip, lat, n_fp, n_ft)
             extra["closed_loop_device_mixed"] = closed_loop_device_mixed(hip, lat, n_fp, n_ft)
+            if n_fp > 8192:            # the fleet size the rounds before quoted (wave-per-job follow kernel below 12 288 planners)
+                m8 = closed_loop_device_mixed(hip, lat, 8192, n_ft)
+                extra["closed_loop_device_mixed"]["at_8192_planners"] = {k: m8[k] for k in ("planner_ticks_per_s", "ms_per_fleet_tick", "matches_recording",
+                                                                                             "planners_digested_on_device")}
             extra["closed_loop_device"] = {"planner_ticks_per_s": cdr, "planners": n_fp, "ticks": n_ft, "ms_per_fleet_tick": cd_ms,
                                            "inputs": "ALL planners replay the SAME recorded inputs (no divergence between the waves, identical "
                                                      "data in the caches); closed_loop_device_mixed runs four different recordings side by side",
@@ -871,7 +875,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--latency-ticks", type=int, default=2000)
     ap.add_argument("--dropin-ticks", type=int, default=2500)
-    ap.add_argument("--fleet-planners", type=int, default=8192, help="extra.closed_loop_device: planners of the fleet")
+    ap.add_argument("--fleet-planners", type=int, default=32768, help="extra.closed_loop_device*: planners of the fleet (round 5: 32 768 like the "
+                    "headline's batch -- a fleet tick is a chain of kernels with one wave per planner, 8 192 waves leave the chip half empty; the "
+                    "8 192-planner rate of the earlier rounds is reported next to it)")
     ap.add_argument("--fleet-ticks", type=int, default=200, help="extra.closed_loop_device: consecutive ticks")
     ap.add_argument("--c3-batch", type=int, default=32768, help="extra.c3: scenarios per step (one size for builder and driver since round 5: the headline's)")
     ap.add_argument("--c5-ticks", type=int, default=400, help="extra.c5: ticks per horizon")

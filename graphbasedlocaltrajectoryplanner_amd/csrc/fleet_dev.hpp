@@ -274,6 +274,9 @@ __global__ __launch_bounds__(64) void k_fleet_fb_lanes(DevVelParams p, const Dev
 // resident per CU) was the longest kernel of a fleet tick -- 180 us for 8 192 planners, more than the path search; this form needs
 // n_planners / 64 waves. The unconstrained profile of a follow key is a forward-backward job of its own (k_fleet_fb_lanes) and the
 // intersection is stage B's, as before.
+#ifndef LTPL_FOLLOW_LANES_MIN_PLANNERS
+#define LTPL_FOLLOW_LANES_MIN_PLANNERS 12288
+#endif
 template <int EM, bool AXM1>
 __global__ __launch_bounds__(64) void k_fleet_follow_lanes(DevLat lat, DevVelParams p, const DevVelJob* jobs, const double* pool, const ke_t* ke, int ke_rows,
                                                            int ke_follow, double* P2, double* P3, int cap, int n_planners, int per, double* out, int* flags)
@@ -480,7 +483,12 @@ try {
     {   // lane planes of the forward-backward jobs (slots 1 .. JOBS_A - 1), tiles of 64 jobs; round 5: behind them the tiles of the follow
         // jobs (slot 0), which run one LANE per job as well (k_fleet_follow_lanes; LTPL_FLEET_FOLLOW_WAVES=1 keeps the wave-per-job form)
         const size_t tiles = ((size_t)N * (fleet::JOBS_A - 1) + 63) / 64, ftiles = ((size_t)N + 63) / 64;
-        const bool follow_lanes = !(getenv("LTPL_FLEET_FOLLOW_WAVES") && atoi(getenv("LTPL_FLEET_FOLLOW_WAVES")) != 0);
+        // same-box A/B on the mixed tape (profiles/r05d_fleet_follow_ab.txt): 32 768 planners 15.9 M planner-ticks/s (lanes) against 14.8 M (waves);
+        // 8 192 planners 12.3 M against 12.5 M -- a small fleet's follow kernel hides behind the forward-backward lane kernel on the second
+        // stream either way, a large fleet's wave-per-job kernel is nine rounds of 14 jobs per CU. The lane form is the default from
+        // LTPL_FOLLOW_LANES_MIN_PLANNERS (12 288) planners on; LTPL_FLEET_FOLLOW_WAVES=1 / =0 forces one or the other.
+        const char* fw = getenv("LTPL_FLEET_FOLLOW_WAVES");
+        const bool follow_lanes = fw ? atoi(fw) == 0 : N >= LTPL_FOLLOW_LANES_MIN_PLANNERS;
         f->JA.ke_rows = (f->D.RV + 7) / 8 * 8;
         if ((rc = fleet_alloc(f.get(), (tiles + (follow_lanes ? ftiles : 0)) * 64 * (size_t)f->JA.ke_rows, &f->JA.ke))) return bail(rc);
         if ((rc = fleet_alloc(f.get(), tiles * 64 * (size_t)f->D.RV, &f->JA.outp))) return bail(rc);

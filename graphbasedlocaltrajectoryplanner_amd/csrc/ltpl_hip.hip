@@ -1356,6 +1356,47 @@ __device__ __forceinline__ double fast_div(double a, double b)
 #define LCHB 12    // backward sweep: (|kappa|, el) + the fp64 profile state per row
 #endif
 
+// DIRECT OUTPUT OF THE GENERIC PROFILES (round 5). The rows of a generic job (every non-follow primitive) used to take a detour: the
+// backward sweep rewrote the plane, k_vel_final read plane and element lengths again, took the root, differentiated and wrote vx / ax.
+// Now the backward sweep of lane_fb_profile<.., EMIT = true> produces vx / ax of the rows it finalises (row r: v = sqrt(w_r),
+// a = (w_r+1 - w_r) / (2 e_r), -5 at standstill, OTH.py:925-941 -- the operations of k_vel_final) and hands a chunk of LCHB rows per lane to
+// lane_emit_flush, which transposes through LDS exactly like k_vel_final: lane = job writes its rows, lane = (job of a group of 8, pair of
+// rows) stores 16 contiguous bytes of the slot's output row. The sweep runs wave-uniformly in this mode (all 64 lanes take part in every
+// flush, lanes that have no rows left contribute none). k_vel_final only serves the follow jobs (compositions, intersections, row-5 choice).
+struct LaneEmit {
+    double* tbuf;                  // LDS [32 * LE_PITCH]
+    int* s_cnt; int* s_rhi;        // LDS [64]: rows of the job's chunk, row of its first value (values run DOWNWARDS from there)
+    unsigned long long* s_o;       // LDS [64]: vx row base of every lane's job (0: idle lane), written by the caller
+    long long ax_delta;            // vout.ax - vout.vx in doubles: the ax row of a job lies at the same offset of the other array
+    double w0;                     // out: v^2 of row 0 after the backward sweep
+};
+#define LE_PITCH (LCHB + 2)        // doubles per job row in LDS (16-byte aligned pairs)
+__device__ __forceinline__ void lane_emit_flush(const LaneEmit& E, int lane, int cnt, int r_hi, const double (&vv)[LCHB], const double (&aa)[LCHB])
+{
+    static_assert(LCHB % 2 == 0 && LCHB <= 16, "pairs of rows, eight pieces per job");
+    E.s_cnt[lane] = cnt; E.s_rhi[lane] = r_hi;
+    const int q = lane >> 3, piece = lane & 7;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int half = pass & 1;                                      // jobs [32 half, 32 half + 32); passes 0, 1: vx, 2, 3: ax
+        if ((lane >> 5) == half) {
+#pragma unroll
+            for (int c = 0; c < LCHB; c += 2) store2(&E.tbuf[(lane & 31) * LE_PITCH + c], pass < 2 ? vv[c] : aa[c], pass < 2 ? vv[c + 1] : aa[c + 1]);
+        }
+        wave_sync_lds();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int jl = k * 8 + q, jj = half * 32 + jl, c = 2 * piece;
+            const int cn = E.s_cnt[jj];
+            if (c >= cn || c >= LCHB) continue;
+            const dbl2 v = *reinterpret_cast<const dbl2*>(&E.tbuf[jl * LE_PITCH + c]);     // rows r - c (x) and r - c - 1 (y)
+            double* o = reinterpret_cast<double*>(E.s_o[jj]) + (pass < 2 ? 0 : E.ax_delta) + (E.s_rhi[jj] - c);
+            if (c + 1 < cn) store2_u(o - 1, v.y, v.x); else o[0] = v.x;
+        }
+        wave_sync_lds();
+    }
+}
+
 // tph.calc_vel_profile(closed=False) for one lane: rows [off, off + n) of the path, result into plane D (as v^2).
 // Rows are processed in register chunks of LCH; the rows of the NEXT chunk are requested before the current chunk's recurrence
 // steps run (double buffer). Two things keep the compiler's s_waitcnt placement tight (measured: a per-step vmcnt(0) -- i.e. a
@@ -1364,10 +1405,10 @@ __device__ __forceinline__ double fast_div(double a, double b)
 //     takes them by reference as generic pointers -> FLAT loads / stores, which always wait on vmcnt(0) and lgkmcnt(0));
 //   * a recurrence step is branch-free (selects instead of `if (active)`), so a chunk is one basic block and the waits are
 //     counted exactly: the stores of a chunk stay in flight while the next chunk's operands are awaited.
-template <int EM, bool AXM1>
+template <int EM, bool AXM1, bool EMIT = false>
 __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, int off, int n, double cax, double cay,
                                                 const DevVelParams& p, const double* axm_tab, double v_max, double v_start,
-                                                bool has_v_end, double v_end, long long* dbg = nullptr, int drow = -1)
+                                                bool has_v_end, double v_end, long long* dbg = nullptr, int drow = -1, LaneEmit* em = nullptr, int lane = 0)
 {
     if (v_start < 0.0) v_start = 0.0;
     if (has_v_end && v_end < 0.0) v_end = 0.0;
@@ -1381,7 +1422,9 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
     double wi = fmin(cay * ke_rcp(rec0), vmax2);
     if (wi > v_start * v_start) wi = v_start * v_start;
     Dp[0] = wi;
-    if (n < 2) return;
+    if constexpr (!EMIT) { if (n < 2) return; }
+    do {                                   // (EMIT: a lane without a profile -- n < 2 -- skips the forward sweep but takes part in the flushes below)
+    if constexpr (EMIT) { if (n < 2) break; }
     // ---- lateral-limit speed + forward sweep (accel_forw) in one pass -------------------------------------------------
     if constexpr (EM == 1 && AXM1) {
         // Affine case (exponent 1, one-row machine table). A velocity wave is alone on its SIMD and issues one instruction every
@@ -1477,9 +1520,67 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
             for (int c = 0; c < LCHF; ++c) kr[c] = kn[c];
         }
     }
+    } while (0);
     vl_stamp(dbg, drow, 8);
     // ---- backward sweep (decel_backw), mirrored indices; with a constant gg the unmirrored-gg quirk is void --------------
-    if constexpr (EM == 1 && AXM1) {
+    if constexpr (EMIT) {
+        // wave-uniform form with direct output (see LaneEmit): every lane walks the chunks of the LONGEST profile of the wave, its own steps
+        // masked by `valid`; the plane is only read (forward values), vx / ax of the finalised rows go out through lane_emit_flush
+        const int nst = n >= 2 ? n - 1 : 0;
+        const double axg = axa * icay;
+        double orig_p = wi, g_p = kabs_i * axg;                       // affine form: operands of the row above
+        double orig_i = wi;                                           // general form
+        bool active = false, prev_acc = false;
+        ke_t kr[LCHB], kn[LCHB]; double wr[LCHB], wq[LCHB];
+#pragma unroll
+        for (int c = 0; c < LCHB; ++c) {
+            const int r = n - 2 - c >= 0 ? n - 2 - c : 0;
+            kr[c] = KE_AT(r); wr[c] = Dp[(size_t)r * 64];
+        }
+        for (int base = 0; __ballot(base < nst) != 0ull; base += LCHB) {
+#pragma unroll
+            for (int c = 0; c < LCHB; ++c) {
+                const int r = n - 2 - base - LCHB - c >= 0 ? n - 2 - base - LCHB - c : 0;
+                kn[c] = KE_AT(r); wq[c] = Dp[(size_t)r * 64];
+            }
+            double vv[LCHB], aa[LCHB];
+#pragma unroll
+            for (int c = 0; c < LCHB; ++c) {
+                const bool valid = base + c < nst;
+                const double wold = wr[c], e_b = (double)kr[c].y, k_c = (double)kr[c].x;
+                double wn; bool acc;
+                if constexpr (EM == 1 && AXM1) {
+                    acc = wold > orig_p;
+                    const double te = 2.0 * e_b, tdm = te * dm, g_n = k_c * axg;
+                    const double w1 = fmax(fma(te, fmax(fma(-g_p, wi, axa), 0.0), fma(tdm, wi, wi)), 0.0);
+                    wn = fmin(fmax(fma(te, fmax(fma(-g_n, w1, axa), 0.0), fma(tdm, w1, wi)), 0.0), w1);
+                } else {
+                    acc = wold - orig_i > 0.0;
+                    const double kq_i = kabs_i * icay, kq_n = k_c * icay;
+                    const double a = ax_poss_w<EM, AXM1, VMODE_DECEL_BACKW>(wi, kq_i, cax, p, axm_tab, axm1);
+                    wn = fmax(wi + 2.0 * a * e_b, 0.0);
+                    const double a2 = ax_poss_w<EM, AXM1, VMODE_DECEL_BACKW>(wn, kq_n, cax, p, axm_tab, axm1);
+                    wn = fmin(fmax(wi + 2.0 * a2 * e_b, 0.0), wn);
+                }
+                const bool act = active || (acc && !prev_acc);
+                const double wnext = (act && wn < wold) ? wn : wold;
+                double v = 0.0, a_out = 0.0;
+                if (valid) {
+                    v = sqrt(wnext);
+                    a_out = (wi - wnext) / (2.0 * e_b);                // (w_r+1 - w_r) / (2 e_r): the row above is the state before this step
+                    if (fabs(v) <= 1e-8 && fabs(a_out) <= 1e-8) a_out = -5.0;
+                    active = act && !(wn > vmax2); prev_acc = acc;
+                    wi = wnext; orig_p = wold; orig_i = wold; g_p = k_c * axg; kabs_i = k_c;
+                }
+                vv[c] = v; aa[c] = a_out;
+            }
+            const int left = nst - base;
+            lane_emit_flush(*em, lane, left < 0 ? 0 : (left < LCHB ? left : LCHB), n - 2 - base, vv, aa);
+#pragma unroll
+            for (int c = 0; c < LCHB; ++c) { kr[c] = kn[c]; wr[c] = wq[c]; }
+        }
+        em->w0 = wi;
+    } else if constexpr (EM == 1 && AXM1) {
         // same form: w1 = max(A0 w + te max(axa - g_i w, 0), 0), w' = min(max(te dm w1 + w + te max(axa - g_n w1, 0), 0), w1),
         // A0 = 1 + te dm (no machine limit under braking)
         const double axg = axa * icay;
@@ -1762,11 +1863,62 @@ __device__ int lane_generic_profile(const DevLat& lat, const DevPathsOut& out, c
     return fabs(sqrt(D[0]) - vel_plan) < v_max_offset ? 1 : 0;
 }
 
+// The same with DIRECT OUTPUT (LaneEmit): vx / ax of the slot are written from here -- the rows the backward sweep finalises through the
+// LDS transposition of lane_emit_flush, the rows it does not own (the profile's last row, the zero tail of a reduced horizon) by the lane
+// itself. Called by ALL 64 lanes of the wave (`have` = the lane owns a job); returns the vel_bound flag.
+template <int EM, bool AXM1>
+__device__ __forceinline__ int lane_generic_profile_emit(const DevLat& lat, const DevPathsOut& out, const LaneProf& L, double* D, bool have, int slot, int n,
+                                                         int reduced, double cax, double cay, const DevVelParams& p, const double* axm_tab,
+                                                         double vel_plan, double v_max_offset, LaneEmit& E, int lane, double* o_vx)
+{
+    double v_end = 0.0; int v_idx = 0;
+    if (have) {
+        const int goal = out.goal_layer[slot];
+        const int end_node = out.nodes[(size_t)slot * out.cap_nodes + out.n_nodes[slot] - 1];
+        int dn = end_node - lat.rl_idx[goal]; if (dn < 0) dn = -dn;
+        const double raceline_offset = (double)dn * lat.lat_offset;
+        if (reduced) {
+            double spl_len = 0.0;
+            for (int i = 0; i < n - 1; ++i) spl_len += (double)L.KE[kep_row(i)].y;
+            int first = -1; double c = 0.0;
+            for (int i = 0; i < n - 1; ++i) { c += (double)L.KE[kep_row(i)].y; if (first < 0 && !(c < (spl_len - 5.0))) first = i; }
+            v_idx = (first < 0 ? 0 : first) + 1;
+            if (v_idx == 1 && n > 1) v_idx = n;
+        } else {
+            v_end = lat.vel_rl[goal];
+            const double red = v_end * lat.vel_decrease_lat * raceline_offset;
+            v_end -= (red < v_end ? red : v_end);
+            v_idx = n;
+        }
+    }
+    const int n_prof = v_idx > 1 ? v_idx : 0;                   // rows of the profile proper (0: the path has none, everything is zero)
+    lane_fb_profile<EM, AXM1, true>(L, D, 0, n_prof, cax, cay, p, axm_tab, p.v_max, vel_plan, true, v_end, nullptr, -1, &E, lane);
+    if (!have) return 0;
+    // rows n_prof - 1 .. n - 1: the profile's last row (its v^2 is in the plane: the backward sweep starts below it) and the zero tail;
+    // ax of a row differentiates towards the row above, which is zero (or absent: last row of the path, ax = 0) for all of them
+    const double w0 = n_prof >= 2 ? E.w0 : 0.0;
+    double* o_ax = o_vx + E.ax_delta;
+    for (int i = (n_prof >= 2 ? n_prof - 1 : 0); i < n; ++i) {
+        const double w = (n_prof >= 2 && i == n_prof - 1) ? D[(size_t)i * 64] : 0.0;
+        const double v = sqrt(w);
+        double a = 0.0;
+        if (i < n - 1) {
+            a = (0.0 - w) / (2.0 * (double)L.KE[kep_row(i)].y);
+            if (fabs(v) <= 1e-8 && fabs(a) <= 1e-8) a = -5.0;
+        }
+        o_vx[i] = v; o_ax[i] = a;
+    }
+    return fabs(sqrt(w0) - vel_plan) < v_max_offset ? 1 : 0;
+}
+
 template <int EM, bool AXM1>
 __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, DevPathsOut out, DevVelParams p,
                                                   DevTickVelIn vin, DevVelPrep prep, VelPlanes vp, int n_slots, int n_scen,
-                                                  int n_blocks0, long long* dbg)
+                                                  int n_blocks0, long long* dbg, DevTickVelOut vout)
 {
+    __shared__ __align__(16) double le_tbuf[32 * LE_PITCH];        // direct output of the generic jobs (LaneEmit)
+    __shared__ int le_cnt[64], le_rhi[64];
+    __shared__ unsigned long long le_o[64];
     // blocks [0, nbG): generic jobs; [nbG, nbG + nbF): follow jobs, controlled part; [nbG + nbF, nbG + 2 nbF): follow jobs,
     // unconstrained profile. Waves beyond the job counters (known only on the device) exit at once.
     __shared__ double axm_tab[128];
@@ -1793,9 +1945,33 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
         vl_stamp(dbg, drow, 6);
         return;
     }
-    const bool fjob = b >= nbG;
-    const int j = (fjob ? b - nbG : b) * 64 + lane;
-    if (j >= (fjob ? cntF : cntG)) return;
+    if (b < nbG) {
+        // ---- generic jobs (every non-follow primitive, OTH.py:834-941): profile AND outputs, all 64 lanes stay for the output transposition ----
+        const int j = b * 64 + lane;
+        const bool have = j < cntG;
+        const int2 js = have ? out.job_slot[j] : make_int2(0, 0);
+        const int slot = js.x, n = have ? js.y : 0;
+        {   // longest profile of the launch (k_vel_final skips row chunks beyond it): one atomic per wave
+            const int nmax = wave_max_i32(n);
+            if (lane == 0) atomicMax(&out.job_cnt[2], nmax);
+        }
+        LaneProf L; L.KE = vp.KE + kep_base(j, vp.plane_rows);
+        double* o_vx = vout.vx + (size_t)slot * out.cap_pts;
+        le_o[lane] = have ? (unsigned long long)o_vx : 0ull;
+        LaneEmit E; E.tbuf = le_tbuf; E.s_cnt = le_cnt; E.s_rhi = le_rhi; E.s_o = le_o; E.ax_delta = (long long)(vout.ax - vout.vx); E.w0 = 0.0;
+        wave_sync_lds();
+        const int bound = lane_generic_profile_emit<EM, AXM1>(lat, out, L, vp.P0 + tile_base(j, vp.cap_pts), have, slot, n, have ? out.reduced[slot] : 0,
+                                                              cax, cay, p, axm_tab, have ? vin.vel_plan[slot / LTPL_MAX_ACTIONS] : 0.0, vin.v_max_offset, E, lane, o_vx);
+        if (have) {
+            vout.vel_bound[slot] = bound; vout.too_close[slot] = 0;
+            vp.flags[j] = VF_BOUND_FOLLOW | (bound ? VF_BOUND_GENERIC : 0);
+        }
+        vl_stamp(dbg, drow, 6);
+        return;
+    }
+    const bool fjob = true;                                     // (generic jobs are done above: follow jobs, controlled part)
+    const int j = (b - nbG) * 64 + lane;
+    if (j >= cntF) return;
     const int tile = fjob ? fbase + j : j;
     const int2 js = out.job_slot[tile];
     const int slot = js.x;
@@ -1864,15 +2040,17 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
 #define FCH 16
 #define FPITCH (FCH + 2)           // doubles per job row in LDS (16-byte aligned pairs, odd multiple of 16 bytes: conflict-free b128 access)
 __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn vin, DevTickVelOut vout, VelPlanes vp, int n_slots,
-                                                  int n_scen)
+                                                  int n_scen, int first_block)
 {
     __shared__ __align__(16) double tbuf[32 * FPITCH];     // 32 jobs at a time: 4.5 KB, so that many blocks fit next to a resident path kernel
     __shared__ int s_slot[64], s_n[64];
     // blocks [0, nbG): generic jobs, [nbG, nbG + nbF): follow jobs; slots without a path were initialised by the path kernel
+    // (round 5: launched for the follow tiles only -- first_block = nbG; the generic jobs' outputs come from the lane kernel's backward sweep)
     const int nbG = (n_slots + 63) / 64;
-    const bool fjob = (int)blockIdx.x >= nbG;
+    const int bx = (int)blockIdx.x + first_block;
+    const bool fjob = bx >= nbG;
     const int lane = threadIdx.x;
-    const int j = (fjob ? blockIdx.x - nbG : blockIdx.x) * 64 + lane;
+    const int j = (fjob ? bx - nbG : bx) * 64 + lane;
     const int cnt = out.job_cnt[fjob ? 1 : 0];
     if ((j - lane) >= cnt) return;                                      // whole tile without jobs (uniform)
     const bool have = j < cnt;
@@ -3142,7 +3320,7 @@ static int vel_variant(const ltpl_vel_params* vp)
 }
 typedef void (*vel_kernel_t)(DevLat, DevVelParams, const DevVelJob*, const double*, double*, int*, int, long long*, DoneSignal, int);
 typedef void (*tick_kernel_t)(DevLat, DevPathsIn, DevPathsOut, TeamLds, DevVelParams, DevTickVelIn, DevTickVelOut, int, int, int);
-typedef void (*lanes_kernel_t)(DevLat, DevPathsIn, DevPathsOut, DevVelParams, DevTickVelIn, DevVelPrep, VelPlanes, int, int, int, long long*);
+typedef void (*lanes_kernel_t)(DevLat, DevPathsIn, DevPathsOut, DevVelParams, DevTickVelIn, DevVelPrep, VelPlanes, int, int, int, long long*, DevTickVelOut);
 static lanes_kernel_t lanes_kernel_of(int v)
 {
     switch (v) {
@@ -3443,12 +3621,12 @@ static int tick_launch_vel(ltpl_handle* h, const TickLayout& t, hipStream_t st, 
     if (!(h->exp_skip & 2))
 #endif
     hipLaunchKernelGGL(lanes_kernel_of(t.variant), dim3(nb0 + 2 * nb1), dim3(64), 0, st, h->lat, t.di, t.dout,
-                       t.p, t.dvin, t.dprep, t.vp, n_slots, t.n_scen, nb0, h->lp4.dbg);
+                       t.p, t.dvin, t.dprep, t.vp, n_slots, t.n_scen, nb0, h->lp4.dbg, t.dvout);
     HIP_TRY(h, hipGetLastError());
 #ifdef LTPL_EXPERIMENT
     if (!(h->exp_skip & 4))
 #endif
-    hipLaunchKernelGGL(k_vel_final, dim3(nb0 + nb1, h->final_y), dim3(64), 0, st, t.dout, t.dvin, t.dvout, t.vp, n_slots, t.n_scen);
+    hipLaunchKernelGGL(k_vel_final, dim3(nb1, h->final_y), dim3(64), 0, st, t.dout, t.dvin, t.dvout, t.vp, n_slots, t.n_scen, nb0);
     HIP_TRY(h, hipGetLastError());
     return LTPL_OK;
 }

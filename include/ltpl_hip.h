@@ -27,7 +27,7 @@
  *   LTPL_NO_SELFTEST=1          skip the create-time self-test (one-wave vs four-wave kernel on probe scenarios)
  *   LTPL_HOST_PROF=1            host-side timing table of the entry points on stderr at exit
  *   LTPL_FLEET_NO_FUSE=1        fleet tape runs with one kernel per stage instead of the fused stage kernels (read by ltpl_fleet_create)
- *   LTPL_FLEET_FOLLOW_WAVES=1   fleet follow jobs one WAVE per job (the form before round 5) instead of one lane per job (ltpl_fleet_create)
+ *   LTPL_FLEET_FOLLOW_WAVES=1/0 fleet follow jobs one WAVE per job / one LANE per job (default: lanes from 12 288 planners on; ltpl_fleet_create)
  *   LTPL_NO_LAYER_GRID=1        closest reference-line layer of an obstacle position by the scan over all layers, no create-time grid
  *   LTPL_TICK_GRAPH=1           the single fused tick (copy in -> kernel [-> copy out]) as ONE hipGraph launch (measured: slower; off)
  * Timing / fault-injection switches (LTPL_ABLATE, LTPL_EXP_SKIP, LTPL_LDS_POISON, LTPL_SCRATCH_POISON, LTPL_DEBUG_TIMING,
