@@ -1914,7 +1914,7 @@ __device__ __forceinline__ int lane_generic_profile_emit(const DevLat& lat, cons
 template <int EM, bool AXM1>
 __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, DevPathsOut out, DevVelParams p,
                                                   DevTickVelIn vin, DevVelPrep prep, VelPlanes vp, int n_slots, int n_scen,
-                                                  int n_blocks0, long long* dbg, DevTickVelOut vout)
+                                                  int n_blocks0, long long* dbg, DevTickVelOut vout, int emit_generic)
 {
     __shared__ __align__(16) double le_tbuf[32 * LE_PITCH];        // direct output of the generic jobs (LaneEmit)
     __shared__ int le_cnt[64], le_rhi[64];
@@ -1945,8 +1945,11 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
         vl_stamp(dbg, drow, 6);
         return;
     }
-    if (b < nbG) {
-        // ---- generic jobs (every non-follow primitive, OTH.py:834-941): profile AND outputs, all 64 lanes stay for the output transposition ----
+    if (b < nbG && emit_generic) {
+        // ---- generic jobs (every non-follow primitive, OTH.py:834-941): profile AND outputs, all 64 lanes stay for the output transposition.
+        //      Batches only (emit_generic = the launch has >= LTPL_EMIT_MIN_SCEN scenarios): the transposition is ~160 instructions per chunk
+        //      of 12 rows on the lane kernel's serial chain -- with a handful of jobs (single ticks on the long-horizon lattice: C5, 1 200
+        //      rows) k_vel_final's many short waves do that work faster (measured: +100 us on a 1.5 ms tick) ----
         const int j = b * 64 + lane;
         const bool have = j < cntG;
         const int2 js = have ? out.job_slot[j] : make_int2(0, 0);
@@ -1969,9 +1972,9 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
         vl_stamp(dbg, drow, 6);
         return;
     }
-    const bool fjob = true;                                     // (generic jobs are done above: follow jobs, controlled part)
-    const int j = (b - nbG) * 64 + lane;
-    if (j >= cntF) return;
+    const bool fjob = b >= nbG;                                 // (follow jobs, controlled part; generic jobs of small launches: profile into P0, outputs by k_vel_final)
+    const int j = (fjob ? b - nbG : b) * 64 + lane;
+    if (j >= (fjob ? cntF : cntG)) return;
     const int tile = fjob ? fbase + j : j;
     const int2 js = out.job_slot[tile];
     const int slot = js.x;
@@ -3320,7 +3323,10 @@ static int vel_variant(const ltpl_vel_params* vp)
 }
 typedef void (*vel_kernel_t)(DevLat, DevVelParams, const DevVelJob*, const double*, double*, int*, int, long long*, DoneSignal, int);
 typedef void (*tick_kernel_t)(DevLat, DevPathsIn, DevPathsOut, TeamLds, DevVelParams, DevTickVelIn, DevTickVelOut, int, int, int);
-typedef void (*lanes_kernel_t)(DevLat, DevPathsIn, DevPathsOut, DevVelParams, DevTickVelIn, DevVelPrep, VelPlanes, int, int, int, long long*, DevTickVelOut);
+typedef void (*lanes_kernel_t)(DevLat, DevPathsIn, DevPathsOut, DevVelParams, DevTickVelIn, DevVelPrep, VelPlanes, int, int, int, long long*, DevTickVelOut, int);
+#ifndef LTPL_EMIT_MIN_SCEN
+#define LTPL_EMIT_MIN_SCEN 256        // launches with at least this many scenarios write the generic jobs' vx / ax from the lane kernel (k_vel_lanes)
+#endif
 static lanes_kernel_t lanes_kernel_of(int v)
 {
     switch (v) {
@@ -3617,16 +3623,18 @@ static int tick_launch_vel(ltpl_handle* h, const TickLayout& t, hipStream_t st, 
     if (ev_after_prep) HIP_TRY(h, hipEventRecord(ev_after_prep, st));
     const int n_slots = t.n_scen * LTPL_MAX_ACTIONS;
     const int nb0 = (n_slots + 63) / 64, nb1 = (t.n_scen + 63) / 64;
+    const int emit_generic = t.n_scen >= LTPL_EMIT_MIN_SCEN ? 1 : 0;
 #ifdef LTPL_EXPERIMENT
     if (!(h->exp_skip & 2))
 #endif
     hipLaunchKernelGGL(lanes_kernel_of(t.variant), dim3(nb0 + 2 * nb1), dim3(64), 0, st, h->lat, t.di, t.dout,
-                       t.p, t.dvin, t.dprep, t.vp, n_slots, t.n_scen, nb0, h->lp4.dbg, t.dvout);
+                       t.p, t.dvin, t.dprep, t.vp, n_slots, t.n_scen, nb0, h->lp4.dbg, t.dvout, emit_generic);
     HIP_TRY(h, hipGetLastError());
 #ifdef LTPL_EXPERIMENT
     if (!(h->exp_skip & 4))
 #endif
-    hipLaunchKernelGGL(k_vel_final, dim3(nb1, h->final_y), dim3(64), 0, st, t.dout, t.dvin, t.dvout, t.vp, n_slots, t.n_scen, nb0);
+    hipLaunchKernelGGL(k_vel_final, dim3(emit_generic ? nb1 : nb0 + nb1, h->final_y), dim3(64), 0, st, t.dout, t.dvin, t.dvout, t.vp, n_slots, t.n_scen,
+                       emit_generic ? nb0 : 0);
     HIP_TRY(h, hipGetLastError());
     return LTPL_OK;
 }

@@ -1196,12 +1196,21 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
             }
             const int tot = c.y + c.w;
             double bd = INFINITY; int bl = 0x7fffffff;
-            for (int k = 0; __ballot(k < tot) != 0ull; ++k) {
-                if (k < tot) {
-                    const int l = k < c.y ? c.x + k : c.z + (k - c.y);
-                    const double dx = at(g_rx, l) - px, dy = at(g_ry, l) - py;
+            // four candidates per round trip (the loads of a group are issued before the first compare; a lane beyond its last candidate
+            // repeats that one: a repeated distance never wins the strict '<')
+            for (int k0 = 0; __ballot(k0 < tot) != 0ull; k0 += 4) {
+                int l4[4]; double x4[4], y4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + u < tot ? k0 + u : (tot > 0 ? tot - 1 : 0);
+                    l4[u] = k < c.y ? c.x + k : c.z + (k - c.y);
+                    x4[u] = at(g_rx, l4[u]); y4[u] = at(g_ry, l4[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double dx = x4[u] - px, dy = y4[u] - py;
                     const double d2 = dx * dx + dy * dy;
-                    if (d2 < bd) { bd = d2; bl = l; }          // (interval 1 lies below interval 2: ascending layers, first minimum)
+                    if (k0 < tot && d2 < bd) { bd = d2; bl = l4[u]; }          // (interval 1 lies below interval 2: ascending layers, first minimum)
                 }
             }
             if (pv) {

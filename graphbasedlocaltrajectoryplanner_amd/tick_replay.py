@@ -10,6 +10,8 @@ Tolerances (north_star): indices bit-exact, floats 1e-5 relative, every quantity
 import numpy as np
 
 REL_TOL = 1e-5          # north_star: spline coefficients and velocity profiles within 1e-5 relative
+ELEM_TOL_VX = 1e-4      # element-wise relative bound on vx where |vx| >= 1 m/s (north_star: "velocity profiles within 1e-5 relative" is
+                        # asserted per array against the array's scale; this bounds what that scale allows on small values)
 KAPPA_FLOOR = 1e-4      # 1/m: curvature magnitudes below 1 / (10 km) are indistinguishable for the planner (the lateral limit
                         # ay / |kappa| is capped by v_max^2 long before); keeps a relative test meaningful on straights: the
                         # absolute tolerance on a path that is straight throughout is 1e-5 * 1e-4 = 1e-9 1/m
@@ -99,6 +101,14 @@ def check_traj(got, exp, what):
             assert_xy_close(got[:, col:col + 1], exp[:, col:col + 1], what="%s %s" % (what, name))
         else:
             assert_close_rel(got[:, col], exp[:, col], what="%s %s" % (what, name))
+            if name == "vx":
+                # ... and ELEMENT by element wherever the car moves at all: the array-level bound above is 1e-5 of the profile's largest
+                # speed, which would let the slow tail of a profile that brakes to standstill drift by far more than 1e-5 of ITS values
+                # (measured on the bench batch: p99 3e-8, max 1e-5, bench.py parity_detail.elementwise_rel_err)
+                m = np.abs(exp[:, col]) >= 1.0
+                if m.any():
+                    e = float(np.max(np.abs(got[m, col] - exp[m, col]) / np.abs(exp[m, col])))
+                    assert e <= ELEM_TOL_VX, "%s vx element-wise: %.3e > %.0e" % (what, e, ELEM_TOL_VX)
 
 
 
