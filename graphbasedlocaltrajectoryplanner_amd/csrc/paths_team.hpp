@@ -861,10 +861,15 @@ struct LayerArgs {
     double fac;
 };
 
+// LTPL_PIPE1 (round 5 experiment, default off -- see DESIGN.md section 9): ONE LAYER OF SOFTWARE PIPELINING for the single-filter runs of the
+// one-wave kernel. The candidate read of layer j + 1 (dist[cur(j)][source of every edge of the NEXT transition], edges already in `en`) is
+// issued together with the read-back of layer j's election words instead of at the top of layer j + 1: one LDS round trip and one wait less
+// per layer. Valid when the node step of layer j cannot remove a node (no zone node in the planning range; planning_range / default alone).
+// pre_mode bit 0: `cpre` holds this layer's source distances; bit 1: fill `cpre` for the next layer (ne_next = its edge count).
 template <class P, int NW, int CH, unsigned ACT>
 __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, const TeamLds& lp, unsigned char* smem,
                                            const LayerArgs& A, const EdgeRegs (&er)[CH], const unsigned blk,
-                                           int wave, int lane)
+                                           int wave, int lane, double (&cpre)[CH], int pre_mode, const EdgeRegs (&en)[CH], int ne_next)
 {
     const unsigned* blocked_bits = K.blocked_bits;
     const unsigned* zone_bits = K.zone_bits;
@@ -908,6 +913,9 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
     for (int ci = 0; ci < CH; ++ci) {
         if (ci >= LTPL_CH_ALWAYS && (ci * NW) * 64 >= A.ne) continue;            // uniform: no edges in this chunk
         const int src = sw_src(er[ci].meta);
+#ifdef LTPL_PIPE1
+        if constexpr (NA == 1 && NW == 1) { if (pre_mode & 1) { cand[ci][0] = cpre[ci]; continue; } }
+#endif
 #pragma unroll
         for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) cand[ci][SL[f]] = dist[poff[f] + src];
     }
@@ -994,6 +1002,18 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
 #pragma unroll
     for (int f = 0; f < NFILT; ++f)
         if ((ACT >> f) & 1u) { const unsigned cw = nv ? cnt_all[f * kpad + n] : 0u; c_r[SL[f]] = cw >> CW_SHIFT; w_r[SL[f]] = cw & (CW_ONE - 1u); }
+#ifdef LTPL_PIPE1
+    if constexpr (NA == 1 && NW == 1) {
+        if (pre_mode & 2) {
+            constexpr int F1 = (ACT & 1u) ? 0 : ((ACT & 2u) ? 1 : ((ACT & 4u) ? 2 : 3));          // the run's one filter
+#pragma unroll
+            for (int ci = 0; ci < CH; ++ci) {
+                if (ci >= LTPL_CH_ALWAYS && ci * 64 >= ne_next) continue;
+                cpre[ci] = dist[coff[F1] + sw_src(en[ci].meta)];
+            }
+        }
+    }
+#endif
     bool zone_rem = false;
     if (K.zone_any && nv) { int nl = A.v0 + n - sc.n_base; if (nl < 0) nl += K.V; zone_rem = (zone_bits[nl >> 5] >> (nl & 31)) & 1u; }
     // exact tie-break (rare): a node whose minimum is attained by several edges takes, in the reference's order, the
@@ -1558,8 +1578,10 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
         // each: as ballots (one scalar pair per chunk and buffer) they were twelve scalar registers that the compiler kept spilling
         // and reloading inside the layer loop.
         unsigned bm = 0u, bn = 0u;
+        int ne_pref = 0;                                          // edges of the transition the last prefetch loaded (LTPL_PIPE1)
         auto prefetch = [&](int j, EdgeRegs (&dr)[CH], unsigned& db) {
             const int4 ly = lay[j];
+            ne_pref = ly.w - ly.z;
             unsigned bw[CH]; int sh[CH];
             const bool look = j > 63 || ((touched >> j) & 1ull);  // uniform: can this transition hold a blocked edge at all?
 #pragma unroll
@@ -1636,13 +1658,24 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
             why = 0;
             int j = j0;
 #ifndef LTPL_ROT2
+            double cpre[CH]; bool have_pre = false;
+#pragma unroll
+            for (int ci = 0; ci < CH; ++ci) cpre[ci] = INFINITY;
+            constexpr bool one_filter = ACT == (1u << F_DEF) || ACT == (1u << F_PR);
             for (; j <= j1; ++j) {
                 const int4 ly = lay[j];
                 if (riding) { if (__ballot(bm != 0u) != 0ull || ly.w - ly.z > CH * SNT) { why = 1; break; } }
                 if constexpr (!P::fixed) { if ((ly.y & 0xffff) > 64) { why = 2; break; } }
                 const LayerArgs A = layer_args(j, ly, from_def && j == j0, er);
                 if (j < H) prefetch(j + 1, en, bn);                // global loads in flight during this layer's LDS work
-                team_layer<P, SWN, CH, ACT>(swk, sc, lp, smem, A, er, bm, swave, lane);
+#ifdef LTPL_PIPE1
+                // (the next layer of THIS run exists, fits the register image -- a tail would read dist itself, which is fine -- and no node can be removed)
+                const bool make_pre = one_filter && SWN == 1 && j < j1 && j < H && !swk.zone_any;
+#else
+                const bool make_pre = false;
+#endif
+                team_layer<P, SWN, CH, ACT>(swk, sc, lp, smem, A, er, bm, swave, lane, cpre, (have_pre ? 1 : 0) | (make_pre ? 2 : 0), en, ne_pref);
+                have_pre = make_pre;
                 rotate();
             }
 #else
@@ -1655,7 +1688,8 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
                 if constexpr (!P::fixed) { if ((ly.y & 0xffff) > 64) { why = 2; return false; } }
                 const LayerArgs A = layer_args(j, ly, from_def && j == j0, cur);
                 if (j < H) prefetch(j + 1, nxt, nb);               // global loads in flight during this layer's LDS work
-                team_layer<P, SWN, CH, ACT>(swk, sc, lp, smem, A, cur, cb, swave, lane);
+                double cdummy[CH] = {};
+                team_layer<P, SWN, CH, ACT>(swk, sc, lp, smem, A, cur, cb, swave, lane, cdummy, 0, nxt, 0);
                 team_sync<SWN>();
                 ++j;
                 return true;
