@@ -128,7 +128,47 @@ def test_resident_batch_is_dropped_by_other_entry_points(monteblanco, hip_backen
         hip_backend.batch_run(reps=1, timed=False)
 
 
-@pytest.mark.parametrize("env", [{"LTPL_POLL": "1"}, {"LTPL_ZC_OUT": "0"}, {"LTPL_ZC_IN": "1", "LTPL_POLL": "1"}])
+def test_obstacles_off_the_closest_layer_grid(monteblanco, hip_backend, oracle_backend, monkeypatch):
+    """Phase 1 of the path kernel looks the closest reference-line layer of an obstacle position up in a create-time grid (round 5). Positions
+    OUTSIDE the grid (far off the track), in its far corners (cells marked "full scan": the middle of the circuit) and NaN-free extremes make
+    the scenario take the scan over all layers -- results must equal the oracle's full argmin either way, in the one-wave and the four-wave
+    kernel, also when only ONE of many positions is off the grid; and a handle created without the grid (LTPL_NO_LAYER_GRID=1) must agree
+    bit for bit with the default one on ordinary scenarios."""
+    lat = monteblanco
+    rng = np.random.default_rng(5)
+    cx, cy = float(np.mean(lat.refline[:, 0])), float(np.mean(lat.refline[:, 1]))
+    far = [np.array([[cx, cy], [cx, cy]]),                                                  # middle of the circuit: many equally distant layers
+           np.array([[float(lat.refline[:, 0].max()) + 500.0, cy], [float(lat.refline[:, 0].max()) + 500.0, cy]]),      # outside the grid
+           np.array([[-1.0e7, 3.0e6], [-1.0e7, 3.0e6]])]                                    # very far outside
+    scen = crowded(lat, 72, n_veh=6, n_pred=1, seed=31)
+    for i, sc in enumerate(scen):
+        if i % 3 == 0:
+            sc["vehicles"] = sc["vehicles"] + [(2.0, far[(i // 3) % 3])]                     # one off-grid vehicle among ordinary ones
+        elif i % 3 == 1:
+            sc["vehicles"] = [(2.0, far[j]) for j in range(3)]                              # only off-grid vehicles
+    for group in (scen, scen[:6]):                                                          # one-wave teams / four-wave teams
+        batch = _capi.PathsBatch(group, w_last_edges=W_LAST)
+        compare_results(hip_backend.plan_paths(batch), oracle_backend.plan_paths(batch), lat)
+    monkeypatch.setenv("LTPL_NO_LAYER_GRID", "1")
+    plain = _capi.HipBackend(lat)
+    ordinary = crowded(lat, 80, n_veh=8, n_pred=1, seed=32)
+    batch = _capi.PathsBatch(ordinary, w_last_edges=W_LAST)
+    a, b = hip_backend.plan_paths(batch), plain.plan_paths(batch)
+    compare_results(a, b, lat)
+    for i in range(len(ordinary)):                            # (entries behind n_actions / n_nodes / n_pts are unspecified padding)
+        na = int(a.n_actions[i])
+        assert na == int(b.n_actions[i]) and int(a.closest_obj_index[i]) == int(b.closest_obj_index[i])
+        for k in range(na):
+            assert int(a.valid[i, k]) == int(b.valid[i, k]) and int(a.action_id[i, k]) == int(b.action_id[i, k])
+            if a.valid[i, k]:
+                nn, npts = int(a.n_nodes[i, k]), int(a.n_pts[i, k])
+                assert nn == int(b.n_nodes[i, k]) and npts == int(b.n_pts[i, k])
+                assert np.array_equal(a.nodes[i, k, :nn], b.nodes[i, k, :nn]) and np.array_equal(a.path_param[i, k, :npts], b.path_param[i, k, :npts])
+    plain.close()
+
+
+@pytest.mark.parametrize("env", [{"LTPL_POLL": "1"}, {"LTPL_ZC_OUT": "0"}, {"LTPL_ZC_IN": "1", "LTPL_POLL": "1"}, {"LTPL_TICK_GRAPH": "1"},
+                                 {"LTPL_TICK_GRAPH": "1", "LTPL_ZC_OUT": "0"}])
 def test_latency_transport_variants_give_identical_results(monteblanco, hip_backend, monkeypatch, env):
     """The transport of the single-tick path (zero-copy outputs in page-locked memory, optional polled completion word, optional
     zero-copy inputs) must not change a bit of the results: a second handle created under the switches against the default one,
