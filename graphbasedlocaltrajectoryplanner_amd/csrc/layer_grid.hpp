@@ -37,6 +37,10 @@ inline Grid build(int L, const double* rx, const double* ry, double margin = 40.
     for (int l = 1; l < L; ++l) { xmin = std::fmin(xmin, rx[l]); xmax = std::fmax(xmax, rx[l]); ymin = std::fmin(ymin, ry[l]); ymax = std::fmax(ymax, ry[l]); }
     xmin -= margin; ymin -= margin; xmax += margin; ymax += margin;
     const double w = xmax - xmin, h = ymax - ymin;
+    // (the construction costs cells x layers distance evaluations on the host: bounded to ~4e8, i.e. well under a second at ltpl_create,
+    //  by a coarser grid for lattices with very many layers)
+    if ((double)max_cells * (double)L > 4.0e8) max_cells = (int)(4.0e8 / (double)L);
+    if (max_cells < 1024) max_cells = 1024;
     double cell = std::sqrt(w * h / (double)max_cells);
     if (cell < 2.0) cell = 2.0;
     g.cell = cell; g.inv_cell = 1.0 / cell; g.x0 = xmin; g.y0 = ymin;

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define LTPL_ABI_VERSION 6
+#define LTPL_ABI_VERSION 7        /* v7 (round 5, additive): ltpl_paths_kernel_symbol, ltpl_layer_grid, ltpl_fleet_digest */
 
 /* status codes */
 #define LTPL_OK               0

@@ -209,7 +209,13 @@ def test_traffic_is_reported_for_the_grid_it_was_measured_on(monkeypatch, capsys
         pmc = json.load(fh)
     n = int(pmc["grid_size"]) // 64
     assert bench.read_traffic(n, pmc.get("workload", "c2"))["hbm_bytes_per_launch"] == pmc["hbm_bytes_per_launch"]
-    assert bench.read_traffic(n // 2, "c2") is None and bench.read_traffic(n, "c3") is None
+    assert bench.read_traffic(n // 2, "c2") is None and bench.read_traffic(n // 2, "c3") is None
+    c3p = os.path.join(bench.ROOT, "profiles", "pmc_traffic_c3.json")          # (C3 has its own files since round 5)
+    if os.path.isfile(c3p):
+        with open(c3p) as fh:
+            c3 = json.load(fh)
+        assert c3["workload"] == "c3" and bench.read_traffic(int(c3["grid_size"]) // 64, "c3")["hbm_bytes_per_launch"] == c3["hbm_bytes_per_launch"]
+        assert bench.read_traffic(int(c3["grid_size"]) // 64, "c2") is None or pmc["grid_size"] == c3["grid_size"]
 
 
 def test_counter_passes_are_tied_to_the_build(monkeypatch, capsys, tmp_path):
