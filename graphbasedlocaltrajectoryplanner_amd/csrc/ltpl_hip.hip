@@ -1345,6 +1345,13 @@ __device__ __forceinline__ double fast_div(double a, double b)
     return a * r;
 }
 
+// Issue priority of the velocity kernels' waves (s_setprio 0 .. 3) inside a SIMD they share with path waves. EXPERIMENT (round 5, -DLTPL_VEL_PRIO=<n>):
+// a velocity wave blocks the slot of a fourth path wave for as long as it lives; with a higher priority it issues whenever it is ready and
+// lives shorter. Default 0 = off (the A/B is in DESIGN.md section 9).
+#ifndef LTPL_VEL_PRIO
+#define LTPL_VEL_PRIO 0
+#endif
+#define LTPL_VEL_SETPRIO() do { if (LTPL_VEL_PRIO > 0) __builtin_amdgcn_s_setprio(LTPL_VEL_PRIO); } while (0)
 #define LCH 8      // rows per register chunk: all loads of a chunk are issued before the chunk's recurrence steps
 #ifndef LCHF
 #define LCHF 16    // forward sweep of lane_fb_profile: one 8-byte (|kappa|, el) load per row -> 16 rows per chunk in 32 registers
@@ -1916,6 +1923,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
                                                   DevTickVelIn vin, DevVelPrep prep, VelPlanes vp, int n_slots, int n_scen,
                                                   int n_blocks0, long long* dbg, DevTickVelOut vout, int emit_generic)
 {
+    LTPL_VEL_SETPRIO();
     __shared__ __align__(16) double le_tbuf[32 * LE_PITCH];        // direct output of the generic jobs (LaneEmit)
     __shared__ int le_cnt[64], le_rhi[64];
     __shared__ unsigned long long le_o[64];
@@ -2045,6 +2053,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
 __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn vin, DevTickVelOut vout, VelPlanes vp, int n_slots,
                                                   int n_scen, int first_block)
 {
+    LTPL_VEL_SETPRIO();
     __shared__ __align__(16) double tbuf[32 * FPITCH];     // 32 jobs at a time: 4.5 KB, so that many blocks fit next to a resident path kernel
     __shared__ int s_slot[64], s_n[64];
     // blocks [0, nbG): generic jobs, [nbG, nbG + nbF): follow jobs; slots without a path were initialised by the path kernel
@@ -2165,6 +2174,7 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
 __global__ __launch_bounds__(64) void k_follow_prep(DevLat lat, DevPathsIn in, DevPathsOut out, DevTickVelIn vin,
                                                     DevVelPrep prep, VelPlanes vp, int n_slots, long long* dbg)
 {
+    LTPL_VEL_SETPRIO();
     const int lane = threadIdx.x, cnt = out.job_cnt[1];
     if ((int)blockIdx.x * 64 >= cnt) return;
     const int drow = blockIdx.x < 64 ? 192 + (int)blockIdx.x : -1;      // LTPL_DEBUG_TIMING: rows 192 .. 255 of the stamp table
@@ -3838,7 +3848,13 @@ try {
     h->last_set = 0;
     if (t->pipeline && !h->no_overlap) {
         // further buffer sets for the software pipeline of ltpl_batch_run
-        for (int i = 0; i < ltpl_handle::VEL_STREAMS; ++i) if (!h->vel_stream[i]) HIP_TRY(h, hipStreamCreateWithFlags(&h->vel_stream[i], hipStreamNonBlocking));
+        for (int i = 0; i < ltpl_handle::VEL_STREAMS; ++i) if (!h->vel_stream[i]) {
+            // LTPL_VEL_STREAM_PRIO=1 (experiment): the velocity streams at the device's highest stream priority (their waves are dispatched
+            // ahead of the path kernel's whenever a slot frees up)
+            static const bool hi = getenv("LTPL_VEL_STREAM_PRIO") && atoi(getenv("LTPL_VEL_STREAM_PRIO")) != 0;
+            if (hi) { int lo_p = 0, hi_p = 0; (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p); HIP_TRY(h, hipStreamCreateWithPriority(&h->vel_stream[i], hipStreamNonBlocking, hi_p)); }
+            else HIP_TRY(h, hipStreamCreateWithFlags(&h->vel_stream[i], hipStreamNonBlocking));
+        }
         {
             const char* ps = getenv("LTPL_PATH_STREAMS");
             h->path_streams = (ps && atoi(ps) == 2) ? 2 : 1;
