@@ -164,7 +164,10 @@ __global__ __launch_bounds__(64) void k_fleet_digest(FleetArgs F, double* out)
     }
 }
 
-__global__ __launch_bounds__(64, 4) void k_fleet_vel_a(FleetArgs F, fleet::FObj ob, fleet::FVelIn vin, fleet::FJobs JA)
+#ifndef LTPL_FLEET_VELA_WAVES
+#define LTPL_FLEET_VELA_WAVES 4       // waves per SIMD the stage-A kernels are compiled for (their register budget): A/B in profiles/r05k_fleet_occ_ab.txt
+#endif
+__global__ __launch_bounds__(64, LTPL_FLEET_VELA_WAVES) void k_fleet_vel_a(FleetArgs F, fleet::FObj ob, fleet::FVelIn vin, fleet::FJobs JA)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
     const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D, F.gg ? F.gg + F.D.gg_stride * (size_t)p : nullptr};
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(64, 4) void k_fleet_vel_a(FleetArgs F, fleet::FObj 
 // ONE kernel -- the scalars are loaded / stored once and a kernel boundary (drain + refill of 8 192 short waves) goes away:
 //   paths_post + vel_a            (behind seam (1))
 //   vel_c | vel_d + paths_pre     (behind the last velocity launch of tick t: the first kernel of tick t + 1)
-__global__ __launch_bounds__(64, 4) void k_fleet_post_vel_a(FleetArgs F, fleet::FPathsOut po, fleet::FObj ob, fleet::FVelIn vin, fleet::FJobs JA)
+__global__ __launch_bounds__(64, LTPL_FLEET_VELA_WAVES) void k_fleet_post_vel_a(FleetArgs F, fleet::FPathsOut po, fleet::FObj ob, fleet::FVelIn vin, fleet::FJobs JA)
 {
     const int p = blockIdx.x; const WaveX x{(int)threadIdx.x};
     const fleet::Block B{F.state + F.D.stride * (size_t)p, F.D, F.gg ? F.gg + F.D.gg_stride * (size_t)p : nullptr};
