@@ -41,6 +41,7 @@
 // ---------------------------------------------------------------------------------------------------------------------
 // device-side views
 // ---------------------------------------------------------------------------------------------------------------------
+#define LTPL_SW_PAD 512      // sentinel entries behind the sweep-order edge tables (DevLat::sw_cost / sw_meta)
 struct DevLat {
     int L, V, E, S, G;
     int mode;
@@ -66,8 +67,8 @@ struct DevLat {
     // nodes, so the LDS atomics of the sweep (ds_min_u64 on the destination's frontier slot) meet at most two lanes per address; in CSC
     // order the ~5 (up to 21) in-edges of a node sit in consecutive lanes and every atomic serialises that many times. A transition's
     // edges occupy the same index range [layer_ebase[l], layer_ebase[l + 1]) in both orders.
-    const double* sw_cost;            // [E + 1] edge cost in sweep order; [E] = +inf (sentinel for the lanes beyond a transition)
-    const unsigned* sw_meta;          // [E + 1] in-edge rank | source node << 8 | destination node << 16, sweep order; [E] = 0 (the low half
+    const double* sw_cost;            // [E + 1 + LTPL_SW_PAD] edge cost in sweep order; [E] = +inf (sentinel for the lanes beyond a transition)
+    const unsigned* sw_meta;          // [same] in-edge rank | source node << 8 | destination node << 16, sweep order; [E] = 0 (the low half
                                       //         is the election key among equal candidates: the reference settles them by source node)
     const int* sw2csc;                // [E]     CSC edge id of sweep position p
     const int* csc2sw;                // [E]     sweep position of CSC edge e
@@ -2784,15 +2785,17 @@ try {
                 return dst8[(size_t)a] < dst8[(size_t)b];
             });
         }
-        std::vector<double> swc((size_t)L.E + 1);
-        std::vector<unsigned> swm((size_t)L.E + 1, 0u);
+        // (LTPL_SW_PAD sentinel entries behind the last edge: the sweep's prefetch reads whole 64-edge chunks from a transition's first edge
+        //  on and replaces what lies beyond the transition by the sentinel in registers -- behind the LAST transition it reads these)
+        std::vector<double> swc((size_t)L.E + 1 + LTPL_SW_PAD, (double)INFINITY);
+        std::vector<unsigned> swm((size_t)L.E + 1 + LTPL_SW_PAD, 0u);
         for (int p = 0; p < L.E; ++p) {
             const int e = h->sw2csc_host[(size_t)p];
             csc2sw[(size_t)e] = p; swc[(size_t)p] = d->edge_cost[e];
             swm[(size_t)p] = (unsigned)rank8[(size_t)e] | ((unsigned)src8[(size_t)e] << 8) | ((unsigned)dst8[(size_t)e] << 16);
         }
         swc[(size_t)L.E] = INFINITY;
-        UP(sw_cost, swc.data(), L.E + 1); UP(sw_meta, swm.data(), L.E + 1);
+        UP(sw_cost, swc.data(), L.E + 1 + LTPL_SW_PAD); UP(sw_meta, swm.data(), L.E + 1 + LTPL_SW_PAD);
         UP(sw2csc, h->sw2csc_host.data(), L.E); UP(csc2sw, csc2sw.data(), L.E);
         if (d->normvec_x && d->normvec_y && d->width_right && d->width_left) {
             // ObjectListInterface.py:71-72 and check_inside_bounds.py:27 (same operations, no contraction)

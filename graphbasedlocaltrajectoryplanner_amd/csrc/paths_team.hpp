@@ -100,6 +100,22 @@ struct TeamLds {                 // dynamic-LDS plan (byte offsets), computed on
 #define LTPL_POISON_ON(lp) false
 #endif
 
+// lane < n as a predicate from a SCALAR lane mask (n uniform): no vector compare, the select reads the mask from a scalar register pair
+__device__ __forceinline__ bool lane_mask_below(int n)
+{
+    const unsigned long long m = n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << (n & 63)) - 1ull));
+    return __builtin_amdgcn_inverse_ballot_w64(m);
+}
+// a value every lane holds alike, moved to scalar registers
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ int4 uniform_i4(const int4 v)
+{
+    return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z),
+                     __builtin_amdgcn_readfirstlane(v.w));
+}
 __device__ __forceinline__ double readlane_f64(double v, int src_lane)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
@@ -866,7 +882,10 @@ struct LayerArgs {
 // issued together with the read-back of layer j's election words instead of at the top of layer j + 1: one LDS round trip and one wait less
 // per layer. Valid when the node step of layer j cannot remove a node (no zone node in the planning range; planning_range / default alone).
 // pre_mode bit 0: `cpre` holds this layer's source distances; bit 1: fill `cpre` for the next layer (ne_next = its edge count).
-template <class P, int NW, int CH, unsigned ACT>
+// NCHK (round 5): 0 = the number of chunks that hold edges is tested at run time at every site (uniform branches); 1 .. CH = exactly the first
+// NCHK chunks hold edges (NCHK < CH: and the transition has no tail) -- the layer loop picks the instance per layer with ONE switch, the body
+// carries no chunk tests, and only the LAST chunk can hold lanes beyond the transition.
+template <class P, int NW, int CH, unsigned ACT, int NCHK = 0>
 __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, const TeamLds& lp, unsigned char* smem,
                                            const LayerArgs& A, const EdgeRegs (&er)[CH], const unsigned blk,
                                            int wave, int lane, double (&cpre)[CH], int pre_mode, const EdgeRegs (&en)[CH], int ne_next)
@@ -880,6 +899,16 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
     unsigned* widx_all = reinterpret_cast<unsigned*>(smem + P::off_widx(lp));
     const int kpad = A.kpad, tid = wave * 64 + lane;
     constexpr int NT = NW * 64;
+    // chunks of the register image that hold edges of this transition (uniform; an integer in a scalar register: as a boolean per site the
+    // compiler carried lane masks from block to block and inverted them through a vector register)
+    const int nch = NCHK > 0 ? NCHK : pin_sgpr((A.ne + NT - 1) / NT);
+    // (run-time form: tested through a fresh copy at every site -- one shared boolean crosses basic blocks as a lane mask and is inverted through
+    //  a vector register)
+    auto absent = [&](int ci) {
+        if constexpr (NCHK > 0) return ci >= NCHK;
+        else return ci >= LTPL_CH_ALWAYS && ci >= pin_sgpr(nch);
+    };
+    const bool any_blk = __ballot(blk != 0u) != 0ull;
     int poff[NFILT], coff[NFILT];
 #pragma unroll
     for (int f = 0; f < NFILT; ++f) {
@@ -894,7 +923,10 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
     }
     team_sync<NW>();
     // the first tail edges of the transition, requested now (P::tail_pf), consumed by tail_edges below
-    const bool has_tail = A.ne > CH * NT;
+    // (a scalar test the compiler cannot fold into the tail loop's per-lane entry condition: folded, every layer paid the lane compare and the
+    //  address arithmetic of a loop that 1 transition in 20 enters)
+    auto has_tail_f = [&]() { if constexpr (NCHK > 0 && NCHK < CH) return false; else return pin_sgpr(A.ne) > CH * NT; };
+#define has_tail has_tail_f()
     EdgeRegs tl; tl.c = INFINITY; tl.meta = 0u;
     if constexpr (P::tail_pf) {
         if (has_tail) { const int ei = CH * NT + tid; const int e = ei < A.ne ? A.eb + ei : K.E; tl.c = at(K.sw_cost, e); tl.meta = at(K.sw_meta, e); }
@@ -911,7 +943,7 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
     double cand[CH][NA];
 #pragma unroll
     for (int ci = 0; ci < CH; ++ci) {
-        if (ci >= LTPL_CH_ALWAYS && (ci * NW) * 64 >= A.ne) continue;            // uniform: no edges in this chunk
+        if (absent(ci)) continue;            // uniform: no edges in this chunk
         const int src = sw_src(er[ci].meta);
 #ifdef LTPL_PIPE1
         if constexpr (NA == 1 && NW == 1) { if (pre_mode & 1) { cand[ci][0] = cpre[ci]; continue; } }
@@ -921,11 +953,20 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
     }
 #pragma unroll
     for (int ci = 0; ci < CH; ++ci) {
-        if (ci >= LTPL_CH_ALWAYS && (ci * NW) * 64 >= A.ne) continue;
+        if (absent(ci)) continue;
         const int dst = sw_dst(er[ci].meta);
+#ifdef LTPL_PREFETCH_CLAMP
         const double c_pr = er[ci].c;                                                  // planning_range: every edge
         // other filters: unblocked edges (bit ci of `blk`: this lane's edge of chunk ci is blocked)
         const double c_np = ((ACT & ~(1u << F_PR)) && ((blk >> ci) & 1u)) ? INFINITY : c_pr;
+#else
+        // planning_range: every edge OF THE TRANSITION -- the lanes of the chunk beyond it hold whatever followed in the table (prefetch)
+        // (with NCHK only the last chunk can; one vector compare against the uniform count -- as a scalar lane mask it was eight scalar instructions)
+        const double c_pr = (NCHK > 0 && ci < NCHK - 1) || lane < A.ne - (ci * NW + wave) * 64 ? er[ci].c : (double)INFINITY;
+        // other filters: unblocked edges (bit ci of `blk`: this lane's edge of chunk ci is blocked; most transitions hold none -- uniform skip)
+        double c_np = c_pr;
+        if ((ACT & ~(1u << F_PR)) && any_blk) c_np = ((blk >> ci) & 1u) ? (double)INFINITY : c_pr;
+#endif
 #pragma unroll
         for (int f = 0; f < NFILT; ++f) {
             if (!((ACT >> f) & 1u)) continue;
@@ -939,6 +980,9 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
     // transitions with more edges than the register image: the rest straight from global memory (rare, not prefetched);
     // ROUND = 0: atomic min of the candidate sums, 1: election among the edges that attain it, 2 / 3: exact tie-break
     auto tail_edges = [&](int ROUND) {
+        // (keeps the block behind its scalar branch: nothing of the loop is hoisted in front of `has_tail`, and no lane constant of it --
+        //  (tid + CH * NT - e_base) was one -- is computed in front of the sweeps, parked in scratch and fetched here)
+        const int e_base_t = pin_sgpr(__builtin_amdgcn_readfirstlane(sc.e_base));
         double* dumin = reinterpret_cast<double*>(smem + P::off_dumin(lp));
         for (int ei = CH * NT + tid; ei < A.ne; ei += NT) {
             const int e = A.eb + ei;
@@ -947,7 +991,7 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
                                                                                                 //  re-read them -- cache hits now -- instead of holding three registers across the election)
             else { c = at(K.sw_cost, e); meta = at(K.sw_meta, e); }
             const int src = sw_src(meta), dst = sw_dst(meta);
-            int el_ = e - sc.e_base; if (el_ < 0) el_ += K.E;
+            int el_ = e - e_base_t; if (el_ < 0) el_ += K.E;
             const bool unbl = !((blocked_bits[el_ >> 5] >> (el_ & 31)) & 1u);
             if (A.fs >= 0 && src == A.fs && dst == A.fd) c *= A.fac;
             const unsigned key = elect_key(meta);
@@ -974,14 +1018,14 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
         double got[CH][NA];
 #pragma unroll
         for (int ci = 0; ci < CH; ++ci) {
-            if (ci >= LTPL_CH_ALWAYS && (ci * NW) * 64 >= A.ne) continue;
+            if (absent(ci)) continue;
             const int dst = sw_dst(er[ci].meta);
 #pragma unroll
             for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) got[ci][SL[f]] = dist[coff[f] + dst];
         }
 #pragma unroll
         for (int ci = 0; ci < CH; ++ci) {
-            if (ci >= LTPL_CH_ALWAYS && (ci * NW) * 64 >= A.ne) continue;
+            if (absent(ci)) continue;
             const int dst = sw_dst(er[ci].meta);
             const unsigned key = elect_key(er[ci].meta);
 #pragma unroll
@@ -1035,7 +1079,7 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
             for (int round = 0; round < 2; ++round) {
 #pragma unroll
                 for (int ci = 0; ci < CH; ++ci) {
-                    if (ci >= LTPL_CH_ALWAYS && (ci * NW) * 64 >= A.ne) continue;
+                    if (absent(ci)) continue;
                     const int src = sw_src(er[ci].meta), dst = sw_dst(er[ci].meta);
                     const unsigned key = elect_key(er[ci].meta);
 #pragma unroll
@@ -1075,6 +1119,7 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
         if (lane == 0) best[f * A.hm + A.j] = any ? -2 : -1;           // the goal node of the last layer is evaluated after the sweep
     }
 }
+#undef has_tail
 
 // ---------------------------------------------------------------------------------------------------------------------
 // the team body. Returns, for every wave, the result of the LAST primitive the wave assembled (NW = 4: wave a <-> slot a)
@@ -1574,13 +1619,17 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
             if (lane == 0) { ts.start_ok[f] = ok; best[f * hm] = -1; }
         }
         EdgeRegs er[CH], en[CH];
+        int4 lyc = make_int4(0, 0, 0, 0), lyn = make_int4(0, 0, 0, 0);     // table rows lay[j] of the current / the prefetched transition (uniform)
         // blocked flags of the lane's edges, bit ci = chunk ci, for the current (bm) and the next (bn) transition. One VECTOR register
         // each: as ballots (one scalar pair per chunk and buffer) they were twelve scalar registers that the compiler kept spilling
         // and reloading inside the layer loop.
         unsigned bm = 0u, bn = 0u;
         int ne_pref = 0;                                          // edges of the transition the last prefetch loaded (LTPL_PIPE1)
+#ifdef LTPL_PREFETCH_CLAMP
+        // (rounds 2-4: every lane forms its own edge index, lanes beyond the transition are redirected to the sentinel edge E)
         auto prefetch = [&](int j, EdgeRegs (&dr)[CH], unsigned& db) {
             const int4 ly = lay[j];
+            lyn = ly;
             ne_pref = ly.w - ly.z;
             unsigned bw[CH]; int sh[CH];
             const bool look = j > 63 || ((touched >> j) & 1ull);  // uniform: can this transition hold a blocked edge at all?
@@ -1589,8 +1638,6 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
                 bw[ci] = 0u; sh[ci] = 32;
                 if (ci >= LTPL_CH_ALWAYS && ly.z + ci * SNT >= ly.w) continue;   // uniform: chunk 0 is always loaded, the rest on demand
                 const int e = ly.z + (ci * SWN + swave) * 64 + lane;
-                // lanes beyond the transition load the SENTINEL edge (index E: cost +inf, source = destination = node 0): a fixed
-                // number of loads in flight lets the compiler wait precisely, and the sweep needs no "is this lane an edge" select
                 const int ec = e < ly.w ? e : swk.E;
                 dr[ci].c = at(swk.sw_cost, ec); dr[ci].meta = at(swk.sw_meta, ec);
                 if (look) {
@@ -1604,8 +1651,50 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
                 for (int ci = 0; ci < CH; ++ci) db |= (sh[ci] < 32 ? ((bw[ci] >> (sh[ci] & 31)) & 1u) : 0u) << ci;
             }
         };
+#else
+        // Round 5: the loads of a chunk are addressed as (uniform pointer to the chunk's first edge) + (lane * element size) -- no per-lane
+        // index, no redirection: a chunk is read whole, and what lies beyond the transition (the next transition's edges, or the sentinel
+        // entries behind the tables: LTPL_SW_PAD) is replaced by the sentinel cost +inf where the layer step CONSUMES the chunk (team_layer,
+        // `lane_mask_below`: a select on a scalar lane mask, no compare; at load time it would wait for the load). The edge word of such a
+        // lane is arbitrary but addresses nodes of the tables: with the candidate +inf it never takes part. The blocked flags are only
+        // formed for a transition that can hold a blocked edge (`touched`), in a block of their own behind the loads.
+        auto prefetch = [&](int j, EdgeRegs (&dr)[CH], unsigned& db) {
+            const int4 ly = uniform_i4(lay[j]);
+            lyn = ly;                                             // (the layer loop takes the next layer's table row from here: LTPL_LY_CARRY)
+            ne_pref = ly.w - ly.z;
+            // (the lane offsets pass through an empty asm statement HERE: hoisted out of the layer loop as 64-bit values they cost two
+            //  register pairs and a 64-bit vector add per load instead of the scalar-base + 32-bit-lane-offset addressing; the chunks of a
+            //  transition differ by an immediate offset)
+            const int e0 = __builtin_amdgcn_readfirstlane(ly.z + swave * 64);     // uniform: first edge of this wave's first chunk
+            const char* pc = reinterpret_cast<const char*>(pin_sgpr(swk.sw_cost + e0));
+            const char* pm = reinterpret_cast<const char*>(pin_sgpr(swk.sw_meta + e0));
+            unsigned o8 = (unsigned)lane * 8u, o4 = (unsigned)lane * 4u;
+            asm volatile("" : "+v"(o8), "+v"(o4));
+#pragma unroll
+            for (int ci = 0; ci < CH; ++ci) {
+                if (ci >= LTPL_CH_ALWAYS && ly.z + ci * SNT >= ly.w) continue;    // uniform: chunk 0 is always loaded, the rest on demand
+                dr[ci].c = *reinterpret_cast<const double*>(pc + o8 + ci * SNT * 8);
+                dr[ci].meta = *reinterpret_cast<const unsigned*>(pm + o4 + ci * SNT * 4);
+            }
+            db = 0u;
+            if (j > 63 || ((touched >> j) & 1ull)) {              // uniform: can this transition hold a blocked edge at all?
+                unsigned bw[CH]; int el[CH];
+#pragma unroll
+                for (int ci = 0; ci < CH; ++ci) {                // (all reads first, one wait; lanes beyond the transition read its last edge's word)
+                    bw[ci] = 0u; el[ci] = ly.w;
+                    if (ci >= LTPL_CH_ALWAYS && ly.z + ci * SNT >= ly.w) continue;
+                    el[ci] = ly.z + (ci * SWN + swave) * 64 + lane;
+                    int el_ = (el[ci] < ly.w ? el[ci] : ly.w - 1) - sc.e_base; if (el_ < 0) el_ += swk.E;
+                    bw[ci] = blocked_bits[el_ >> 5] >> (el_ & 31);
+                }
+#pragma unroll
+                for (int ci = 0; ci < CH; ++ci) db |= (el[ci] < ly.w ? (bw[ci] & 1u) : 0u) << ci;
+            }
+        };
+#endif
         team_sync<SWN>();
         prefetch(1, er, bm);
+        lyc = lyn;
         // `planning_range` (every edge) and `default` (unblocked edges) only differ from the first transition on that holds a
         // blocked edge: in front of it the planning_range sweep is not run, `default`'s frontier, parents and reachability are
         // copied when the sweeps part (one-wave batch form; a transition with edges beyond the register image parts conservatively)
@@ -1631,9 +1720,12 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
             A.j = j; A.b = b; A.v0 = ly.x; A.Kb = ly.y & 0xffff; A.ne = ly.w - ly.z; A.eb = ly.z; A.kpad = kpad; A.hm = hm; A.cur = j & 1; A.prv = (j - 1) & 1;
             A.H = H; A.cl_hit = (b == t_cl) ? 1 : 0; A.cn = t_cn;
             A.fs = -1; A.fd = -1; A.fac = 1.0;
-            if (j <= fac_jmax) {
+            if (j <= fac_jmax) {                                  // (first layers only; the values are uniform: scalar registers, scalar tests)
                 for (int i = 0; i < sc.n_fac; ++i)
-                    if (ts.fac_j[i] == j) { A.fs = ts.fac_src[i]; A.fd = ts.fac_dst[i]; A.fac = ts.fac[i]; break; }
+                    if (__builtin_amdgcn_readfirstlane(ts.fac_j[i]) == j) {
+                        A.fs = __builtin_amdgcn_readfirstlane(ts.fac_src[i]); A.fd = __builtin_amdgcn_readfirstlane(ts.fac_dst[i]);
+                        A.fac = uniform_f64(ts.fac[i]); break;
+                    }
             }
             A.from_def = from_def;
             if (A.fs >= 0) {
@@ -1647,7 +1739,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
         auto rotate = [&]() {
 #pragma unroll
             for (int ci = 0; ci < CH; ++ci) er[ci] = en[ci];
-            bm = bn;
+            bm = bn; lyc = lyn;
             team_sync<SWN>();
         };
         // layers j0 .. j1 for the compile-time filter set of `act_tag`; stops in front of the first layer that needs something else:
@@ -1663,7 +1755,11 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
             for (int ci = 0; ci < CH; ++ci) cpre[ci] = INFINITY;
             constexpr bool one_filter = ACT == (1u << F_DEF) || ACT == (1u << F_PR);
             for (; j <= j1; ++j) {
+#ifdef LTPL_NO_LY_CARRY
                 const int4 ly = lay[j];
+#else
+                const int4 ly = lyc;                               // = lay[j], read with the prefetch of this transition one layer ago
+#endif
                 if (riding) { if (__ballot(bm != 0u) != 0ull || ly.w - ly.z > CH * SNT) { why = 1; break; } }
                 if constexpr (!P::fixed) { if ((ly.y & 0xffff) > 64) { why = 2; break; } }
                 const LayerArgs A = layer_args(j, ly, from_def && j == j0, er);
@@ -1674,7 +1770,20 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
 #else
                 const bool make_pre = false;
 #endif
-                team_layer<P, SWN, CH, ACT>(swk, sc, lp, smem, A, er, bm, swave, lane, cpre, (have_pre ? 1 : 0) | (make_pre ? 2 : 0), en, ne_pref);
+                const int pm_ = (have_pre ? 1 : 0) | (make_pre ? 2 : 0);
+#ifdef LTPL_NO_NCHK
+                team_layer<P, SWN, CH, ACT>(swk, sc, lp, smem, A, er, bm, swave, lane, cpre, pm_, en, ne_pref);
+#else
+                if constexpr (SWN == 1 && CH == 3) {               // one-wave batch form: the layer body specialised for 1 / 2 / 3 chunks of edges
+                    if (A.ne <= 64) team_layer<P, SWN, CH, ACT, 1>(swk, sc, lp, smem, A, er, bm, swave, lane, cpre, pm_, en, ne_pref);
+#ifdef LTPL_NCHK_ONE
+                    else team_layer<P, SWN, CH, ACT, 0>(swk, sc, lp, smem, A, er, bm, swave, lane, cpre, pm_, en, ne_pref);
+#else
+                    else if (A.ne <= 128) team_layer<P, SWN, CH, ACT, 2>(swk, sc, lp, smem, A, er, bm, swave, lane, cpre, pm_, en, ne_pref);
+                    else team_layer<P, SWN, CH, ACT, 3>(swk, sc, lp, smem, A, er, bm, swave, lane, cpre, pm_, en, ne_pref);
+#endif
+                } else team_layer<P, SWN, CH, ACT>(swk, sc, lp, smem, A, er, bm, swave, lane, cpre, pm_, en, ne_pref);
+#endif
                 have_pre = make_pre;
                 rotate();
             }
