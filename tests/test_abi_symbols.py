@@ -57,10 +57,14 @@ def test_path_kernels_have_no_register_spills():
     paths = {k: v for k, v in res.items() if "k_paths" in k or "k_tick" in k}
     assert len(paths) >= 3                                  # runtime plan (1 and 4 waves) + compile-time plan classes
     for name, r in paths.items():
-        # at most a value parked in scratch across the once-per-path assembly; check_no_register_spills verifies on the ISA that no
-        # scratch instruction sits in the sweeps, and that the fixed-plan batch kernels keep 4 waves per SIMD
-        assert r["vgpr_spill_count"] <= 4 and r["private_segment_fixed_size"] <= 16, name
+        # at most a few values parked in scratch across the sweeps; check_no_register_spills verifies on the ISA that no scratch
+        # instruction sits in a layer loop of the sweeps, and that the fixed-plan batch kernels keep 4 waves per SIMD
+        assert r["vgpr_spill_count"] <= g.PARKED_VGPRS_MAX and r["private_segment_fixed_size"] <= g.PARKED_BYTES_MAX, name
+        if "k_pathsILi1E6PlanFx" not in name:
+            assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, name
         if "k_pathsILi1E6PlanFx" in name:
             assert r["vgpr_count"] <= 128, name
     assert all(r["vgpr_spill_count"] == 0 for k, r in res.items() if k not in paths)
     g.check_no_register_spills(g.HIP_LIB)
+    loops = g.layer_loop_ops(g.HIP_LIB, [k for k in paths if "k_pathsILi1E6PlanFx" in k])
+    assert loops and all(m["loops"] >= 1 and m["scratch"] == 0 for m in loops.values()), loops
