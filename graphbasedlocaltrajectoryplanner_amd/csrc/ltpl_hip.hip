@@ -82,7 +82,15 @@ struct DevLat {
     // closest-layer grid (layer_grid.hpp): per cell the <= 2 intervals of reference-line layers that can be closest to a point of the cell
     // (first layer, length, first layer, length; length -1 = scan all layers); null: phase 1 scans all layers (LTPL_NO_LAYER_GRID=1)
     const int4* lgrid; double lg_x0, lg_y0, lg_inv; int lg_nx, lg_ny;
+    // PATH ASSEMBLY RECORDS (round 5): what the assembly of a path gathers per node / per edge, as ONE record each, so that the chain of
+    // dependent global round trips behind the backtrack is node record -> edge record (it was layer_off -> in_ptr -> edge_src8 ->
+    // samp_ptr -> sx / sy / ssc: five round trips of ~600 cycles per path on a wave that has nothing else to do meanwhile)
+    const int4* node_rec;             // [V] first in-edge (CSC id), then the source nodes of the node's first 12 in-edges as bytes (0xff = none)
+    const double* edge_rec;           // [E][LTPL_EDGE_REC] (first sample | #samples << 32 as bit pattern, edge length, x, y of the first sample,
+                                      //     x, y of the last sample, sin, cos of the first sample's heading, sin, cos of the last sample's)
 };
+#define LTPL_EDGE_REC 10
+#define LTPL_NODE_REC_SRC 12
 
 struct DevPathsIn {
     int n_scen, n_w_last;
@@ -2769,6 +2777,33 @@ try {
         for (int v = 0; v < L.V; ++v)
             for (int e = d->in_ptr[v]; e < d->in_ptr[v + 1]; ++e) rank8[(size_t)e] = (unsigned char)(e - d->in_ptr[v]);
         UP(edge_rank8, rank8.data(), L.E);
+        {
+            // path assembly records (see DevLat)
+            std::vector<int> nrec((size_t)L.V * 4);
+            for (int v = 0; v < L.V; ++v) {
+                const int e0 = d->in_ptr[v], e1 = d->in_ptr[v + 1];
+                unsigned char b[LTPL_NODE_REC_SRC];
+                for (int k = 0; k < LTPL_NODE_REC_SRC; ++k) b[k] = e0 + k < e1 ? src8[(size_t)(e0 + k)] : (unsigned char)0xff;
+                nrec[(size_t)v * 4] = e0;
+                memcpy(&nrec[(size_t)v * 4 + 1], b, LTPL_NODE_REC_SRC);
+            }
+            const int4* nr = nullptr;
+            if ((rc = upload(h, reinterpret_cast<const int4*>(nrec.data()), (size_t)L.V, &nr)) != LTPL_OK) return fail(rc);
+            L.node_rec = nr;
+            std::vector<double> erec((size_t)L.E * LTPL_EDGE_REC, 0.0);
+            for (int e = 0; e < L.E; ++e) {
+                const int k0 = d->samp_ptr[e], k1 = d->samp_ptr[e + 1];
+                double* r = &erec[(size_t)e * LTPL_EDGE_REC];
+                const unsigned long long w = (unsigned long long)(unsigned)k0 | ((unsigned long long)(unsigned)(k1 - k0) << 32);
+                memcpy(&r[0], &w, 8);
+                r[1] = d->edge_len[e];
+                if (k1 > k0) {
+                    r[2] = d->samp_x[k0]; r[3] = d->samp_y[k0]; r[4] = d->samp_x[k1 - 1]; r[5] = d->samp_y[k1 - 1];
+                    r[6] = sin(d->samp_psi[k0]); r[7] = cos(d->samp_psi[k0]); r[8] = sin(d->samp_psi[k1 - 1]); r[9] = cos(d->samp_psi[k1 - 1]);
+                }
+            }
+            UP(edge_rec, erec.data(), (size_t)L.E * LTPL_EDGE_REC);
+        }
         std::vector<int> ldeg((size_t)L.L, 0);
         for (int l = 0; l < L.L; ++l)
             for (int v = d->layer_node_off[l]; v < d->layer_node_off[l + 1]; ++v)

@@ -252,6 +252,17 @@ struct PlanFx {
 #undef LTPL_PLAN_FIELD
 };
 
+// Where the rows of team_backtrack_all live: one-wave teams with compile-time plans keep the path scratch ON the frontier / election arrays
+// (dead during path assembly); the tie-break array behind the scratch stays free -- LTPL_MAX_ACTIONS rows of LTPL_BT_PITCH bytes go there.
+#define LTPL_BT_PITCH 64
+template <class P, int NW, bool F = P::fixed> struct BtPlace { static constexpr int off = -1; };
+template <class P, int NW> struct BtPlace<P, NW, true> {
+    static constexpr bool ok = NW == 1 && P::c_n_path_bufs == 1 && !P::par_global && P::par_entry == 1 && P::c_hmax <= LTPL_BT_PITCH &&
+                               P::c_off_dumin >= P::c_off_path + P::c_path_stride &&
+                               P::c_off_dumin + LTPL_MAX_ACTIONS * LTPL_BT_PITCH <= P::c_end_elect;
+    static constexpr int off = ok ? P::c_off_dumin : -1;
+};
+
 // runtime plan with the parent tables in a per-scenario slab of global memory (L2 resident): planning horizons whose
 // tables do not fit in LDS next to the path scratch (e.g. 600 layers at 0.5 m layer spacing)
 struct PlanRtG : PlanRt { static constexpr bool par_global = true; };
@@ -490,13 +501,19 @@ __device__ LTPL_RESWEEP_ATTR void team_resweep(const DevLat& lat, const DevPaths
 //      in-edge ranks -> pedge[0 .. J-1]; writes out.n_nodes / n_ties of the slot
 template <class P>
 __device__ __forceinline__ void team_backtrack(const DevPathsOut& out, const TeamLds& lp, unsigned char* smem, int slot, int f, int J,
-                                               int jcl, bool share_prefix, int lane, unsigned char* pw)
+                                               int jcl, bool share_prefix, int lane, unsigned char* pw, const unsigned char* bt_row)
 {
     const int hm = P::hmax(lp);
     const unsigned char* par = par_base<P>(lp, smem);
     const int* best = reinterpret_cast<const int*>(smem + P::off_best(lp));
     double* kx = reinterpret_cast<double*>(pw);
     int* pedge = reinterpret_cast<int*>(kx + 7 * hm); int* pidx = pedge + hm + 1;
+    if (bt_row) {
+        // the nodes of this path were chased together with those of the scenario's other paths (team_backtrack_all): copy the row
+        for (int j = lane; j <= J; j += 64) pidx[j] = bt_row[j];
+        wave_sync_lds();
+        return;
+    }
     bool staged = false;
     if constexpr (P::par_global) {
         // Parent tables in global memory: a lane-0 chase would pay one global round trip per layer. Blocks of 64 table rows
@@ -563,6 +580,38 @@ __device__ __forceinline__ void team_backtrack(const DevPathsOut& out, const Tea
     wave_sync_lds();
 }
 
+// ---- the backtracks of ALL paths of a scenario at once (one-wave batch form, one-byte parents in LDS): lane a chases the parents of action
+//      slot a. The chase is a chain of J dependent LDS round trips with a handful of instructions between them; per path it was the longest
+//      stretch of the assembly in which the wave only waits (~2.5 k cycles), and a scenario has 1.8 paths on average -- now once per scenario.
+//      Rows: bt[a * LTPL_BT_PITCH + j] = node of layer j; n_nodes / n_ties of the slots are written here.
+template <class P>
+__device__ __forceinline__ void team_backtrack_all(const DevPathsOut& out, const TeamLds& lp, unsigned char* smem, int s, int my_pk, int my_f,
+                                                   bool my_sp, int jcl, int lane, int n_act, unsigned char* bt)
+{
+    const int hm = P::hmax(lp), kpad = P::kpad(lp);
+    const unsigned char* par = par_base<P>(lp, smem);
+    const int* best = reinterpret_cast<const int*>(smem + P::off_best(lp));
+    if (lane < n_act && (my_pk & 1)) {
+        const int J = my_pk >> 8;
+        const int bj = best[my_f * hm + J];
+        int ties = (bj >> 30) & 1;
+        int n = bj & 0xffff;
+        unsigned char* row = bt + lane * LTPL_BT_PITCH;
+        for (int j = J; j >= 1; --j) {
+            const int pf = (my_sp && j < jcl) ? F_DEF : my_f;
+            const unsigned pr = par[((size_t)par_tab(pf) * hm + j) * kpad + n];
+            row[j] = (unsigned char)n;
+            ties += pr >> 7;
+            n = (int)(pr & 0x7fu);
+        }
+        row[0] = (unsigned char)n;
+        const int slot = s * LTPL_MAX_ACTIONS + lane;
+        out.n_nodes[slot] = J + 1;
+        out.n_ties[slot] = ties;
+    }
+    wave_sync_lds();
+}
+
 // ---- everything behind the backtrack: edge look-up, gather, spline, re-sampling (main_online_path_gen.py:260-328). Needs the path's
 //      nodes in pidx[0 .. N] (and, with `by_rank`, the in-edge ranks in pedge[0 .. N-1]) and nothing else of the team's LDS. (Round 3
 //      ran it as a kernel of its own over the slots of a batch -- one wave per action slot, 78 VGPRs, the one-wave path kernel ending
@@ -573,7 +622,7 @@ template <bool RL = false>
 __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevPathsIn& in_, const DevPathsOut& out_, int s, int sl, int flags,
                                                   int hm, bool by_rank, int slot, int N, int lane, unsigned char* pw, long long* adbg,
                                                   bool skip_pp, double* vel_kappa, double* vel_len, double* vel_x, double* vel_y, int vtile,
-                                                  const double* ts_psi)
+                                                  const double* ts_psi, const int4* lay)
 {
     // (RL: argument structs in the kernarg segment, re-read at every stage of the assembly -- see karg_reload)
     const DevLat* latp = LTPL_KARG_LAT(&lat_); const DevPathsIn* inp = LTPL_KARG_IN(&in_); const DevPathsOut* outp = LTPL_KARG_OUT(&out_);
@@ -596,6 +645,7 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
             int b = sl + i; if (b >= L) b -= L;
             if (by_rank) e = at(lat.in_ptr, lat.layer_off[b] + node) + pedge[i - 1];
             else {
+#ifdef LTPL_NO_ASM_RECORDS
                 // the table only holds the source NODE: look the in-edge (source -> node) up in the node's CSC segment
                 // (sorted by source): its first 16 sources in two (unaligned) 8-byte loads, longer segments serially
                 const int src = pidx[i - 1], gid = at(lat.layer_off, b) + node;
@@ -611,6 +661,26 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
                 int k = z0 ? (__ffsll((long long)z0) - 1) >> 3 : (z1 ? 8 + ((__ffsll((long long)z1) - 1) >> 3) : 16);
                 if (k >= 16) { k = 16; while (e + k < e1 - 1 && (int)at(lat.edge_src8, e + k) != src) ++k; }
                 e += k;
+#else
+                // the table only holds the source NODE: look the in-edge (source -> node) up in the node's record (DevLat::node_rec: first
+                // in-edge + the sources of the first 12 in-edges, sorted by source, ONE 16-byte load; the node's global id from the per-layer
+                // table in LDS); longer segments serially
+                const int src = pidx[i - 1], gid = lay[i].x + node;
+                const int4 nr = at(lat.node_rec, gid);
+                e = nr.x;
+                const unsigned pat = 0x01010101u * (unsigned)src;
+                const unsigned x0 = (unsigned)nr.y ^ pat, x1 = (unsigned)nr.z ^ pat, x2 = (unsigned)nr.w ^ pat;
+                // exact zero-byte detector (no false positives from borrows): bytes are < 0x80 or the 0xff padding
+                const unsigned z0 = ~(((x0 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x0 | 0x7f7f7f7fu);
+                const unsigned z1 = ~(((x1 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x1 | 0x7f7f7f7fu);
+                const unsigned z2 = ~(((x2 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x2 | 0x7f7f7f7fu);
+                int k = z0 ? (__ffs((int)z0) - 1) >> 3 : (z1 ? 4 + ((__ffs((int)z1) - 1) >> 3) : (z2 ? 8 + ((__ffs((int)z2) - 1) >> 3) : LTPL_NODE_REC_SRC));
+                if (k >= LTPL_NODE_REC_SRC) {
+                    const int e1 = at(lat.in_ptr, gid + 1);
+                    while (e + k < e1 - 1 && (int)at(lat.edge_src8, e + k) != src) ++k;
+                }
+                e += k;
+#endif
             }
         }
         wave_sync_lds();
@@ -623,6 +693,8 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
     LTPL_KARGS();
     // gather: rows per edge, node row indices, knots, element lengths (:260-297)
     int run = 0;
+    bool seg_dup = true;                                     // (uniform) some segment starts where its predecessor starts: rows -> segments by search
+#ifdef LTPL_NO_ASM_RECORDS
     for (int i0 = 0; i0 < N; i0 += 64) {
         const int i = i0 + lane;
         int take = 0, e = 0, k0 = 0, k1 = 0;
@@ -643,6 +715,37 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
         }
         run += tot;
     }
+#else
+    // Everything of an edge comes from its record (DevLat::edge_rec), requested in ONE round trip: sample range and length, first knot; the
+    // first / last segment also take the last knot and the (sin, cos) of the end headings (spline end slopes; parked in rows 0 and N of the
+    // right-hand sides, unused until the solve). (Before: samp_ptr -> sx / sy / ssc, two dependent round trips.)
+    seg_dup = false;
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        const int i = i0 + lane;
+        int take = 0, k0 = 0, ns = 0;
+        dbl2 r01, r23, r45, r67, r89;
+        r01.x = r01.y = r23.x = r23.y = r45.x = r45.y = r67.x = r67.y = r89.x = r89.y = 0.0;
+        if (i < N) {
+            const double* r = lat.edge_rec + (unsigned)pedge[i] * (unsigned)LTPL_EDGE_REC;
+            r01 = *reinterpret_cast<const dbl2*>(r); r23 = *reinterpret_cast<const dbl2*>(r + 2);
+            if (i == 0) r67 = *reinterpret_cast<const dbl2*>(r + 6);
+            if (i == N - 1) { r45 = *reinterpret_cast<const dbl2*>(r + 4); r89 = *reinterpret_cast<const dbl2*>(r + 8); }
+            const long long w = __double_as_longlong(r01.x);
+            k0 = (int)(unsigned)w; ns = (int)(w >> 32);
+            take = (i == N - 1) ? ns : ns - 1;
+        }
+        seg_dup = seg_dup || __ballot(i < N && take <= 0) != 0ull;
+        int tot; const int off = wave_excl_scan(take, lane, tot);
+        if (i < N) {
+            pidx[i] = run + off;
+            kx[i] = r23.x; ky[i] = r23.y; el[i] = r01.y;
+            pedge[i] = k0;                                   // from here on: first sample of the segment's edge
+            if (i == 0) { mx[0] = r67.x; my[0] = r67.y; }
+            if (i == N - 1) { kx[N] = r45.x; ky[N] = r45.y; pidx[N] = run + off + take - 1; mx[N] = r89.x; my[N] = r89.y; }
+        }
+        run += tot;
+    }
+#endif
     const int n_pts = run;
     wave_sync_lds();
     {
@@ -760,9 +863,29 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
             a_vxy = out.vxy + 2 * (((size_t)(fj >> 6) * nrb * 64 + (fj & 63)) * KE_RB);
         }
     }
+    // Row -> segment (segment i with pidx[i] <= r < pidx[i+1]; last: <=). Round 5: the first rows of segments 1 .. N-1 are marked in a bit
+    // string (LDS, `cpx`: free behind the solve); the segment of row r is the number of marks at or below r -- per block of 64 rows ONE uniform
+    // 8-byte read, a running scalar count and a lane-prefix population count. (It was a binary search over pidx per row: five dependent LDS
+    // round trips per block. Kept for paths with a segment that contributes no row, whose marks would coincide.)
+    unsigned* segw = reinterpret_cast<unsigned*>(cpx);
+    if (((n_pts + 63) >> 6) > hm) seg_dup = true;            // (the bit string has to fit `cpx`: hm * 64 rows)
+    if (!seg_dup) {
+        for (int w = lane; w < ((n_pts + 63) >> 6) * 2; w += 64) segw[w] = 0u;
+        wave_sync_lds();
+        for (int i = 1 + lane; i <= N - 1; i += 64) { const int q = pidx[i]; atomicOr(&segw[q >> 5], 1u << (q & 31)); }
+        wave_sync_lds();
+    }
+    int seg_carry = 0;
     for (int r = lane; r < n_pts; r += 64) {
-        int lo = 0, hi = N;                                // segment i with pidx[i] <= r < pidx[i+1] (last: <=)
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pidx[mid] <= r) lo = mid; else hi = mid; }
+        int lo = 0, hi = N;
+        if (seg_dup) { while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pidx[mid] <= r) lo = mid; else hi = mid; } }
+        else {
+            const uint2 mk = *reinterpret_cast<const uint2*>(segw + ((r - lane) >> 5));             // uniform address: the block's 64 marks
+            const unsigned m0 = __builtin_amdgcn_readfirstlane(mk.x), m1 = __builtin_amdgcn_readfirstlane(mk.y);
+            const unsigned own = lane < 32 ? (m0 >> lane) & 1u : (m1 >> (lane - 32)) & 1u;
+            lo = seg_carry + (int)__builtin_amdgcn_mbcnt_hi(m1, __builtin_amdgcn_mbcnt_lo(m0, 0u)) + (int)own;
+            seg_carry += __builtin_popcount(m0) + __builtin_popcount(m1);
+        }
         const int i = lo, k = r - pidx[i];
         const int n_i = pidx[i + 1] - pidx[i] + 1;
         const double t = (k == n_i - 1) ? 1.0 : (double)k * fast_rcp((double)(n_i - 1));
@@ -809,7 +932,8 @@ template <class P, bool RL = false>
 __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const Scen& sc,
                                   const TeamLds& lp, unsigned char* smem, int a, int f, int J, int name, int reduced,
                                   int jcl, bool share_prefix, int lane, unsigned char* pw,
-                                  double* vel_kappa, double* vel_len, double* vel_x, double* vel_y, int vtile_in, const double* ts_psi)
+                                  double* vel_kappa, double* vel_len, double* vel_x, double* vel_y, int vtile_in, const double* ts_psi,
+                                  const unsigned char* bt_row = nullptr)
 {
     const int hm = P::hmax(lp), s = sc.s;
     const int slot = s * LTPL_MAX_ACTIONS + a;
@@ -828,10 +952,11 @@ __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const De
     }
     long long* const adbg = a == 0 ? lp.dbg : nullptr;        // experiment build: phase stamps 8 .. 13 of the first primitive's assembly
     dbg_stamp(adbg, 8);
-    team_backtrack<P>(out, lp, smem, slot, f, J, jcl, share_prefix, lane, pw);
+    team_backtrack<P>(out, lp, smem, slot, f, J, jcl, share_prefix, lane, pw, bt_row);
     const int end_node = reinterpret_cast<const int*>(reinterpret_cast<double*>(pw) + 7 * hm)[hm + 1 + J];      // pidx[J]
     const int n_pts = team_assemble_rest<RL>(lat, in, out, s, sc.sl, sc.flags, hm, P::par_entry == 2, slot, J, lane, pw, adbg,
-                                         LTPL_ABLATED(lp, 16), vel_kappa, vel_len, vel_x, vel_y, vtile, ts_psi);
+                                         LTPL_ABLATED(lp, 16), vel_kappa, vel_len, vel_x, vel_y, vtile, ts_psi,
+                                         reinterpret_cast<const int4*>(smem + P::off_lay(lp)));
     const int L = lat.L;
     wp.n_pts = n_pts; wp.n_nodes = J + 1;
     { int gl = sc.sl + J; if (gl >= L) gl -= L; wp.goal_layer = gl; }
@@ -1975,6 +2100,20 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
     // ---- phase 6: wave (a mod NW) assembles primitive a --------------------------------------------------------------
     WavePath wp; wp.valid = 0; wp.n_pts = 0; wp.n_nodes = 0; wp.name = LTPL_ACT_NONE; wp.reduced = 0; wp.goal_layer = -1;
     wp.end_node = -1;
+    // one-wave batch form with one-byte parents in LDS: all backtracks of the scenario in one pass (rows in the frontier arrays, which are
+    // free behind the goal evaluation and the re-sweeps)
+    constexpr int BT_OFF = BtPlace<P, NW>::off;              // (-1: this plan has no room / no one-byte parents -- every path chases its own)
+    constexpr bool BT_ALL = BT_OFF >= 0;
+    unsigned char* bt = smem + (BT_ALL ? BT_OFF : 0);
+    if constexpr (BT_ALL) {
+        if (!LTPL_ABLATED(lp, 4)) {
+            int my_pk = 0, my_f = 0;
+#pragma unroll
+            for (int a = 0; a < LTPL_MAX_ACTIONS; ++a) if (lane == a) { my_pk = slot_pk[a]; my_f = filt[a]; }
+            const bool my_sp = share_prefix && (my_f == F_LEFT || my_f == F_RIGHT) && (my_pk >> 8) == H;
+            team_backtrack_all<P>(out, lp, smem, sc.s, my_pk, my_f, my_sp, jcl, lane, n_act, bt);
+        }
+    }
     for (int a = wave; a < n_act; a += NW) {
         wp.name = slot_name(a); wp.reduced = slot_red(a); wp.valid = 0;
         if (!slot_valid(a) || LTPL_ABLATED(lp, 4)) continue;
@@ -1991,7 +2130,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
             }
         }
         wp = team_assemble<P, RL>(lat, in, out, sc, lp, smem, a, filt[a], slot_j(a), slot_name(a), slot_red(a), jcl, sp, lane, pw,
-                               vel_kappa, vel_len, vel_x, vel_y, vtile_in, ts.psi_sc);
+                               vel_kappa, vel_len, vel_x, vel_y, vtile_in, ts.psi_sc, BT_ALL ? bt + a * LTPL_BT_PITCH : nullptr);
     }
     dbg_stamp(lp.dbg, 7);
     return wp;
