@@ -4310,6 +4310,31 @@ try {
 } LTPL_ABI_CATCH(nullptr)
 #endif
 
+#ifdef LTPL_EXPERIMENT
+// experiment build only: heading_atan2 (path re-sampling) for n caller-provided (y, x) pairs (host memory)
+__global__ void k_exp_heading(const double* y, const double* x, double* out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = heading_atan2(y[i], x[i]);
+}
+extern "C" int ltpl_exp_heading_atan2(int32_t device, const double* y, const double* x, double* out, int32_t n)
+try {
+    if (!y || !x || !out || n <= 0) return LTPL_ERR_INVALID_ARG;
+    if (hipSetDevice(device) != hipSuccess) return LTPL_ERR_HIP;
+    double* d = nullptr;
+    int rc = LTPL_OK;
+    const size_t b = sizeof(double) * (size_t)n;
+    if (hipMalloc(&d, 3 * b) != hipSuccess) return LTPL_ERR_HIP;
+    if (hipMemcpy(d, y, b, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d + n, x, b, hipMemcpyHostToDevice) != hipSuccess) rc = LTPL_ERR_HIP;
+    if (!rc) {
+        hipLaunchKernelGGL(k_exp_heading, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d, d + n, d + 2 * (size_t)n, n);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(out, d + 2 * (size_t)n, b, hipMemcpyDeviceToHost) != hipSuccess) rc = LTPL_ERR_HIP;
+    }
+    (void)hipFree(d);
+    return rc;
+} LTPL_ABI_CATCH(nullptr)
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------
 // fleet (ABI v5): planners with device-resident state
 // ---------------------------------------------------------------------------------------------------------------------

@@ -37,6 +37,29 @@ __device__ __forceinline__ double fast_rcp(double b)
     return r;
 }
 
+// atan2(y, x) for the heading of a path sample (round 5; the library routine is ~80 vector instructions per row block of the re-sampling):
+// t = min(|x|, |y|) / max(|x|, |y|) is reduced by k pi / 8 (k = 0, 1, 2) WITHOUT a second division --
+//   z = (t - c) / (1 + t c) = (mn - c mx) / (mx + c mn),  c = tan(k pi / 8),  |z| <= tan(pi / 16) = 0.199
+// -- and atan(z) is its Taylor series through z^17 (remainder < z^19 / 19 = 2.5e-15); then the octant, quadrant and sign. Agrees with
+// atan2 to a few 1e-15 rad (tests/test_gpu_wave_ops.py checks it over all octants and on the axes); not for (0, 0).
+__device__ __forceinline__ double heading_atan2(double y, double x)
+{
+    const double ay = fabs(y), ax = fabs(x);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    const bool k1 = mn > 0.19891236737965800 * mx, k2 = mn > 0.66817863791929891 * mx;     // tan(pi / 16), tan(3 pi / 16)
+    const double c = k2 ? 1.0 : (k1 ? 0.41421356237309503 : 0.0);                             // tan(k pi / 8)
+    const double off = k2 ? 0.78539816339744831 : (k1 ? 0.39269908169872414 : 0.0);           // k pi / 8
+    const double z = fma(-c, mx, mn) * fast_rcp(fma(c, mn, mx));
+    const double w = z * z;
+    double p = fma(w, 1.0 / 17.0, -1.0 / 15.0);
+    p = fma(w, p, 1.0 / 13.0); p = fma(w, p, -1.0 / 11.0); p = fma(w, p, 1.0 / 9.0); p = fma(w, p, -1.0 / 7.0); p = fma(w, p, 1.0 / 5.0);
+    p = fma(w, p, -1.0 / 3.0);
+    double r = off + fma(z, w * p, z);
+    if (ay > ax) r = 1.57079632679489662 - r;
+    if (x < 0.0) r = D_PI - r;
+    return copysign(r, y);
+}
+
 // (|kappa|, e) / (x, y) planes of the batch velocity stage: tiled by job and BLOCKED by rows -- element (job, row) lives at
 //   ((job / 64 * plane_rows / 8 + row / 8) * 64 + job % 64) * 8 + row % 8
 // so that the path kernel (lane = row of ONE job) writes 8 rows = 64 contiguous bytes per block instead of one 8-byte element on
@@ -903,7 +926,11 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
         const double q = xd * xd + yd * yd;
         double* row = o_pp + (size_t)r * 5;
         // psi = normalize(atan2(y', x') - pi/2) = atan2(-x', y') (rotation by -90 degrees), range [-pi, pi)
+#ifdef LTPL_LIBM_ATAN2
         double psi_r = atan2(-xd, yd);
+#else
+        double psi_r = heading_atan2(-xd, yd);
+#endif
         if (psi_r >= D_PI) psi_r -= 2.0 * D_PI;
         const double kap = (xd * ydd - yd * xdd) * fast_rcp(q * sqrt(q));
         const double len_r = at(a_slen, pedge[i] + k);
@@ -1539,13 +1566,30 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
             }
         }
         touched |= jbits;
+        // The capsule records of a transition's FIRST chunk are requested one transition ahead (round 5): for the first transition here, in
+        // front of the loop -- its round trip passes behind the position loads above --, for every other one while its predecessor is
+        // evaluated. (A transition was: broadcast the queries, request the first chunk, wait a full global round trip, evaluate.)
+        float4 pf0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pf1 = pf0;
+        auto cap_first = [&](int jn) {
+            const int4 lyn = lay[jn];
+            if (lyn.z + wave * 64 < lyn.w) { const int en_ = min(lyn.z + wave * 64 + lane, lyn.w - 1); pf0 = at(m_cap, 2 * en_); pf1 = at(m_cap, 2 * en_ + 1); }
+        };
+#ifndef LTPL_NO_CAP_AHEAD
+        // (planning ranges beyond 63 layers walk every transition and find most of them untouched: no look-ahead there)
+        { const int j0 = (sparse && jbits) ? __ffsll((long long)jbits) - 1 : 0; if (j0 >= 1 && j0 <= H) cap_first(j0); }
+#endif
         for (int j = 1; j <= H; ++j) {
             if (sparse) { if (!jbits) break; j = __ffsll((long long)jbits) - 1; jbits &= jbits - 1; }
             int b = sc.sl + j; if (b >= L) b -= L;
             unsigned long long m = __ballot(ol >= 0 && (ol == b || ol + 1 == b));
-            if (m == 0ull) continue;
             const int4 ly = lay[j];
             const int eb = ly.z, ee = ly.w;
+#ifndef LTPL_NO_CAP_AHEAD
+            const float4 cur0 = pf0, cur1 = pf1;                 // this transition's first chunk (requested one transition ago)
+            { const int jn = (sparse && jbits) ? __ffsll((long long)jbits) - 1 : 0; if (jn >= 1 && jn <= H) cap_first(jn); }
+            bool first_round = sparse;
+#endif
+            if (m == 0ull) continue;
             while (m) {
                 // up to MQ matching positions per round, broadcast into uniform registers
                 constexpr int MQ = LTPL_MQ;
@@ -1569,6 +1613,10 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
                 // the capsule records of the NEXT chunk of 64 edges are requested before the current chunk is evaluated (round 5: a wide
                 // transition -- 245 edges on the C3 oval -- was four dependent load -> evaluate steps per pass)
                 float4 nx0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nx1 = nx0;
+#ifndef LTPL_NO_CAP_AHEAD
+                if (first_round) { nx0 = cur0; nx1 = cur1; first_round = false; }
+                else
+#endif
                 if (eb + wave * 64 < ee) { const int en_ = min(eb + wave * 64 + lane, ee - 1); nx0 = at(m_cap, 2 * en_); nx1 = at(m_cap, 2 * en_ + 1); }
                 for (int e0 = eb + wave * 64; e0 < ee; e0 += NT) {
                     // (predicated, not branched: the list bookkeeping below is wave-uniform)

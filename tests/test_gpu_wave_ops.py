@@ -42,3 +42,24 @@ def test_cross_lane_helpers_match_plain_loops():
                                      rounds, C.byref(n_bad))
     assert rc == 0
     assert n_bad.value == 0
+
+
+def test_heading_atan2_matches_numpy():
+    """heading_atan2 (csrc/paths_team.hpp: the heading of a re-sampled path point, octant reduction + series instead of the library
+    routine) against numpy.arctan2: all octants, the reduction's break points, the axes, magnitudes from 1e-6 to 1e6."""
+    lib = C.CDLL(_capi.experiment_library_path())
+    assert hasattr(lib, "ltpl_exp_heading_atan2")
+    rng = np.random.default_rng(9)
+    ang = np.concatenate((rng.uniform(-np.pi, np.pi, 200000), np.arange(-16, 17) * np.pi / 16, np.arange(-16, 17) * np.pi / 16 + 1e-9,
+                          np.arange(-16, 17) * np.pi / 16 - 1e-9))
+    mag = 10.0 ** rng.uniform(-6, 6, ang.size)
+    y, x = mag * np.sin(ang), mag * np.cos(ang)
+    y = np.concatenate((y, [0.0, 0.0, 1.0, -1.0, 3.0, -3.0, 0.0])); x = np.concatenate((x, [1.0, -1.0, 0.0, 0.0, 3.0, -3.0, 2.5]))
+    out = np.empty_like(y)
+    pd = C.POINTER(C.c_double)
+    rc = lib.ltpl_exp_heading_atan2(0, y.ctypes.data_as(pd), x.ctypes.data_as(pd), out.ctypes.data_as(pd), y.size)
+    assert rc == 0
+    ref = np.arctan2(y, x)
+    d = np.abs(out - ref)
+    d = np.minimum(d, 2 * np.pi - d)                  # (+pi and -pi are the same heading)
+    assert float(d.max()) <= 4e-15, float(d.max())
