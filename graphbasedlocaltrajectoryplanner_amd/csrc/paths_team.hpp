@@ -37,6 +37,17 @@ __device__ __forceinline__ double fast_rcp(double b)
     return r;
 }
 
+// q^(-3/2), q > 0 (curvature of a path sample: cross / |tangent|^3): hardware reciprocal square root + two Newton steps, cubed -- 10 vector
+// instructions (round 5); q * sqrt(q) through the library's correctly rounded sqrt and a reciprocal was ~26. Relative error a few 1e-16.
+__device__ __forceinline__ double rsqrt_cubed(double q)
+{
+    double r = __builtin_amdgcn_rsq(q);
+    const double h = 0.5 * q;
+    r = r * fma(-(h * r), r, 1.5);
+    r = r * fma(-(h * r), r, 1.5);
+    return (r * r) * r;
+}
+
 // atan2(y, x) for the heading of a path sample (round 5; the library routine is ~80 vector instructions per row block of the re-sampling):
 // t = min(|x|, |y|) / max(|x|, |y|) is reduced by k pi / 8 (k = 0, 1, 2) WITHOUT a second division --
 //   z = (t - c) / (1 + t c) = (mn - c mx) / (mx + c mn),  c = tan(k pi / 8),  |z| <= tan(pi / 16) = 0.199
@@ -932,7 +943,11 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
         double psi_r = heading_atan2(-xd, yd);
 #endif
         if (psi_r >= D_PI) psi_r -= 2.0 * D_PI;
+#ifdef LTPL_KAPPA_SQRT
         const double kap = (xd * ydd - yd * xdd) * fast_rcp(q * sqrt(q));
+#else
+        const double kap = (xd * ydd - yd * xdd) * rsqrt_cubed(q);          // q^(-3/2); q = |tangent|^2 > 0
+#endif
         const double len_r = at(a_slen, pedge[i] + k);
         if (!skip_pp)           // (experiment build: LTPL_ABLATE bit 16 drops the path_param stores, timing only)
         { store2_u(row, x, y); store2_u(row + 2, psi_r, kap); row[4] = len_r; }
@@ -1125,8 +1140,17 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
             cand[ci][SL[f]] = cand[ci][SL[f]] + (f == F_PR ? c_pr : c_np);
             // (conditional: unused lanes would all hit one address -- the sentinel's destination -- and serialise in the LDS; measured
             //  +18 % on the whole kernel with unconditional atomics)
+#ifndef LTPL_COND_MIN
+            // EVERY lane issues the minimum (round 5): +inf changes nothing, and since the chunk loads take whatever follows the transition in the
+            // table (prefetch) the unused lanes address scattered nodes instead of meeting in the sentinel's. No compare, no exec-mask save /
+            // restore around the atomic, and the atomics of a layer's chunks issue back to back: +2.7 % ticks/s (profiles/r05q_ab_bench.txt).
+            // (Rounds 2 - 4: conditional -- the unused lanes all held the sentinel edge, destination node 0, and serialised in the LDS: +18 %
+            //  kernel time when it was tried unconditionally then.)
+            atomicMin(reinterpret_cast<unsigned long long*>(&dist[coff[f] + dst]), (unsigned long long)__double_as_longlong(cand[ci][SL[f]]));
+#else
             if (cand[ci][SL[f]] < INFINITY)
                 atomicMin(reinterpret_cast<unsigned long long*>(&dist[coff[f] + dst]), (unsigned long long)__double_as_longlong(cand[ci][SL[f]]));
+#endif
         }
     }
     // transitions with more edges than the register image: the rest straight from global memory (rare, not prefetched);
@@ -1181,10 +1205,15 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
             const int dst = sw_dst(er[ci].meta);
             const unsigned key = elect_key(er[ci].meta);
 #pragma unroll
-            for (int f = 0; f < NFILT; ++f)
-                if (((ACT >> f) & 1u) && got[ci][SL[f]] == cand[ci][SL[f]] && cand[ci][SL[f]] < INFINITY) {
-                    atomicAdd(&cnt_all[f * kpad + dst], CW_ONE | key);
-                }
+            for (int f = 0; f < NFILT; ++f) {
+                if (!((ACT >> f) & 1u)) continue;
+                const bool win = got[ci][SL[f]] == cand[ci][SL[f]] && cand[ci][SL[f]] < INFINITY;
+#ifdef LTPL_UNCOND_ADD
+                atomicAdd(&cnt_all[f * kpad + dst], win ? (CW_ONE | key) : 0u);          // (variant: every lane adds, the others add nothing)
+#else
+                if (win) atomicAdd(&cnt_all[f * kpad + dst], CW_ONE | key);
+#endif
+            }
         }
     }
     if (has_tail) tail_edges(1);
