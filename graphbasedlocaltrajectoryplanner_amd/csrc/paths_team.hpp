@@ -258,6 +258,8 @@ struct PlanFx {
     // trips per layer less). Class A / C lattices (Monteblanco: 42 % of the transitions have a tail) keep their register budget.
 #ifdef LTPL_NO_TAIL_PF
     static constexpr bool tail_pf = false;
+#elif defined(LTPL_TAIL_PF_ALL)
+    static constexpr bool tail_pf = NW == 1;
 #else
     static constexpr bool tail_pf = HM > 32 && NW == 1;
 #endif
@@ -1177,6 +1179,23 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
                 const double du = dist[poff[f] + src];
                 bool ok = du < INFINITY;
                 if (f != F_PR) ok = ok && unbl;
+#ifndef LTPL_COND_MIN
+                // (rounds 0 / 1 without control flow, like the register chunks: an edge that must not be used carries +inf / adds nothing. The
+                //  cost is then needed by every lane, so its load is issued WITH the edge word's at the top of the iteration -- as `if (!ok)
+                //  continue` the compiler had sunk it behind the frontier read: two dependent global round trips per round, on 42 % of
+                //  Monteblanco's transitions)
+                if (ROUND == 0) {
+                    const double cd0 = ok ? du + c : (double)INFINITY;
+                    atomicMin(reinterpret_cast<unsigned long long*>(&dist[coff[f] + dst]), (unsigned long long)__double_as_longlong(cd0));
+                    continue;
+                }
+                if (ROUND == 1) {
+                    const double cd1 = du + c, g1 = dist[coff[f] + dst];
+                    const bool win = (g1 == cd1) & ok;                        // (no short circuit: the cost stays an unconditional load)
+                    atomicAdd(&cnt_all[f * kpad + dst], win ? (CW_ONE | key) : 0u);
+                    continue;
+                }
+#endif
                 if (!ok) continue;
                 const double cd = du + c;
                 if (ROUND == 0) { atomicMin(reinterpret_cast<unsigned long long*>(&dist[coff[f] + dst]), (unsigned long long)__double_as_longlong(cd)); continue; }
@@ -1208,8 +1227,8 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
             for (int f = 0; f < NFILT; ++f) {
                 if (!((ACT >> f) & 1u)) continue;
                 const bool win = got[ci][SL[f]] == cand[ci][SL[f]] && cand[ci][SL[f]] < INFINITY;
-#ifdef LTPL_UNCOND_ADD
-                atomicAdd(&cnt_all[f * kpad + dst], win ? (CW_ONE | key) : 0u);          // (variant: every lane adds, the others add nothing)
+#ifndef LTPL_COND_ADD
+                atomicAdd(&cnt_all[f * kpad + dst], win ? (CW_ONE | key) : 0u);          // (every lane adds, the others add nothing: +0.7 %, r05r_ab_bench.txt)
 #else
                 if (win) atomicAdd(&cnt_all[f * kpad + dst], CW_ONE | key);
 #endif
@@ -1821,6 +1840,10 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
             if (lane == 0) { ts.start_ok[f] = ok; best[f * hm] = -1; }
         }
         EdgeRegs er[CH], en[CH];
+        // (every chunk starts as the sentinel edge: the chunks a transition does not fill are never processed, but they ARE copied by the
+        //  rotation and looked at by the discount patch -- reading an indeterminate value is undefined behaviour the optimiser may build on)
+#pragma unroll
+        for (int ci = 0; ci < CH; ++ci) { er[ci].c = INFINITY; er[ci].meta = 0u; en[ci].c = INFINITY; en[ci].meta = 0u; }
         int4 lyc = make_int4(0, 0, 0, 0), lyn = make_int4(0, 0, 0, 0);     // table rows lay[j] of the current / the prefetched transition (uniform)
         // blocked flags of the lane's edges, bit ci = chunk ci, for the current (bm) and the next (bn) transition. One VECTOR register
         // each: as ballots (one scalar pair per chunk and buffer) they were twelve scalar registers that the compiler kept spilling
@@ -2179,7 +2202,11 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
     wp.end_node = -1;
     // one-wave batch form with one-byte parents in LDS: all backtracks of the scenario in one pass (rows in the frontier arrays, which are
     // free behind the goal evaluation and the re-sweeps)
-    constexpr int BT_OFF = BtPlace<P, NW>::off;              // (-1: this plan has no room / no one-byte parents -- every path chases its own)
+#ifdef LTPL_NO_BT_ALL
+    constexpr int BT_OFF = -1;
+#else
+    constexpr int BT_OFF = BtPlace<P, NW>::off;
+#endif              // (-1: this plan has no room / no one-byte parents -- every path chases its own)
     constexpr bool BT_ALL = BT_OFF >= 0;
     unsigned char* bt = smem + (BT_ALL ? BT_OFF : 0);
     if constexpr (BT_ALL) {
