@@ -4317,6 +4317,29 @@ __global__ void k_exp_heading(const double* y, const double* x, double* out, int
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = heading_atan2(y[i], x[i]);
 }
+__global__ void k_exp_sincos(const double* x, double* sn, double* cs, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) heading_sincos(x[i], &sn[i], &cs[i]);
+}
+// experiment build only: heading_sincos (start heading of a scenario) for n caller-provided angles (host memory)
+extern "C" int ltpl_exp_heading_sincos(int32_t device, const double* x, double* sn, double* cs, int32_t n)
+try {
+    if (!x || !sn || !cs || n <= 0) return LTPL_ERR_INVALID_ARG;
+    if (hipSetDevice(device) != hipSuccess) return LTPL_ERR_HIP;
+    double* d = nullptr;
+    int rc = LTPL_OK;
+    const size_t b = sizeof(double) * (size_t)n;
+    if (hipMalloc(&d, 3 * b) != hipSuccess) return LTPL_ERR_HIP;
+    if (hipMemcpy(d, x, b, hipMemcpyHostToDevice) != hipSuccess) rc = LTPL_ERR_HIP;
+    if (!rc) {
+        hipLaunchKernelGGL(k_exp_sincos, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d, d + n, d + 2 * (size_t)n, n);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(sn, d + n, b, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(cs, d + 2 * (size_t)n, b, hipMemcpyDeviceToHost) != hipSuccess) rc = LTPL_ERR_HIP;
+    }
+    (void)hipFree(d);
+    return rc;
+} LTPL_ABI_CATCH(nullptr)
 extern "C" int ltpl_exp_heading_atan2(int32_t device, const double* y, const double* x, double* out, int32_t n)
 try {
     if (!y || !x || !out || n <= 0) return LTPL_ERR_INVALID_ARG;

@@ -37,6 +37,29 @@ __device__ __forceinline__ double fast_rcp(double b)
     return r;
 }
 
+// sin and cos of a heading (round 5: the start heading of a scenario's constant path segment; the library's sincos is ~185 vector
+// instructions with its large-argument reduction): k = rint(x 2 / pi), r = x - k pi / 2 in two steps, the fdlibm kernel polynomials on
+// |r| <= pi / 4, quadrant by k. Error <= 2.3e-16 for |x| <= 4 pi (checked in tests/test_gpu_wave_ops.py); the caller falls back to sincos beyond.
+__device__ __forceinline__ void heading_sincos(double x, double* sn, double* cs)
+{
+    const double k = rint(x * 0.63661977236758138);
+    double r = fma(-k, 1.5707963267948966, x);
+    r = fma(-k, 6.123233995736766e-17, r);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06); ps = fma(z, ps, -1.98412698298579493134e-04); ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07); pc = fma(z, pc, 2.48015872894767294178e-05); pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)k & 3;
+    const double a = (q & 1) ? c : s, b = (q & 1) ? s : c;           // sin <- (s, c, -s, -c)[q], cos <- (c, -s, -c, s)[q]
+    *sn = (q & 2) ? -a : a;
+    *cs = ((q + 1) & 2) ? -b : b;
+}
+
 // q^(-3/2), q > 0 (curvature of a path sample: cross / |tangent|^3): hardware reciprocal square root + two Newton steps, cubed -- 10 vector
 // instructions (round 5); q * sqrt(q) through the library's correctly rounded sqrt and a reciprocal was ~26. Relative error a few 1e-16.
 __device__ __forceinline__ double rsqrt_cubed(double q)
@@ -134,12 +157,6 @@ struct TeamLds {                 // dynamic-LDS plan (byte offsets), computed on
 #define LTPL_POISON_ON(lp) false
 #endif
 
-// lane < n as a predicate from a SCALAR lane mask (n uniform): no vector compare, the select reads the mask from a scalar register pair
-__device__ __forceinline__ bool lane_mask_below(int n)
-{
-    const unsigned long long m = n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << (n & 63)) - 1ull));
-    return __builtin_amdgcn_inverse_ballot_w64(m);
-}
 // a value every lane holds alike, moved to scalar registers
 __device__ __forceinline__ double uniform_f64(double v)
 {
@@ -1245,7 +1262,10 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
     unsigned c_r[NA], w_r[NA];
 #pragma unroll
     for (int f = 0; f < NFILT; ++f)
-        if ((ACT >> f) & 1u) { const unsigned cw = nv ? cnt_all[f * kpad + n] : 0u; c_r[SL[f]] = cw >> CW_SHIFT; w_r[SL[f]] = cw & (CW_ONE - 1u); }
+        if ((ACT >> f) & 1u) {
+            const unsigned cw = nv ? cnt_all[f * kpad + n] : 0u;       // (read by every lane + select: -1 % ticks/s, profiles/r05u_ab_bench.txt)
+            c_r[SL[f]] = cw >> CW_SHIFT; w_r[SL[f]] = cw & (CW_ONE - 1u);
+        }
 #ifdef LTPL_PIPE1
     if constexpr (NA == 1 && NW == 1) {
         if (pre_mode & 2) {
@@ -1404,7 +1424,12 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
     }
     if (wave == 0 && (sc.flags & LTPL_FLAG_HAS_PSI_S)) {        // start heading of the constant path segment: one sincos per scenario, not per path
         double sn, cs;
-        sincos(in.psi_s[sc.s], &sn, &cs);
+        const double psi0 = in.psi_s[sc.s];                         // (uniform)
+#ifdef LTPL_LIBM_SINCOS
+        sincos(psi0, &sn, &cs);
+#else
+        if (fabs(psi0) <= 12.0) heading_sincos(psi0, &sn, &cs); else sincos(psi0, &sn, &cs);
+#endif
         if (lane == 0) { ts.psi_sc[0] = sn; ts.psi_sc[1] = cs; }
     }
     // vehicle of every position (radius lookup in phase 2)
@@ -1561,6 +1586,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
     auto flush_shell = [&](double mx, double my, double mr) {
         if (n_shell == 0) return;
         wave_sync_lds();
+#ifdef LTPL_SHELL_4
         for (int t0 = 0; t0 < n_shell; t0 += 4) {
             const int t = t0 + (lane >> 4), slot = lane & 15;
             const bool tv = t < n_shell;
@@ -1580,6 +1606,52 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
                 atomicOr(&blocked_bits[el_ >> 5], 1u << (el_ & 31));
             }
         }
+#else
+        // SIXTEEN entries per pass, as two independent groups of eight entries x eight sample slots (round 5): a pass is one LDS read and one
+        // dependent global round trip (the samples) long whatever it holds, and a scenario with an object in range lists ~45 entries --
+        // twelve passes of four entries x 16 slots were the longest stretch of the mask phase (an edge of the reference's tracks has 5 - 7
+        // samples). The first LTPL_SHELL_SS samples of both groups are requested before either is evaluated; longer ranges continue per group.
+#ifndef LTPL_SHELL_SS
+#define LTPL_SHELL_SS 8
+#endif
+        constexpr int SS = LTPL_SHELL_SS, EPG = 64 / SS;          // sample slots per entry, entries per group
+        for (int t0 = 0; t0 < n_shell; t0 += 2 * EPG) {
+            const int slot = lane & (SS - 1);
+            int e_[2], ql_[2], k0_[2], ns_[2]; bool tv_[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int t = t0 + EPG * g + lane / SS;
+                tv_[g] = t < n_shell;
+                const uint2 en_ = shell[tv_[g] ? t : t0];
+                e_[g] = (int)(en_.x & 0xffffffu); ql_[g] = (int)(en_.x >> 24);
+                k0_[g] = (int)(en_.y & 0xffffffu); ns_[g] = (int)(en_.y >> 24);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                if (ns_[g] == 0) { const int ec_ = at(lat.sw2csc, e_[g]); k0_[g] = at(lat.samp_ptr, ec_); ns_[g] = at(lat.samp_ptr, ec_ + 1) - k0_[g]; }   // (range too large for the packing)
+            double sx_[2], sy_[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {                         // first SS samples of both groups: one round trip
+                const int k = slot < ns_[g] ? slot : 0;
+                sx_[g] = at(m_sx, k0_[g] + k); sy_[g] = at(m_sy, k0_[g] + k);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const double px = __shfl(mx, ql_[g]), py = __shfl(my, ql_[g]), pr = __shfl(mr, ql_[g]);
+                bool hit = false;
+                { const double dx = sx_[g] - px, dy = sy_[g] - py; hit = slot < ns_[g] && (dx * dx + dy * dy <= pr); }
+                for (int k = slot + SS; k < ns_[g]; k += SS) {
+                    const double dx = at(m_sx, k0_[g] + k) - px, dy = at(m_sy, k0_[g] + k) - py;
+                    hit = hit || (dx * dx + dy * dy <= pr);
+                }
+                const unsigned long long hm = __ballot(tv_[g] && hit);
+                if (tv_[g] && slot == 0 && ((hm >> (lane & (64 - SS))) & ((1ull << SS) - 1ull))) {
+                    int el_ = e_[g] - sc.e_base; if (el_ < 0) el_ += m_E;
+                    atomicOr(&blocked_bits[el_ >> 5], 1u << (el_ & 31));
+                }
+            }
+        }
+#endif
         n_shell = 0;
         wave_sync_lds();
     };
@@ -1879,9 +1951,9 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
 #else
         // Round 5: the loads of a chunk are addressed as (uniform pointer to the chunk's first edge) + (lane * element size) -- no per-lane
         // index, no redirection: a chunk is read whole, and what lies beyond the transition (the next transition's edges, or the sentinel
-        // entries behind the tables: LTPL_SW_PAD) is replaced by the sentinel cost +inf where the layer step CONSUMES the chunk (team_layer,
-        // `lane_mask_below`: a select on a scalar lane mask, no compare; at load time it would wait for the load). The edge word of such a
-        // lane is arbitrary but addresses nodes of the tables: with the candidate +inf it never takes part. The blocked flags are only
+        // entries behind the tables: LTPL_SW_PAD) is replaced by the sentinel cost +inf where the layer step CONSUMES the chunk (team_layer:
+        // one compare of the lane against the uniform edge count; at load time the select would wait for the load). The edge word of such a
+        // lane is arbitrary but addresses nodes of the tables: with the candidate +inf it changes nothing (its atomics are issued all the same). The blocked flags are only
         // formed for a transition that can hold a blocked edge (`touched`), in a block of their own behind the loads.
         auto prefetch = [&](int j, EdgeRegs (&dr)[CH], unsigned& db) {
             const int4 ly = uniform_i4(lay[j]);

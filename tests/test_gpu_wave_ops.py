@@ -63,3 +63,16 @@ def test_heading_atan2_matches_numpy():
     d = np.abs(out - ref)
     d = np.minimum(d, 2 * np.pi - d)                  # (+pi and -pi are the same heading)
     assert float(d.max()) <= 4e-15, float(d.max())
+
+
+def test_heading_sincos_matches_numpy():
+    """heading_sincos (csrc/paths_team.hpp: sin / cos of a scenario's start heading) against numpy on [-12, 12] (the kernel calls the library
+    routine beyond), the quadrant borders and zero."""
+    lib = C.CDLL(_capi.experiment_library_path())
+    assert hasattr(lib, "ltpl_exp_heading_sincos")
+    rng = np.random.default_rng(10)
+    x = np.concatenate((rng.uniform(-12.0, 12.0, 200000), np.arange(-15, 16) * np.pi / 4, np.arange(-15, 16) * np.pi / 4 + 1e-12, [0.0, 1e-300, -1e-9]))
+    sn, cs = np.empty_like(x), np.empty_like(x)
+    pd = C.POINTER(C.c_double)
+    assert lib.ltpl_exp_heading_sincos(0, x.ctypes.data_as(pd), sn.ctypes.data_as(pd), cs.ctypes.data_as(pd), x.size) == 0
+    assert float(np.abs(sn - np.sin(x)).max()) <= 4e-16 and float(np.abs(cs - np.cos(x)).max()) <= 4e-16
