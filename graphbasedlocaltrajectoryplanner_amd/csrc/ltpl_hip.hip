@@ -3890,6 +3890,19 @@ try {
             // LTPL_VEL_STREAM_PRIO=1 (experiment): the velocity streams at the device's highest stream priority (their waves are dispatched
             // ahead of the path kernel's whenever a slot frees up)
             static const bool hi = getenv("LTPL_VEL_STREAM_PRIO") && atoi(getenv("LTPL_VEL_STREAM_PRIO")) != 0;
+            // LTPL_VEL_CUS=<n> (round-5 experiment): the velocity streams confined to n compute units by a CU mask. The velocity waves are few,
+            // long-lived (a serial recurrence over the rows of a profile) and hold 197 VGPRs: next to one of them a SIMD keeps two path waves
+            // instead of four. Confined, they run among themselves on a corner of the chip. 0 / unset: no mask.
+            static const int vel_cus = getenv("LTPL_VEL_CUS") ? atoi(getenv("LTPL_VEL_CUS")) : 0;
+            bool made = false;
+            if (vel_cus > 0) {
+                const int ncu = h->caps.num_cus > 0 ? h->caps.num_cus : 256;
+                std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+                for (int c = 0; c < vel_cus && c < ncu; ++c) mask[(size_t)c >> 5] |= 1u << (c & 31);
+                made = hipExtStreamCreateWithCUMask(&h->vel_stream[i], (uint32_t)mask.size(), mask.data()) == hipSuccess;
+                if (!made) { (void)hipGetLastError(); h->vel_stream[i] = nullptr; }
+            }
+            if (made) continue;
             if (hi) { int lo_p = 0, hi_p = 0; (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p); HIP_TRY(h, hipStreamCreateWithPriority(&h->vel_stream[i], hipStreamNonBlocking, hi_p)); }
             else HIP_TRY(h, hipStreamCreateWithFlags(&h->vel_stream[i], hipStreamNonBlocking));
         }

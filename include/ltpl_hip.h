@@ -30,6 +30,8 @@
  *   LTPL_FLEET_FOLLOW_WAVES=1/0 fleet follow jobs one WAVE per job / one LANE per job (default: lanes from 12 288 planners on; ltpl_fleet_create)
  *   LTPL_NO_LAYER_GRID=1        closest reference-line layer of an obstacle position by the scan over all layers, no create-time grid
  *   LTPL_TICK_GRAPH=1           the single fused tick (copy in -> kernel [-> copy out]) as ONE hipGraph launch (measured: slower; off)
+ *   LTPL_VEL_CUS=<n>            velocity streams of the resident-batch pipeline confined to n compute units by a CU mask (measured: the
+ *                               velocity chain becomes the bottleneck below ~128 CUs, no gain above; off)
  * Timing / fault-injection switches (LTPL_ABLATE, LTPL_EXP_SKIP, LTPL_LDS_POISON, LTPL_SCRATCH_POISON, LTPL_DEBUG_TIMING,
  * LTPL_DEBUG_OCC) skip work, overwrite memory or instrument kernels; they are compiled into the EXPERIMENT build only
  * (-DLTPL_EXPERIMENT -> libltpl_hip_exp.so, used by tools/ and one fault-injection test) and do not exist in libltpl_hip.so.
