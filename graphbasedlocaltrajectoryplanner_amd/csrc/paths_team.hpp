@@ -1123,9 +1123,9 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
     // An edge that must not be used (beyond the transition, blocked, unreachable source) simply carries the candidate
     // +inf: inf + cost = inf never wins the atomic min and never matches a finite minimum, so the rounds need no
     // per-lane bookkeeping and no divergent control flow.
-    // Lanes beyond the transition hold the SENTINEL edge (cost +inf, lattice edge id E: prefetch), so every lane of a loaded chunk runs
-    // the same code: all LDS reads of a round are issued before the first wait and no lane needs an "is this an edge" select. Chunks
-    // from the second on (LTPL_CH_ALWAYS) are skipped when empty (uniform; 111 edges per transition on average).
+    // Lanes beyond the transition get the cost +inf below (their edge word is whatever followed the transition in the table: prefetch), so
+    // every lane of a loaded chunk runs the same code: all LDS reads of a round are issued before the first wait. Chunks that hold no
+    // edge are not processed (NCHK: compile time; else uniform tests; 111 edges per transition on average).
     double cand[CH][NA];
 #pragma unroll
     for (int ci = 0; ci < CH; ++ci) {
@@ -1157,8 +1157,6 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
         for (int f = 0; f < NFILT; ++f) {
             if (!((ACT >> f) & 1u)) continue;
             cand[ci][SL[f]] = cand[ci][SL[f]] + (f == F_PR ? c_pr : c_np);
-            // (conditional: unused lanes would all hit one address -- the sentinel's destination -- and serialise in the LDS; measured
-            //  +18 % on the whole kernel with unconditional atomics)
 #ifndef LTPL_COND_MIN
             // EVERY lane issues the minimum (round 5): +inf changes nothing, and since the chunk loads take whatever follows the transition in the
             // table (prefetch) the unused lanes address scattered nodes instead of meeting in the sentinel's. No compare, no exec-mask save /
