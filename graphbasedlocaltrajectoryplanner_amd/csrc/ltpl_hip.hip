@@ -25,6 +25,7 @@
 #include "fleet_api.hpp"
 #include "capsule.hpp"
 #include "layer_grid.hpp"
+#include "assembly_records.hpp"
 
 #define WG_THREADS 256
 #define PIPELINE_MIN_SCEN 64   // batches from this size on use the one-wave-per-scenario pipeline
@@ -89,8 +90,6 @@ struct DevLat {
     const double* edge_rec;           // [E][LTPL_EDGE_REC] (first sample | #samples << 32 as bit pattern, edge length, x, y of the first sample,
                                       //     x, y of the last sample, sin, cos of the first sample's heading, sin, cos of the last sample's)
 };
-#define LTPL_EDGE_REC 10
-#define LTPL_NODE_REC_SRC 12
 
 struct DevPathsIn {
     int n_scen, n_w_last;
@@ -2778,30 +2777,12 @@ try {
             for (int e = d->in_ptr[v]; e < d->in_ptr[v + 1]; ++e) rank8[(size_t)e] = (unsigned char)(e - d->in_ptr[v]);
         UP(edge_rank8, rank8.data(), L.E);
         {
-            // path assembly records (see DevLat)
-            std::vector<int> nrec((size_t)L.V * 4);
-            for (int v = 0; v < L.V; ++v) {
-                const int e0 = d->in_ptr[v], e1 = d->in_ptr[v + 1];
-                unsigned char b[LTPL_NODE_REC_SRC];
-                for (int k = 0; k < LTPL_NODE_REC_SRC; ++k) b[k] = e0 + k < e1 ? src8[(size_t)(e0 + k)] : (unsigned char)0xff;
-                nrec[(size_t)v * 4] = e0;
-                memcpy(&nrec[(size_t)v * 4 + 1], b, LTPL_NODE_REC_SRC);
-            }
+            // path assembly records (see DevLat; csrc/assembly_records.hpp)
+            std::vector<int32_t> nrec; std::vector<double> erec;
+            ltplrec::build(L.V, L.E, d->in_ptr, d->edge_src, d->edge_len, d->samp_ptr, d->samp_x, d->samp_y, d->samp_psi, nrec, erec);
             const int4* nr = nullptr;
             if ((rc = upload(h, reinterpret_cast<const int4*>(nrec.data()), (size_t)L.V, &nr)) != LTPL_OK) return fail(rc);
             L.node_rec = nr;
-            std::vector<double> erec((size_t)L.E * LTPL_EDGE_REC, 0.0);
-            for (int e = 0; e < L.E; ++e) {
-                const int k0 = d->samp_ptr[e], k1 = d->samp_ptr[e + 1];
-                double* r = &erec[(size_t)e * LTPL_EDGE_REC];
-                const unsigned long long w = (unsigned long long)(unsigned)k0 | ((unsigned long long)(unsigned)(k1 - k0) << 32);
-                memcpy(&r[0], &w, 8);
-                r[1] = d->edge_len[e];
-                if (k1 > k0) {
-                    r[2] = d->samp_x[k0]; r[3] = d->samp_y[k0]; r[4] = d->samp_x[k1 - 1]; r[5] = d->samp_y[k1 - 1];
-                    r[6] = sin(d->samp_psi[k0]); r[7] = cos(d->samp_psi[k0]); r[8] = sin(d->samp_psi[k1 - 1]); r[9] = cos(d->samp_psi[k1 - 1]);
-                }
-            }
             UP(edge_rec, erec.data(), (size_t)L.E * LTPL_EDGE_REC);
         }
         std::vector<int> ldeg((size_t)L.L, 0);
@@ -4265,6 +4246,19 @@ try {
         if ((size_t)cap_cells < (size_t)g.nx * g.ny) return LTPL_ERR_CAPACITY;
         memcpy(cells, g.cells.data(), sizeof(int32_t) * g.cells.size());
     }
+    return LTPL_OK;
+} LTPL_ABI_CATCH(nullptr)
+
+extern "C" int ltpl_assembly_records(int32_t n_nodes, int32_t n_edges, const int32_t* in_ptr, const int32_t* edge_src, const double* edge_len,
+                                     const int32_t* samp_ptr, const double* samp_x, const double* samp_y, const double* samp_psi,
+                                     int32_t* node_rec_out, double* edge_rec_out)
+try {
+    if (n_nodes < 1 || n_edges < 1 || !in_ptr || !edge_src || !edge_len || !samp_ptr || !samp_x || !samp_y || !samp_psi || !node_rec_out ||
+        !edge_rec_out) return LTPL_ERR_INVALID_ARG;
+    std::vector<int32_t> nrec; std::vector<double> erec;
+    ltplrec::build(n_nodes, n_edges, in_ptr, edge_src, edge_len, samp_ptr, samp_x, samp_y, samp_psi, nrec, erec);
+    memcpy(node_rec_out, nrec.data(), sizeof(int32_t) * nrec.size());
+    memcpy(edge_rec_out, erec.data(), sizeof(double) * erec.size());
     return LTPL_OK;
 } LTPL_ABI_CATCH(nullptr)
 

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define LTPL_ABI_VERSION 7        /* v7 (round 5, additive): ltpl_paths_kernel_symbol, ltpl_layer_grid, ltpl_fleet_digest */
+#define LTPL_ABI_VERSION 8        /* v7 (round 5, additive): ltpl_paths_kernel_symbol, ltpl_layer_grid, ltpl_fleet_digest; v8 (additive): ltpl_assembly_records */
 
 /* status codes */
 #define LTPL_OK               0
@@ -343,6 +343,15 @@ int ltpl_edge_capsules(int32_t n_edges, const int32_t* samp_ptr, const double* s
  *     scan. tests/test_layer_grid.py checks against the brute-force argmin that the true answer is always among the candidates. --------- */
 int ltpl_layer_grid(int32_t n_layers, const double* ref_x, const double* ref_y, double* origin_cell, int32_t* dims, int32_t* cells,
                     int32_t cap_cells);
+
+/* --- diagnostics (host only, no device needed): the per-node / per-edge records ltpl_create derives for the path assembly
+ *     (main_online_path_gen.py:260-328: the nodes of a path -> its edges -> the spline samples' coordinates and end headings). node_rec_out:
+ *     4 ints per node = first in-edge (CSC id) + the source nodes of its first 12 in-edges as bytes (0xff = none); edge_rec_out: 10 doubles
+ *     per edge = first sample | #samples << 32 (bit pattern), edge length, x, y of the first and of the last sample, sin, cos of the first
+ *     and of the last sample's heading. tests/test_assembly_records.py checks them against the lattice arrays they replace. ----------- */
+int ltpl_assembly_records(int32_t n_nodes, int32_t n_edges, const int32_t* in_ptr, const int32_t* edge_src, const double* edge_len,
+                          const int32_t* samp_ptr, const double* samp_x, const double* samp_y, const double* samp_psi,
+                          int32_t* node_rec_out, double* edge_rec_out);
 
 /* --- object ingestion: ObjectListInterface.py:75-153, check_inside_bounds.py:7-59 --------------------------------- */
 int ltpl_process_objects(ltpl_handle* handle, const ltpl_objects_in* in, ltpl_objects_out* out);

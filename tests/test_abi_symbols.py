@@ -29,8 +29,9 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(lib_path)
     for sym in declared_symbols():
         assert hasattr(lib, sym), "libltpl_hip.so does not export %s" % sym
-    assert lib.ltpl_version() == 7          # v6: per-planner vel_max / machine tables in the fleet, ltpl_fleet_set_start_range;
-                                            # v7 (additive): ltpl_paths_kernel_symbol, ltpl_layer_grid, ltpl_fleet_digest
+    assert lib.ltpl_version() == 8          # v6: per-planner vel_max / machine tables in the fleet, ltpl_fleet_set_start_range;
+                                            # v7 (additive): ltpl_paths_kernel_symbol, ltpl_layer_grid, ltpl_fleet_digest;
+                                            # v8 (additive): ltpl_assembly_records
 
 
 def test_product_fails_loudly_without_library(monteblanco, tmp_path):
