@@ -2048,7 +2048,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
             double cpre[CH]; bool have_pre = false;
 #pragma unroll
             for (int ci = 0; ci < CH; ++ci) cpre[ci] = INFINITY;
-            constexpr bool one_filter = ACT == (1u << F_DEF) || ACT == (1u << F_PR);
+            [[maybe_unused]] constexpr bool one_filter = ACT == (1u << F_DEF) || ACT == (1u << F_PR);
             for (; j <= j1; ++j) {
 #ifdef LTPL_NO_LY_CARRY
                 const int4 ly = lay[j];
