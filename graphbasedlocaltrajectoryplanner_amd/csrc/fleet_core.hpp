@@ -212,13 +212,13 @@ FLT_FN JobCar car_of(const FVelIn& vin, int p)
     return c;
 }
 // Lane plane (device only, stage-A table): the forward-backward jobs of slots >= 1 are solved one LANE per job (k_fleet_fb_lanes), so their
-// operands go into a plane tiled by job and blocked by rows, (|kappa|, element length) as an fp32 pair (`ke`, layout = kep_base / kep_row of
+// operands go into a plane tiled by job and blocked by rows, (|kappa|, element length) as an fp64 pair (`ke`, layout = kep_base / kep_row of
 // the batch velocity stage); plane index q = p (per_planner - 1) + slot - 1. The results come back job-major in `out` like every other
 // job's. Null: operands through `pool` (host harness, follow and brake jobs).
-#ifdef LTPL_VEL_F64_OPERANDS
-typedef double ke_scalar_f;         // (operand records of the lane kernels as fp64 pairs: the precision A/B build, see ke_t in ltpl_hip.hip)
+#ifndef LTPL_VEL_F32_OPERANDS
+typedef double ke_scalar_f;         // operand records of the lane kernels: fp64 pairs like ke_t in ltpl_hip.hip (the reference is fp64 throughout)
 #else
-typedef float ke_scalar_f;
+typedef float ke_scalar_f;          // (the rounds-3..5 form, opt-in)
 #endif
 struct F2 { ke_scalar_f x, y; };
 struct FJobs { VelJob* jobs; double* pool; const double* out; const int* flags; int per_planner; F2* ke; int ke_rows;

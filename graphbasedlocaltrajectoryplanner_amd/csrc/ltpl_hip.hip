@@ -121,11 +121,11 @@ __device__ __forceinline__ void signal_done(const DoneSignal& d)
     }
 }
 
-// Operand records of the batch velocity stage (|kappa|, element length per path row). Default: an fp32 PAIR -- one 8-byte load per row and
-// lane, and 1 / |kappa| from v_rcp_f32; the profile state and every output stay fp64 (error budget used: 1.6e-6 of the 1e-5 tolerance).
-// -DLTPL_VEL_F64_OPERANDS builds the same kernels with fp64 operand records (16-byte loads, fp64 reciprocal): the A/B of round 4
-// (profiles/r04*_vel_precision.txt: ticks/s and max_rel_err of both builds).
-#ifdef LTPL_VEL_F64_OPERANDS
+// Operand records of the batch velocity stage (|kappa|, element length per path row): an fp64 PAIR, one 16-byte load per row and lane,
+// 1 / |kappa| in fp64 -- the reference is IEEE fp64 throughout (VpForwardBackward.py:194-227) and so is every operand, state and output
+// of this stage (element-wise vx error against the oracle ~1e-13). -DLTPL_VEL_F32_OPERANDS builds the rounds-3..5 form (fp32 pair,
+// v_rcp_f32: +6.5 % ticks/s, element-wise vx error up to 1e-5 -- profiles/r04f_vel_precision.txt); not shipped, not tested.
+#ifndef LTPL_VEL_F32_OPERANDS
 typedef double ke_scalar;
 typedef double ke_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ ke_t make_ke(double k, double e) { ke_t v; v.x = k; v.y = e; return v; }
@@ -148,7 +148,7 @@ struct DevPathsOut {
     int* end_layer; int* closest_obj_index; int* closest_obj_node; int* n_actions;
     int* action_id; int* valid; int* reduced; int* goal_layer; int* n_nodes; int* n_pts; int* n_ties;
     int* nodes; int* node_idx; double* coeff; double* path_param;
-    ke_t* vke;                       // optional tiled plane (|kappa|, element length) as fp32 pairs for the batch velocity stage
+    ke_t* vke;                       // optional tiled plane (|kappa|, element length) as fp64 pairs for the batch velocity stage
     double* vxy;                     // optional tiled plane (x, y) of the FOLLOW jobs' path points (tile = follow job index): k_follow_prep
     // job compaction of the batch velocity stage (all nullptr outside the pipeline): every valid path takes a job index
     // from a counter of its class (0 = generic forward-backward profile, 1 = follow); its planes are tiled by JOB, so
@@ -1323,8 +1323,7 @@ struct DevVelPrep {             // per-slot scalars produced by k_follow_prep (f
 };
 
 struct VelPlanes {              // tiled planes (doubles), tile index = job index: generic jobs [0, n_slots_pad), follow jobs behind
-    ke_t* KE;                   // (|kappa|, element length) as an fp32 pair: ONE 8-byte load per row and lane (the operands only enter
-                                // results with a 1e-5 tolerance; the profile state itself stays fp64)   n_slots_pad + n_scen_pad tiles
+    ke_t* KE;                   // (|kappa|, element length) as an fp64 pair: ONE 16-byte load per row and lane   n_slots_pad + n_scen_pad tiles
     double* P0;                 // type 0 result: follow -> "vx_profile" (:289/:294), else the generic profile     (same size)
     double* P1;                 // type 1 result: unconstrained profile of a follow job                n_scen_pad tiles
     double* P2;                 // ego brake profile (follow)                                           n_scen_pad tiles
@@ -1456,7 +1455,7 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #pragma unroll
         for (int c = 0; c < LCHA; ++c) { const int r = 1 + c < n ? 1 + c : n - 1; kr[c] = KE_AT(r); }
         auto step = [&](const ke_t& rec, int i, bool valid) {
-            const double w0n = fmin(cay * ke_rcp(rec), vmax2);    // 1 / |kappa| in fp32 (1 ulp), inf on straights
+            const double w0n = fmin(cay * ke_rcp(rec), vmax2);    // inf on straights
             const bool acc = w0n > orig_p;
             const bool act = active || (acc && !prev_acc);
             const double te = e_p + e_p;
@@ -2120,7 +2119,7 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
         // rows beyond n - 1 are unused padding of the block -- never NaN-sensitive: their ax is discarded)
 #pragma unroll
         for (int c = 0; c < FCH; c += 2) {
-#ifdef LTPL_VEL_F64_OPERANDS
+#ifndef LTPL_VEL_F32_OPERANDS
             er[c] = KE[kep_row(base + c)].y; er[c + 1] = KE[kep_row(base + c + 1)].y;
 #else
             const float4 v = *reinterpret_cast<const float4*>(&KE[kep_row(base + c)]);
@@ -3563,7 +3562,8 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
     {
         const size_t tiles = (size_t)t->n_slots_pad + (size_t)t->n_scen_pad;
         const size_t plane_rows = align_up((size_t)cap_pts, 8);
-        t->planes_bytes = t->pipeline ? sizeof(double) * ((size_t)cap_pts * (3 * tiles + 3 * (size_t)t->n_scen_pad) + 2 * plane_rows * (size_t)t->n_scen_pad)
+        // (the operand plane holds plane_rows = cap_pts rounded up to 8 records of sizeof(ke_t) = 16 bytes per tile)
+        t->planes_bytes = t->pipeline ? sizeof(double) * (2 * plane_rows * tiles + (size_t)cap_pts * (tiles + 3 * (size_t)t->n_scen_pad) + 2 * plane_rows * (size_t)t->n_scen_pad)
                                             + sizeof(int) * (3 * tiles + 16 + 2 * (size_t)t->n_scen_pad) : 0;
     }
     t->prep_off = 0; t->prep_stride = 0;
@@ -3590,10 +3590,11 @@ static void tick_bind_outputs(TickLayout* t, unsigned char* dob, double* planes)
     if (t->pipeline && planes) {
         const size_t tiles = (size_t)t->n_slots_pad + (size_t)t->n_scen_pad;
         const size_t per_all = (size_t)t->cap_pts * tiles, per_scen = (size_t)t->cap_pts * (size_t)t->n_scen_pad;
-        t->vp.KE = reinterpret_cast<ke_t*>(planes); t->vp.P0 = planes + 2 * per_all;       // (the second plane-sized region is unused)
-        t->vp.P1 = planes + 3 * per_all; t->vp.P2 = t->vp.P1 + per_scen; t->vp.P3 = t->vp.P2 + per_scen;
-        t->vp.XY = t->vp.P3 + per_scen;
         const size_t plane_rows = align_up((size_t)t->cap_pts, 8);
+        static_assert(sizeof(ke_t) <= 2 * sizeof(double), "operand plane: two doubles per row and tile");
+        t->vp.KE = reinterpret_cast<ke_t*>(planes); t->vp.P0 = planes + 2 * plane_rows * tiles;
+        t->vp.P1 = t->vp.P0 + per_all; t->vp.P2 = t->vp.P1 + per_scen; t->vp.P3 = t->vp.P2 + per_scen;
+        t->vp.XY = t->vp.P3 + per_scen;
         int* ints = reinterpret_cast<int*>(t->vp.XY + 2 * plane_rows * (size_t)t->n_scen_pad);
         t->vp.flags = ints; t->dout.job_slot = reinterpret_cast<int2*>(ints + tiles); t->dout.job_cnt = ints + 3 * tiles; t->vp.fseg = ints + 3 * tiles + 16;
         t->dout.n_slots_pad = t->n_slots_pad;

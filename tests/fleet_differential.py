@@ -8,7 +8,7 @@ previous action, blocked tracks, dropped keys, backup brake plans) with two impl
 """
 import numpy as np
 
-from graphbasedlocaltrajectoryplanner_amd.tick_replay import KAPPA_FLOOR
+from graphbasedlocaltrajectoryplanner_amd.tick_replay import KAPPA_FLOOR, assert_elementwise, ELEM_FLOOR_VX, ELEM_TOL_VX
 
 from graphbasedlocaltrajectoryplanner_amd._capi import BackendError
 from graphbasedlocaltrajectoryplanner_amd.scenario_gen import raceline_state
@@ -46,7 +46,8 @@ def same_trajectories(a, b, exact=True, what=""):
             vmax = float(np.max(np.abs(y[:, 5])))
             sc = np.array([max(float(np.max(np.abs(y[:, 0]))), 1.0), max(float(np.ptp(y[:, 1])), 1.0), max(float(np.ptp(y[:, 2])), 1.0), np.pi,
                            max(float(np.max(np.abs(y[:, 4]))), KAPPA_FLOOR), max(vmax, 1.0), max(vmax * vmax / 2.0, 5.0)])
-            assert np.all(err <= 2e-5 * sc), (what, k, err / sc)
+            assert np.all(err <= 1e-5 * sc), (what, k, err / sc)
+            assert_elementwise(x[:, 5], y[:, 5], ELEM_FLOOR_VX, ELEM_TOL_VX, "%s %s vx" % (what, k))
 
 
 def drive(lat, A, B, seed, n_ticks, exact=True, scen_a=0, scen_b=0, gg_phases=False):

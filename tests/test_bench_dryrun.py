@@ -156,7 +156,7 @@ def test_the_line_carries_the_drivers_contract(monkeypatch, capsys):
         assert isinstance(out[key], typ), key
     # no published reference number exists: vs_baseline is null; the ratio to BASELINE.json's stated target has its own name
     assert out["vs_baseline"] is None and out["vs_target"] == pytest.approx(out["value"] / 10000.0) and "target" in out["vs_target_basis"]
-    assert out["unit"] == "ticks/s" and out["scaling"] == "weak" and out["dtype"].startswith("f64") and "f32" in out["dtype"]
+    assert out["unit"] == "ticks/s" and out["scaling"] == "weak" and out["dtype"] == "f64"        # (round 6: no fp32 operand anywhere on the path)
     assert len(out["per_rank_ms_per_step"]) == 1 and out["efficiency_vs_n1"] is None
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["timed_steps"] == 3
     assert "workload" in out["config"] and "model" not in out["config"]
@@ -164,12 +164,15 @@ def test_the_line_carries_the_drivers_contract(monkeypatch, capsys):
     assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 64.0) < 1e-6          # value = units of all ranks / timed region
 
     r = out["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == bench.HBM_PEAK_GBPS
+    # `contract_bound`: the roofline achieved / peak / frac are priced against (the bench contract's vocabulary); `bound`: what binds the
+    # kernel -- the same word as binding.bound and limiter (round-5 review, item 9: the fields must agree)
+    assert r["contract_bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == bench.HBM_PEAK_GBPS
+    assert r["bound"] == "latency / " + r["binding"]["bound"] and r["limiter"].startswith(r["bound"])
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert r["kernel_ms"] == pytest.approx(0.8)                                # the live, in-region duration wins over the profile's
     assert r["traffic"] is None and r["traffic_frac"] is None                  # PMC summary is for the 32768-scenario grid only
-    assert r["issue"] is None and "issue" in r["limiter"] and r["binding"]["issue_frac"] is None
+    assert r["issue"] is None and r["binding"]["issue_frac"] is None
     assert r["frac_refline_per_position"] >= r["frac"]                         # (the round-3 model charged the reference line per position)
     # the re-based byte model never exceeds the survey's (which charged every window edge all its samples, every sweep its own edges)
     assert r["split_per_tick"]["mask"] <= r["survey_model_per_tick"]["mask"] and r["split_per_tick"]["sweep"] <= r["survey_model_per_tick"]["sweep"]
@@ -196,11 +199,14 @@ def test_the_line_carries_the_drivers_contract(monkeypatch, capsys):
     assert cm["planners"] == 4 and len(cm["groups"]) == 4 and cm["matches_recording"] is True and cm["planner_checks"] == 3 * 4 and len(cm["checked_at_ticks"]) == 3
     c3 = out["extra"]["c3"]
     assert c3["batch"] == 6 and c3["ticks_per_s"] > 0 and c3["parity_checked"] is True and 0 < c3["roofline_frac"] <= c3["roofline_frac_refline_per_position"]
+    c4 = out["extra"]["c4"]                                                    # C4 as BASELINE states it (clipped to the dry run's batch)
+    assert c4["one_gpu"]["scenarios"] == 64 and c4["shard"]["scenarios"] == 8 and c4["shard"]["resident_ticks_per_s"] > 0
+    assert c4["one_gpu"]["pcie_us_per_call_p99"] >= c4["one_gpu"]["pcie_us_per_call_p50"] > 0 and "projection" in c4["projected_8gpu_ticks_per_s"]["basis"]
     c5 = out["extra"]["c5"]
     assert c5["horizon_300m"]["ticks"] == 2 and c5["horizon_100m"]["p99_us"] >= c5["horizon_100m"]["p50_us"] > 0
     assert 1.0 <= out["paths_per_tick"] <= 4.0
     # order of the device calls: resident inputs before any run, and the sample re-uploaded for the device-only latency
-    assert hip.calls[0] == "batch_upload" and hip.calls.count("batch_upload") == 4
+    assert hip.calls[0] == "batch_upload" and hip.calls.count("batch_upload") == 6
 
 
 def test_traffic_is_reported_for_the_grid_it_was_measured_on(monkeypatch, capsys):
@@ -258,7 +264,7 @@ def test_refuses_to_run_without_a_gpu(monkeypatch):
         bench.worker(argparse.Namespace(gpus=1, steps=1, warmup=0, batch=8, workload="c2"))
 
 
-def _rank_main(rank, port, out_dir):
+def _rank_main(rank, port, out_dir, strong=False):
     """One rank of the two-rank rehearsal (spawned process: patches by hand, no pytest fixtures here)."""
     import contextlib
     import os
@@ -272,7 +278,7 @@ def _rank_main(rank, port, out_dir):
     torch.cuda.set_device = lambda d: None
     torch.cuda.synchronize = lambda *a: None
     args = argparse.Namespace(gpus=2, steps=2, warmup=1, batch=64, cpu_sample=8, latency_ticks=0, dropin_ticks=0, no_cpu=False,
-                              no_extra=True, exact_steps=True, workload="c2")
+                              no_extra=True, exact_steps=True, workload="c2", scaling="strong" if strong else "weak", batch_total=100)
     with open(os.path.join(out_dir, "rank%d.out" % rank), "w") as fh, contextlib.redirect_stdout(fh):
         bench.worker(args)
 
@@ -292,3 +298,20 @@ def test_two_ranks_print_one_line_with_the_whole_job_rate(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and "x2" in out["config"]["parallelism"]
     assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 128.0) < 1e-6
     assert out["cpu_baseline"]["cores"] == 1 and out["parity_checked"] is True
+
+
+def test_two_ranks_strong_scaling_share_one_fixed_batch(tmp_path):
+    """--scaling strong --batch-total T (BASELINE config C4: a fixed batch block-partitioned over the ranks): value counts T scenarios per
+    step, every rank runs its block of the SAME batch, the line says "strong"."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_rank_main, args=(port, str(tmp_path), True), nprocs=2, join=True)
+    out0 = [l for l in (tmp_path / "rank0.out").read_text().splitlines() if l.startswith("{")]
+    assert len(out0) == 1 and (tmp_path / "rank1.out").read_text().strip() == ""
+    out = json.loads(out0[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["batch_total"] == 100 and out["config"]["batch_per_gpu"] == 50
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 100.0) < 1e-6
+    assert out["parity_checked"] is True

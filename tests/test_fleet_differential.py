@@ -31,14 +31,17 @@ def test_the_driver_reaches_the_rare_branches(monteblanco):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [1, 3, 4])
-def test_fleet_and_host_planner_agree_on_the_device(monteblanco, seed):
+@pytest.mark.parametrize("seed,follow_form", [(1, None), (3, None), (4, None), (1, "0"), (4, "0")])
+def test_fleet_and_host_planner_agree_on_the_device(monteblanco, monkeypatch, seed, follow_form):
     """The same on the MI355X: ltpl_fleet_* (device-resident state, 70 planners = one-wave batch path kernel) against ltpl_planner_* on the
-    same handle. Not bit-equal (the fleet solves forward-backward jobs one lane per job on fp32 operands): node lists, indices, keys and ids
-    identical, arrays to 1e-6 / 2e-5 relative."""
+    same handle. Not bit-equal (the fleet solves forward-backward jobs one lane per job as w = v^2 recurrences, the host planner goes through
+    the wave-per-job kernel): node lists, indices, keys and ids identical, arrays to 1e-5 relative, vx sample by sample. follow_form "0":
+    LTPL_FLEET_FOLLOW_WAVES=0, the lane form of the FOLLOW jobs that fleets of >= 12 288 planners run by default."""
     from graphbasedlocaltrajectoryplanner_amd import _capi
     from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
     from graphbasedlocaltrajectoryplanner_amd.planner import Planner
+    if follow_form is not None:
+        monkeypatch.setenv("LTPL_FLEET_FOLLOW_WAVES", follow_form)
     hip = _capi.HipBackend(monteblanco)
     A, B = Planner(hip, 1), Fleet(hip, 70)
     st = drive(monteblanco, A, B, seed, 300, exact=False, scen_b=69)
@@ -58,14 +61,16 @@ def test_friction_rows_then_constants_with_a_loss_of_grip(monteblanco, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [1, 2])
-def test_friction_rows_then_constants_on_the_device(monteblanco, seed):
+@pytest.mark.parametrize("seed,follow_form", [(1, None), (2, None), (2, "0")])
+def test_friction_rows_then_constants_on_the_device(monteblanco, monkeypatch, seed, follow_form):
     """The same on the MI355X: round 4 chose the friction-row form of the brake-job kernel by whether the CURRENT call carried rows, so a
     backup plan with stored rows was solved with its first row's limits once the rows stopped coming (advisor finding, round 4); the fleet
     now launches the rows form for backup / emergency jobs from the first call with rows on (fleet_dev.hpp, `seen_gg`)."""
     from graphbasedlocaltrajectoryplanner_amd import _capi
     from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
     from graphbasedlocaltrajectoryplanner_amd.planner import Planner
+    if follow_form is not None:                      # (the lane form of the follow jobs in the phases without rows, wave-per-job in those with)
+        monkeypatch.setenv("LTPL_FLEET_FOLLOW_WAVES", follow_form)
     hip = _capi.HipBackend(monteblanco)
     A, B = Planner(hip, 1), Fleet(hip, 70)
     st = drive(monteblanco, A, B, seed, 260, exact=False, scen_b=69, gg_phases=True)

@@ -14,7 +14,7 @@ four velocity parameter sets (local gg, safety distance, machine limits, v_max).
 import numpy as np
 import pytest
 
-from helpers import load_golden, assert_close_rel, assert_xy_close, REL_TOL, KAPPA_FLOOR
+from helpers import load_golden, assert_close_rel, assert_xy_close, assert_vx_elementwise, assert_ax_elementwise, REL_TOL, KAPPA_FLOOR
 from graphbasedlocaltrajectoryplanner_amd import _capi
 
 PARAM_KEYS = ("gg", "safety_d", "ax_max_machines", "vel_max")
@@ -77,6 +77,8 @@ def check_record(lat, res, vres, i, rec, what):
         scale = max(float(np.max(np.abs(tr[:, 5]))) ** 2 / 2.0, 5.0)   # ax = d(v^2) / (2 ds): against the scale of v^2 / ds
         err = float(np.max(np.abs(ax - tr[:, 6])))
         assert err <= 1e-5 * scale, "%s/%s ax: %.3e" % (what, k, err)
+        assert_vx_elementwise(vx, tr[:, 5], "%s/%s" % (what, k))
+        assert_ax_elementwise(ax, tr[:, 6], "%s/%s" % (what, k))
         # standstill rule (OTH.py:938): exactly -5 where the reference has it
         assert np.array_equal(ax == -5.0, tr[:, 6] == -5.0), "%s/%s: standstill rows" % (what, k)
         if k in ("left", "right"):

@@ -286,3 +286,77 @@ def test_a_tape_with_machine_tables_and_friction_rows(hip, monteblanco):
             assert np.array_equal(ta[k][0], tb[k][0]), (q, k)
         pr.check_trajectories(tb, ib, rb, recs[0 if q < reps else 1][T - 1], "tape planner %d" % q)
     a.close(); b.close()
+
+
+# ---- the LANE form of the follow jobs (k_fleet_follow_lanes) at test sizes ------------------------------------------------------------
+# The lane-per-job follow kernel is the default from 12 288 planners on (fleet_dev.hpp) -- the size of the bench's fleet legs -- and no test
+# creates a fleet that large: LTPL_FLEET_FOLLOW_WAVES=0 (read when the fleet is created) forces it for the small fleets below, so the kernel
+# the headline fleet numbers run on is held to the recordings of the reference and to the wave-per-job form (advisor finding, round 5).
+
+@pytest.mark.parametrize("name,n,must_see", [
+    ("c2", 3, {"straight", "follow", "left", "right"}),
+    ("overtake", 70, {"follow", "left", "right", "emergency"}),
+    ("zonewall", 3, {"straight", "follow", "right"}),
+    ("car2", 2, {"follow"}),
+])
+def test_lane_form_of_the_follow_jobs_replays_the_recordings(hip, monteblanco, monkeypatch, name, n, must_see):
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    monkeypatch.setenv("LTPL_FLEET_FOLLOW_WAVES", "0")
+    ticks = pr.load_ticks(name)
+    fleet = Fleet(hip, n)
+    seen = pr.replay(fleet, monteblanco, ticks, scen=n - 1)
+    assert must_see <= seen['keys'] and seen['full'] >= 15, seen
+    fleet.close()
+
+
+def test_lane_form_next_to_jobs_with_friction_rows_in_one_call(hip, monteblanco, monkeypatch):
+    """One job table, both kernels: the follow jobs of the planners on the friction MAP (rows per path coordinate) stay wave-per-job, those
+    of the planners with a constant tuple go to the lane kernel -- in the same ltpl_fleet_calc_vel_profile call, every tick, against the
+    recordings of both halves."""
+    from test_fleet_host_logic import friction_rows_next_to_constants
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    monkeypatch.setenv("LTPL_FLEET_FOLLOW_WAVES", "0")
+    fleet = Fleet(hip, 66)
+    keys = friction_rows_next_to_constants(fleet, monteblanco, n_ticks=200, reps=33)
+    fleet.close()
+    assert {"follow", "emergency", "right"} <= keys, keys
+
+
+def test_lane_form_and_wave_form_of_the_follow_jobs_agree(hip, monteblanco, monkeypatch):
+    """The same mixed tape (four recordings side by side, 120 ticks, state carried on the device) through a fleet with the lane form and one
+    with the wave-per-job form of the follow jobs: every looked-at planner ends with the same keys / ids / cut indices / node lists and
+    trajectories that agree to 1e-9 relative (both forms are fp64 since round 6; they order the arithmetic differently -- w = v^2 recurrence
+    per lane against the systolic wave -- so not bit for bit)."""
+    from graphbasedlocaltrajectoryplanner_amd.fleet import Fleet
+    names, per, T = ("c2", "overtake", "zonewall", "c1"), 18, 120
+    recs = [pr.load_ticks(nm) for nm in names]
+
+    def run(form):
+        monkeypatch.setenv("LTPL_FLEET_FOLLOW_WAVES", form)
+        fleet = Fleet(hip, per * len(names))
+        for g, ticks in enumerate(recs):
+            st = ticks[0]['start']
+            fleet.set_start_range(g * per, (g + 1) * per, st['pos'], st['heading'], st['vel'], st['max_heading_offset'])
+        for k in range(T):
+            fleet.tape_append_groups([(per, group_inputs(monteblanco, ticks[k])) for ticks in recs], ax_max_machines=recs[0][k]['vel_args']['ax_max_machines'])
+        fleet.tape_run(0, T)
+        out = [(fleet.trajectories(p), fleet.paths(p)) for g in range(len(names)) for p in (g * per, g * per + per // 2, g * per + per - 1)]
+        dig = fleet.digest()
+        fleet.close()
+        return out, dig
+    (lanes, dl), (waves, dw) = run("0"), run("1")
+    n_follow = 0
+    for (ta, pa), (tb, pb) in zip(lanes, waves):
+        assert list(ta[0].keys()) == list(tb[0].keys()) and ta[1] == tb[1] and ta[2]['cut_index_pos'] == tb[2]['cut_index_pos'] and ta[2]['cut_layer'] == tb[2]['cut_layer']
+        assert pa['keys'] == pb['keys'] and pa['nodes'] == pb['nodes'] and pa['node_idx'] == pb['node_idx']
+        n_follow += int("follow" in ta[0])
+        for k in ta[0]:
+            x, y = ta[0][k][0], tb[0][k][0]
+            assert x.shape == y.shape, k
+            assert np.array_equal(x[:, :5], y[:, :5]), k                                   # s, x, y, psi, kappa: the same path kernel
+            assert float(np.max(np.abs(x[:, 5] - y[:, 5]))) <= 1e-9 * max(1.0, float(np.max(np.abs(y[:, 5])))), (k, "vx")
+            assert float(np.max(np.abs(x[:, 6] - y[:, 6]))) <= 1e-7 * max(5.0, float(np.max(np.abs(y[:, 5]))) ** 2 / 2.0), (k, "ax")
+    assert n_follow >= 3
+    # ... and every planner of both fleets through the device digest (integers exact, floats 1e-9)
+    assert dl.shape == dw.shape and np.array_equal(dl[:, :5], dw[:, :5])
+    assert np.allclose(dl, dw, rtol=1e-9, atol=1e-9)

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from helpers import load_golden, assert_close_rel
+from helpers import load_golden, assert_close_rel, assert_vx_elementwise, assert_ax_elementwise
 from scenarios import random_scenarios, raceline_state
 from test_oracle_vel_golden import make_vp, replay_vel_call, check_vel_output
 from graphbasedlocaltrajectoryplanner_amd import _capi
@@ -69,6 +69,7 @@ def test_hip_vel_matches_oracle_on_random_jobs(monteblanco, hip_backend, oracle_
     n_flag_mismatch = 0
     for i, ((vx, tc, vb), (rx, rtc, rvb)) in enumerate(zip(got, exp_)):
         assert_close_rel(vx, rx, what="job %d mode %d n %d" % (i, jobs[i]["mode"], jobs[i]["kappa"].size))
+        assert_vx_elementwise(vx, rx, "job %d mode %d" % (i, jobs[i]["mode"]))
         assert tc == rtc
         n_flag_mismatch += int(vb != rvb)
     assert n_flag_mismatch == 0
@@ -102,6 +103,9 @@ def compare_tick(res, vres, ref, vref):
                 scale = max(float(np.max(np.abs(vref.vx[s, a, :n]))) ** 2 / 2.0, 5.0)
                 err = float(np.max(np.abs(vres.ax[s, a, :n] - vref.ax[s, a, :n])))
                 assert err <= 1e-5 * scale, "ax s%d a%d err %.3e" % (s, a, err)
+                # ... and sample by sample (north_star: velocity profiles within 1e-5 relative; every operand of the stage is fp64)
+                assert_vx_elementwise(vres.vx[s, a, :n], vref.vx[s, a, :n], "s%d a%d" % (s, a))
+                assert_ax_elementwise(vres.ax[s, a, :n], vref.ax[s, a, :n], "s%d a%d" % (s, a))
 
 
 @pytest.mark.parametrize("seed,n_veh", [(0, 8), (7, 3), (9, 0)])

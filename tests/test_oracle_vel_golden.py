@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from helpers import load_golden, assert_close_rel
+from helpers import load_golden, assert_close_rel, assert_vx_elementwise
 from graphbasedlocaltrajectoryplanner_amd.vp_forward_backward import VpForwardBackward
 
 
@@ -41,14 +41,17 @@ def check_vel_output(out, rec, what):
     m = rec['method']
     if m == 'check_brake_prefix':
         assert_close_rel(out[0], exp[0], what=what + " vx_prefix")
+        assert_vx_elementwise(out[0], exp[0], what + " prefix")
         assert int(out[1]) == int(exp[1]), what + " pref_idx"
         assert abs(float(out[2]) - float(exp[2])) <= 1e-5 * max(abs(float(exp[2])), 1.0)
     elif m == 'calc_vel_profile_follow':
         assert_close_rel(out[0], exp[0], what=what + " vx")
+        assert_vx_elementwise(out[0], exp[0], what)
         assert bool(out[1]) == bool(exp[1]), what + " too_close"
         assert bool(out[2]) == bool(exp[2]), what + " vel_bound"
     else:
         assert_close_rel(out, exp, what=what + " vx")
+        assert_vx_elementwise(out, exp, what)
 
 
 @pytest.mark.parametrize("fixture", ["c2_vel_calls.npz", "c1_vel_calls.npz", "zonewall_vel_calls.npz"])
