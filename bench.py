@@ -304,6 +304,52 @@ def single_tick_latency(hip, lat, scen, vel, batch, n_ticks):
     return np.array(lat_us), (b1, v1)
 
 
+def persistent_tick_latency(lat, scen, vel, batch, n_ticks, device, launched_hip):
+    """The same single ticks through the RESIDENT kernel (ltpl_create_ex(LTPL_CREATE_PERSISTENT_TICK), k_tick_persistent: one workgroup
+    that stays on the device and receives every tick through a mailbox in page-locked memory -- no launch, no H2D copy call, warm
+    instruction cache). Own handle, closed before anything else touches the device (a resident kernel keeps device-wide synchronisations
+    waiting until its idle limit). `bit_identical`: the first 64 ticks against the launched kernel's results, every output array."""
+    hp = _capi.HipBackend(lat, device=device, persistent_tick=True)
+    try:
+        st0 = hp.persistent_stats()
+        if not st0["enabled"]:
+            return {"enabled": False, "why": "the lattice's single-tick kernel has no compile-time LDS plan"}
+        res, vres = hp.new_paths_result(1), _capi.TickVelResult(1, hp.caps.max_path_pts)
+        ref, vref = launched_hip.new_paths_result(1), _capi.TickVelResult(1, launched_hip.caps.max_path_pts)
+        same = True
+        lat_us = []
+        for i in range(100 + n_ticks):
+            k = i % 64
+            t1 = time.perf_counter()
+            b1 = _capi.PathsBatch([scen[k]], w_last_edges=W_LAST)
+            v1 = _capi.TickVelBatch(vel.params, 1, vel.vel_plan[k:k + 1], vel.vel_est[k:k + 1], np.array([[vel.pos_x[k], vel.pos_y[k]]]),
+                                    vel.veh_vel[batch.veh_off[k]:batch.veh_off[k + 1]])
+            hp.tick_batch(b1, v1, res, vres)
+            res.action_sets(0, scen[k]['start_node'][0], lat.num_layers)
+            if i >= 100:
+                lat_us.append((time.perf_counter() - t1) * 1e6)
+            elif i < 64:
+                launched_hip.tick_batch(b1, v1, ref, vref)
+                na = int(ref.n_actions[0])
+                same = same and int(res.n_actions[0]) == na and all(
+                    np.array_equal(getattr(res, f)[0, :na], getattr(ref, f)[0, :na]) for f in ("action_id", "valid", "reduced", "n_nodes", "n_pts", "n_ties"))
+                for a in range(na):
+                    if ref.valid[0, a]:
+                        n, nn = int(ref.n_pts[0, a]), int(ref.n_nodes[0, a])
+                        same = same and np.array_equal(res.nodes[0, a, :nn], ref.nodes[0, a, :nn]) and np.array_equal(res.coeff[0, a, :nn - 1], ref.coeff[0, a, :nn - 1]) \
+                            and np.array_equal(res.path_param[0, a, :n], ref.path_param[0, a, :n]) and np.array_equal(vres.vx[0, a, :n], vref.vx[0, a, :n]) \
+                            and np.array_equal(vres.ax[0, a, :n], vref.ax[0, a, :n])
+        st = hp.persistent_stats()
+        lat_us = np.array(lat_us)
+        return {"enabled": True, "p50": float(np.percentile(lat_us, 50)), "p99": float(np.percentile(lat_us, 99)), "mean": float(lat_us.mean()),
+                "ticks": int(lat_us.size), "device_us": st["device_us_mean"], "kernel_starts": int(st["launches"]), "bit_identical": bool(same),
+                "idle_limit_ms": st["idle_ms"],
+                "what": "the single tick of `p50/p99` served by the resident kernel; device_us = sequence number seen .. outputs fenced out "
+                        "(wall_clock64 inside the kernel, mean over all ticks)"}
+    finally:
+        hp.close()
+
+
 def dropin_latency(hip, lat, max_ticks):
     """One closed-loop tick of the planner entry points (the C++ OnlineTrajectoryHandler behind the ABI): replay of the
     recorded C2 loop (tests/golden/c2_ticks.npz: inputs of the unmodified reference, tick by tick). Inside the timer: packing
@@ -737,7 +783,7 @@ def worker(args):
         dom_ms = paths_ms_live if paths_ms_live > 0.0 else prof_ms[0]
         achieved = ab_paths / (dom_ms * 1e-3) / 1e9
         extra = {}
-        lat_us, device_us, drop_us, drop_ok = np.zeros(0), None, np.zeros(0), None
+        lat_us, device_us, drop_us, drop_ok, persistent = np.zeros(0), None, np.zeros(0), None, None
         # N > 1 is the scaling run: whole-job throughput only. The single-GPU legs (latency, extras, the CPU baseline and the parity
         # full-size CPU baseline) belong to the N = 1 line -- the other ranks would sit in the final barrier while rank 0 runs them
         solo = world == 1
@@ -748,6 +794,7 @@ def worker(args):
             hip.batch_upload(single[0], single[1])
             hip.batch_run(reps=20, timed=False)
             device_us = hip.batch_run(reps=200, timed=True) / 200 * 1e3
+            persistent = persistent_tick_latency(lat, scen, vel, batch, args.latency_ticks, dev_index, hip)
             if args.workload == "c2":
                 drop_us, drop_ok = dropin_latency(hip, lat, args.dropin_ticks)
         if args.workload == "c2" and not args.no_extra and solo:
@@ -903,6 +950,7 @@ def worker(args):
                            "dropin_p99": float(np.percentile(drop_us, 99)) if drop_us.size else None,
                            "dropin_mean": float(drop_us.mean()) if drop_us.size else None,
                            "dropin_ticks": int(drop_us.size), "dropin_keys_match_recording": drop_ok,
+                           "persistent_tick": persistent,
                            "what": "p50/p99: one scenario per ltpl_tick_batch call, host wall time incl. packing into the ABI structs, "
                                    "PCIe both ways and unpacking into the reference's dict structures; device_us: the tick kernel "
                                    "alone (HIP events, back-to-back launches); dropin_*: one closed-loop tick of the planner entry "

@@ -539,10 +539,20 @@ class BackendError(RuntimeError):
     pass
 
 
+CREATE_PERSISTENT_TICK = 1      # LTPL_CREATE_PERSISTENT_TICK
+
+
+class PersistentStats(C.Structure):        # ltpl_persistent_stats
+    _fields_ = [("enabled", C.c_int32), ("resident", C.c_int32), ("ticks", C.c_int64), ("launches", C.c_int64),
+                ("device_us_mean", C.c_double), ("device_us_last", C.c_double), ("idle_ms", C.c_double)]
+
+
 class HipBackend(object):
     """One handle = one lattice resident in the HBM of one MI355X. Raises if the HIP library / device is missing."""
 
-    def __init__(self, lattice: Lattice, device: int = -1, lib_path: str = None):
+    def __init__(self, lattice: Lattice, device: int = -1, lib_path: str = None, persistent_tick: bool = False):
+        """``persistent_tick``: ltpl_create_ex(LTPL_CREATE_PERSISTENT_TICK) -- single-scenario ``tick_batch`` calls are served by a resident
+        kernel behind a mailbox in page-locked memory (include/ltpl_hip.h; ``persistent_stats()`` tells whether the lattice engages it)."""
         path = lib_path or os.environ.get("LTPL_HIP_LIB") or default_library_path()
         if not os.path.isfile(path):
             raise BackendError("libltpl_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
@@ -553,7 +563,13 @@ class HipBackend(object):
         self.binding = LatticeBinding(lattice)
         self.lattice = lattice
         self.handle = C.c_void_p()
-        rc = self.lib.ltpl_create(C.byref(self.binding.desc), int(device), C.byref(self.handle))
+        if persistent_tick:
+            if not hasattr(self.lib, "ltpl_create_ex"):
+                raise BackendError("this libltpl_hip.so predates ltpl_create_ex (ABI v9): no persistent tick")
+            self.lib.ltpl_create_ex.argtypes = [C.POINTER(LatticeDesc), C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
+            rc = self.lib.ltpl_create_ex(C.byref(self.binding.desc), int(device), CREATE_PERSISTENT_TICK, C.byref(self.handle))
+        else:
+            rc = self.lib.ltpl_create(C.byref(self.binding.desc), int(device), C.byref(self.handle))
         if rc != 0:
             msg = self.lib.ltpl_last_error(None)
             raise BackendError("ltpl_create failed (%s): %s" % (_STATUS.get(rc, rc), (msg or b"").decode()))
@@ -592,6 +608,20 @@ class HipBackend(object):
         f = self.lib.ltpl_paths_kernel_symbol
         f.argtypes, f.restype = [C.c_void_p, C.c_int32], C.c_char_p
         return (f(self.handle, int(team_waves)) or b"").decode()
+
+    def persistent_stats(self):
+        """ltpl_tick_persistent_stats as a dict (enabled, resident, ticks, launches, device_us_mean, device_us_last, idle_ms)."""
+        st = PersistentStats()
+        f = self.lib.ltpl_tick_persistent_stats
+        f.argtypes = [C.c_void_p, C.POINTER(PersistentStats)]
+        self._check(f(self.handle, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in PersistentStats._fields_}
+
+    def persistent_stop(self):
+        """The resident tick kernel leaves now (it is started again by the next single tick); no-op when none is resident."""
+        f = self.lib.ltpl_tick_persistent_stop
+        f.argtypes = [C.c_void_p]
+        self._check(f(self.handle))
 
     def _check(self, rc):
         if rc != 0:

@@ -366,7 +366,9 @@ struct ltpl_fleet {
     FleetTickIn cur, curv;                            // inputs of the per-call entry points: calc_paths / calc_vel_profile
     void* h_stage = nullptr; size_t h_stage_cap = 0;  // page-locked staging of the inputs
     std::vector<FleetTickIn> tape;
-    std::vector<unsigned char> image;                 // host image of one planner block (queries)
+    std::vector<unsigned char> image;                 // host image of one planner block (queries: the views of get_paths / get_trajectories point into it)
+    std::vector<unsigned char> start_image;           // scratch image of set_start / set_start_range (a rejected pose leaves `image` alone)
+    double* d_digest = nullptr;                       // [N][LTPL_FLEET_DIGEST] of ltpl_fleet_digest, allocated at the first call (in `allocs`)
     bool began = false;
     // some call of this fleet carried friction rows (local_gg as a dict): from then on a planner's MEMORY may hold a backup plan with rows of
     // its own (PlannerS / Block::gg), and vel_b builds the backup brake job from them whatever the current call carries (OTH.py:963-968) --
@@ -539,8 +541,10 @@ try {
     fleet::PlannerS prev;
     unsigned char* blk = f->d_state + f->D.stride * (size_t)p;
     FLEET_TRY(f, hipMemcpy(&prev, blk, sizeof(prev), hipMemcpyDeviceToHost));
-    const int rc = fleet::start_block(f->h->hostlat, f->D, x, y, heading, vel, mho, in_track, cor_heading, f->image.data(), &prev, &f->err);
-    if (rc) return rc;
+    if (f->start_image.size() != f->image.size()) f->start_image.assign(f->image.size(), 0);
+    const int rc = fleet::start_block(f->h->hostlat, f->D, x, y, heading, vel, mho, in_track, cor_heading, f->start_image.data(), &prev, &f->err);
+    if (rc) return rc;                                // (rejected pose: neither the planner's block nor the query image was touched)
+    f->image = f->start_image;
     FLEET_TRY(f, hipMemcpy(blk, f->image.data(), f->D.stride, hipMemcpyHostToDevice));
     return LTPL_OK;
 } LTPL_ABI_CATCH(abi_err_of(f))
@@ -556,8 +560,11 @@ try {
     if (p0 < 0 || p1 > f->D.N || p0 >= p1) { f->err = "fleet: planner range out of bounds"; return LTPL_ERR_INVALID_ARG; }
     // the start pose first: it only needs the host's lattice tables, and a pose off the track (or a heading the track does not allow) must
     // cost neither a device synchronisation nor a read-back, and must leave the planners' memory untouched
-    const int rc = fleet::start_block(f->h->hostlat, f->D, x, y, heading, vel, mho, in_track, cor_heading, f->image.data(), nullptr, &f->err);
+    // (built in a scratch image: a rejected pose leaves the image the views of earlier get_paths / get_trajectories calls point into alone)
+    if (f->start_image.size() != f->image.size()) f->start_image.assign(f->image.size(), 0);
+    const int rc = fleet::start_block(f->h->hostlat, f->D, x, y, heading, vel, mho, in_track, cor_heading, f->start_image.data(), nullptr, &f->err);
     if (rc) return rc;
+    f->image = f->start_image;
     FLEET_TRY(f, hipSetDevice(f->h->device));
     FLEET_TRY(f, hipStreamSynchronize(f->h->stream));
     const size_t cnt = (size_t)(p1 - p0), hs = sizeof(fleet::PlannerS);
@@ -936,9 +943,11 @@ try {
     if (cap_doubles_per_planner != LTPL_FLEET_DIGEST) { f->err = "fleet: digest record size mismatch"; return LTPL_ERR_INVALID_ARG; }
     FLEET_TRY(f, hipSetDevice(f->h->device));
     const size_t n = (size_t)f->D.N * LTPL_FLEET_DIGEST;
-    double* d = nullptr;
-    struct Guard { void* a = nullptr; ~Guard() { if (a) (void)hipFree(a); } } g;
-    FLEET_TRY(f, hipMalloc(reinterpret_cast<void**>(&d), sizeof(double) * n)); g.a = d;
+    if (!f->d_digest) {                               // once per fleet (freed with the fleet's other allocations): no hipFree -- an implicit device synchronisation -- per call
+        const int rc = fleet_alloc(f, n, &f->d_digest, false);
+        if (rc) return rc;
+    }
+    double* d = f->d_digest;
     hipLaunchKernelGGL(k_fleet_digest, dim3(f->D.N), dim3(64), 0, f->h->stream, f->args, d);
     FLEET_TRY(f, hipGetLastError());
     FLEET_TRY(f, hipMemcpyAsync(out, d, sizeof(double) * n, hipMemcpyDeviceToHost, f->h->stream));

@@ -133,9 +133,20 @@ __device__ __forceinline__ double ke_rcp(const ke_t& r)        // 1 / |kappa|: h
 {
     double q = __builtin_amdgcn_rcp(r.x);
     q = fma(fma(-r.x, q, 1.0), q, q);
+#ifndef LTPL_KE_RCP_ONE_STEP
     q = fma(fma(-r.x, q, 1.0), q, q);
+#endif
     return r.x == 0.0 ? (double)INFINITY : q;
 }
+// plane accesses of the lane kernels that are the LAST use of a line (operands and forward values in the backward sweep): -DLTPL_VEL_NT marks
+// them non-temporal (experiment, round 6: does the velocity stage's streaming traffic evict the path kernel's lattice from L2?)
+#ifdef LTPL_VEL_NT
+#define KE_LOAD_LAST(p) __builtin_nontemporal_load(p)
+#define D_LOAD_LAST(p) __builtin_nontemporal_load(p)
+#else
+#define KE_LOAD_LAST(p) (*(p))
+#define D_LOAD_LAST(p) (*(p))
+#endif
 #else
 typedef float ke_scalar;
 typedef float2 ke_t;
@@ -195,6 +206,9 @@ __device__ __forceinline__ void vl_stamp(long long*, int, int) {}
 // ALL 64 LANES MUST BE ACTIVE at the call (wave-uniform control flow): a DPP move from an inactive lane delivers no data.
 // -DLTPL_SHFL_REDUCE restores the round-4 shuffle forms (same-box A/B, tools/ab_bench.sh).
 #ifndef LTPL_SHFL_REDUCE
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the DPP / v_permlane16_swap / v_permlane32_swap reductions below are gfx950 code: build with --offload-arch=gfx950 (or -DLTPL_SHFL_REDUCE for the shuffle forms)"
+#endif
 #define DPP_XOR1 0xB1                   // quad_perm:[1,0,3,2]
 #define DPP_XOR2 0x4E                   // quad_perm:[2,3,0,1]
 #define DPP_HALF_MIRROR 0x141           // lane i <-> 7 - i  of every 8: the partner at distance 4 once the quads are uniform
@@ -491,7 +505,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? (P::fixed ? 4 : LTPL_RT_WAVES) 
         // instead of being held in scalar registers -- and spilled into vector-register lanes -- from entry to last use; the by-value
         // parameters only define the kernarg layout
         const PathsKArgs* ka = paths_kargs();
-        (void)team_paths_body<NW, P, true>(ka->lat, ka->in, ka->out, ka->lp, smem, ts, nullptr, nullptr, nullptr, nullptr);
+        (void)team_paths_body<NW, P, 1>(ka->lat, ka->in, ka->out, ka->lp, smem, ts, nullptr, nullptr, nullptr, nullptr);
         if constexpr (NW != 1) signal_done(ka->out.done);
         return;
     }
@@ -1236,7 +1250,7 @@ static_assert(sizeof(DevVelParams) % 8 == 0 && sizeof(DevTickVelIn) % 8 == 0 && 
 static constexpr size_t KOFF_TP = offsetof(TickKArgs, p), KOFF_TVIN = offsetof(TickKArgs, vin), KOFF_TVOUT = offsetof(TickKArgs, vout);
 
 // body of k_tick. RL = true: every argument struct is a reference INTO THE KERNARG SEGMENT, re-read per stage (karg_reload, paths_team.hpp)
-template <int EM, bool AXM1, class P, bool RL>
+template <int EM, bool AXM1, class P, int RL>
 __device__ __forceinline__ void tick_body(const DevLat& lat_, const DevPathsIn& in_, const DevPathsOut& out_, const TeamLds& lp_,
                                           const DevVelParams& p_, const DevTickVelIn& vin_, const DevTickVelOut& vout_,
                                           int vel_off, int vel_stride, int vel_cap, unsigned char* smem, TeamShared& ts, int& sh_follow_n)
@@ -1295,12 +1309,111 @@ __global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, 
     if constexpr (P::fixed) {
         // (the by-value parameters only define the kernarg layout: see k_paths)
         const TickKArgs* tk = (const TickKArgs*)(const TickKArgs LTPL_AS4*)__builtin_amdgcn_kernarg_segment_ptr();
-        tick_body<EM, AXM1, P, true>(tk->pk.lat, tk->pk.in, tk->pk.out, tk->pk.lp, tk->p, tk->vin, tk->vout, tk->vel_off, tk->vel_stride, tk->vel_cap,
+        tick_body<EM, AXM1, P, 1>(tk->pk.lat, tk->pk.in, tk->pk.out, tk->pk.lp, tk->p, tk->vin, tk->vout, tk->vel_off, tk->vel_stride, tk->vel_cap,
                                      smem, ts, sh_follow_n);
         return;
     }
 #endif
-    tick_body<EM, AXM1, P, false>(lat, in, out, lp, p, vin, vout, vel_off, vel_stride, vel_cap, smem, ts, sh_follow_n);
+    tick_body<EM, AXM1, P, 0>(lat, in, out, lp, p, vin, vout, vel_off, vel_stride, vel_cap, smem, ts, sh_follow_n);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PERSISTENT SINGLE TICK (round 6): k_tick as a RESIDENT kernel behind a mailbox in page-locked memory
+// ---------------------------------------------------------------------------------------------------------------------
+// One car, one tick at a time (the only use the reference has: OnlineTrajectoryHandler.py:353-366 spends a 0.1 s budget per tick) is a
+// LATENCY problem, and the round-5 counters say where a launched tick loses it (profiles/r05D_icache_tick.txt): every launch starts with
+// a cold instruction cache (the kernel's ~70 KB come back through L2: 1.1 k line fetches per tick), pays the dispatch of a grid on an
+// idle chip and two runtime calls (H2D copy + launch) on the host. This kernel is launched ONCE per handle -- one workgroup of four waves,
+// the team of k_tick -- and then serves ticks until it is told to leave or has idled for `idle_limit`:
+//   host:   pack the inputs into the page-locked staging buffer (as for k_tick), write the tick's argument block into the mailbox,
+//           store-release the next sequence number, spin on the completion word (the DoneSignal the fused tick already carries);
+//   kernel: thread 0 polls the sequence word (system-scope acquire loads: they bypass the caches), the others sleep at the barrier;
+//           all threads copy the argument block and the packed inputs into device memory (two coalesced passes over PCIe instead of
+//           dependent zero-copy reads inside the phases), fence, invalidate the scalar cache (the arguments are read with scalar loads)
+//           and run tick_body<.., RL = 2> -- the SAME body as k_tick, its argument block addressed through the kernel's first argument.
+// Outputs go straight into page-locked memory as for every call with <= 8 scenarios (LTPL_ZC_OUT). No hipMemcpyAsync, no launch, no
+// stream synchronisation on the tick's path. Results are bit-identical to k_tick's (same code, same order of operations).
+// A RESIDENT kernel never completes: device-wide synchronisations of the process (hipDeviceSynchronize, hipFree) would wait for it. That
+// is why the mode is opt-in (ltpl_create_ex / LTPL_PERSISTENT_TICK), why every other entry point of the handle stops the kernel first
+// (persist_stop) and why the kernel leaves BY ITSELF after `idle_limit` (default 250 ms) without a tick; the host notices (`exited`)
+// and starts it again with the next tick. Only for lattices whose four-wave kernel has a compile-time LDS plan (PlanA4).
+#define PT_CMD_TICK 0u
+#define PT_CMD_EXIT 1u
+struct TickMailbox {
+    // host -> kernel
+    unsigned seq;                  // number of the posted tick; written LAST, with release semantics
+    unsigned cmd;                  // PT_CMD_*
+    unsigned in_bytes;             // packed inputs of the tick: bytes to copy from the staging buffer to its device twin (multiple of 16)
+    unsigned pad0;
+    // kernel -> host
+    unsigned exited;               // 0 while the kernel is resident; its last store: 1
+    unsigned n_done;               // ticks served by this residency
+    unsigned long long busy_clk;   // wall_clock64 ticks (100 MHz) between "sequence number seen" and "tick done", summed over n_done ticks
+    unsigned long long last_clk;   // ... of the last tick
+    unsigned long long pad1;
+    alignas(16) unsigned char args[2048];      // TickKArgs of the posted tick
+};
+static_assert(sizeof(TickKArgs) <= 2048 && sizeof(TickKArgs) % 8 == 0, "mailbox argument block");
+
+template <int EM, bool AXM1, class P>
+__global__ __launch_bounds__(WG_THREADS) void k_tick_persistent(const TickKArgs* d_args, TickMailbox* mb, const unsigned char* h_in, unsigned char* d_in,
+                                                                unsigned start_seq, unsigned long long idle_limit)
+{
+    static_assert(P::fixed, "the persistent tick reads its arguments like the compile-time plan classes do");
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ TeamShared ts;
+    __shared__ int sh_follow_n;
+    __shared__ unsigned sh_seq, sh_cmd, sh_in_bytes;
+    unsigned last = start_seq, n_done = 0;
+    unsigned long long busy = 0;
+    for (;;) {
+        unsigned long long t_seen = 0;
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = wall_clock64();
+            unsigned sq, cmd = PT_CMD_TICK;
+            for (;;) {
+                sq = __hip_atomic_load(&mb->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (sq != last) { cmd = __hip_atomic_load(&mb->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                if (wall_clock64() - t0 > idle_limit) { cmd = PT_CMD_EXIT; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            t_seen = wall_clock64();
+            sh_seq = sq; sh_cmd = cmd;
+            sh_in_bytes = __hip_atomic_load(&mb->in_bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+        if (sh_cmd != PT_CMD_TICK) break;
+        last = sh_seq;
+        // argument block and packed inputs: page-locked memory -> device memory, 16 bytes per thread and pass
+        {
+            __threadfence_system();                                  // (acquire side: nothing of the previous tick's host data in the caches)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4* sa = reinterpret_cast<const u32x4*>(mb->args);
+            u32x4* da = reinterpret_cast<u32x4*>(const_cast<TickKArgs*>(d_args));
+            for (unsigned i = threadIdx.x; i < (unsigned)(sizeof(TickKArgs) + 15) / 16; i += WG_THREADS) da[i] = sa[i];
+            const u32x4* si = reinterpret_cast<const u32x4*>(h_in);
+            u32x4* di = reinterpret_cast<u32x4*>(d_in);
+            const unsigned nq = sh_in_bytes >> 4;
+            for (unsigned i = threadIdx.x; i < nq; i += WG_THREADS) di[i] = si[i];
+            __threadfence_system();                                  // the copies are in L2 ...
+            __syncthreads();
+            __threadfence_system();                                  // ... and no stale line of either buffer is left in this CU's vector cache,
+            __builtin_amdgcn_s_dcache_inv();                         // nor an argument of the previous tick in the scalar cache
+        }
+        tick_body<EM, AXM1, P, 2>(d_args->pk.lat, d_args->pk.in, d_args->pk.out, d_args->pk.lp, d_args->p, d_args->vin, d_args->vout,
+                                  *karg_at<2, int, offsetof(TickKArgs, vel_off)>((const int*)nullptr), *karg_at<2, int, offsetof(TickKArgs, vel_stride)>((const int*)nullptr),
+                                  *karg_at<2, int, offsetof(TickKArgs, vel_cap)>((const int*)nullptr), smem, ts, sh_follow_n);
+        // (tick_body ends with signal_done: outputs fenced out, completion word stored -- the host may already be packing the next tick)
+        if (threadIdx.x == 0) {
+            const unsigned long long dt = wall_clock64() - t_seen;
+            busy += dt; ++n_done;
+            __hip_atomic_store(&mb->last_clk, dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&mb->busy_clk, busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&mb->n_done, n_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();                                             // (sh_seq / sh_cmd are rewritten by thread 0 in the next round)
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&mb->exited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1549,13 +1662,13 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #pragma unroll
         for (int c = 0; c < LCHB; ++c) {
             const int r = n - 2 - c >= 0 ? n - 2 - c : 0;
-            kr[c] = KE_AT(r); wr[c] = Dp[(size_t)r * 64];
+            kr[c] = KE_LOAD_LAST(&KE_AT(r)); wr[c] = D_LOAD_LAST(&Dp[(size_t)r * 64]);
         }
         for (int base = 0; __ballot(base < nst) != 0ull; base += LCHB) {
 #pragma unroll
             for (int c = 0; c < LCHB; ++c) {
                 const int r = n - 2 - base - LCHB - c >= 0 ? n - 2 - base - LCHB - c : 0;
-                kn[c] = KE_AT(r); wq[c] = Dp[(size_t)r * 64];
+                kn[c] = KE_LOAD_LAST(&KE_AT(r)); wq[c] = D_LOAD_LAST(&Dp[(size_t)r * 64]);
             }
             double vv[LCHB], aa[LCHB];
 #pragma unroll
@@ -1605,7 +1718,7 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #pragma unroll
         for (int c = 0; c < LCHB; ++c) {
             const int r = n - 2 - c >= 0 ? n - 2 - c : 0;
-            kr[c] = KE_AT(r); wr[c] = Dp[(size_t)r * 64];
+            kr[c] = KE_LOAD_LAST(&KE_AT(r)); wr[c] = D_LOAD_LAST(&Dp[(size_t)r * 64]);
         }
         auto step = [&](const ke_t& rec, double wold, int i, bool valid) {
             const bool acc = wold > orig_p;
@@ -1629,7 +1742,7 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #pragma unroll
             for (int c = 0; c < LCHB; ++c) {
                 const int r = n - 2 - base - LCHB - c >= 0 ? n - 2 - base - LCHB - c : 0;
-                kn[c] = KE_AT(r); wq[c] = Dp[(size_t)r * 64];
+                kn[c] = KE_LOAD_LAST(&KE_AT(r)); wq[c] = D_LOAD_LAST(&Dp[(size_t)r * 64]);
             }
 #pragma unroll
             for (int c = 0; c < LCHB; ++c) step(kr[c], wr[c], base + c, true);
@@ -1647,14 +1760,14 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #pragma unroll
         for (int c = 0; c < LCHB; ++c) {
             const int r = n - 2 - c >= 0 ? n - 2 - c : 0;
-            kr[c] = KE_AT(r); wr[c] = Dp[(size_t)r * 64];
+            kr[c] = KE_LOAD_LAST(&KE_AT(r)); wr[c] = D_LOAD_LAST(&Dp[(size_t)r * 64]);
         }
         for (int base = 0; base < n - 1; base += LCHB) {
             // rows of the next chunk are not written by this chunk's steps (a step only rewrites its own row n - 2 - i)
 #pragma unroll
             for (int c = 0; c < LCHB; ++c) {
                 const int r = n - 2 - base - LCHB - c >= 0 ? n - 2 - base - LCHB - c : 0;
-                kn[c] = KE_AT(r); wq[c] = Dp[(size_t)r * 64];
+                kn[c] = KE_LOAD_LAST(&KE_AT(r)); wq[c] = D_LOAD_LAST(&Dp[(size_t)r * 64]);
             }
 #pragma unroll
             for (int c = 0; c < LCHB; ++c) {
@@ -2436,6 +2549,19 @@ struct ltpl_handle {
     // [-> D2H copy of the outputs] -- submitted as ONE hipGraph launch instead of two or three stream calls. The executable graph is
     // built at the first tick and re-parameterised per tick (the pointers into the staging buffers move with the tick's counts).
     int tick_graph = 0;
+    // PERSISTENT SINGLE TICK (round 6, k_tick_persistent): opt-in by ltpl_create_ex(LTPL_CREATE_PERSISTENT_TICK) or LTPL_PERSISTENT_TICK=1
+    struct PersistTick {
+        int enabled = 0;                    // requested AND the lattice's four-wave kernel has a compile-time LDS plan
+        int running = 0, variant = -1; size_t lds = 0;
+        TickMailbox* mb = nullptr;          // page-locked
+        TickKArgs* d_args = nullptr;        // device copy of the argument block (the resident kernel's "kernarg segment")
+        hipStream_t stream = nullptr;
+        const void* h_in = nullptr; void* d_in = nullptr;      // staging buffers the resident kernel was started on
+        unsigned seq = 0;
+        double idle_ms = 250.0;             // LTPL_PERSIST_IDLE_MS: the kernel leaves by itself after this long without a tick
+        unsigned long long ticks = 0, launches = 0;            // served ticks, kernel starts (1 + restarts after idling out / other entry points)
+        unsigned long long busy_clk = 0, busy_n = 0;           // device-side time of completed residencies (wall_clock64 ticks), their ticks
+    } pt;
     hipGraph_t tg_graph = nullptr; hipGraphExec_t tg_exec = nullptr;
     hipGraphNode_t tg_n_in = nullptr, tg_n_k = nullptr, tg_n_out = nullptr;
     const void* tg_func = nullptr; int tg_has_out = 0;
@@ -2673,6 +2799,8 @@ static std::string* abi_err_of(const ltpl_planner* p) { return p ? const_cast<st
 
 extern "C" int ltpl_version(void) { return LTPL_ABI_VERSION; }
 
+static void persist_stop(ltpl_handle* h);      // (the resident single-tick kernel leaves: defined next to ltpl_tick_batch)
+
 extern "C" const char* ltpl_last_error(const ltpl_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 extern "C" int ltpl_destroy(ltpl_handle* h)
@@ -2680,6 +2808,10 @@ extern "C" int ltpl_destroy(ltpl_handle* h)
     if (!h) return LTPL_ERR_INVALID_ARG;
     if (h->n_planners > 0) { h->err = "ltpl_destroy: planners created on this handle are still alive (destroy them first)"; return LTPL_ERR_INVALID_ARG; }
     (void)hipSetDevice(h->device);
+    persist_stop(h);
+    if (h->pt.stream) (void)hipStreamDestroy(h->pt.stream);
+    if (h->pt.mb) (void)hipHostFree(h->pt.mb);
+    if (h->pt.d_args) (void)hipFree(h->pt.d_args);
     for (void* p : h->dev_allocs) (void)hipFree(p);
     if (h->d_in) (void)hipFree(h->d_in);
     if (h->d_out) (void)hipFree(h->d_out);
@@ -2709,8 +2841,14 @@ extern "C" int ltpl_destroy(ltpl_handle* h)
 }
 
 extern "C" int ltpl_create(const ltpl_lattice_desc* d, int device, ltpl_handle** out_handle)
+{
+    return ltpl_create_ex(d, device, 0u, out_handle);
+}
+
+extern "C" int ltpl_create_ex(const ltpl_lattice_desc* d, int device, uint32_t flags, ltpl_handle** out_handle)
 try {
     g_create_error.clear();
+    if (flags & ~(uint32_t)LTPL_CREATE_PERSISTENT_TICK) { g_create_error = "ltpl_create_ex: unknown flag"; return LTPL_ERR_INVALID_ARG; }
     if (!d || !out_handle) { g_create_error = "null argument"; return LTPL_ERR_INVALID_ARG; }
     if (d->num_layers < 4 || d->num_nodes < 1 || d->num_edges < 1) { g_create_error = "empty lattice"; return LTPL_ERR_INVALID_ARG; }
     int ndev = 0;
@@ -2935,7 +3073,14 @@ try {
     if (const char* e = getenv("LTPL_TICK_GRAPH")) h->tick_graph = atoi(e);
     if (const char* e = getenv("LTPL_POLL_SYNC_EVERY")) h->poll_sync_every = atoi(e);
     if (const char* e = getenv("LTPL_POLL_QUERY")) h->poll_query = atoi(e);
-    if (h->poll) {
+    // the persistent single tick: requested by flag or environment, engaged where the four-wave kernel has a compile-time LDS plan
+    {
+        const char* e = getenv("LTPL_PERSISTENT_TICK");
+        const bool want = (flags & LTPL_CREATE_PERSISTENT_TICK) != 0u || (e && atoi(e) != 0);
+        h->pt.enabled = (want && h->plan_class4 == 1 && !h->long_horizon && h->zc_out) ? 1 : 0;
+        if (const char* m = getenv("LTPL_PERSIST_IDLE_MS")) { const double v = atof(m); if (v > 0.0) h->pt.idle_ms = v; }
+    }
+    if (h->poll || h->pt.enabled) {
         if (hipHostMalloc(reinterpret_cast<void**>(&h->h_flag), 64, hipHostMallocDefault) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&h->d_done_cnt), 64) != hipSuccess ||
             hipMemset(h->d_done_cnt, 0, 64) != hipSuccess) { h->err = "cannot allocate the completion word"; return fail(LTPL_ERR_HIP); }
@@ -3013,9 +3158,11 @@ struct Arena {
 // The device-resident batch of ltpl_batch_upload points into the staging buffers (d_in / d_out / d_planes). Every other
 // entry point reuses (and may reallocate) them, so it drops the resident batch first: a later ltpl_batch_run / _download then
 // fails with "no resident batch" instead of reading overwritten or freed memory.
-static void drop_resident(ltpl_handle* h)
+static void drop_resident(ltpl_handle* h, bool keep_persistent_tick = false)
 {
-    if (h->resident || h->resident_x[0]) (void)hipDeviceSynchronize();
+    // (a resident tick kernel reads the staging buffers too -- and would keep a device-wide synchronisation waiting: it leaves first)
+    if (!keep_persistent_tick) persist_stop(h);
+    if (h->resident || h->resident_x[0]) { persist_stop(h); (void)hipDeviceSynchronize(); }
     free_resident(h->resident); h->resident = nullptr;
     for (int i = 0; i < ltpl_handle::PIPE_SETS - 1; ++i) { free_resident(h->resident_x[i]); h->resident_x[i] = nullptr; }
 }
@@ -3745,16 +3892,144 @@ static int tick_launch_graph(ltpl_handle* h, TickLayout& t, bool zc)
     return LTPL_OK;
 }
 
+// ---- the persistent single tick (k_tick_persistent): host side --------------------------------------------------------------------------
+typedef void (*ptick_kernel_t)(const TickKArgs*, TickMailbox*, const unsigned char*, unsigned char*, unsigned, unsigned long long);
+static ptick_kernel_t ptick_kernel_of(int v)
+{
+    switch (v) {
+        case 0: return k_tick_persistent<0, false, PlanA4>; case 1: return k_tick_persistent<0, true, PlanA4>;
+        case 2: return k_tick_persistent<1, false, PlanA4>; case 3: return k_tick_persistent<1, true, PlanA4>;
+        case 4: return k_tick_persistent<2, false, PlanA4>; default: return k_tick_persistent<2, true, PlanA4>;
+    }
+}
+
+// Tell the resident kernel to leave and wait until it has (every entry point that reuses the staging buffers or synchronises the device
+// calls this first; ltpl_destroy too). Cheap when nothing is resident.
+static void persist_stop(ltpl_handle* h)
+{
+    ltpl_handle::PersistTick& P = h->pt;
+    if (!P.running) return;
+    __atomic_store_n(&P.mb->cmd, PT_CMD_EXIT, __ATOMIC_RELAXED);
+    if (++P.seq == 0u) ++P.seq;
+    __atomic_store_n(&P.mb->seq, P.seq, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize(P.stream);                     // the kernel sees the command within one poll (or had idled out already)
+    P.busy_clk += P.mb->busy_clk; P.busy_n += P.mb->n_done;
+    P.running = 0;
+}
+
+static int persist_start(ltpl_handle* h, const TickLayout& t, unsigned start_seq)
+{
+    ltpl_handle::PersistTick& P = h->pt;
+    if (!P.stream) HIP_TRY(h, hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking));
+    if (!P.mb) {
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&P.mb), sizeof(TickMailbox), hipHostMallocDefault));
+        memset(P.mb, 0, sizeof(TickMailbox));
+    }
+    if (!P.d_args) HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&P.d_args), 2048));
+    const void* func = reinterpret_cast<const void*>(ptick_kernel_of(t.variant));
+    if (t.lds > 48 * 1024) HIP_TRY(h, hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds));
+    P.mb->exited = 0; P.mb->n_done = 0; P.mb->busy_clk = 0; P.mb->cmd = PT_CMD_TICK;
+    __atomic_store_n(&P.mb->seq, start_seq, __ATOMIC_RELEASE);
+    const unsigned long long idle_limit = (unsigned long long)(P.idle_ms * 1e5);           // wall_clock64 counts at 100 MHz
+    hipLaunchKernelGGL(ptick_kernel_of(t.variant), dim3(1), dim3(WG_THREADS), t.lds, P.stream, (const TickKArgs*)P.d_args, P.mb,
+                       static_cast<const unsigned char*>(h->h_in), static_cast<unsigned char*>(h->d_in), start_seq, idle_limit);
+    HIP_TRY(h, hipGetLastError());
+    P.running = 1; P.variant = t.variant; P.lds = t.lds; P.h_in = h->h_in; P.d_in = h->d_in; P.seq = start_seq; ++P.launches;
+    return LTPL_OK;
+}
+
+// one tick through the resident kernel: staging buffers packed as for k_tick (zero-copy outputs, polled completion word)
+static int persist_tick(ltpl_handle* h, TickLayout& t)
+{
+    ltpl_handle::PersistTick& P = h->pt;
+    // the kernel idled out since the last tick (its last store: `exited`), or serves another kernel variant / other buffers: (re)start
+    if (P.running && __atomic_load_n(&P.mb->exited, __ATOMIC_ACQUIRE) != 0u) {
+        HIP_TRY(h, hipStreamSynchronize(P.stream));
+        P.busy_clk += P.mb->busy_clk; P.busy_n += P.mb->n_done; P.running = 0;
+    }
+    if (P.running && (P.variant != t.variant || P.lds != t.lds || P.h_in != h->h_in || P.d_in != h->d_in)) persist_stop(h);
+    int rc;
+    if (!P.running && (rc = persist_start(h, t, P.seq))) return rc;
+    TickKArgs ka;
+    memset(&ka, 0, sizeof(ka));
+    ka.pk.lat = h->lat; ka.pk.in = t.di; ka.pk.out = t.dout; ka.pk.lp = h->lp4;
+    ka.p = t.p; ka.vin = t.dvin; ka.vout = t.dvout; ka.vel_off = t.vel_off; ka.vel_stride = t.vel_stride; ka.vel_cap = t.vel_cap;
+    memcpy(P.mb->args, &ka, sizeof(ka));
+    P.mb->in_bytes = (unsigned)align_up(t.in_total, 16);
+    P.mb->cmd = PT_CMD_TICK;
+    if (++P.seq == 0u) ++P.seq;
+    __atomic_store_n(&P.mb->seq, P.seq, __ATOMIC_RELEASE);
+    const unsigned want = t.dout.done.seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1;; ++spins) {
+        if (__atomic_load_n(h->h_flag, __ATOMIC_ACQUIRE) == want) break;
+        if ((spins & 0xfffu) != 0u) continue;
+        if (__atomic_load_n(&P.mb->exited, __ATOMIC_ACQUIRE) != 0u) {
+            // the kernel left (idle limit) between our check and our post: it cannot have seen this tick -- unless the completion word says so
+            HIP_TRY(h, hipStreamSynchronize(P.stream));
+            P.busy_clk += P.mb->busy_clk; P.busy_n += P.mb->n_done; P.running = 0;
+            if (__atomic_load_n(h->h_flag, __ATOMIC_ACQUIRE) == want) break;
+            const unsigned posted = P.seq;
+            if ((rc = persist_start(h, t, posted - 1u))) return rc;    // the new kernel starts "one behind" ...
+            P.seq = posted;
+            __atomic_store_n(&P.mb->seq, posted, __ATOMIC_RELEASE);  // ... and finds the tick that is still in the mailbox
+            continue;
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2000)) {
+            __atomic_store_n(&P.mb->cmd, PT_CMD_EXIT, __ATOMIC_RELAXED);
+            h->err = "persistent tick: no completion within 2 s"; return LTPL_ERR_HIP;
+        }
+    }
+    ++P.ticks;
+    return LTPL_OK;
+}
+
+extern "C" int ltpl_tick_persistent_stop(ltpl_handle* h)
+try {
+    if (!h) return LTPL_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    persist_stop(h);
+    return LTPL_OK;
+} LTPL_ABI_CATCH(abi_err_of(h))
+
+extern "C" int ltpl_tick_persistent_stats(ltpl_handle* h, ltpl_persistent_stats* st)
+try {
+    if (!h || !st) return LTPL_ERR_INVALID_ARG;
+    const ltpl_handle::PersistTick& P = h->pt;
+    st->enabled = P.enabled; st->resident = (P.running && P.mb && __atomic_load_n(&P.mb->exited, __ATOMIC_ACQUIRE) == 0u) ? 1 : 0;
+    st->ticks = (long long)P.ticks; st->launches = (long long)P.launches;
+    unsigned long long clk = P.busy_clk, n = P.busy_n;
+    if (P.running && P.mb) { clk += P.mb->busy_clk; n += P.mb->n_done; }
+    st->device_us_mean = n ? (double)clk / (double)n / 100.0 : 0.0;
+    st->device_us_last = (P.mb ? (double)P.mb->last_clk : 0.0) / 100.0;
+    st->idle_ms = P.idle_ms;
+    return LTPL_OK;
+} LTPL_ABI_CATCH(abi_err_of(h))
+
 extern "C" int ltpl_tick_batch(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin, ltpl_paths_out* out,
                                ltpl_tick_vel_out* vout)
 try {
     if (!h) return LTPL_ERR_INVALID_ARG;
     if (!out || !vout) { h->err = "null output"; return LTPL_ERR_INVALID_ARG; }
     HIP_TRY(h, hipSetDevice(h->device));
-    drop_resident(h);
+    const bool persistent = h->pt.enabled && in && in->n_scen == 1 && h->zc_out && !h->d_dbg;
+    drop_resident(h, persistent);
     TickLayout t;
     int rc = tick_prepare(h, in, vin, out->cap_nodes, out->cap_pts, &t);
     if (rc) return rc;
+    if (persistent && !t.pipeline) {
+        // (growing a staging buffer frees the old one: the resident kernel leaves first -- persist_tick starts it again on the new buffers)
+        if (t.in_total > h->h_in_cap || t.in_total > h->d_in_cap || t.out_total > h->h_out_cap || t.out_total > h->d_out_cap) persist_stop(h);
+        if ((rc = ensure(h, &h->h_in, &h->h_in_cap, &h->d_in, &h->d_in_cap, align_up(t.in_total, 16)))) return rc;
+        if ((rc = ensure(h, &h->h_out, &h->h_out_cap, &h->d_out, &h->d_out_cap, t.out_total))) return rc;
+        if ((rc = tick_pack(h, in, vin, &t, static_cast<unsigned char*>(h->h_in), static_cast<unsigned char*>(h->d_in),
+                            static_cast<unsigned char*>(h->h_out)))) return rc;
+        t.dout.done = next_done_signal(h);
+        if ((rc = persist_tick(h, t))) return rc;
+        tick_scatter(static_cast<const unsigned char*>(h->h_out), t, out, vout);
+        return LTPL_OK;
+    }
+    persist_stop(h);
     if ((rc = ensure(h, &h->h_in, &h->h_in_cap, &h->d_in, &h->d_in_cap, t.in_total))) return rc;
     if ((rc = ensure(h, &h->h_out, &h->h_out_cap, &h->d_out, &h->d_out_cap, t.out_total))) return rc;
     // single ticks (fused kernel): outputs straight into the page-locked buffer, completion through the polled word (see plan_paths_impl)

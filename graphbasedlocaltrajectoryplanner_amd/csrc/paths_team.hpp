@@ -183,7 +183,7 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)
 // instruction, no register held across phases) that is passed through an empty asm statement at every phase boundary: the compiler
 // cannot merge loads across such a point, so every phase loads what IT needs and drops it afterwards.
 #define LTPL_AS4 __attribute__((address_space(4)))
-template <bool RL, class T>
+template <int RL, class T>
 __device__ __forceinline__ const T* karg_reload(const T* p)
 {
     if constexpr (RL) {
@@ -219,10 +219,18 @@ __device__ __forceinline__ const PathsKArgs* paths_kargs()
 // arguments of k_paths / k_tick). karg_reload launders a pointer that has to stay alive between the phases -- four pointers = eight
 // scalar registers that the compiler parked in vector lanes around every phase (52 of the kernel's lane moves were attributed to that
 // asm statement, -gline-tables-only build); the segment pointer itself is a kernel input the hardware provides.
-template <bool RL, class T, size_t OFF>
+// RL = 2 (round 6, the PERSISTENT single-tick kernel k_tick_persistent): the argument block is not the kernel's own kernarg segment -- a
+// resident kernel receives new arguments every tick -- but a copy in device memory whose ADDRESS is the kernel's first argument: one more
+// (cached) scalar load per derivation, everything else as RL = 1. The caller invalidates the scalar cache between ticks (s_dcache_inv).
+template <int RL, class T, size_t OFF>
 __device__ __forceinline__ const T* karg_at(const T* p)
 {
-    if constexpr (RL) {
+    if constexpr (RL == 2) {
+        unsigned long long seg = (unsigned long long)(const char LTPL_AS4*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(seg));
+        const unsigned long long v = *(const unsigned long long LTPL_AS4*)seg;     // first kernel argument = address of the argument block
+        return (const T*)(const T LTPL_AS4*)(v + OFF);
+    } else if constexpr (RL == 1) {
 #ifdef LTPL_KARG_CARRY
         return karg_reload<RL>(p);
 #else
@@ -671,7 +679,7 @@ __device__ __forceinline__ void team_backtrack_all(const DevPathsOut& out, const
 //      behind the backtrack: 31.5 instead of 33.0 M ticks/s. Fused, the instruction-heavy assembly of one scenario overlaps the
 //      latency-bound sweeps of its neighbours on the SIMD; apart, the hand-over and the second launch cost more than the higher
 //      occupancy returns.) Returns the number of path samples.
-template <bool RL = false>
+template <int RL = 0>
 __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevPathsIn& in_, const DevPathsOut& out_, int s, int sl, int flags,
                                                   int hm, bool by_rank, int slot, int N, int lane, unsigned char* pw, long long* adbg,
                                                   bool skip_pp, double* vel_kappa, double* vel_len, double* vel_x, double* vel_y, int vtile,
@@ -974,7 +982,11 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
         if (a_vke) {
             // r = lane + 64 k, so kep_row(r) = kep_row(lane) + 64 (r - lane)
             const size_t ro = (size_t)(((lane >> 3) << 9) + (lane & 7)) + (size_t)(r - lane) * 64;
+#ifdef LTPL_VEL_NT
+            __builtin_nontemporal_store(make_ke(fabs(kap), len_r), &a_vke[ro]);
+#else
             a_vke[ro] = make_ke(fabs(kap), len_r);
+#endif
             if (a_vxy) store2(a_vxy + 2 * ro, x, y);
         }
         if (vel_x) { vel_x[r] = x; vel_y[r] = y; }
@@ -989,7 +1001,7 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
 #undef out
 }
 
-template <class P, bool RL = false>
+template <class P, int RL = 0>
 __device__ LTPL_ASSEMBLE_ATTR WavePath team_assemble(const DevLat& lat, const DevPathsIn& in, const DevPathsOut& out, const Scen& sc,
                                   const TeamLds& lp, unsigned char* smem, int a, int f, int J, int name, int reduced,
                                   int jcl, bool share_prefix, int lane, unsigned char* pw,
@@ -1344,7 +1356,7 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
 // ---------------------------------------------------------------------------------------------------------------------
 // RL = true: the four argument structs are references INTO THE KERNARG SEGMENT (paths_kargs()) and are re-read per phase (karg_reload);
 // RL = false: plain references to the kernel's by-value arguments, as before.
-template <int NW, class P, bool RL = false>
+template <int NW, class P, int RL = 0>
 __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const DevPathsIn& in_, const DevPathsOut& out_,
                                                     const TeamLds& lp_, unsigned char* smem, TeamShared& ts,
                                                     double* vel_kappa, double* vel_len, double* vel_x, double* vel_y)

@@ -29,6 +29,7 @@
  *   LTPL_FLEET_NO_FUSE=1        fleet tape runs with one kernel per stage instead of the fused stage kernels (read by ltpl_fleet_create)
  *   LTPL_FLEET_FOLLOW_WAVES=1/0 fleet follow jobs one WAVE per job / one LANE per job (default: lanes from 12 288 planners on; ltpl_fleet_create)
  *   LTPL_NO_LAYER_GRID=1        closest reference-line layer of an obstacle position by the scan over all layers, no create-time grid
+ *   LTPL_PERSISTENT_TICK=1      ltpl_create behaves like ltpl_create_ex(LTPL_CREATE_PERSISTENT_TICK); LTPL_PERSIST_IDLE_MS=<ms>: idle limit (250)
  *   LTPL_TICK_GRAPH=1           the single fused tick (copy in -> kernel [-> copy out]) as ONE hipGraph launch (measured: slower; off)
  *   LTPL_VEL_CUS=<n>            velocity streams of the resident-batch pipeline confined to n compute units by a CU mask (measured: the
  *                               velocity chain becomes the bottleneck below ~128 CUs, no gain above; off)
@@ -45,7 +46,8 @@
 extern "C" {
 #endif
 
-#define LTPL_ABI_VERSION 8        /* v7 (round 5, additive): ltpl_paths_kernel_symbol, ltpl_layer_grid, ltpl_fleet_digest; v8 (additive): ltpl_assembly_records */
+#define LTPL_ABI_VERSION 9        /* v7 (round 5, additive): ltpl_paths_kernel_symbol, ltpl_layer_grid, ltpl_fleet_digest; v8 (additive): ltpl_assembly_records;
+                                     v9 (round 6, additive): ltpl_create_ex, ltpl_tick_persistent_stop / _stats */
 
 /* status codes */
 #define LTPL_OK               0
@@ -294,6 +296,28 @@ typedef struct {
 /* Uploads the lattice to HBM once (replaces the pickled GraphBase handed to OnlineTrajectoryHandler,
  * Graph_LTPL.py:202-229). device < 0 selects the current device. */
 int ltpl_create(const ltpl_lattice_desc* lattice, int device, ltpl_handle** out_handle);
+/* v9: the same with flags. LTPL_CREATE_PERSISTENT_TICK: single-scenario ltpl_tick_batch calls are served by a RESIDENT kernel (one
+ * workgroup, started at the first such call) that receives every tick through a mailbox in page-locked memory instead of being launched
+ * per tick -- the latency form for the reference's own use, one car and one tick at a time inside its 0.1 s budget
+ * (OnlineTrajectoryHandler.py:353-366). Results are bit-identical to the launched form (same device code). Engaged for lattices whose
+ * single-tick kernel has a compile-time LDS plan (ltpl_persistent_stats.enabled tells); otherwise the call behaves like ltpl_create.
+ * A resident kernel never completes, so device-wide synchronisations of the process (hipDeviceSynchronize, hipFree) wait for it: every
+ * other entry point of the handle stops it first, ltpl_tick_persistent_stop does so on request, and it leaves by itself after
+ * LTPL_PERSIST_IDLE_MS (250) ms without a tick -- the next tick starts it again. Environment: LTPL_PERSISTENT_TICK=1 sets the flag for
+ * ltpl_create. */
+#define LTPL_CREATE_PERSISTENT_TICK 1u
+int ltpl_create_ex(const ltpl_lattice_desc* lattice, int device, uint32_t flags, ltpl_handle** out_handle);
+typedef struct {
+    int32_t enabled;                /* 1: single ticks of this handle go through the resident kernel                         */
+    int32_t resident;               /* 1: the kernel is resident right now                                                    */
+    int64_t ticks;                  /* ticks served through the mailbox                                                       */
+    int64_t launches;               /* kernel starts (first tick, after idling out, after another entry point stopped it)     */
+    double  device_us_mean;         /* device-side time per tick: "sequence number seen" .. "outputs fenced out", mean / last */
+    double  device_us_last;
+    double  idle_ms;                /* idle limit in force                                                                    */
+} ltpl_persistent_stats;
+int ltpl_tick_persistent_stop(ltpl_handle* handle);       /* the resident kernel leaves now (no-op when none is resident)           */
+int ltpl_tick_persistent_stats(ltpl_handle* handle, ltpl_persistent_stats* stats);
 int ltpl_destroy(ltpl_handle* handle);
 int ltpl_get_caps(const ltpl_handle* handle, ltpl_caps* caps);
 const char* ltpl_last_error(const ltpl_handle* handle);   /* NULL handle -> last create() error */

@@ -70,7 +70,8 @@ class StandInFleet(object):
 class StandInBackend(object):
     """HipBackend's surface as bench.py uses it; results from the oracle, durations invented."""
 
-    def __init__(self, lattice, device=-1):
+    def __init__(self, lattice, device=-1, persistent_tick=False):
+        self.persistent_tick, self.n_single = persistent_tick, 0
         self.orc = OracleBackend(lattice)
         self.host = HostPlannerBackend(lattice)
         self.fleet_host = HostFleetBackend(lattice)
@@ -86,8 +87,13 @@ class StandInBackend(object):
     def new_paths_result(self, n_scen):
         return self.orc.new_paths_result(n_scen)
 
+    def persistent_stats(self):
+        return {"enabled": int(self.persistent_tick), "resident": 0, "ticks": self.n_single, "launches": 1, "device_us_mean": 33.0, "device_us_last": 33.0,
+                "idle_ms": 250.0}
+
     def tick_batch(self, batch, vel, result=None, vresult=None):
         self.calls.append("tick_batch")
+        self.n_single += int(batch.n_scen == 1)
         return self.orc.tick_batch(batch, vel, result, vresult)
 
     def new_compact_trajectories(self, n_scen, max_rows=115, capacity_rows=None):
@@ -126,8 +132,8 @@ def run_worker(monkeypatch, capsys, **over):
     from graphbasedlocaltrajectoryplanner_amd import planner as planner_mod
     made = []
 
-    def backend(lattice, device=-1):
-        made.append(StandInBackend(lattice, device))
+    def backend(lattice, device=-1, persistent_tick=False):
+        made.append(StandInBackend(lattice, device, persistent_tick))
         return made[-1]
 
     monkeypatch.setattr(_capi, "HipBackend", backend)
@@ -189,6 +195,8 @@ def test_the_line_carries_the_drivers_contract(monkeypatch, capsys):
     l = out["latency_us"]
     assert l["ticks"] == 4 and l["p50"] > 0 and l["device_us"] == pytest.approx(900.0)
     assert l["dropin_ticks"] == 40 and l["dropin_keys_match_recording"] is True
+    pt = l["persistent_tick"]                                                    # the same ticks through the resident kernel (own handle)
+    assert pt["enabled"] is True and pt["ticks"] == 4 and pt["bit_identical"] is True and pt["device_us"] == pytest.approx(33.0) and pt["p99"] >= pt["p50"] > 0
     assert out["extra"]["pcie_inclusive"]["scenarios_per_call"] == 64 and out["extra"]["three_slot_paths_per_tick"] >= 1.0
     cl = out["extra"]["closed_loop"]
     assert cl["planners"] == 256 and cl["planner_ticks_per_s"] > 0 and cl["keys_match_recording"] is True
@@ -272,7 +280,7 @@ def _rank_main(rank, port, out_dir, strong=False):
     from graphbasedlocaltrajectoryplanner_amd import planner as planner_mod
     os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1",
                        "MASTER_PORT": str(port), "LTPL_BENCH_SHARE_GPU": "1"})       # share: gloo + CPU tensors for the max
-    _capi.HipBackend = lambda lattice, device=-1: StandInBackend(lattice, device)
+    _capi.HipBackend = lambda lattice, device=-1, persistent_tick=False: StandInBackend(lattice, device, persistent_tick)
     planner_mod.Planner = lambda hip, n_scen=1, **cfg: hip.host.planner(n_scen, **cfg)
     torch.cuda.is_available = lambda: True
     torch.cuda.set_device = lambda d: None
