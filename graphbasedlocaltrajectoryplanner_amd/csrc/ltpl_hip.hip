@@ -204,10 +204,9 @@ __device__ __forceinline__ void vl_stamp(long long*, int, int) {}
 // through DPP row operations (partner at distance 1, 2, 4, 8 inside a row of 16 lanes) and the gfx950 row / half swaps
 // (v_permlane16_swap, v_permlane32_swap: distance 16 and 32) instead: no LDS instruction, no lgkmcnt wait.
 // ALL 64 LANES MUST BE ACTIVE at the call (wave-uniform control flow): a DPP move from an inactive lane delivers no data.
-// -DLTPL_SHFL_REDUCE restores the round-4 shuffle forms (same-box A/B, tools/ab_bench.sh).
-#ifndef LTPL_SHFL_REDUCE
+// (the round-4 `__shfl_xor` forms: tools/experiments/r05_lost_switches.patch)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
-#error "the DPP / v_permlane16_swap / v_permlane32_swap reductions below are gfx950 code: build with --offload-arch=gfx950 (or -DLTPL_SHFL_REDUCE for the shuffle forms)"
+#error "the DPP / v_permlane16_swap / v_permlane32_swap reductions below are gfx950 code: build with --offload-arch=gfx950 (the round-4 shuffle forms: tools/experiments/r05_lost_switches.patch)"
 #endif
 #define DPP_XOR1 0xB1                   // quad_perm:[1,0,3,2]
 #define DPP_XOR2 0x4E                   // quad_perm:[2,3,0,1]
@@ -353,70 +352,6 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total)
     total = __builtin_amdgcn_readlane(x, 63);
     return x - v;
 }
-#else       // ---- round-4 forms: every exchange is a ds_bpermute ---------------------------------------------------------------------
-__device__ __forceinline__ double wave_min_f64(double k)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { const double o = __shfl_xor(k, m); k = o < k ? o : k; }
-    return k;
-}
-__device__ __forceinline__ int wave_min_i32(int k)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(k, m); k = o < k ? o : k; }
-    return k;
-}
-__device__ __forceinline__ int wave_max_i32(int k)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(k, m); k = o > k ? o : k; }
-    return k;
-}
-__device__ __forceinline__ int oct_max_i32(int k)
-{
-#pragma unroll
-    for (int m = 1; m < 8; m <<= 1) { const int o = __shfl_xor(k, m); k = o > k ? o : k; }
-    return k;
-}
-__device__ __forceinline__ void wave_min3(double& k1, double& k2, int& idx)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        double o1 = __shfl_xor(k1, m), o2 = __shfl_xor(k2, m);
-        int oi = __shfl_xor(idx, m);
-        bool take = (o1 < k1) || (o1 == k1 && ((o2 < k2) || (o2 == k2 && oi < idx)));
-        if (take) { k1 = o1; k2 = o2; idx = oi; }
-    }
-}
-__device__ __forceinline__ void wave_min2(double& k, int& idx)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double o = __shfl_xor(k, m);
-        const int oi = __shfl_xor(idx, m);
-        const bool take = (o < k) || (o == k && oi < idx);
-        if (take) { k = o; idx = oi; }
-    }
-}
-__device__ __forceinline__ void wave_min2_from(double& k, int& idx, int np2)
-{
-    for (int m = np2; m < 64; m <<= 1) {
-        const double o = __shfl_xor(k, m); const int oi = __shfl_xor(idx, m);
-        if (o < k || (o == k && oi < idx)) { k = o; idx = oi; }
-    }
-}
-__device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total)
-{
-    int x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    total = __shfl(x, 63);
-    return x - v;
-}
-#endif
 
 #ifdef LTPL_EXPERIMENT
 // Self-check of the cross-lane helpers above (experiment build only; tests/test_gpu_wave_ops.py through ltpl_exp_wave_ops_check):
@@ -499,7 +434,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? (P::fixed ? 4 : LTPL_RT_WAVES) 
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ TeamShared ts;
-#ifndef LTPL_NO_KARG_RELOAD
     if constexpr (P::fixed) {
         // compile-time plan classes: the argument structs are read from the kernarg segment phase by phase (karg_reload, paths_team.hpp)
         // instead of being held in scalar registers -- and spilled into vector-register lanes -- from entry to last use; the by-value
@@ -509,7 +443,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? (P::fixed ? 4 : LTPL_RT_WAVES) 
         if constexpr (NW != 1) signal_done(ka->out.done);
         return;
     }
-#endif
     (void)team_paths_body<NW, P>(lat, in, out, lp, smem, ts, nullptr, nullptr, nullptr, nullptr);
     if constexpr (NW != 1) signal_done(out.done);          // (only the four-wave latency form is launched with a completion word)
 }
@@ -1111,10 +1044,8 @@ __global__ __launch_bounds__(64) void k_vel_profile(DevLat lat, DevVelParams p_,
     if (jb.n <= 0) { signal_done(done); return; }          // unused slot of a fleet's job table (fleet_dev.hpp); seam (2) itself rejects empty jobs
     // the car of the job: its own vel_max / machine table (a fleet of different cars), else the launch's
     DevVelParams p = p_;
-#ifndef LTPL_VELJOB_UNIFORM_CAR
     if (jb.v_max > 0.0) p.v_max = jb.v_max;
     if (jb.n_axm > 0) { p.n_axm = jb.n_axm; p.axm = p_.axm + 2 * jb.axm_off; }
-#endif
     const bool follow = jb.mode == LTPL_VEL_FOLLOW || jb.mode == LTPL_VEL_FOLLOW_CONTROLLED;
     if constexpr (SEL == 1) { if (follow) return; }
     if constexpr (SEL == 2) { if (!follow || jb.lane_form) return; }      // (fleet: follow jobs without friction rows run one lane per job, k_fleet_follow_lanes)
@@ -1305,7 +1236,6 @@ __global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, 
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ TeamShared ts;
     __shared__ int sh_follow_n;
-#ifndef LTPL_NO_KARG_RELOAD
     if constexpr (P::fixed) {
         // (the by-value parameters only define the kernarg layout: see k_paths)
         const TickKArgs* tk = (const TickKArgs*)(const TickKArgs LTPL_AS4*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1313,7 +1243,6 @@ __global__ __launch_bounds__(WG_THREADS) void k_tick(DevLat lat, DevPathsIn in, 
                                      smem, ts, sh_follow_n);
         return;
     }
-#endif
     tick_body<EM, AXM1, P, 0>(lat, in, out, lp, p, vin, vout, vel_off, vel_stride, vel_cap, smem, ts, sh_follow_n);
 }
 
@@ -1609,11 +1538,7 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #pragma unroll
             for (int c = 0; c < LCHF; ++c) {                   // operands of the next chunk (clamped rows: harmless re-reads at the end)
                 const int r = base + LCHF + 1 + c < n ? base + LCHF + 1 + c : n - 1;
-#ifdef LTPL_EXP_NOLOAD
-                kn[c] = make_ke(0.01 + 1e-6 * (double)r, 2.0);
-#else
                 kn[c] = KE_AT(r);
-#endif
             }
 #pragma unroll
             for (int c = 0; c < LCHF; ++c) {
@@ -1637,9 +1562,7 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
                 double wnext = (act && wn < w0n) ? wn : w0n;
                 const bool act_out = act && !(wn > vmax2);
                 wnext = (i + 1 == n - 1 && wnext > vend2) ? vend2 : wnext;
-#ifndef LTPL_EXP_NOSTORE
                 if (valid) Dp[(size_t)(i + 1) * 64] = wnext;
-#endif
                 active = valid ? act_out : active; prev_acc = valid ? acc : prev_acc;
                 orig_i = valid ? w0n : orig_i; wi = valid ? wnext : wi; kabs_i = valid ? k_c : kabs_i; e_i = valid ? e_c : e_i;
             }

@@ -231,13 +231,9 @@ __device__ __forceinline__ const T* karg_at(const T* p)
         const unsigned long long v = *(const unsigned long long LTPL_AS4*)seg;     // first kernel argument = address of the argument block
         return (const T*)(const T LTPL_AS4*)(v + OFF);
     } else if constexpr (RL == 1) {
-#ifdef LTPL_KARG_CARRY
-        return karg_reload<RL>(p);
-#else
         unsigned long long v = (unsigned long long)(const char LTPL_AS4*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(v));
         return (const T*)(const T LTPL_AS4*)(v + OFF);
-#endif
     } else return p;
 }
 // (constants, not offsetof in the macros: the kernel bodies #define lat / in / out / lp)
@@ -281,13 +277,7 @@ struct PlanFx {
     // (HM = 40: the C3 oval with 245 edges per transition, lvms up to 330) meets them on EVERY layer: there the first 64 tail edges are
     // requested at the top of the layer step and arrive while the register chunks are processed (round 5; C3: two dependent global round
     // trips per layer less). Class A / C lattices (Monteblanco: 42 % of the transitions have a tail) keep their register budget.
-#ifdef LTPL_NO_TAIL_PF
-    static constexpr bool tail_pf = false;
-#elif defined(LTPL_TAIL_PF_ALL)
-    static constexpr bool tail_pf = NW == 1;
-#else
     static constexpr bool tail_pf = HM > 32 && NW == 1;
-#endif
     static constexpr int c_kpad = KPAD, c_hmax = HM;
     static constexpr int c_n_path_bufs = NW < LTPL_MAX_ACTIONS ? NW : LTPL_MAX_ACTIONS;
     static constexpr int c_off_dist = 0;
@@ -377,16 +367,9 @@ __device__ __forceinline__ void team_sync()
 {
     if constexpr (NW == 1) {
         // one wave: DS operations of a wave execute in order, so only the compiler has to be kept from reordering
-#ifdef LTPL_WG_FENCE                     // spill study (tools/ubench/spill_study): workgroup-scope fences + explicit LDS drain
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#else
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
     } else {
         // LDS-only workgroup barrier: the team only exchanges data through LDS, so outstanding GLOBAL loads (the edge
         // prefetch of the next layer) must not be drained here -- __syncthreads() would wait for vmcnt(0) as well
@@ -502,11 +485,7 @@ __device__ __forceinline__ void team_factor(int L, const int* ll, const int* ln,
         if (ll[i] == pb && ll[i + 1] == b) { fac_src = ln[i]; fac_dst = ln[i + 1]; fac = w_last[i]; break; }
 }
 
-#ifdef LTPL_NOINLINE_ASSEMBLE
-#define LTPL_RESWEEP_ATTR __attribute__((noinline))
-#else
 #define LTPL_RESWEEP_ATTR __forceinline__
-#endif
 // Re-sweep of one filter up to layer J straight from global memory (reduced-horizon paths only: the goal node of a
 // layer in front of the planning horizon is needed). Parents are rewritten with identical values.
 template <class P>
@@ -553,11 +532,7 @@ __device__ LTPL_RESWEEP_ATTR void team_resweep(const DevLat& lat, const DevPaths
 // Always inlined. An out-of-line copy (the compiler's own choice for the larger plan classes in round 1) takes the kernel-argument
 // structs by reference -- they are then copied to private memory -- and, inside the one-wave kernel, ran into wrong results when
 // the caller also spilled registers (spill study, DESIGN.md section 4.1: LTPL_NOINLINE_ASSEMBLE reproduces it).
-#ifdef LTPL_NOINLINE_ASSEMBLE
-#define LTPL_ASSEMBLE_ATTR __attribute__((noinline))
-#else
 #define LTPL_ASSEMBLE_ATTR __forceinline__
-#endif
 // ---- backtrack: node per layer along the parent tables -> pidx[0 .. J] (LDS path scratch `pw`), for 2-byte parent entries also the
 //      in-edge ranks -> pedge[0 .. J-1]; writes out.n_nodes / n_ties of the slot
 template <class P>
@@ -706,23 +681,6 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
             int b = sl + i; if (b >= L) b -= L;
             if (by_rank) e = at(lat.in_ptr, lat.layer_off[b] + node) + pedge[i - 1];
             else {
-#ifdef LTPL_NO_ASM_RECORDS
-                // the table only holds the source NODE: look the in-edge (source -> node) up in the node's CSC segment
-                // (sorted by source): its first 16 sources in two (unaligned) 8-byte loads, longer segments serially
-                const int src = pidx[i - 1], gid = at(lat.layer_off, b) + node;
-                const int e1 = at(lat.in_ptr, gid + 1);
-                e = at(lat.in_ptr, gid);
-                unsigned long long w0, w1;
-                __builtin_memcpy(&w0, lat.edge_src8 + e, 8); __builtin_memcpy(&w1, lat.edge_src8 + e + 8, 8);
-                const unsigned long long pat = 0x0101010101010101ull * (unsigned long long)src;
-                const unsigned long long x0 = w0 ^ pat, x1 = w1 ^ pat;
-                // exact zero-byte detector (no false positives from borrows): bytes are < 0x80 or the 0xff padding
-                const unsigned long long z0 = ~(((x0 & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x0 | 0x7f7f7f7f7f7f7f7full);
-                const unsigned long long z1 = ~(((x1 & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x1 | 0x7f7f7f7f7f7f7f7full);
-                int k = z0 ? (__ffsll((long long)z0) - 1) >> 3 : (z1 ? 8 + ((__ffsll((long long)z1) - 1) >> 3) : 16);
-                if (k >= 16) { k = 16; while (e + k < e1 - 1 && (int)at(lat.edge_src8, e + k) != src) ++k; }
-                e += k;
-#else
                 // the table only holds the source NODE: look the in-edge (source -> node) up in the node's record (DevLat::node_rec: first
                 // in-edge + the sources of the first 12 in-edges, sorted by source, ONE 16-byte load; the node's global id from the per-layer
                 // table in LDS); longer segments serially
@@ -741,7 +699,6 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
                     while (e + k < e1 - 1 && (int)at(lat.edge_src8, e + k) != src) ++k;
                 }
                 e += k;
-#endif
             }
         }
         wave_sync_lds();
@@ -755,28 +712,6 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
     // gather: rows per edge, node row indices, knots, element lengths (:260-297)
     int run = 0;
     bool seg_dup = true;                                     // (uniform) some segment starts where its predecessor starts: rows -> segments by search
-#ifdef LTPL_NO_ASM_RECORDS
-    for (int i0 = 0; i0 < N; i0 += 64) {
-        const int i = i0 + lane;
-        int take = 0, e = 0, k0 = 0, k1 = 0;
-        if (i < N) {
-            e = pedge[i]; k0 = at(lat.samp_ptr, e); k1 = at(lat.samp_ptr, e + 1);
-            take = (i == N - 1) ? (k1 - k0) : (k1 - k0 - 1);
-        }
-        int tot; const int off = wave_excl_scan(take, lane, tot);
-        if (i < N) {
-            pidx[i] = run + off;
-            kx[i] = at(lat.sx, k0); ky[i] = at(lat.sy, k0); el[i] = at(lat.edge_len, e);
-            pedge[i] = k0;                                   // from here on: first sample of the segment's edge
-            // (sin, cos) of the heading of the first / last gathered sample (spline end slopes) from the lattice's table, parked in rows 0 and
-            // N of the right-hand sides (unused until the solve)
-            if (i == 0) { mx[0] = at(lat.ssc, 2 * k0); my[0] = at(lat.ssc, 2 * k0 + 1); }
-            if (i == N - 1) { kx[N] = at(lat.sx, k1 - 1); ky[N] = at(lat.sy, k1 - 1); pidx[N] = run + off + take - 1;
-                              mx[N] = at(lat.ssc, 2 * (k1 - 1)); my[N] = at(lat.ssc, 2 * (k1 - 1) + 1); }
-        }
-        run += tot;
-    }
-#else
     // Everything of an edge comes from its record (DevLat::edge_rec), requested in ONE round trip: sample range and length, first knot; the
     // first / last segment also take the last knot and the (sin, cos) of the end headings (spline end slopes; parked in rows 0 and N of the
     // right-hand sides, unused until the solve). (Before: samp_ptr -> sx / sy / ssc, two dependent round trips.)
@@ -806,7 +741,6 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
         }
         run += tot;
     }
-#endif
     const int n_pts = run;
     wave_sync_lds();
     {
@@ -964,17 +898,9 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
         const double q = xd * xd + yd * yd;
         double* row = o_pp + (size_t)r * 5;
         // psi = normalize(atan2(y', x') - pi/2) = atan2(-x', y') (rotation by -90 degrees), range [-pi, pi)
-#ifdef LTPL_LIBM_ATAN2
-        double psi_r = atan2(-xd, yd);
-#else
         double psi_r = heading_atan2(-xd, yd);
-#endif
         if (psi_r >= D_PI) psi_r -= 2.0 * D_PI;
-#ifdef LTPL_KAPPA_SQRT
-        const double kap = (xd * ydd - yd * xdd) * fast_rcp(q * sqrt(q));
-#else
         const double kap = (xd * ydd - yd * xdd) * rsqrt_cubed(q);          // q^(-3/2); q = |tangent|^2 > 0
-#endif
         const double len_r = at(a_slen, pedge[i] + k);
         if (!skip_pp)           // (experiment build: LTPL_ABLATE bit 16 drops the path_param stores, timing only)
         { store2_u(row, x, y); store2_u(row + 2, psi_r, kap); row[4] = len_r; }
@@ -1075,18 +1001,15 @@ struct LayerArgs {
     double fac;
 };
 
-// LTPL_PIPE1 (round 5 experiment, default off -- see DESIGN.md section 9): ONE LAYER OF SOFTWARE PIPELINING for the single-filter runs of the
-// one-wave kernel. The candidate read of layer j + 1 (dist[cur(j)][source of every edge of the NEXT transition], edges already in `en`) is
-// issued together with the read-back of layer j's election words instead of at the top of layer j + 1: one LDS round trip and one wait less
-// per layer. Valid when the node step of layer j cannot remove a node (no zone node in the planning range; planning_range / default alone).
-// pre_mode bit 0: `cpre` holds this layer's source distances; bit 1: fill `cpre` for the next layer (ne_next = its edge count).
+// (one layer of software pipelining -- the candidate read of layer j + 1 issued with the read-back of layer j -- was built and lost its A/B twice:
+//  docs/HISTORY.md, tools/experiments/r05_lost_switches.patch)
 // NCHK (round 5): 0 = the number of chunks that hold edges is tested at run time at every site (uniform branches); 1 .. CH = exactly the first
 // NCHK chunks hold edges (NCHK < CH: and the transition has no tail) -- the layer loop picks the instance per layer with ONE switch, the body
 // carries no chunk tests, and only the LAST chunk can hold lanes beyond the transition.
 template <class P, int NW, int CH, unsigned ACT, int NCHK = 0>
 __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, const TeamLds& lp, unsigned char* smem,
                                            const LayerArgs& A, const EdgeRegs (&er)[CH], const unsigned blk,
-                                           int wave, int lane, double (&cpre)[CH], int pre_mode, const EdgeRegs (&en)[CH], int ne_next)
+                                           int wave, int lane)
 {
     const unsigned* blocked_bits = K.blocked_bits;
     const unsigned* zone_bits = K.zone_bits;
@@ -1143,9 +1066,6 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
     for (int ci = 0; ci < CH; ++ci) {
         if (absent(ci)) continue;            // uniform: no edges in this chunk
         const int src = sw_src(er[ci].meta);
-#ifdef LTPL_PIPE1
-        if constexpr (NA == 1 && NW == 1) { if (pre_mode & 1) { cand[ci][0] = cpre[ci]; continue; } }
-#endif
 #pragma unroll
         for (int f = 0; f < NFILT; ++f) if ((ACT >> f) & 1u) cand[ci][SL[f]] = dist[poff[f] + src];
     }
@@ -1153,33 +1073,22 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
     for (int ci = 0; ci < CH; ++ci) {
         if (absent(ci)) continue;
         const int dst = sw_dst(er[ci].meta);
-#ifdef LTPL_PREFETCH_CLAMP
-        const double c_pr = er[ci].c;                                                  // planning_range: every edge
-        // other filters: unblocked edges (bit ci of `blk`: this lane's edge of chunk ci is blocked)
-        const double c_np = ((ACT & ~(1u << F_PR)) && ((blk >> ci) & 1u)) ? INFINITY : c_pr;
-#else
         // planning_range: every edge OF THE TRANSITION -- the lanes of the chunk beyond it hold whatever followed in the table (prefetch)
         // (with NCHK only the last chunk can; one vector compare against the uniform count -- as a scalar lane mask it was eight scalar instructions)
         const double c_pr = (NCHK > 0 && ci < NCHK - 1) || lane < A.ne - (ci * NW + wave) * 64 ? er[ci].c : (double)INFINITY;
         // other filters: unblocked edges (bit ci of `blk`: this lane's edge of chunk ci is blocked; most transitions hold none -- uniform skip)
         double c_np = c_pr;
         if ((ACT & ~(1u << F_PR)) && any_blk) c_np = ((blk >> ci) & 1u) ? (double)INFINITY : c_pr;
-#endif
 #pragma unroll
         for (int f = 0; f < NFILT; ++f) {
             if (!((ACT >> f) & 1u)) continue;
             cand[ci][SL[f]] = cand[ci][SL[f]] + (f == F_PR ? c_pr : c_np);
-#ifndef LTPL_COND_MIN
             // EVERY lane issues the minimum (round 5): +inf changes nothing, and since the chunk loads take whatever follows the transition in the
             // table (prefetch) the unused lanes address scattered nodes instead of meeting in the sentinel's. No compare, no exec-mask save /
             // restore around the atomic, and the atomics of a layer's chunks issue back to back: +2.7 % ticks/s (profiles/r05q_ab_bench.txt).
             // (Rounds 2 - 4: conditional -- the unused lanes all held the sentinel edge, destination node 0, and serialised in the LDS: +18 %
             //  kernel time when it was tried unconditionally then.)
             atomicMin(reinterpret_cast<unsigned long long*>(&dist[coff[f] + dst]), (unsigned long long)__double_as_longlong(cand[ci][SL[f]]));
-#else
-            if (cand[ci][SL[f]] < INFINITY)
-                atomicMin(reinterpret_cast<unsigned long long*>(&dist[coff[f] + dst]), (unsigned long long)__double_as_longlong(cand[ci][SL[f]]));
-#endif
         }
     }
     // transitions with more edges than the register image: the rest straight from global memory (rare, not prefetched);
@@ -1206,7 +1115,6 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
                 const double du = dist[poff[f] + src];
                 bool ok = du < INFINITY;
                 if (f != F_PR) ok = ok && unbl;
-#ifndef LTPL_COND_MIN
                 // (rounds 0 / 1 without control flow, like the register chunks: an edge that must not be used carries +inf / adds nothing. The
                 //  cost is then needed by every lane, so its load is issued WITH the edge word's at the top of the iteration -- as `if (!ok)
                 //  continue` the compiler had sunk it behind the frontier read: two dependent global round trips per round, on 42 % of
@@ -1222,7 +1130,6 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
                     atomicAdd(&cnt_all[f * kpad + dst], win ? (CW_ONE | key) : 0u);
                     continue;
                 }
-#endif
                 if (!ok) continue;
                 const double cd = du + c;
                 if (ROUND == 0) { atomicMin(reinterpret_cast<unsigned long long*>(&dist[coff[f] + dst]), (unsigned long long)__double_as_longlong(cd)); continue; }
@@ -1254,11 +1161,7 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
             for (int f = 0; f < NFILT; ++f) {
                 if (!((ACT >> f) & 1u)) continue;
                 const bool win = got[ci][SL[f]] == cand[ci][SL[f]] && cand[ci][SL[f]] < INFINITY;
-#ifndef LTPL_COND_ADD
                 atomicAdd(&cnt_all[f * kpad + dst], win ? (CW_ONE | key) : 0u);          // (every lane adds, the others add nothing: +0.7 %, r05r_ab_bench.txt)
-#else
-                if (win) atomicAdd(&cnt_all[f * kpad + dst], CW_ONE | key);
-#endif
             }
         }
     }
@@ -1276,18 +1179,6 @@ __device__ __forceinline__ void team_layer(const SweepK& K, const Scen& sc, cons
             const unsigned cw = nv ? cnt_all[f * kpad + n] : 0u;       // (read by every lane + select: -1 % ticks/s, profiles/r05u_ab_bench.txt)
             c_r[SL[f]] = cw >> CW_SHIFT; w_r[SL[f]] = cw & (CW_ONE - 1u);
         }
-#ifdef LTPL_PIPE1
-    if constexpr (NA == 1 && NW == 1) {
-        if (pre_mode & 2) {
-            constexpr int F1 = (ACT & 1u) ? 0 : ((ACT & 2u) ? 1 : ((ACT & 4u) ? 2 : 3));          // the run's one filter
-#pragma unroll
-            for (int ci = 0; ci < CH; ++ci) {
-                if (ci >= LTPL_CH_ALWAYS && ci * 64 >= ne_next) continue;
-                cpre[ci] = dist[coff[F1] + sw_src(en[ci].meta)];
-            }
-        }
-    }
-#endif
     bool zone_rem = false;
     if (K.zone_any && nv) { int nl = A.v0 + n - sc.n_base; if (nl < 0) nl += K.V; zone_rem = (zone_bits[nl >> 5] >> (nl & 31)) & 1u; }
     // exact tie-break (rare): a node whose minimum is attained by several edges takes, in the reference's order, the
@@ -1435,11 +1326,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
     if (wave == 0 && (sc.flags & LTPL_FLAG_HAS_PSI_S)) {        // start heading of the constant path segment: one sincos per scenario, not per path
         double sn, cs;
         const double psi0 = in.psi_s[sc.s];                         // (uniform)
-#ifdef LTPL_LIBM_SINCOS
-        sincos(psi0, &sn, &cs);
-#else
         if (fabs(psi0) <= 12.0) heading_sincos(psi0, &sn, &cs); else sincos(psi0, &sn, &cs);
-#endif
         if (lane == 0) { ts.psi_sc[0] = sn; ts.psi_sc[1] = cs; }
     }
     // vehicle of every position (radius lookup in phase 2)
@@ -1596,27 +1483,6 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
     auto flush_shell = [&](double mx, double my, double mr) {
         if (n_shell == 0) return;
         wave_sync_lds();
-#ifdef LTPL_SHELL_4
-        for (int t0 = 0; t0 < n_shell; t0 += 4) {
-            const int t = t0 + (lane >> 4), slot = lane & 15;
-            const bool tv = t < n_shell;
-            const uint2 en_ = shell[tv ? t : t0];
-            const int e = (int)(en_.x & 0xffffffu), ql = (int)(en_.x >> 24);
-            int k0 = (int)(en_.y & 0xffffffu), ns = (int)(en_.y >> 24);
-            if (ns == 0) { const int ec_ = at(lat.sw2csc, e); k0 = at(lat.samp_ptr, ec_); ns = at(lat.samp_ptr, ec_ + 1) - k0; }   // (range too large for the packing)
-            const double px = __shfl(mx, ql), py = __shfl(my, ql), pr = __shfl(mr, ql);
-            bool hit = false;
-            for (int k = slot; k < ns; k += 16) {
-                const double dx = at(m_sx, k0 + k) - px, dy = at(m_sy, k0 + k) - py;
-                hit = hit || (dx * dx + dy * dy <= pr);
-            }
-            const unsigned long long hm = __ballot(tv && hit);
-            if (tv && slot == 0 && ((hm >> (lane & 48)) & 0xffffull)) {
-                int el_ = e - sc.e_base; if (el_ < 0) el_ += m_E;
-                atomicOr(&blocked_bits[el_ >> 5], 1u << (el_ & 31));
-            }
-        }
-#else
         // SIXTEEN entries per pass, as two independent groups of eight entries x eight sample slots (round 5): a pass is one LDS read and one
         // dependent global round trip (the samples) long whatever it holds, and a scenario with an object in range lists ~45 entries --
         // twelve passes of four entries x 16 slots were the longest stretch of the mask phase (an edge of the reference's tracks has 5 - 7
@@ -1661,7 +1527,6 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
                 }
             }
         }
-#endif
         n_shell = 0;
         wave_sync_lds();
     };
@@ -1704,21 +1569,17 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
             const int4 lyn = lay[jn];
             if (lyn.z + wave * 64 < lyn.w) { const int en_ = min(lyn.z + wave * 64 + lane, lyn.w - 1); pf0 = at(m_cap, 2 * en_); pf1 = at(m_cap, 2 * en_ + 1); }
         };
-#ifndef LTPL_NO_CAP_AHEAD
         // (planning ranges beyond 63 layers walk every transition and find most of them untouched: no look-ahead there)
         { const int j0 = (sparse && jbits) ? __ffsll((long long)jbits) - 1 : 0; if (j0 >= 1 && j0 <= H) cap_first(j0); }
-#endif
         for (int j = 1; j <= H; ++j) {
             if (sparse) { if (!jbits) break; j = __ffsll((long long)jbits) - 1; jbits &= jbits - 1; }
             int b = sc.sl + j; if (b >= L) b -= L;
             unsigned long long m = __ballot(ol >= 0 && (ol == b || ol + 1 == b));
             const int4 ly = lay[j];
             const int eb = ly.z, ee = ly.w;
-#ifndef LTPL_NO_CAP_AHEAD
             const float4 cur0 = pf0, cur1 = pf1;                 // this transition's first chunk (requested one transition ago)
             { const int jn = (sparse && jbits) ? __ffsll((long long)jbits) - 1 : 0; if (jn >= 1 && jn <= H) cap_first(jn); }
             bool first_round = sparse;
-#endif
             if (m == 0ull) continue;
             while (m) {
                 // up to MQ matching positions per round, broadcast into uniform registers
@@ -1743,10 +1604,8 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
                 // the capsule records of the NEXT chunk of 64 edges are requested before the current chunk is evaluated (round 5: a wide
                 // transition -- 245 edges on the C3 oval -- was four dependent load -> evaluate steps per pass)
                 float4 nx0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nx1 = nx0;
-#ifndef LTPL_NO_CAP_AHEAD
                 if (first_round) { nx0 = cur0; nx1 = cur1; first_round = false; }
                 else
-#endif
                 if (eb + wave * 64 < ee) { const int en_ = min(eb + wave * 64 + lane, ee - 1); nx0 = at(m_cap, 2 * en_); nx1 = at(m_cap, 2 * en_ + 1); }
                 for (int e0 = eb + wave * 64; e0 < ee; e0 += NT) {
                     // (predicated, not branched: the list bookkeeping below is wave-uniform)
@@ -1889,13 +1748,11 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
     LTPL_KARGS();
     // does any zone node lie in the planning range at all? (every wave reads the complete bitmap: the same answer team-wide)
     bool zone_any = true;
-#ifndef LTPL_NO_ZGATE
     {
         unsigned zw = 0u;
         for (int i = lane; i < lp.words_zone; i += 64) zw |= zone_bits[i];
         zone_any = __ballot(zw != 0u) != 0ull;
     }
-#endif
     const SweepK swk{pin_sgpr(lat.sw_cost), pin_sgpr(lat.sw_meta), pin_sgpr(lat.E), pin_sgpr(lat.V), blocked_bits, zone_bits, zone_any};
     // ---- phase 4: layered min-plus sweeps (GraphBase.search_graph_layer, GraphBase.py:854-894) ---------------------
     // Edge-parallel (team_layer): the edges of a transition (cost + packed source / destination / rank) are loaded with
@@ -1931,34 +1788,6 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
         // each: as ballots (one scalar pair per chunk and buffer) they were twelve scalar registers that the compiler kept spilling
         // and reloading inside the layer loop.
         unsigned bm = 0u, bn = 0u;
-        int ne_pref = 0;                                          // edges of the transition the last prefetch loaded (LTPL_PIPE1)
-#ifdef LTPL_PREFETCH_CLAMP
-        // (rounds 2-4: every lane forms its own edge index, lanes beyond the transition are redirected to the sentinel edge E)
-        auto prefetch = [&](int j, EdgeRegs (&dr)[CH], unsigned& db) {
-            const int4 ly = lay[j];
-            lyn = ly;
-            ne_pref = ly.w - ly.z;
-            unsigned bw[CH]; int sh[CH];
-            const bool look = j > 63 || ((touched >> j) & 1ull);  // uniform: can this transition hold a blocked edge at all?
-#pragma unroll
-            for (int ci = 0; ci < CH; ++ci) {
-                bw[ci] = 0u; sh[ci] = 32;
-                if (ci >= LTPL_CH_ALWAYS && ly.z + ci * SNT >= ly.w) continue;   // uniform: chunk 0 is always loaded, the rest on demand
-                const int e = ly.z + (ci * SWN + swave) * 64 + lane;
-                const int ec = e < ly.w ? e : swk.E;
-                dr[ci].c = at(swk.sw_cost, ec); dr[ci].meta = at(swk.sw_meta, ec);
-                if (look) {
-                    int el_ = (e < ly.w ? e : ly.w - 1) - sc.e_base; if (el_ < 0) el_ += swk.E;
-                    bw[ci] = blocked_bits[el_ >> 5]; sh[ci] = (e < ly.w) ? (el_ & 31) : 32;
-                }
-            }
-            db = 0u;
-            if (look) {
-#pragma unroll
-                for (int ci = 0; ci < CH; ++ci) db |= (sh[ci] < 32 ? ((bw[ci] >> (sh[ci] & 31)) & 1u) : 0u) << ci;
-            }
-        };
-#else
         // Round 5: the loads of a chunk are addressed as (uniform pointer to the chunk's first edge) + (lane * element size) -- no per-lane
         // index, no redirection: a chunk is read whole, and what lies beyond the transition (the next transition's edges, or the sentinel
         // entries behind the tables: LTPL_SW_PAD) is replaced by the sentinel cost +inf where the layer step CONSUMES the chunk (team_layer:
@@ -1968,7 +1797,6 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
         auto prefetch = [&](int j, EdgeRegs (&dr)[CH], unsigned& db) {
             const int4 ly = uniform_i4(lay[j]);
             lyn = ly;                                             // (the layer loop takes the next layer's table row from here: LTPL_LY_CARRY)
-            ne_pref = ly.w - ly.z;
             // (the lane offsets pass through an empty asm statement HERE: hoisted out of the layer loop as 64-bit values they cost two
             //  register pairs and a 64-bit vector add per load instead of the scalar-base + 32-bit-lane-offset addressing; the chunks of a
             //  transition differ by an immediate offset)
@@ -1998,7 +1826,6 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
                 for (int ci = 0; ci < CH; ++ci) db |= (el[ci] < ly.w ? (bw[ci] & 1u) : 0u) << ci;
             }
         };
-#endif
         team_sync<SWN>();
         prefetch(1, er, bm);
         lyc = lyn;
@@ -2056,71 +1883,20 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
             constexpr unsigned ACT = decltype(act_tag)::value;
             why = 0;
             int j = j0;
-#ifndef LTPL_ROT2
-            double cpre[CH]; bool have_pre = false;
-#pragma unroll
-            for (int ci = 0; ci < CH; ++ci) cpre[ci] = INFINITY;
             [[maybe_unused]] constexpr bool one_filter = ACT == (1u << F_DEF) || ACT == (1u << F_PR);
             for (; j <= j1; ++j) {
-#ifdef LTPL_NO_LY_CARRY
-                const int4 ly = lay[j];
-#else
                 const int4 ly = lyc;                               // = lay[j], read with the prefetch of this transition one layer ago
-#endif
                 if (riding) { if (__ballot(bm != 0u) != 0ull || ly.w - ly.z > CH * SNT) { why = 1; break; } }
                 if constexpr (!P::fixed) { if ((ly.y & 0xffff) > 64) { why = 2; break; } }
                 const LayerArgs A = layer_args(j, ly, from_def && j == j0, er);
                 if (j < H) prefetch(j + 1, en, bn);                // global loads in flight during this layer's LDS work
-#ifdef LTPL_PIPE1
-                // (the next layer of THIS run exists, fits the register image -- a tail would read dist itself, which is fine -- and no node can be removed)
-                const bool make_pre = one_filter && SWN == 1 && j < j1 && j < H && !swk.zone_any;
-#else
-                const bool make_pre = false;
-#endif
-                const int pm_ = (have_pre ? 1 : 0) | (make_pre ? 2 : 0);
-#ifdef LTPL_NO_NCHK
-                team_layer<P, SWN, CH, ACT>(swk, sc, lp, smem, A, er, bm, swave, lane, cpre, pm_, en, ne_pref);
-#else
                 if constexpr (SWN == 1 && CH == 3) {               // one-wave batch form: the layer body specialised for 1 / 2 / 3 chunks of edges
-                    if (A.ne <= 64) team_layer<P, SWN, CH, ACT, 1>(swk, sc, lp, smem, A, er, bm, swave, lane, cpre, pm_, en, ne_pref);
-#ifdef LTPL_NCHK_ONE
-                    else team_layer<P, SWN, CH, ACT, 0>(swk, sc, lp, smem, A, er, bm, swave, lane, cpre, pm_, en, ne_pref);
-#else
-                    else if (A.ne <= 128) team_layer<P, SWN, CH, ACT, 2>(swk, sc, lp, smem, A, er, bm, swave, lane, cpre, pm_, en, ne_pref);
-                    else team_layer<P, SWN, CH, ACT, 3>(swk, sc, lp, smem, A, er, bm, swave, lane, cpre, pm_, en, ne_pref);
-#endif
-                } else team_layer<P, SWN, CH, ACT>(swk, sc, lp, smem, A, er, bm, swave, lane, cpre, pm_, en, ne_pref);
-#endif
-                have_pre = make_pre;
+                    if (A.ne <= 64) team_layer<P, SWN, CH, ACT, 1>(swk, sc, lp, smem, A, er, bm, swave, lane);
+                    else if (A.ne <= 128) team_layer<P, SWN, CH, ACT, 2>(swk, sc, lp, smem, A, er, bm, swave, lane);
+                    else team_layer<P, SWN, CH, ACT, 3>(swk, sc, lp, smem, A, er, bm, swave, lane);
+                } else team_layer<P, SWN, CH, ACT>(swk, sc, lp, smem, A, er, bm, swave, lane);
                 rotate();
             }
-#else
-            // Two layers per iteration with the two register images changing roles (round 4): the rotation `er = en` was 3 * CH + 1
-            // register moves per layer. One layer: `cur` holds this transition's edges, the next transition's are fetched into `nxt`.
-            // Returns false when the layer needs something else (`why`).
-            auto step = [&](EdgeRegs (&cur)[CH], unsigned& cb, EdgeRegs (&nxt)[CH], unsigned& nb) -> bool {
-                const int4 ly = lay[j];
-                if (riding) { if (__ballot(cb != 0u) != 0ull || ly.w - ly.z > CH * SNT) { why = 1; return false; } }
-                if constexpr (!P::fixed) { if ((ly.y & 0xffff) > 64) { why = 2; return false; } }
-                const LayerArgs A = layer_args(j, ly, from_def && j == j0, cur);
-                if (j < H) prefetch(j + 1, nxt, nb);               // global loads in flight during this layer's LDS work
-                double cdummy[CH] = {};
-                team_layer<P, SWN, CH, ACT>(swk, sc, lp, smem, A, cur, cb, swave, lane, cdummy, 0, nxt, 0);
-                team_sync<SWN>();
-                ++j;
-                return true;
-            };
-            auto swap_back = [&]() {                               // the current image lives in `en`: back into `er` (once per run at most)
-#pragma unroll
-                for (int ci = 0; ci < CH; ++ci) er[ci] = en[ci];
-                bm = bn;
-            };
-            while (j <= j1) {
-                if (!step(er, bm, en, bn)) break;
-                if (j > j1) { swap_back(); break; }
-                if (!step(en, bn, er, bm)) { swap_back(); break; }
-            }
-#endif
             return j;
         };
         // one layer in the serial form (lane = node): more than 64 nodes in the layer, or a filter set without a specialisation
@@ -2284,11 +2060,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
     wp.end_node = -1;
     // one-wave batch form with one-byte parents in LDS: all backtracks of the scenario in one pass (rows in the frontier arrays, which are
     // free behind the goal evaluation and the re-sweeps)
-#ifdef LTPL_NO_BT_ALL
-    constexpr int BT_OFF = -1;
-#else
     constexpr int BT_OFF = BtPlace<P, NW>::off;
-#endif              // (-1: this plan has no room / no one-byte parents -- every path chases its own)
     constexpr bool BT_ALL = BT_OFF >= 0;
     unsigned char* bt = smem + (BT_ALL ? BT_OFF : 0);
     if constexpr (BT_ALL) {

@@ -50,6 +50,17 @@ def assert_same_tick(a, b, what):
             assert np.array_equal(va.vx[0, k, :n], vb.vx[0, k, :n]) and np.array_equal(va.ax[0, k, :n], vb.ax[0, k, :n]), (what, k, "vx / ax")
 
 
+def device_synchronize():
+    """hipDeviceSynchronize of the HIP runtime the library itself uses (the process holds ONE runtime: torch's bundled copy, initialised
+    second, would not find the device)."""
+    import ctypes
+    with open("/proc/self/maps") as fh:                       # the copy libltpl_hip.so pulled in, by its path
+        paths = sorted({l.split()[-1] for l in fh if "libamdhip64" in l})
+    assert paths, "libltpl_hip.so is loaded, so is its HIP runtime"
+    rt = ctypes.CDLL(paths[0])
+    assert rt.hipDeviceSynchronize() == 0
+
+
 def copy_of(res_vres):
     import copy
     return copy.deepcopy(res_vres[0]), copy.deepcopy(res_vres[1])
@@ -72,8 +83,7 @@ def test_resident_kernel_gives_the_launched_kernels_results_bit_for_bit(montebla
     assert 0.0 < st["device_us_mean"] < 5000.0 and st["device_us_last"] > 0.0, st
     assert n_follow >= 3
     pers.close()                                               # (a resident kernel: ltpl_destroy makes it leave first)
-    import torch
-    torch.cuda.synchronize()                                   # nothing of it is left on the device
+    device_synchronize()                                       # nothing of it is left on the device
 
 
 def test_other_entry_points_of_the_handle_stop_and_restart_the_resident_kernel(monteblanco, hip_backend, monkeypatch):
@@ -115,7 +125,6 @@ def test_other_entry_points_of_the_handle_stop_and_restart_the_resident_kernel(m
 def test_the_resident_kernel_leaves_by_itself_and_comes_back(monteblanco, hip_backend, monkeypatch):
     """Idle limit 5 ms: after a pause the kernel has left (nothing resident, a device-wide synchronisation returns at once); the next
     tick starts it again; ticks posted right at the limit -- the race between the kernel's last poll and the host's post -- are served."""
-    import torch
     monkeypatch.setenv("LTPL_PERSIST_IDLE_MS", "5")
     pers = _capi.HipBackend(monteblanco, persistent_tick=True)
     ticks = single_ticks(monteblanco, 40, seed=21)
@@ -123,7 +132,7 @@ def test_the_resident_kernel_leaves_by_itself_and_comes_back(monteblanco, hip_ba
     assert_same_tick(pers.tick_batch(*ticks[0]), exp[0], "first")
     time.sleep(0.05)
     assert pers.persistent_stats()["resident"] == 0
-    t0 = time.perf_counter(); torch.cuda.synchronize(); assert time.perf_counter() - t0 < 0.05
+    t0 = time.perf_counter(); device_synchronize(); assert time.perf_counter() - t0 < 0.05
     assert_same_tick(pers.tick_batch(*ticks[1]), exp[1], "after the pause")
     assert pers.persistent_stats()["launches"] == 2
     rng = np.random.default_rng(3)
@@ -136,7 +145,6 @@ def test_the_resident_kernel_leaves_by_itself_and_comes_back(monteblanco, hip_ba
 
 
 def test_stop_on_request_and_device_wide_synchronisation(monteblanco, hip_backend, monkeypatch):
-    import torch
     monkeypatch.setenv("LTPL_PERSIST_IDLE_MS", "250")
     pers = _capi.HipBackend(monteblanco, persistent_tick=True)
     b, v = single_ticks(monteblanco, 1, seed=2)[0]
@@ -144,11 +152,11 @@ def test_stop_on_request_and_device_wide_synchronisation(monteblanco, hip_backen
     assert pers.persistent_stats()["resident"] == 1
     pers.persistent_stop()
     assert pers.persistent_stats()["resident"] == 0
-    t0 = time.perf_counter(); torch.cuda.synchronize(); assert time.perf_counter() - t0 < 0.1
+    t0 = time.perf_counter(); device_synchronize(); assert time.perf_counter() - t0 < 0.1
     pers.persistent_stop()                                      # no-op
     assert_same_tick(pers.tick_batch(b, v), hip_backend.tick_batch(b, v), "tick after the stop")
     # a device-wide synchronisation WITH a resident kernel waits for the idle limit, not for ever
-    t0 = time.perf_counter(); torch.cuda.synchronize(); waited = time.perf_counter() - t0
+    t0 = time.perf_counter(); device_synchronize(); waited = time.perf_counter() - t0
     assert waited < 2.0 and pers.persistent_stats()["resident"] == 0, waited
     pers.close()
 

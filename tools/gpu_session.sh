@@ -56,6 +56,7 @@ for STEP in "$@"; do
       MIX=1 timeout 1500 tools/ab_fleet.sh $(echo $ARG | tr ',' ' ') > $O/ab_fleet.txt 2>&1; cat $O/ab_fleet.txt ;;
     tick)
       IFS='|' read -ra ENVS <<< "$ARG"
+      for i in "${!ENVS[@]}"; do [ "${ENVS[$i]}" = "-" ] && ENVS[$i]="LTPL_AB_DEFAULT=1"; done      # ("-" = the default settings)
       timeout 1200 tools/tick_ab.sh "${ENVS[@]}" > $O/tick_ab.txt 2>&1; cat $O/tick_ab.txt ;;
     c3)
       timeout 600 python tools/c3_rate.py $ARG > $O/c3.txt 2>&1; cat $O/c3.txt ;;
