@@ -129,24 +129,16 @@ __device__ __forceinline__ void signal_done(const DoneSignal& d)
 typedef double ke_scalar;
 typedef double ke_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ ke_t make_ke(double k, double e) { ke_t v; v.x = k; v.y = e; return v; }
-__device__ __forceinline__ double ke_rcp(const ke_t& r)        // 1 / |kappa|: hardware reciprocal + two Newton steps (0 -> NaN: treated as +inf by the callers' fmin)
+// 1 / |kappa|: hardware reciprocal + ONE Newton step. Measured on gfx950 over 4 M values of |kappa| between 1e-12 and 4e3 1/m
+// (tools/ubench/rcp/rcp_f64.hip, profiles/r06c_rcp_f64.txt): v_rcp_f64 alone 4.6e-8 relative, one step 2.2e-15 (20 ulp), two steps correctly
+// rounded. The limit speed ay / |kappa| enters results that are compared at 1e-5 (element-wise error of vx against the oracle ~1e-13 with either);
+// the second step was two dependent fma on the lane kernels' serial chain: +1.7 % ticks/s without it (same-box A/B, profiles/r06b_ab_bench.txt).
+__device__ __forceinline__ double ke_rcp(const ke_t& r)        // (0 -> NaN: treated as +inf by the callers' fmin)
 {
     double q = __builtin_amdgcn_rcp(r.x);
     q = fma(fma(-r.x, q, 1.0), q, q);
-#ifndef LTPL_KE_RCP_ONE_STEP
-    q = fma(fma(-r.x, q, 1.0), q, q);
-#endif
     return r.x == 0.0 ? (double)INFINITY : q;
 }
-// plane accesses of the lane kernels that are the LAST use of a line (operands and forward values in the backward sweep): -DLTPL_VEL_NT marks
-// them non-temporal (experiment, round 6: does the velocity stage's streaming traffic evict the path kernel's lattice from L2?)
-#ifdef LTPL_VEL_NT
-#define KE_LOAD_LAST(p) __builtin_nontemporal_load(p)
-#define D_LOAD_LAST(p) __builtin_nontemporal_load(p)
-#else
-#define KE_LOAD_LAST(p) (*(p))
-#define D_LOAD_LAST(p) (*(p))
-#endif
 #else
 typedef float ke_scalar;
 typedef float2 ke_t;
@@ -1313,21 +1305,32 @@ __global__ __launch_bounds__(WG_THREADS) void k_tick_persistent(const TickKArgs*
         __syncthreads();
         if (sh_cmd != PT_CMD_TICK) break;
         last = sh_seq;
-        // argument block and packed inputs: page-locked memory -> device memory, 16 bytes per thread and pass
+        // argument block and packed inputs: page-locked memory -> device memory, 16 bytes per thread and pass. Page-locked memory is not
+        // cached on the device (fine-grained: every read crosses PCIe), so ALL loads are issued before the first store -- one PCIe round
+        // trip for the block and the first 8 KB of inputs (a C2 tick packs ~2 KB) -- and nothing has to be invalidated for them.
         {
-            __threadfence_system();                                  // (acquire side: nothing of the previous tick's host data in the caches)
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            constexpr unsigned NA = (unsigned)(sizeof(TickKArgs) + 15) / 16;
+            static_assert(NA <= WG_THREADS, "one pass over the argument block");
             const u32x4* sa = reinterpret_cast<const u32x4*>(mb->args);
             u32x4* da = reinterpret_cast<u32x4*>(const_cast<TickKArgs*>(d_args));
-            for (unsigned i = threadIdx.x; i < (unsigned)(sizeof(TickKArgs) + 15) / 16; i += WG_THREADS) da[i] = sa[i];
             const u32x4* si = reinterpret_cast<const u32x4*>(h_in);
             u32x4* di = reinterpret_cast<u32x4*>(d_in);
-            const unsigned nq = sh_in_bytes >> 4;
-            for (unsigned i = threadIdx.x; i < nq; i += WG_THREADS) di[i] = si[i];
-            __threadfence_system();                                  // the copies are in L2 ...
+            const unsigned nq = sh_in_bytes >> 4, t = threadIdx.x;
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            const u32x4 a = t < NA ? sa[t] : zero;
+            const u32x4 b0 = t < nq ? si[t] : zero, b1 = t + WG_THREADS < nq ? si[t + WG_THREADS] : zero;
+            if (t < NA) da[t] = a;
+            if (t < nq) di[t] = b0;
+            if (t + WG_THREADS < nq) di[t + WG_THREADS] = b1;
+            for (unsigned i = t + 2 * WG_THREADS; i < nq; i += WG_THREADS) di[i] = si[i];
+            // the copies are consumed by THIS workgroup: stores retired (they write through to L2), then no stale line of the two buffers in
+            // the CU's vector cache and no argument of the previous tick in the scalar cache -- no system-scope fence, no L2 write-back
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
-            __threadfence_system();                                  // ... and no stale line of either buffer is left in this CU's vector cache,
-            __builtin_amdgcn_s_dcache_inv();                         // nor an argument of the previous tick in the scalar cache
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __builtin_amdgcn_s_dcache_inv();
         }
         tick_body<EM, AXM1, P, 2>(d_args->pk.lat, d_args->pk.in, d_args->pk.out, d_args->pk.lp, d_args->p, d_args->vin, d_args->vout,
                                   *karg_at<2, int, offsetof(TickKArgs, vel_off)>((const int*)nullptr), *karg_at<2, int, offsetof(TickKArgs, vel_stride)>((const int*)nullptr),
@@ -1585,13 +1588,13 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #pragma unroll
         for (int c = 0; c < LCHB; ++c) {
             const int r = n - 2 - c >= 0 ? n - 2 - c : 0;
-            kr[c] = KE_LOAD_LAST(&KE_AT(r)); wr[c] = D_LOAD_LAST(&Dp[(size_t)r * 64]);
+            kr[c] = KE_AT(r); wr[c] = Dp[(size_t)r * 64];
         }
         for (int base = 0; __ballot(base < nst) != 0ull; base += LCHB) {
 #pragma unroll
             for (int c = 0; c < LCHB; ++c) {
                 const int r = n - 2 - base - LCHB - c >= 0 ? n - 2 - base - LCHB - c : 0;
-                kn[c] = KE_LOAD_LAST(&KE_AT(r)); wq[c] = D_LOAD_LAST(&Dp[(size_t)r * 64]);
+                kn[c] = KE_AT(r); wq[c] = Dp[(size_t)r * 64];
             }
             double vv[LCHB], aa[LCHB];
 #pragma unroll
@@ -1641,7 +1644,7 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #pragma unroll
         for (int c = 0; c < LCHB; ++c) {
             const int r = n - 2 - c >= 0 ? n - 2 - c : 0;
-            kr[c] = KE_LOAD_LAST(&KE_AT(r)); wr[c] = D_LOAD_LAST(&Dp[(size_t)r * 64]);
+            kr[c] = KE_AT(r); wr[c] = Dp[(size_t)r * 64];
         }
         auto step = [&](const ke_t& rec, double wold, int i, bool valid) {
             const bool acc = wold > orig_p;
@@ -1665,7 +1668,7 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #pragma unroll
             for (int c = 0; c < LCHB; ++c) {
                 const int r = n - 2 - base - LCHB - c >= 0 ? n - 2 - base - LCHB - c : 0;
-                kn[c] = KE_LOAD_LAST(&KE_AT(r)); wq[c] = D_LOAD_LAST(&Dp[(size_t)r * 64]);
+                kn[c] = KE_AT(r); wq[c] = Dp[(size_t)r * 64];
             }
 #pragma unroll
             for (int c = 0; c < LCHB; ++c) step(kr[c], wr[c], base + c, true);
@@ -1683,14 +1686,14 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #pragma unroll
         for (int c = 0; c < LCHB; ++c) {
             const int r = n - 2 - c >= 0 ? n - 2 - c : 0;
-            kr[c] = KE_LOAD_LAST(&KE_AT(r)); wr[c] = D_LOAD_LAST(&Dp[(size_t)r * 64]);
+            kr[c] = KE_AT(r); wr[c] = Dp[(size_t)r * 64];
         }
         for (int base = 0; base < n - 1; base += LCHB) {
             // rows of the next chunk are not written by this chunk's steps (a step only rewrites its own row n - 2 - i)
 #pragma unroll
             for (int c = 0; c < LCHB; ++c) {
                 const int r = n - 2 - base - LCHB - c >= 0 ? n - 2 - base - LCHB - c : 0;
-                kn[c] = KE_LOAD_LAST(&KE_AT(r)); wq[c] = D_LOAD_LAST(&Dp[(size_t)r * 64]);
+                kn[c] = KE_AT(r); wq[c] = Dp[(size_t)r * 64];
             }
 #pragma unroll
             for (int c = 0; c < LCHB; ++c) {

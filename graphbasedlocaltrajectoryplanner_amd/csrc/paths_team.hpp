@@ -272,7 +272,10 @@ struct PlanFx {
     static constexpr bool fixed = true;
     static constexpr bool par_global = false;
     static constexpr int par_entry = 1;           // KPAD <= 127: the source node and the tie bit share one byte
-    static constexpr int ch1 = 3;                 // 192 edges in registers: fits 128 VGPRs without spills (4 waves per SIMD)
+#ifndef LTPL_CH_B
+#define LTPL_CH_B 3                               // (experiment, round 6: -DLTPL_CH_B=4 gives plan class B a fourth register chunk -- C3's 245 edges per transition without a tail)
+#endif
+    static constexpr int ch1 = (HM > 32 && NW == 1) ? LTPL_CH_B : 3;    // 192 edges in registers: fits 128 VGPRs without spills (4 waves per SIMD)
     // The edges of a transition beyond the register image (`tail_edges`) are read from global memory inside the layer step. Plan class B
     // (HM = 40: the C3 oval with 245 edges per transition, lvms up to 330) meets them on EVERY layer: there the first 64 tail edges are
     // requested at the top of the layer step and arrive while the register chunks are processed (round 5; C3: two dependent global round
@@ -908,11 +911,7 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
         if (a_vke) {
             // r = lane + 64 k, so kep_row(r) = kep_row(lane) + 64 (r - lane)
             const size_t ro = (size_t)(((lane >> 3) << 9) + (lane & 7)) + (size_t)(r - lane) * 64;
-#ifdef LTPL_VEL_NT
-            __builtin_nontemporal_store(make_ke(fabs(kap), len_r), &a_vke[ro]);
-#else
-            a_vke[ro] = make_ke(fabs(kap), len_r);
-#endif
+            a_vke[ro] = make_ke(fabs(kap), len_r);     // (non-temporal hints on the planes' stores and last loads: -10 % ticks/s, profiles/r06b_ab_bench.txt)
             if (a_vxy) store2(a_vxy + 2 * ro, x, y);
         }
         if (vel_x) { vel_x[r] = x; vel_y[r] = y; }
@@ -1894,6 +1893,11 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
                     if (A.ne <= 64) team_layer<P, SWN, CH, ACT, 1>(swk, sc, lp, smem, A, er, bm, swave, lane);
                     else if (A.ne <= 128) team_layer<P, SWN, CH, ACT, 2>(swk, sc, lp, smem, A, er, bm, swave, lane);
                     else team_layer<P, SWN, CH, ACT, 3>(swk, sc, lp, smem, A, er, bm, swave, lane);
+                } else if constexpr (SWN == 1 && CH == 4) {
+                    if (A.ne <= 64) team_layer<P, SWN, CH, ACT, 1>(swk, sc, lp, smem, A, er, bm, swave, lane);
+                    else if (A.ne <= 128) team_layer<P, SWN, CH, ACT, 2>(swk, sc, lp, smem, A, er, bm, swave, lane);
+                    else if (A.ne <= 192) team_layer<P, SWN, CH, ACT, 3>(swk, sc, lp, smem, A, er, bm, swave, lane);
+                    else team_layer<P, SWN, CH, ACT, 4>(swk, sc, lp, smem, A, er, bm, swave, lane);
                 } else team_layer<P, SWN, CH, ACT>(swk, sc, lp, smem, A, er, bm, swave, lane);
                 rotate();
             }
