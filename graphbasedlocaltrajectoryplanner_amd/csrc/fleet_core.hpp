@@ -223,8 +223,11 @@ typedef float ke_scalar_f;          // (the rounds-3..5 form, opt-in)
 struct F2 { ke_scalar_f x, y; };
 struct FJobs { VelJob* jobs; double* pool; const double* out; const int* flags; int per_planner; F2* ke; int ke_rows;
                int ke_follow; };    // >= 0: the follow jobs (slot 0) without friction rows go to the lane plane as well, job index ke_follow + p (round 5)
-FLT_FN unsigned kep_base_f(int job, int plane_rows) { return ((unsigned)(job >> 6) * (unsigned)(plane_rows >> 3) * 64u + (unsigned)(job & 63)) * 8u; }
-FLT_FN unsigned kep_row_f(int r) { return ((unsigned)(r >> 3) << 9) + (unsigned)(r & 7); }
+#ifndef LTPL_KE_RB
+#define LTPL_KE_RB 8                // rows per block of the operand planes: the layout of kep_base / kep_row (paths_team.hpp)
+#endif
+FLT_FN unsigned kep_base_f(int job, int plane_rows) { return ((unsigned)(job >> 6) * ((unsigned)plane_rows / LTPL_KE_RB) * 64u + (unsigned)(job & 63)) * LTPL_KE_RB; }
+FLT_FN unsigned kep_row_f(int r) { return ((unsigned)r / LTPL_KE_RB) * (64u * LTPL_KE_RB) + ((unsigned)r % LTPL_KE_RB); }
 // result i of the job in `slot` of planner p
 FLT_FN double job_out(const FJobs& J, const Dims& D, int p, int slot, int i) { return J.out[(size_t)(p * J.per_planner + slot) * D.R + i]; }
 

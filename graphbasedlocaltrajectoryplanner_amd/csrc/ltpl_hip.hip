@@ -2161,6 +2161,7 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
 #ifndef LTPL_VEL_F32_OPERANDS
             er[c] = KE[kep_row(base + c)].y; er[c + 1] = KE[kep_row(base + c + 1)].y;
 #else
+            static_assert(KE_RB >= 2, "pairs of rows in one load");
             const float4 v = *reinterpret_cast<const float4*>(&KE[kep_row(base + c)]);
             er[c] = (double)v.y; er[c + 1] = (double)v.w;
 #endif

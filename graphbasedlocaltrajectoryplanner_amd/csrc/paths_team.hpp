@@ -95,17 +95,22 @@ __device__ __forceinline__ double heading_atan2(double y, double x)
 }
 
 // (|kappa|, e) / (x, y) planes of the batch velocity stage: tiled by job and BLOCKED by rows -- element (job, row) lives at
-//   ((job / 64 * plane_rows / 8 + row / 8) * 64 + job % 64) * 8 + row % 8
-// so that the path kernel (lane = row of ONE job) writes 8 rows = 64 contiguous bytes per block instead of one 8-byte element on
-// each of 64 cache lines (measured: the scattered plane stores were 45 us of the 1.1 ms launch), while the velocity kernels
-// (lane = job) still find the rows of a chunk in the lines they already touched.
-#define KE_RB 8
+//   ((job / 64 * plane_rows / KE_RB + row / KE_RB) * 64 + job % 64) * KE_RB + row % KE_RB           (plane_rows: a multiple of 8)
+// so that the path kernel (lane = row of ONE job) writes KE_RB rows = KE_RB * 16 contiguous bytes per block instead of one element on each of
+// 64 cache lines (measured in round 2: the scattered plane stores were 45 us of the 1.1 ms launch), while the velocity kernels (lane = job)
+// still find the rows of a chunk in the lines they already touched. KE_RB = 8 with 16-byte records: one 128-byte line per (job, 8 rows);
+// a row access of a velocity wave then touches 64 lines (KE_RB = 1: the 8 lines of a fully coalesced kilobyte).
+#ifndef LTPL_KE_RB
+#define LTPL_KE_RB 8
+#endif
+#define KE_RB LTPL_KE_RB
+static_assert(KE_RB == 1 || KE_RB == 2 || KE_RB == 4 || KE_RB == 8, "rows per block of the operand planes");
 // (32-bit element indices: a plane holds < 2^31 elements for any batch that fits the device)
 __device__ __forceinline__ unsigned kep_base(int job, int plane_rows)
 {
-    return ((unsigned)(job >> 6) * (unsigned)(plane_rows >> 3) * 64u + (unsigned)(job & 63)) * KE_RB;
+    return ((unsigned)(job >> 6) * ((unsigned)plane_rows / KE_RB) * 64u + (unsigned)(job & 63)) * KE_RB;
 }
-__device__ __forceinline__ unsigned kep_row(int r) { return ((unsigned)(r >> 3) << 9) + (unsigned)(r & 7); }
+__device__ __forceinline__ unsigned kep_row(int r) { return ((unsigned)r / KE_RB) * (64u * KE_RB) + ((unsigned)r % KE_RB); }
 
 // element i of a lattice array (0 <= i, array < 4 GB): the byte offset is formed in 32 bits, which lets the compiler address the
 // element as scalar base + 32-bit lane offset instead of building a 64-bit address per lane
@@ -272,10 +277,10 @@ struct PlanFx {
     static constexpr bool fixed = true;
     static constexpr bool par_global = false;
     static constexpr int par_entry = 1;           // KPAD <= 127: the source node and the tie bit share one byte
-#ifndef LTPL_CH_B
-#define LTPL_CH_B 3                               // (experiment, round 6: -DLTPL_CH_B=4 gives plan class B a fourth register chunk -- C3's 245 edges per transition without a tail)
-#endif
-    static constexpr int ch1 = (HM > 32 && NW == 1) ? LTPL_CH_B : 3;    // 192 edges in registers: fits 128 VGPRs without spills (4 waves per SIMD)
+    // 192 edges in registers: fits 128 VGPRs without spills in the layer loops (4 waves per SIMD). A FOURTH chunk for plan class B (C3's 245 edges
+    // per transition without a tail, round 6): 31 registers parked with scratch accesses inside the layer loops, 17.0 against 17.9 M ticks/s
+    // on C3 (profiles/r06d_c3_ch4.txt) -- not kept.
+    static constexpr int ch1 = 3;
     // The edges of a transition beyond the register image (`tail_edges`) are read from global memory inside the layer step. Plan class B
     // (HM = 40: the C3 oval with 245 edges per transition, lvms up to 330) meets them on EVERY layer: there the first 64 tail edges are
     // requested at the top of the layer step and arrive while the register chunks are processed (round 5; C3: two dependent global round
@@ -854,7 +859,7 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
     const double* const a_slen = pin_sgpr(lat.slen);
     ke_t* a_vke = pin_sgpr(out.vke); double* a_vxy = nullptr;
     if (a_vke) {                                          // planes of the batch velocity stage, blocked by 8 rows (kep_base / kep_row)
-        const int nrb = (out.cap_pts + 7) >> 3, nsp = out.n_slots_pad;
+        const int nrb = (((out.cap_pts + 7) >> 3) << 3) / KE_RB, nsp = out.n_slots_pad;      // row blocks per tile (plane_rows / KE_RB)
         a_vke += ((size_t)(vtile >> 6) * nrb * 64 + (vtile & 63)) * KE_RB;
         if (vtile >= nsp) {                               // follow job: (x, y) for the lane-per-job follow preparation
             const int fj = vtile - nsp;
@@ -910,7 +915,7 @@ __device__ __forceinline__ int team_assemble_rest(const DevLat& lat_, const DevP
         if (vel_kappa) { vel_kappa[r] = kap; vel_len[r] = len_r; }
         if (a_vke) {
             // r = lane + 64 k, so kep_row(r) = kep_row(lane) + 64 (r - lane)
-            const size_t ro = (size_t)(((lane >> 3) << 9) + (lane & 7)) + (size_t)(r - lane) * 64;
+            const size_t ro = (size_t)kep_row(lane) + (size_t)(r - lane) * 64;
             a_vke[ro] = make_ke(fabs(kap), len_r);     // (non-temporal hints on the planes' stores and last loads: -10 % ticks/s, profiles/r06b_ab_bench.txt)
             if (a_vxy) store2(a_vxy + 2 * ro, x, y);
         }
@@ -1893,11 +1898,6 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
                     if (A.ne <= 64) team_layer<P, SWN, CH, ACT, 1>(swk, sc, lp, smem, A, er, bm, swave, lane);
                     else if (A.ne <= 128) team_layer<P, SWN, CH, ACT, 2>(swk, sc, lp, smem, A, er, bm, swave, lane);
                     else team_layer<P, SWN, CH, ACT, 3>(swk, sc, lp, smem, A, er, bm, swave, lane);
-                } else if constexpr (SWN == 1 && CH == 4) {
-                    if (A.ne <= 64) team_layer<P, SWN, CH, ACT, 1>(swk, sc, lp, smem, A, er, bm, swave, lane);
-                    else if (A.ne <= 128) team_layer<P, SWN, CH, ACT, 2>(swk, sc, lp, smem, A, er, bm, swave, lane);
-                    else if (A.ne <= 192) team_layer<P, SWN, CH, ACT, 3>(swk, sc, lp, smem, A, er, bm, swave, lane);
-                    else team_layer<P, SWN, CH, ACT, 4>(swk, sc, lp, smem, A, er, bm, swave, lane);
                 } else team_layer<P, SWN, CH, ACT>(swk, sc, lp, smem, A, er, bm, swave, lane);
                 rotate();
             }

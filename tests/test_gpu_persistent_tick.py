@@ -75,9 +75,19 @@ def device_synchronize():
     assert rt.hipDeviceSynchronize() == 0
 
 
+class _Arrays(object):
+    """The output arrays of a result object, copied (the objects themselves hold ctypes pointers and cannot be copied)."""
+
+    def __init__(self, obj, names):
+        for name in names:
+            setattr(self, name, np.array(getattr(obj, name), copy=True))
+
+
 def copy_of(res_vres):
-    import copy
-    return copy.deepcopy(res_vres[0]), copy.deepcopy(res_vres[1])
+    res, vres = res_vres
+    return (_Arrays(res, ("n_actions", "end_layer", "closest_obj_index", "action_id", "valid", "reduced", "goal_layer", "n_nodes", "n_pts", "n_ties",
+                          "nodes", "node_idx", "coeff", "path_param")),
+            _Arrays(vres, ("vx", "ax", "vel_bound", "too_close")))
 
 
 def test_resident_kernel_gives_the_launched_kernels_results_bit_for_bit(monteblanco, hip_backend, monkeypatch):
