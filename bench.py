@@ -556,7 +556,10 @@ def c4_legs(hip, scen, batch, vel, total=1024, n_gpus=8, min_s=0.5):
     256 CUs is a latency run, not a throughput run: us per call is the figure."""
     out = {"what": "C4 as BASELINE states it: %d scenarios in total; `one_gpu` = all of them in one call, `shard` = the %d scenarios one of %d "
                    "GPUs owns (the 8-GPU job's time per step is the shard's: no collective on the data path). resident_* = inputs in HBM, "
-                   "back-to-back steps; pcie_* = ltpl_tick_batch_compact per call, host wall time" % (total, total // n_gpus, n_gpus)}
+                   "back-to-back steps; pcie_* = ltpl_tick_batch_compact per call, host wall time. The library serves batches of up to two fused "
+                   "workgroups per compute unit (512 scenarios on the MI355X) with the fused tick kernel -- one launch -- and larger ones with the "
+                   "one-wave pipeline (round 6, profiles/r06h_c4_fused_ab.txt): the shard runs fused, the whole batch on one GPU the pipeline"
+                   % (total, total // n_gpus, n_gpus)}
     total = min(total, len(scen))
     for key, n in (("one_gpu", total), ("shard", max(1, total // n_gpus))):
         b, v = sub_batch(scen, batch, vel, 0, n)

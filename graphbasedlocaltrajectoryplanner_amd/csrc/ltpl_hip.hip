@@ -28,7 +28,8 @@
 #include "assembly_records.hpp"
 
 #define WG_THREADS 256
-#define PIPELINE_MIN_SCEN 64   // batches from this size on use the one-wave-per-scenario pipeline
+#define PIPELINE_MIN_SCEN 64   // seam (1) alone: batches from this size on use one-wave teams (nw1_min_scen). The fused tick against the batch
+                               // pipeline has its own, device-dependent threshold since round 6: ltpl_handle::pipeline_min_scen
 #define NUM_WAVES 4
 #define MAX_POS 192      // obstacle positions (own + predicted) per scenario
 #define MAX_VEH 96       // vehicles per scenario
@@ -2419,6 +2420,15 @@ struct ltpl_handle {
     int plan_class4 = 0;             // LDS plan of the four-wave kernels: 0 = runtime, 1 = PlanA4
     int long_horizon = 0;            // 1: parent tables in global memory (PlanRtG), velocity stage always through the lane kernels
     int nw1_min_scen = PIPELINE_MIN_SCEN;   // calls with at least this many scenarios use one-wave teams
+    // ltpl_tick_batch & co: calls with at least this many scenarios run the batch PIPELINE (one wave per scenario + the three velocity kernels),
+    // smaller ones the FUSED tick kernel (one four-wave workgroup per scenario, one launch). Rounds 1-5: 64. Round 6, measured on the MI355X
+    // with resident inputs (tools/c4_fused_ab.py, profiles/r06h_c4_fused_ab.txt; us per step, fused / pipeline): 128 scenarios 81 / 110,
+    // 256: 81 / 109, 512: 92 / 111, 1024: 152 / 117 -- while every workgroup of the fused kernel finds a compute unit of its own (or shares
+    // one with a single neighbour) a step costs ONE tick's latency, the pipeline pays four dependent launches. BASELINE config C4 shards
+    // 1024 scenarios over 8 GPUs: 128 per GPU. Default: more than 2 workgroups per compute unit (fewer where the fused kernel's LDS
+    // footprint lets fewer be resident) -> pipeline; LTPL_PIPELINE_MIN_SCEN=<n> overrides (the GPU test-suite pins 64: its batches of
+    // 64 .. 256 scenarios are there to exercise the pipeline).
+    int pipeline_min_scen = PIPELINE_MIN_SCEN;
     void* d_par = nullptr; size_t d_par_cap = 0;         // parent-table slabs of the long-horizon mode
     ltpl_caps caps{};
     std::vector<void*> dev_allocs;
@@ -3057,6 +3067,15 @@ try {
     // 128-byte line, so the 128-byte chunks the final velocity kernel writes are whole sectors (measured write traffic was 1.8x the data)
     h->caps.max_path_nodes = hmax; h->caps.max_path_pts = (int)align_up((size_t)ptsmax, 16); h->caps.max_horizon_edges = ehmax;
     h->caps.device = device; h->caps.num_cus = prop.multiProcessorCount; h->caps.lds_bytes_paths = h->lp1.total;
+    {
+        // fused tick vs pipeline (see pipeline_min_scen): workgroups of the fused kernel that fit one compute unit by LDS (its footprint is
+        // the four-wave path plan + the velocity scratch of three primitives), at most two counted
+        const size_t lds_tick = (size_t)h->lp4.total + vel_scratch_bytes(h->caps.max_path_pts, false, true) * LTPL_MAX_ACTIONS + (size_t)h->caps.max_path_pts + 32;
+        const int per_cu = lds_tick > 0 && 160 * 1024 / lds_tick >= 2 ? 2 : 1;
+        h->pipeline_min_scen = (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * per_cu + 1;
+        if (h->pipeline_min_scen < PIPELINE_MIN_SCEN) h->pipeline_min_scen = PIPELINE_MIN_SCEN;
+        if (const char* e = getenv("LTPL_PIPELINE_MIN_SCEN")) { if (atoi(e) > 0) h->pipeline_min_scen = atoi(e); }
+    }
     if (d->raceline_x && d->raceline_y && d->node_psi) {
         std::string why;
         h->has_hostlat = h->hostlat.init(d, h->caps.max_path_nodes, h->caps.max_path_pts, &why) == LTPL_OK;
@@ -3591,7 +3610,7 @@ struct TickLayout {
     DevPathsIn di; DevPathsOut dout; DevVelParams p; DevTickVelIn dvin; DevTickVelOut dvout;
     int vel_off, vel_stride, vel_cap; size_t lds;
     int variant;
-    // two-kernel batch pipeline (n_scen >= PIPELINE_MIN_SCEN)
+    // two-kernel batch pipeline (n_scen >= pipeline_min_scen)
     bool pipeline; size_t prep_odist, prep_vobj, prep_ox, prep_oy, prep_idx; size_t planes_bytes;
     DevVelPrep dprep; int prep_off, prep_stride;
     VelPlanes vp{}; int n_slots_pad = 0, n_scen_pad = 0;
@@ -3624,7 +3643,7 @@ static int tick_prepare(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick
     t->ax = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS * (size_t)cap_pts);
     t->vel_bound = b.add(sizeof(int) * (size_t)n * LTPL_MAX_ACTIONS);
     t->too_close = b.add(sizeof(int) * (size_t)n * LTPL_MAX_ACTIONS);
-    t->pipeline = h->long_horizon || (n >= PIPELINE_MIN_SCEN && !h->force_fused);
+    t->pipeline = h->long_horizon || (n >= h->pipeline_min_scen && !h->force_fused);
     t->prep_odist = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS);
     t->prep_vobj = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS);
     t->prep_ox = b.add(sizeof(double) * (size_t)n * LTPL_MAX_ACTIONS);

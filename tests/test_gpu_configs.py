@@ -123,6 +123,35 @@ def test_c4_sharded_batch_is_bit_identical(monteblanco, hip_backend):
     assert int(full.valid.sum()) >= n
 
 
+@pytest.mark.parametrize("n", [128, 513])
+def test_small_batches_fused_by_default_match_the_pipeline(monteblanco, hip_backend, monkeypatch, n):
+    """BASELINE config C4's shard is 128 scenarios per GPU. A handle created WITHOUT the suite's LTPL_PIPELINE_MIN_SCEN=64 serves batches up to
+    two workgroups per compute unit with the fused tick kernel (one launch; 81 against 110 us per step at 128 scenarios, profiles/
+    r06h_c4_fused_ab.txt) and larger ones with the pipeline: either way the outputs are those of the suite's pipeline handle -- integers
+    identical, floats to 1e-9 (the two velocity formulations order their fp64 arithmetic differently)."""
+    from test_gpu_vel import make_tick_inputs
+    monkeypatch.delenv("LTPL_PIPELINE_MIN_SCEN", raising=False)
+    dflt = _capi.HipBackend(monteblanco)
+    batch, vel = make_tick_inputs(monteblanco, n, seed=31)
+    (ra, va), (rb, vb) = dflt.tick_batch(batch, vel), hip_backend.tick_batch(batch, vel)
+    assert np.array_equal(ra.n_actions, rb.n_actions) and np.array_equal(va.vel_bound, vb.vel_bound) and np.array_equal(va.too_close, vb.too_close)
+    n_paths = 0
+    for s in range(n):
+        na = int(ra.n_actions[s])
+        for name in ("action_id", "valid", "reduced", "n_nodes", "n_pts", "n_ties"):
+            assert np.array_equal(getattr(ra, name)[s, :na], getattr(rb, name)[s, :na]), (s, name)
+        for k in range(na):
+            if ra.valid[s, k]:
+                m, nn = int(ra.n_pts[s, k]), int(ra.n_nodes[s, k])
+                n_paths += 1
+                assert np.array_equal(ra.nodes[s, k, :nn], rb.nodes[s, k, :nn]) and np.array_equal(ra.path_param[s, k, :m], rb.path_param[s, k, :m]), (s, k)
+                vmax = max(1.0, float(np.max(np.abs(vb.vx[s, k, :m]))))
+                assert float(np.max(np.abs(va.vx[s, k, :m] - vb.vx[s, k, :m]))) <= 1e-9 * vmax, (s, k, "vx")
+                assert float(np.max(np.abs(va.ax[s, k, :m] - vb.ax[s, k, :m]))) <= 1e-7 * max(5.0, vmax * vmax / 2.0), (s, k, "ax")
+    assert n_paths >= n
+    dflt.close()
+
+
 def test_c5_highres_follow_ticks_match_oracle():
     from oracle.oracle_lib import OracleBackend
     lat = c5_lattice()
