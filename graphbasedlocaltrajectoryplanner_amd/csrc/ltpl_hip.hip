@@ -1430,10 +1430,16 @@ struct LaneEmit {
     long long ax_delta;            // vout.ax - vout.vx in doubles: the ax row of a job lies at the same offset of the other array
     double w0;                     // out: v^2 of row 0 after the backward sweep
 };
-#define LE_PITCH (LCHB + 2)        // doubles per job row in LDS (16-byte aligned pairs)
-__device__ __forceinline__ void lane_emit_flush(const LaneEmit& E, int lane, int cnt, int r_hi, const double (&vv)[LCHB], const double (&aa)[LCHB])
+#define LE_PITCH (LCHB + 2)        // doubles per job row in LDS (16-byte aligned pairs); the buffer is sized for the longest chunk
+#ifndef LCHC
+#define LCHC 8                     // rows per chunk of the CAPPED backward sweep (follow jobs, round 6): three operands per row -- (|kappa|, el), the forward
+                                   // value, the cap -- double-buffered next to the chunk's outputs: 8 rows keep the kernel at 256 registers
+#endif
+template <int NCH>
+__device__ __forceinline__ void lane_emit_flush(const LaneEmit& E, int lane, int cnt, int r_hi, const double (&vv)[NCH], const double (&aa)[NCH])
 {
-    static_assert(LCHB % 2 == 0 && LCHB <= 16, "pairs of rows, eight pieces per job");
+    static_assert(NCH % 2 == 0 && NCH <= 16 && NCH <= LCHB, "pairs of rows, eight pieces per job, the LDS buffer of the longest chunk");
+    constexpr int PITCH = NCH + 2;
     E.s_cnt[lane] = cnt; E.s_rhi[lane] = r_hi;
     const int q = lane >> 3, piece = lane & 7;
 #pragma unroll
@@ -1441,15 +1447,15 @@ __device__ __forceinline__ void lane_emit_flush(const LaneEmit& E, int lane, int
         const int half = pass & 1;                                      // jobs [32 half, 32 half + 32); passes 0, 1: vx, 2, 3: ax
         if ((lane >> 5) == half) {
 #pragma unroll
-            for (int c = 0; c < LCHB; c += 2) store2(&E.tbuf[(lane & 31) * LE_PITCH + c], pass < 2 ? vv[c] : aa[c], pass < 2 ? vv[c + 1] : aa[c + 1]);
+            for (int c = 0; c < NCH; c += 2) store2(&E.tbuf[(lane & 31) * PITCH + c], pass < 2 ? vv[c] : aa[c], pass < 2 ? vv[c + 1] : aa[c + 1]);
         }
         wave_sync_lds();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int jl = k * 8 + q, jj = half * 32 + jl, c = 2 * piece;
             const int cn = E.s_cnt[jj];
-            if (c >= cn || c >= LCHB) continue;
-            const dbl2 v = *reinterpret_cast<const dbl2*>(&E.tbuf[jl * LE_PITCH + c]);     // rows r - c (x) and r - c - 1 (y)
+            if (c >= cn || c >= NCH) continue;
+            const dbl2 v = *reinterpret_cast<const dbl2*>(&E.tbuf[jl * PITCH + c]);     // rows r - c (x) and r - c - 1 (y)
             double* o = reinterpret_cast<double*>(E.s_o[jj]) + (pass < 2 ? 0 : E.ax_delta) + (E.s_rhi[jj] - c);
             if (c + 1 < cn) store2_u(o - 1, v.y, v.x); else o[0] = v.x;
         }
@@ -1465,10 +1471,28 @@ __device__ __forceinline__ void lane_emit_flush(const LaneEmit& E, int lane, int
 //     takes them by reference as generic pointers -> FLAT loads / stores, which always wait on vmcnt(0) and lgkmcnt(0));
 //   * a recurrence step is branch-free (selects instead of `if (active)`), so a chunk is one basic block and the waits are
 //     counted exactly: the stores of a chunk stay in flight while the next chunk's operands are awaited.
-template <int EM, bool AXM1, bool EMIT = false>
+// What the EMIT form puts out per finalised row: the profile's own v^2 (NoCap: the generic jobs), or -- FollowCap, round 6 -- the MINIMUM of it and
+// the row of the follow job's "vx_profile" (calc_vel_profile_follow.py:289 / :294: ego brake profile P2 in front of row n_decel - 1, segment
+// profile P3 up to stop_idx, zeros behind), i.e. what k_vel_final composed from four planes for every follow job: the unconstrained profile's
+// backward sweep now finalises the follow job's rows itself and k_vel_final only serves the (rare) reduced-horizon follow jobs.
+struct NoCap { static constexpr bool active = false; __device__ __forceinline__ double at(int) const { return INFINITY; } };
+struct FollowCap {
+    static constexpr bool active = true;
+    const double* P2; const double* P3; int nd, stop_idx;          // nd < 0: every row from the brake profile
+    __device__ __forceinline__ double at(int r) const
+    {
+        const bool from_b = nd < 0 || r < nd - 1;
+        const double* src = from_b ? P2 : P3;
+        const double v = src[(size_t)r * 64];
+        return (!from_b && r > stop_idx) ? 0.0 : v;
+    }
+};
+
+template <int EM, bool AXM1, bool EMIT = false, class CAP = NoCap>
 __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, int off, int n, double cax, double cay,
                                                 const DevVelParams& p, const double* axm_tab, double v_max, double v_start,
-                                                bool has_v_end, double v_end, long long* dbg = nullptr, int drow = -1, LaneEmit* em = nullptr, int lane = 0)
+                                                bool has_v_end, double v_end, long long* dbg = nullptr, int drow = -1, LaneEmit* em = nullptr, int lane = 0,
+                                                const CAP& cap = CAP())
 {
     if (v_start < 0.0) v_start = 0.0;
     if (has_v_end && v_end < 0.0) v_end = 0.0;
@@ -1493,13 +1517,14 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
         // the smallest instruction COUNT:  w' = max(A0 w + te min(max(axa - g w, 0), axm), 0)  with te = 2 e, A0 = 1 - te dm,
         // g = axa |kappa| / ay  -- algebraically the reference's min(tyre, machine) - drag step; the limit speed comes from the
         // fp32 hardware reciprocal of |kappa| (no fp64 division), full chunks run without the `valid` selects (the partial chunk at the end has them).
+        constexpr int CA = CAP::active ? LCHC : LCHA;             // rows per register chunk (the capped form carries more state through the sweeps)
         const double axg = axa * icay;
         double orig_p = wi, g_p = kabs_i * axg, e_p = e_i;      // operands of the row in front of the current step
         bool active = false, prev_acc = false;
-        ke_t kr[LCHA], kn[LCHA];
+        ke_t kr[CA], kn[CA];
         const int nst = n - 1;
 #pragma unroll
-        for (int c = 0; c < LCHA; ++c) { const int r = 1 + c < n ? 1 + c : n - 1; kr[c] = KE_AT(r); }
+        for (int c = 0; c < CA; ++c) { const int r = 1 + c < n ? 1 + c : n - 1; kr[c] = KE_AT(r); }
         auto step = [&](const ke_t& rec, int i, bool valid) {
             const double w0n = fmin(cay * ke_rcp(rec), vmax2);    // inf on straights
             const bool acc = w0n > orig_p;
@@ -1515,20 +1540,20 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
             }
         };
         int base = 0;
-        for (; base + LCHA <= nst; base += LCHA) {
+        for (; base + CA <= nst; base += CA) {
 #pragma unroll
-            for (int c = 0; c < LCHA; ++c) {                   // operands of the next chunk (clamped rows: harmless re-reads at the end)
-                const int r = base + LCHA + 1 + c < n ? base + LCHA + 1 + c : n - 1;
+            for (int c = 0; c < CA; ++c) {                   // operands of the next chunk (clamped rows: harmless re-reads at the end)
+                const int r = base + CA + 1 + c < n ? base + CA + 1 + c : n - 1;
                 kn[c] = KE_AT(r);
             }
 #pragma unroll
-            for (int c = 0; c < LCHA; ++c) step(kr[c], base + c, true);
+            for (int c = 0; c < CA; ++c) step(kr[c], base + c, true);
 #pragma unroll
-            for (int c = 0; c < LCHA; ++c) kr[c] = kn[c];
+            for (int c = 0; c < CA; ++c) kr[c] = kn[c];
         }
         if (base < nst) {
 #pragma unroll
-            for (int c = 0; c < LCHA; ++c) step(kr[c], base + c, base + c < nst);
+            for (int c = 0; c < CA; ++c) step(kr[c], base + c, base + c < nst);
         }
         if (wi > vend2) { wi = vend2; Dp[(size_t)(n - 1) * 64] = wi; }            // the end-velocity clamp of the last step
         kabs_i = (double)KE_AT(n - 1).x;                             // |kappa| of the last row (start of the backward sweep)
@@ -1580,26 +1605,32 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
     if constexpr (EMIT) {
         // wave-uniform form with direct output (see LaneEmit): every lane walks the chunks of the LONGEST profile of the wave, its own steps
         // masked by `valid`; the plane is only read (forward values), vx / ax of the finalised rows go out through lane_emit_flush
+        constexpr int CB = CAP::active ? LCHC : LCHB;             // rows per chunk
         const int nst = n >= 2 ? n - 1 : 0;
         const double axg = axa * icay;
         double orig_p = wi, g_p = kabs_i * axg;                       // affine form: operands of the row above
         double orig_i = wi;                                           // general form
         bool active = false, prev_acc = false;
-        ke_t kr[LCHB], kn[LCHB]; double wr[LCHB], wq[LCHB];
+        ke_t kr[CB], kn[CB]; double wr[CB], wq[CB];
+        [[maybe_unused]] double cr[CB], cq[CB];                   // CAP: the cap's rows of the current / the next chunk
+        [[maybe_unused]] double fprev = 0.0;                          // CAP: the value put out for the row above
+        if constexpr (CAP::active) { if (n >= 1) fprev = fmin(cap.at(n - 1), wi); }
 #pragma unroll
-        for (int c = 0; c < LCHB; ++c) {
+        for (int c = 0; c < CB; ++c) {
             const int r = n - 2 - c >= 0 ? n - 2 - c : 0;
             kr[c] = KE_AT(r); wr[c] = Dp[(size_t)r * 64];
+            if constexpr (CAP::active) cr[c] = cap.at(r);
         }
-        for (int base = 0; __ballot(base < nst) != 0ull; base += LCHB) {
+        for (int base = 0; __ballot(base < nst) != 0ull; base += CB) {
 #pragma unroll
-            for (int c = 0; c < LCHB; ++c) {
-                const int r = n - 2 - base - LCHB - c >= 0 ? n - 2 - base - LCHB - c : 0;
+            for (int c = 0; c < CB; ++c) {
+                const int r = n - 2 - base - CB - c >= 0 ? n - 2 - base - CB - c : 0;
                 kn[c] = KE_AT(r); wq[c] = Dp[(size_t)r * 64];
+                if constexpr (CAP::active) cq[c] = cap.at(r);
             }
-            double vv[LCHB], aa[LCHB];
+            double vv[CB], aa[CB];
 #pragma unroll
-            for (int c = 0; c < LCHB; ++c) {
+            for (int c = 0; c < CB; ++c) {
                 const bool valid = base + c < nst;
                 const double wold = wr[c], e_b = (double)kr[c].y, k_c = (double)kr[c].x;
                 double wn; bool acc;
@@ -1620,8 +1651,15 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
                 const double wnext = (act && wn < wold) ? wn : wold;
                 double v = 0.0, a_out = 0.0;
                 if (valid) {
-                    v = sqrt(wnext);
-                    a_out = (wi - wnext) / (2.0 * e_b);                // (w_r+1 - w_r) / (2 e_r): the row above is the state before this step
+                    if constexpr (CAP::active) {
+                        const double f = fmin(cr[c], wnext);           // the follow job's row: min("vx_profile", unconstrained profile)
+                        v = sqrt(f);
+                        a_out = (fprev - f) / (2.0 * e_b);
+                        fprev = f;
+                    } else {
+                        v = sqrt(wnext);
+                        a_out = (wi - wnext) / (2.0 * e_b);            // (w_r+1 - w_r) / (2 e_r): the row above is the state before this step
+                    }
                     if (fabs(v) <= 1e-8 && fabs(a_out) <= 1e-8) a_out = -5.0;
                     active = act && !(wn > vmax2); prev_acc = acc;
                     wi = wnext; orig_p = wold; orig_i = wold; g_p = k_c * axg; kabs_i = k_c;
@@ -1629,9 +1667,9 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
                 vv[c] = v; aa[c] = a_out;
             }
             const int left = nst - base;
-            lane_emit_flush(*em, lane, left < 0 ? 0 : (left < LCHB ? left : LCHB), n - 2 - base, vv, aa);
+            lane_emit_flush(*em, lane, left < 0 ? 0 : (left < CB ? left : CB), n - 2 - base, vv, aa);
 #pragma unroll
-            for (int c = 0; c < LCHB; ++c) { kr[c] = kn[c]; wr[c] = wq[c]; }
+            for (int c = 0; c < CB; ++c) { kr[c] = kn[c]; wr[c] = wq[c]; if constexpr (CAP::active) cr[c] = cq[c]; }
         }
         em->w0 = wi;
     } else if constexpr (EM == 1 && AXM1) {
@@ -1738,6 +1776,7 @@ __device__ __forceinline__ void lane_fb_profile(const LaneProf& L, double* D, in
 #define VF_HAS_GENERIC  4
 #define VF_BOUND_GENERIC 8
 #define VF_COMPOSE 16
+#define VF_DONE 32                 // the lane kernel wrote the slot's vx / ax / flags itself (round 6: follow jobs of batches): nothing left for k_vel_final
 
 // The CONTROLLED part of calc_vel_profile_follow.py:78-294 for one lane (= one follow job): ego brake profile -> plane P2, opponent stop
 // distance on the global race line from index idx_s_opp, characteristic indices, segment profile -> plane P3. "vx_profile" (:289 / :294)
@@ -1888,7 +1927,7 @@ __device__ __forceinline__ LaneFollowOut lane_follow_controlled(const DevLat& la
 
 // the generic forward-backward profile of a slot (OTH.py:834-903) into plane D; returns its vel_bound flag
 template <int EM, bool AXM1>
-__device__ int lane_generic_profile(const DevLat& lat, const DevPathsOut& out, const LaneProf& L, double* D, int slot, int n,
+__device__ __forceinline__ int lane_generic_profile(const DevLat& lat, const DevPathsOut& out, const LaneProf& L, double* D, int slot, int n,
                                     int reduced, double cax, double cay, const DevVelParams& p, const double* axm_tab,
                                     double vel_plan, double v_max_offset)
 {
@@ -1965,8 +2004,12 @@ __device__ __forceinline__ int lane_generic_profile_emit(const DevLat& lat, cons
     return fabs(sqrt(w0) - vel_plan) < v_max_offset ? 1 : 0;
 }
 
+// amdgpu_waves_per_eu(2): at most 256 registers. A velocity wave shares its SIMD with path waves of 128 registers each (4 x 128 = the whole
+// file): one of up to 256 registers waits for TWO of them to retire, one of 257+ for THREE. Same-box A/B of this kernel at 265 registers
+// (what the allocator takes when left alone, round 6) against 256 with four values parked in scratch: 38.4 against 40.6 M ticks/s
+// (profiles/r06j_ab_follow_emit.txt) -- the footprint of a velocity wave is what the path kernel pays for.
 template <int EM, bool AXM1>
-__global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, DevPathsOut out, DevVelParams p,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_vel_lanes(DevLat lat, DevPathsIn in, DevPathsOut out, DevVelParams p,
                                                   DevTickVelIn vin, DevVelPrep prep, VelPlanes vp, int n_slots, int n_scen,
                                                   int n_blocks0, long long* dbg, DevTickVelOut vout, int emit_generic)
 {
@@ -1994,6 +2037,7 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
         if (j >= cntF) return;
         const int2 js = out.job_slot[fbase + j];
         const int slot = js.x;
+        if (emit_generic && !out.reduced[slot]) return;               // (batches: the follow block above runs this profile itself and puts the job's rows out)
         LaneProf L; L.KE = vp.KE + kep_base(fbase + j, vp.plane_rows);
         lane_fb_profile<EM, AXM1>(L, vp.P1 + tile_base(j, vp.cap_pts), 0, js.y, cax, cay, p, axm_tab, p.v_max,
                                   vin.vel_plan[slot / LTPL_MAX_ACTIONS], false, 0.0, dbg, drow);
@@ -2023,6 +2067,71 @@ __global__ __launch_bounds__(64) void k_vel_lanes(DevLat lat, DevPathsIn in, Dev
         if (have) {
             vout.vel_bound[slot] = bound; vout.too_close[slot] = 0;
             vp.flags[j] = VF_BOUND_FOLLOW | (bound ? VF_BOUND_GENERIC : 0);
+        }
+        vl_stamp(dbg, drow, 6);
+        return;
+    }
+    if (b >= nbG && emit_generic) {
+        // ---- follow jobs of batches (round 6): the controlled part, then the UNCONSTRAINED profile in the same lane, whose backward sweep puts out
+        //      min("vx_profile", unconstrained profile) -- the follow job's rows (FollowCap) -- with vx / ax through the same LDS transposition as the
+        //      generic jobs. Before, the two halves ran on two waves and k_vel_final read four planes per follow job to compose, intersect,
+        //      differentiate and transpose: as much wave-time as the lane kernel itself (profiles/r06f_vel_pmc.txt). Same operations on the same
+        //      values in the same order: results unchanged bit for bit. Reduced-horizon follow jobs (rare) keep the old route inside this block.
+        const int j = (b - nbG) * 64 + lane;
+        const bool have = j < cntF;
+        const int tile = fbase + j;                                   // (the planes hold n_scen_pad follow tiles: a lane without a job has one too)
+        const int2 js = have ? out.job_slot[tile] : make_int2(0, 0);
+        const int slot = js.x, n = have ? js.y : 0;
+        {
+            const int nmax = wave_max_i32(n);
+            if (lane == 0) atomicMax(&out.job_cnt[2], nmax);
+        }
+        const int s = slot / LTPL_MAX_ACTIONS;
+        LaneProf L; L.KE = vp.KE + kep_base(tile, vp.plane_rows);
+        double* P2 = vp.P2 + tile_base(j, vp.cap_pts);
+        double* P3 = vp.P3 + tile_base(j, vp.cap_pts);
+        const double vel_plan = have ? vin.vel_plan[s] : 0.0;
+        const int reduced = have ? out.reduced[slot] : 0;
+        FollowCap cap; cap.P2 = P2; cap.P3 = P3; cap.nd = -1; cap.stop_idx = 0;
+        bool direct = false;
+        int o_bound = 0, o_close = 0;
+        if (have) {
+            const LaneFollowOut fo = lane_follow_controlled<EM, AXM1>(lat, L, P2, P3, n, cax, cay, p, axm_tab, vel_plan, vin.vel_est[s], prep.v_obj[slot],
+                                                                      prep.obj_dist[slot], vin.safety_d, prep.idx_s_opp[slot], dbg, drow);
+            o_bound = fo.vel_bound; o_close = fo.too_close;
+            if (!reduced) { direct = true; cap.nd = fo.two_seg ? fo.n_decel : -1; cap.stop_idx = fo.stop_idx; }
+            else {
+                // reduced horizon: "vx_profile" materialised in P0, the generic profile on top of it in P3 (OTH.py:834-923), k_vel_final chooses by
+                // row 5; the unconstrained profile of such a job comes from its own wave below
+                double* P0 = vp.P0 + tile_base(tile, vp.cap_pts);
+                int flags = VF_BOUND_FOLLOW | VF_HAS_GENERIC;
+                if (fo.too_close) flags |= VF_TOO_CLOSE;
+                if (!fo.vel_bound) flags &= ~VF_BOUND_FOLLOW;
+                const bool two_seg = fo.two_seg != 0;
+                for (int i = 0; i < n; ++i) {
+                    const bool from_b = !two_seg || i < fo.n_decel - 1;
+                    P0[(size_t)i * 64] = from_b ? P2[(size_t)i * 64] : ((i > fo.stop_idx) ? 0.0 : P3[(size_t)i * 64]);
+                }
+                if (lane_generic_profile<EM, AXM1>(lat, out, L, P3, slot, n, reduced, cax, cay, p, axm_tab, vel_plan, vin.v_max_offset))
+                    flags |= VF_BOUND_GENERIC;
+                vp.flags[tile] = flags;
+            }
+        }
+        double* o_vx = vout.vx + (size_t)slot * out.cap_pts;
+        le_o[lane] = direct ? (unsigned long long)o_vx : 0ull;
+        LaneEmit E; E.tbuf = le_tbuf; E.s_cnt = le_cnt; E.s_rhi = le_rhi; E.s_o = le_o; E.ax_delta = (long long)(vout.ax - vout.vx); E.w0 = 0.0;
+        wave_sync_lds();
+        // (a lane that puts nothing out walks the sweep with zero rows; its one store -- the start value of row 0 -- goes to its brake plane, not to the
+        //  unconstrained plane another wave may be writing for a reduced-horizon job)
+        double* D = direct ? vp.P1 + tile_base(j, vp.cap_pts) : P2;
+        lane_fb_profile<EM, AXM1, true, FollowCap>(L, D, 0, direct && n >= 2 ? n : 0, cax, cay, p, axm_tab, p.v_max, vel_plan, false, 0.0, nullptr, -1, &E, lane, cap);
+        if (direct) {
+            // the top row: the backward sweep starts below it; its ax differentiates towards nothing (last row of the path)
+            const int i = n - 1;
+            const double w = fmin(cap.at(i), D[(size_t)i * 64]);
+            o_vx[i] = sqrt(w); o_vx[i + E.ax_delta] = 0.0;
+            vout.vel_bound[slot] = o_bound; vout.too_close[slot] = o_close;
+            vp.flags[tile] = VF_DONE;
         }
         vl_stamp(dbg, drow, 6);
         return;
@@ -2116,7 +2225,12 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
     const int tile = fjob ? out.n_slots_pad + j : j;
     const int nmax_all = out.job_cnt[2];                                // longest profile of the launch (lane kernel)
     const int2 js = have ? out.job_slot[tile] : make_int2(0, 0);
-    const int slot = js.x, n = js.y;
+    const int slot = js.x;
+    // (round 6: a follow job of a batch is finished by the lane kernel -- VF_DONE -- unless its horizon is reduced; such a job counts zero rows here,
+    //  and a tile without anything left leaves at once)
+    const int tflags = have ? vp.flags[tile] : VF_DONE;
+    const int n = (tflags & VF_DONE) ? 0 : js.y;
+    if (__ballot(n > 0) == 0ull) return;
     s_slot[lane] = slot; s_n[lane] = n;
     // blockIdx.y strides over the row chunks: a few long-lived blocks per tile instead of one block per (tile, chunk), most of
     // which used to find nothing to do
@@ -2125,7 +2239,7 @@ __global__ __launch_bounds__(64) void k_vel_final(DevPathsOut out, DevTickVelIn 
     if (__ballot(act) == 0ull) continue;                                // uniform
     double vv[FCH], aa[FCH];
     if (act) {
-        const int flags = vp.flags[tile];
+        const int flags = tflags;
         const bool follow = fjob;
         const double* P0 = vp.P0 + tile_base(tile, vp.cap_pts);
         const double* P1 = vp.P1 + tile_base(fjob ? j : 0, vp.cap_pts);
