@@ -2011,7 +2011,7 @@ __device__ __forceinline__ int lane_generic_profile_emit(const DevLat& lat, cons
 template <int EM, bool AXM1>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_vel_lanes(DevLat lat, DevPathsIn in, DevPathsOut out, DevVelParams p,
                                                   DevTickVelIn vin, DevVelPrep prep, VelPlanes vp, int n_slots, int n_scen,
-                                                  int n_blocks0, long long* dbg, DevTickVelOut vout, int emit_generic)
+                                                  int n_blocks0, long long* dbg, DevTickVelOut vout, int emit)
 {
     LTPL_VEL_SETPRIO();
     __shared__ __align__(16) double le_tbuf[32 * LE_PITCH];        // direct output of the generic jobs (LaneEmit)
@@ -2037,13 +2037,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
         if (j >= cntF) return;
         const int2 js = out.job_slot[fbase + j];
         const int slot = js.x;
-        if (emit_generic && !out.reduced[slot]) return;               // (batches: the follow block above runs this profile itself and puts the job's rows out)
+        if ((emit & 2) && !out.reduced[slot]) return;                 // (large batches: the follow block below runs this profile itself and puts the job's rows out)
         LaneProf L; L.KE = vp.KE + kep_base(fbase + j, vp.plane_rows);
         lane_fb_profile<EM, AXM1>(L, vp.P1 + tile_base(j, vp.cap_pts), 0, js.y, cax, cay, p, axm_tab, p.v_max,
                                   vin.vel_plan[slot / LTPL_MAX_ACTIONS], false, 0.0, dbg, drow);
         vl_stamp(dbg, drow, 6);
         return;
     }
+    const bool emit_generic = (emit & 1) != 0;                       // emit bit 0: generic jobs write their outputs here; bit 1: follow jobs do
     if (b < nbG && emit_generic) {
         // ---- generic jobs (every non-follow primitive, OTH.py:834-941): profile AND outputs, all 64 lanes stay for the output transposition.
         //      Batches only (emit_generic = the launch has >= LTPL_EMIT_MIN_SCEN scenarios): the transposition is ~160 instructions per chunk
@@ -2071,12 +2072,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
         vl_stamp(dbg, drow, 6);
         return;
     }
-    if (b >= nbG && emit_generic) {
-        // ---- follow jobs of batches (round 6): the controlled part, then the UNCONSTRAINED profile in the same lane, whose backward sweep puts out
-        //      min("vx_profile", unconstrained profile) -- the follow job's rows (FollowCap) -- with vx / ax through the same LDS transposition as the
-        //      generic jobs. Before, the two halves ran on two waves and k_vel_final read four planes per follow job to compose, intersect,
+    if (b >= nbG && (emit & 2)) {
+        // ---- follow jobs of LARGE batches (round 6): the controlled part, then the UNCONSTRAINED profile in the same lane, whose backward sweep puts
+        //      out min("vx_profile", unconstrained profile) -- the follow job's rows (FollowCap) -- with vx / ax through the same LDS transposition as
+        //      the generic jobs. Otherwise the two halves run on two waves and k_vel_final reads four planes per follow job to compose, intersect,
         //      differentiate and transpose: as much wave-time as the lane kernel itself (profiles/r06f_vel_pmc.txt). Same operations on the same
         //      values in the same order: results unchanged bit for bit. Reduced-horizon follow jobs (rare) keep the old route inside this block.
+        //      Large batches only (ltpl_handle::follow_emit_min_scen): the lane now runs five sweeps one after the other instead of three next to
+        //      two -- neutral on the throughput of 32 768 scenarios per step, 135 against 117 us for a step of 1 024 (profiles/r06z_bench.json).
         const int j = (b - nbG) * 64 + lane;
         const bool have = j < cntF;
         const int tile = fbase + j;                                   // (the planes hold n_scen_pad follow tiles: a lane without a job has one too)
@@ -2543,6 +2546,10 @@ struct ltpl_handle {
     // footprint lets fewer be resident) -> pipeline; LTPL_PIPELINE_MIN_SCEN=<n> overrides (the GPU test-suite pins 64: its batches of
     // 64 .. 256 scenarios are there to exercise the pipeline).
     int pipeline_min_scen = PIPELINE_MIN_SCEN;
+    // pipeline launches with at least this many scenarios finish their follow jobs inside the lane kernel (k_vel_lanes, emit bit 1); smaller ones
+    // keep the two halves of a follow job on two waves + k_vel_final: a shorter chain, which is what a small batch's step is made of.
+    // LTPL_FOLLOW_EMIT_MIN_SCEN overrides (the GPU test-suite sets 256 so that its batches exercise the form the headline runs on).
+    int follow_emit_min_scen = 8192;
     void* d_par = nullptr; size_t d_par_cap = 0;         // parent-table slabs of the long-horizon mode
     ltpl_caps caps{};
     std::vector<void*> dev_allocs;
@@ -3189,6 +3196,7 @@ try {
         h->pipeline_min_scen = (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * per_cu + 1;
         if (h->pipeline_min_scen < PIPELINE_MIN_SCEN) h->pipeline_min_scen = PIPELINE_MIN_SCEN;
         if (const char* e = getenv("LTPL_PIPELINE_MIN_SCEN")) { if (atoi(e) > 0) h->pipeline_min_scen = atoi(e); }
+        if (const char* e = getenv("LTPL_FOLLOW_EMIT_MIN_SCEN")) { if (atoi(e) > 0) h->follow_emit_min_scen = atoi(e); }
     }
     if (d->raceline_x && d->raceline_y && d->node_psi) {
         std::string why;
@@ -3861,11 +3869,12 @@ static int tick_launch_vel(ltpl_handle* h, const TickLayout& t, hipStream_t st, 
     const int n_slots = t.n_scen * LTPL_MAX_ACTIONS;
     const int nb0 = (n_slots + 63) / 64, nb1 = (t.n_scen + 63) / 64;
     const int emit_generic = t.n_scen >= LTPL_EMIT_MIN_SCEN ? 1 : 0;
+    const int emit = emit_generic | ((emit_generic && t.n_scen >= h->follow_emit_min_scen) ? 2 : 0);
 #ifdef LTPL_EXPERIMENT
     if (!(h->exp_skip & 2))
 #endif
     hipLaunchKernelGGL(lanes_kernel_of(t.variant), dim3(nb0 + 2 * nb1), dim3(64), 0, st, h->lat, t.di, t.dout,
-                       t.p, t.dvin, t.dprep, t.vp, n_slots, t.n_scen, nb0, h->lp4.dbg, t.dvout, emit_generic);
+                       t.p, t.dvin, t.dprep, t.vp, n_slots, t.n_scen, nb0, h->lp4.dbg, t.dvout, emit);
     HIP_TRY(h, hipGetLastError());
 #ifdef LTPL_EXPERIMENT
     if (!(h->exp_skip & 4))

@@ -12,6 +12,10 @@ if ROOT not in sys.path:
 # LTPL_PIPELINE_MIN_SCEN: measured faster below ~2 workgroups per compute unit); the suite pins the rounds-1..5 threshold so that its
 # coverage stays what it was, and tests/test_gpu_configs.py::test_small_batches_fused_by_default_match_the_pipeline covers the default.
 os.environ.setdefault("LTPL_PIPELINE_MIN_SCEN", "64")
+# ... and the form of the velocity stage the headline's 32 768-scenario batches run (follow jobs finished by the lane kernel: default from 8 192
+# scenarios on) is engaged for the suite's batches too; test_gpu_vel.py::test_follow_jobs_finished_by_the_lane_kernel_or_by_the_final_kernel
+# compares it with the other form bit for bit.
+os.environ.setdefault("LTPL_FOLLOW_EMIT_MIN_SCEN", "256")
 
 
 def pytest_configure(config):

@@ -184,3 +184,32 @@ def test_compact_trajectories_equal_the_slab_outputs(monteblanco, hip_backend):
                 s_ref = np.concatenate(([0.0], np.cumsum(res.path_param[s, a, :m - 1, 4])))
                 assert_close_rel(t[:, 0], s_ref, what="s column")
                 assert comp.vel_bound[s * 3 + a] == vres.vel_bound[s, a] and comp.reduced[s * 3 + a] == res.reduced[s, a]
+
+
+def test_follow_jobs_finished_by_the_lane_kernel_or_by_the_final_kernel(monteblanco, hip_backend, monkeypatch):
+    """Round 6: in large batches the lane kernel finishes a follow job itself (controlled part and unconstrained profile in one lane, capped
+    backward sweep); in smaller ones the two halves run on two waves and k_vel_final composes. Same operations on the same values: every
+    output of a 600-scenario batch with an opponent ahead in every scenario is IDENTICAL bit for bit between a handle that takes the first
+    route (the suite's setting) and one that takes the second."""
+    from graphbasedlocaltrajectoryplanner_amd.scenario_gen import c2_scenarios
+    n = 600
+    scen, vels = c2_scenarios(monteblanco, n, seed=77, lead_gap=(20.0, 80.0))
+    rng = np.random.default_rng(5)
+    params = _capi.VelParamSet(len_veh=monteblanco.veh_length)
+    vplan = rng.uniform(5.0, 60.0, n)
+    pos = np.array([monteblanco.node_pos[monteblanco.layer_off[s['start_node'][0]] + s['start_node'][1]] for s in scen])
+    batch = _capi.PathsBatch(scen, w_last_edges=[0.0, 0.5, 0.8])
+    vel = _capi.TickVelBatch(params, n, vplan, vplan, pos, np.concatenate(vels))
+    monkeypatch.setenv("LTPL_FOLLOW_EMIT_MIN_SCEN", "1000000")
+    other = _capi.HipBackend(monteblanco)
+    (ra, va), (rb, vb) = hip_backend.tick_batch(batch, vel), other.tick_batch(batch, vel)
+    assert np.array_equal(ra.n_actions, rb.n_actions) and np.array_equal(va.vel_bound, vb.vel_bound) and np.array_equal(va.too_close, vb.too_close)
+    n_follow = 0
+    for s in range(n):
+        for k in range(int(ra.n_actions[s])):
+            if ra.valid[s, k]:
+                m = int(ra.n_pts[s, k])
+                n_follow += int(ra.action_id[s, k] == _capi.ACT_FOLLOW)
+                assert np.array_equal(va.vx[s, k, :m], vb.vx[s, k, :m]) and np.array_equal(va.ax[s, k, :m], vb.ax[s, k, :m]), (s, k)
+    assert n_follow >= n // 2, n_follow
+    other.close()
