@@ -1,10 +1,10 @@
 #!/bin/bash
 # fp32 vs fp64 operand records of the lane kernels (|kappa|, element length): ticks/s and worst relative error per quantity of both builds on
-# ONE box.   tools/vel_precision_ab.sh <fp64 variant library>     (built with -DLTPL_VEL_F64_OPERANDS)
+# ONE box.   tools/vel_precision_ab.sh <fp32 variant library>     (round 6: fp64 records are the default; the variant is built with -DLTPL_VEL_F32_OPERANDS)
 ARGS="--steps 100 --warmup 10 --latency-ticks 0 --dropin-ticks 0 --no-extra --cpu-sample 1024"
 for round in 1 2; do
   for V in base "$1"; do
-    if [ "$V" = base ]; then unset LTPL_HIP_LIB; T="fp32 operands (default)"; else export LTPL_HIP_LIB=$PWD/$V; T="fp64 operands ($V)"; fi
+    if [ "$V" = base ]; then unset LTPL_HIP_LIB; T="fp64 operands (default)"; else export LTPL_HIP_LIB=$PWD/$V; T="fp32 operands ($V)"; fi
     python bench.py $ARGS 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline()); r = d['roofline']; p = d['parity_detail']
