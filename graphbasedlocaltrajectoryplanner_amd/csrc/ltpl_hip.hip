@@ -346,9 +346,9 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total)
     return x - v;
 }
 
-#ifdef LTPL_EXPERIMENT
-// Self-check of the cross-lane helpers above (experiment build only; tests/test_gpu_wave_ops.py through ltpl_exp_wave_ops_check):
-// every helper against a plain loop over the wave's values in LDS. err[0] = number of lanes that disagree.
+// Self-check of the cross-lane helpers above: every helper against a plain loop over the wave's values in LDS. err[0] = number of lanes that
+// disagree. Part of the create-time self-test of the product library since round 6 (wave_ops_selftest: the helpers are DPP / permlane-swap code
+// that only exists for gfx950 and assumes 64 active lanes); tests/test_gpu_wave_ops.py drives it with its own data through the experiment build.
 __global__ __launch_bounds__(64) void k_exp_wave_ops(const double* vals, const int* ivals, int rounds, int* err)
 {
     __shared__ double sd[64], sd2[64];
@@ -387,7 +387,6 @@ __global__ __launch_bounds__(64) void k_exp_wave_ops(const double* vals, const i
     }
     if (bad) atomicAdd(err, 1);
 }
-#endif
 
 // LDS hand-over between the lanes of ONE wave: DS operations of a wave execute in order, so only the compiler has to be
 // kept from reordering (wavefront-scope fences emit no s_waitcnt vmcnt and do not serialise outstanding global loads)
@@ -4486,8 +4485,39 @@ try {
 // IDENTICAL from both, otherwise the handle is refused. Guards against a toolchain that miscompiles one of them
 //  for lattices no parity test has seen. LTPL_NO_SELFTEST=1 skips it.
 // ---------------------------------------------------------------------------------------------------------------------
+// the cross-lane helpers of the kernels (reductions, scans, lexicographic minima: DPP row operations + v_permlane16/32_swap) against plain loops,
+// on 16 waves of values with many ties -- one launch of k_exp_wave_ops at create time
+static int wave_ops_selftest(ltpl_handle* h)
+{
+    const int rounds = 16;
+    std::vector<double> vals((size_t)rounds * 128); std::vector<int> ivals((size_t)rounds * 64);
+    unsigned long long x = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() { x = x * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(x >> 33); };
+    for (size_t i = 0; i < vals.size(); ++i) vals[i] = (double)(next() % 23u) * 0.25 - 2.0;          // few distinct values: ties in every reduction
+    for (size_t i = 0; i < ivals.size(); ++i) ivals[i] = (int)(next() % 200u) - 60;
+    double* dv = nullptr; int* di = nullptr; int* de = nullptr;
+    struct Guard { void** p[3]; ~Guard() { for (void** q : p) if (*q) (void)hipFree(*q); } } guard{{reinterpret_cast<void**>(&dv), reinterpret_cast<void**>(&di), reinterpret_cast<void**>(&de)}};
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&dv), sizeof(double) * vals.size()));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&di), sizeof(int) * ivals.size()));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&de), sizeof(int)));
+    HIP_TRY(h, hipMemcpy(dv, vals.data(), sizeof(double) * vals.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(di, ivals.data(), sizeof(int) * ivals.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemset(de, 0, sizeof(int)));
+    hipLaunchKernelGGL(k_exp_wave_ops, dim3(1), dim3(64), 0, h->stream, dv, di, rounds, de);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    int bad = 0;
+    HIP_TRY(h, hipMemcpy(&bad, de, sizeof(int), hipMemcpyDeviceToHost));
+    if (bad) { h->err = "self-test failed: the wave reductions / scans of the kernels disagree with plain loops on this device"; return LTPL_ERR_UNSUPPORTED; }
+    return LTPL_OK;
+}
+
 static int self_test(ltpl_handle* h, const ltpl_lattice_desc* d)
 {
+    {
+        const int rc = wave_ops_selftest(h);
+        if (rc) return rc;
+    }
     const int n = 64, L = d->num_layers, A = LTPL_MAX_ACTIONS;
     std::vector<int> sl(n), sn(n), flags(n, LTPL_FLAG_ACTION_SETS), la(n, LTPL_ACT_NONE), cc(n, -1), veh_off(n + 1), pos_off(n + 1),
         zone_off(n + 1, 0), zone(1, 0), n_last(n, 0), ll((size_t)n * LTPL_MAX_LAST_NODES, -1), ln((size_t)n * LTPL_MAX_LAST_NODES, -1);

@@ -67,7 +67,7 @@ def test_path_kernels_have_no_register_spills():
             assert r["vgpr_count"] <= 128, name
     assert all(r["vgpr_spill_count"] == 0 for k, r in res.items() if k not in paths and "k_vel_lanes" not in k)
     # k_vel_lanes is held to 256 registers (two waves per SIMD: what it displaces next to a resident path kernel) and parks a few values for it
-    assert all(r["vgpr_count"] <= 256 and r["vgpr_spill_count"] <= (40 if "k_vel_lanesILi0E" in k else 8) for k, r in res.items() if "k_vel_lanes" in k)
+    assert all(r["vgpr_count"] <= 256 and r["vgpr_spill_count"] <= (48 if "k_vel_lanesILi0E" in k else 8) for k, r in res.items() if "k_vel_lanes" in k)
     g.check_no_register_spills(g.HIP_LIB)
     loops = g.layer_loop_ops(g.HIP_LIB, [k for k in paths if "k_pathsILi1E6PlanFx" in k])
     assert loops and all(m["loops"] >= 1 and m["scratch"] == 0 for m in loops.values()), loops

@@ -300,6 +300,27 @@ def test_object_ingestion_matches_reference_and_oracle(monteblanco, hip_backend,
 
 
 @pytest.mark.gpu
+def test_bench_two_ranks_strong_scaling_on_one_gpu():
+    """BASELINE config C4 as a bench mode: `bench.py --gpus 2 --scaling strong --batch-total 1024` -- a FIXED batch of 1 024 scenarios block-
+    partitioned over the ranks (here: two ranks sharing device 0, gloo for the barrier / max): the line says "strong", counts 1 024 scenarios per
+    step whatever the rank count, every rank ran 512, and rank 0's shard is checked against the oracle."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, LTPL_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3", "--scaling", "strong",
+                        "--batch-total", "1024", "--exact-steps", "--cpu-sample", "64", "--no-extra", "--latency-ticks", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["parity_checked"] is True
+    assert out["config"]["batch_total"] == 1024 and out["config"]["batch_per_gpu"] == 512
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 1024) < 1e-3 * 1024
+    assert len(out["per_rank_ms_per_step"]) == 2
+
+
 def test_bench_two_ranks_on_one_gpu(tmp_path):
     """SURVEY section 8e readiness without an 8-GPU node: bench.py --gpus 2 spawns two ranks (LTPL_BENCH_SHARE_GPU=1: both on device 0, gloo
     for the barrier / max / gather) -- the N > 1 code path of the driver's scaling run end to end on real kernels: one line from rank 0,
