@@ -22,9 +22,16 @@ The JSON line also carries
   parity_checked  the GPU results of those sample scenarios compared with the oracle's results of the cpu_baseline leg
   latency_us      single-scenario ticks: `p50/p99` one synchronous ltpl_tick_batch call including packing, PCIe and unpacking
                   into the reference's Python structures; `dropin_*` one full closed-loop tick of the planner entry points
-                  (ltpl_planner_calc_paths + ltpl_planner_calc_vel_profile + copy-out) replaying the recorded C2 loop
+                  (ltpl_planner_calc_paths + ltpl_planner_calc_vel_profile + copy-out) replaying the recorded C2 loop;
+                  `persistent_tick` the same single ticks served by the RESIDENT kernel (ltpl_create_ex(LTPL_CREATE_PERSISTENT_TICK):
+                  no launch, no copy call; own handle, outputs compared bit for bit with the launched kernel's)
   extra           three_slot_ticks_per_s (every scenario has an opponent 20-80 m ahead: three primitives live),
-                  pcie_inclusive (host buffers in and out per call)
+                  pcie_inclusive (host buffers in and out per call), closed_loop* (host planner / device-resident fleet),
+                  c4 (BASELINE config C4 as stated: 1024 scenarios in one call and the 128-scenario shard of one of 8 GPUs, resident and
+                  PCIe-inclusive), c3 (the "HBM roofline run" with its own roofline / binding / parity), c5 (high-resolution latency run)
+
+  --scaling strong --batch-total T   a FIXED batch of T scenarios block-partitioned over the ranks (C4 as a bench mode) instead of the
+                  default weak scaling (--batch scenarios per GPU); the line then says "scaling": "strong" and `value` counts T per step.
 """
 import argparse
 import json
