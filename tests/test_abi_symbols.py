@@ -71,3 +71,19 @@ def test_path_kernels_have_no_register_spills():
     g.check_no_register_spills(g.HIP_LIB)
     loops = g.layer_loop_ops(g.HIP_LIB, [k for k in paths if "k_pathsILi1E6PlanFx" in k])
     assert loops and all(m["loops"] >= 1 and m["scratch"] == 0 for m in loops.values()), loops
+
+
+def test_create_ex_and_the_persistent_entry_points_check_their_arguments_without_a_device():
+    """ABI v9 (round 6): argument errors of ltpl_create_ex / ltpl_tick_persistent_* come back as status codes before any HIP call (no GPU here)."""
+    import __graft_entry__ as ge
+    lib = ctypes.CDLL(ge.build_hip())
+    lib.ltpl_create_ex.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]
+    lib.ltpl_last_error.restype = ctypes.c_char_p
+    lib.ltpl_last_error.argtypes = [ctypes.c_void_p]
+    h = ctypes.c_void_p()
+    desc = (ctypes.c_char * 2048)()                                           # (never read: the flag check comes first)
+    assert lib.ltpl_create_ex(ctypes.byref(desc), 0, 0x80, ctypes.byref(h)) == 1 and b"unknown flag" in lib.ltpl_last_error(None)
+    assert lib.ltpl_create_ex(None, 0, 1, ctypes.byref(h)) == 1                # LTPL_ERR_INVALID_ARG: null lattice
+    lib.ltpl_tick_persistent_stop.argtypes = [ctypes.c_void_p]
+    lib.ltpl_tick_persistent_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    assert lib.ltpl_tick_persistent_stop(None) == 1 and lib.ltpl_tick_persistent_stats(None, None) == 1
