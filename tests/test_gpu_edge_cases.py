@@ -168,7 +168,8 @@ def test_obstacles_off_the_closest_layer_grid(monteblanco, hip_backend, oracle_b
 
 
 @pytest.mark.parametrize("env", [{"LTPL_POLL": "1"}, {"LTPL_ZC_OUT": "0"}, {"LTPL_ZC_IN": "1", "LTPL_POLL": "1"}, {"LTPL_TICK_GRAPH": "1"},
-                                 {"LTPL_TICK_GRAPH": "1", "LTPL_ZC_OUT": "0"}])
+                                 {"LTPL_TICK_GRAPH": "1", "LTPL_ZC_OUT": "0"},
+                                 {"LTPL_PERSISTENT_TICK": "1", "LTPL_PERSIST_IDLE_MS": "50"}])     # (round 6: the resident tick kernel, by environment)
 def test_latency_transport_variants_give_identical_results(monteblanco, hip_backend, monkeypatch, env):
     """The transport of the single-tick path (zero-copy outputs in page-locked memory, optional polled completion word, optional
     zero-copy inputs) must not change a bit of the results: a second handle created under the switches against the default one,
@@ -201,3 +202,4 @@ def test_latency_transport_variants_give_identical_results(monteblanco, hip_back
                 n = int(ra.n_pts[0, k])
                 assert np.array_equal(va.vx[0, k, :n], vb.vx[0, k, :n]) and np.array_equal(va.ax[0, k, :n], vb.ax[0, k, :n]), (i, k)
         assert np.array_equal(va.vel_bound, vb.vel_bound) and np.array_equal(va.too_close, vb.too_close)
+    other.close()
