@@ -740,6 +740,7 @@ static int fleet_launch_paths(ltpl_fleet* f, const FleetTickIn& t, bool pre, boo
     di.veh_off = t.ob.veh_off; di.pos_off = t.ob.pos_off; di.veh_radius = t.ob.radius; di.pos_x = t.ob.px; di.pos_y = t.ob.py;
     di.zone_off = t.zone_off; di.zone_gid = t.zone_gid;
     di.n_last = f->pin.n_last; di.last_layer = f->pin.last_layer; di.last_node = f->pin.last_node;
+    di.order = nullptr;                 // (planner p is planned by block p: the start layers live in device memory, the fleet does not reorder)
     const int nw = (N >= h->nw1_min_scen && h->batch_nw == 1) ? 1 : NUM_WAVES;
     const int rc = launch_paths(h, nw, N, st, di, f->dout);
     if (rc) { f->err = h->err; return rc; }

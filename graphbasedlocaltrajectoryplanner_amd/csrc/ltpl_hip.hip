@@ -100,6 +100,15 @@ struct DevPathsIn {
     const int* veh_off; const int* pos_off; const double* veh_radius; const double* pos_x; const double* pos_y;
     const int* zone_off; const int* zone_gid;
     const int* n_last; const int* last_layer; const int* last_node;
+    // BLOCK -> SCENARIO ORDER (round 6; one-wave batches, null otherwise: block b plans scenario b): order[b] = the scenario of block b, the
+    // scenarios sorted by start layer. Blocks are dispatched in index order, so at any time the whole chip works on one region of the track:
+    // the waves of a moment share their lattice lines, and the velocity jobs -- numbered in the order their paths complete -- come in runs of
+    // similar length, so that the 64 profiles of a lane-kernel wave end together (lane kernel alone 0.265 against 0.282 ms; +2 % ticks/s,
+    // profiles/r06r_ab_order.txt). Tried first and NOT kept: the sorted sequence dealt out in eighths, one per XCD (block b runs on XCD b % 8,
+    // each XCD with its own 4 MiB L2 and an eighth of the 6 MB lattice to itself) -- 37.8 against 40.1 M ticks/s: the eighths of a track are
+    // not equal work (planning ranges of 11 to 29 layers), and the lattice was not missing in L2 to begin with (path kernel alone: unchanged by
+    // the order that won). Outputs are indexed by scenario: results do not depend on the order.
+    const int* order;
 };
 
 // completion signal of the latency path: the LAST block of a launch writes a sequence number into page-locked host memory after
@@ -2549,6 +2558,8 @@ struct ltpl_handle {
     // keep the two halves of a follow job on two waves + k_vel_final: a shorter chain, which is what a small batch's step is made of.
     // LTPL_FOLLOW_EMIT_MIN_SCEN overrides (the GPU test-suite sets 256 so that its batches exercise the form the headline runs on).
     int follow_emit_min_scen = 8192;
+    int scen_order = 1;              // batches of >= LTPL_SCEN_ORDER_MIN_SCEN scenarios are planned in the order of their start layers (DevPathsIn::order);
+                                     // LTPL_NO_SCEN_ORDER=1: in the caller's order (identical results: tests, same-box A/B)
     void* d_par = nullptr; size_t d_par_cap = 0;         // parent-table slabs of the long-horizon mode
     ltpl_caps caps{};
     std::vector<void*> dev_allocs;
@@ -3196,6 +3207,7 @@ try {
         if (h->pipeline_min_scen < PIPELINE_MIN_SCEN) h->pipeline_min_scen = PIPELINE_MIN_SCEN;
         if (const char* e = getenv("LTPL_PIPELINE_MIN_SCEN")) { if (atoi(e) > 0) h->pipeline_min_scen = atoi(e); }
         if (const char* e = getenv("LTPL_FOLLOW_EMIT_MIN_SCEN")) { if (atoi(e) > 0) h->follow_emit_min_scen = atoi(e); }
+        if (getenv("LTPL_NO_SCEN_ORDER")) h->scen_order = 0;
     }
     if (d->raceline_x && d->raceline_y && d->node_psi) {
         std::string why;
@@ -3255,7 +3267,7 @@ static int ensure(ltpl_handle* h, void** hp, size_t* hcap, void** dp, size_t* dc
 
 struct InLayout {
     size_t w_last, start_layer, start_node, flags, last_action, const_closest, psi_s, veh_off, pos_off, veh_radius,
-        pos_x, pos_y, zone_off, zone_gid, n_last, last_layer, last_node, total;
+        pos_x, pos_y, zone_off, zone_gid, n_last, last_layer, last_node, order, total;
     int n_veh, n_pos, n_zone;
 };
 
@@ -3295,11 +3307,15 @@ static int validate_and_layout(ltpl_handle* h, const ltpl_paths_in* in, InLayout
     lo->n_last = a.add(sizeof(int) * (size_t)n);
     lo->last_layer = a.add(sizeof(int) * (size_t)n * LTPL_MAX_LAST_NODES);
     lo->last_node = a.add(sizeof(int) * (size_t)n * LTPL_MAX_LAST_NODES);
+    lo->order = a.add(sizeof(int) * (size_t)n);
     lo->total = a.size;
     return LTPL_OK;
 }
 
-static void pack_in(const ltpl_paths_in* in, const InLayout& lo, unsigned char* hb, const unsigned char* db, DevPathsIn* di)
+#ifndef LTPL_SCEN_ORDER_MIN_SCEN
+#define LTPL_SCEN_ORDER_MIN_SCEN 2048       // batches from this size on plan their scenarios in the order of their start layers (DevPathsIn::order)
+#endif
+static void pack_in(const ltpl_paths_in* in, const InLayout& lo, unsigned char* hb, const unsigned char* db, DevPathsIn* di, bool scen_order = true)
 {
     const int n = in->n_scen;
 #define CP(field, src, count, T) do { if ((count) > 0) memcpy(hb + lo.field, src, sizeof(T) * (size_t)(count)); } while (0)
@@ -3327,6 +3343,18 @@ static void pack_in(const ltpl_paths_in* in, const InLayout& lo, unsigned char* 
     di->pos_y = reinterpret_cast<const double*>(db + lo.pos_y);
     di->zone_off = reinterpret_cast<const int*>(db + lo.zone_off);
     di->zone_gid = reinterpret_cast<const int*>(db + lo.zone_gid);
+    di->order = nullptr;
+    if (n >= LTPL_SCEN_ORDER_MIN_SCEN && scen_order) {
+        // counting sort of the scenarios by start layer (stable: equal layers keep the caller's order)
+        int* ord = reinterpret_cast<int*>(hb + lo.order);
+        int lmax = 0;
+        for (int i = 0; i < n; ++i) { const int l = in->start_layer[i]; if (l > lmax) lmax = l; }
+        std::vector<int> cnt((size_t)(lmax > 0 ? lmax : 0) + 2, 0);
+        for (int i = 0; i < n; ++i) { const int l = in->start_layer[i]; ++cnt[(size_t)(l > 0 ? l : 0) + 1]; }
+        for (size_t l = 1; l < cnt.size(); ++l) cnt[l] += cnt[l - 1];
+        for (int i = 0; i < n; ++i) { const int l = in->start_layer[i]; ord[(size_t)cnt[(size_t)(l > 0 ? l : 0)]++] = i; }
+        di->order = reinterpret_cast<const int*>(db + lo.order);
+    }
     di->n_last = reinterpret_cast<const int*>(db + lo.n_last);
     di->last_layer = reinterpret_cast<const int*>(db + lo.last_layer);
     di->last_node = reinterpret_cast<const int*>(db + lo.last_node);
@@ -3471,7 +3499,7 @@ static int plan_paths_impl(ltpl_handle* h, const ltpl_paths_in* in, ltpl_paths_o
     if ((rc = ensure(h, &h->h_out, &h->h_out_cap, &h->d_out, &h->d_out_cap, lo.total))) return rc;
     DevPathsIn di; DevPathsOut dout;
     const bool zci = h->zc_in && in->n_scen <= 8;
-    pack_in(in, li, static_cast<unsigned char*>(h->h_in), static_cast<const unsigned char*>(zci ? h->h_in : h->d_in), &di);
+    pack_in(in, li, static_cast<unsigned char*>(h->h_in), static_cast<const unsigned char*>(zci ? h->h_in : h->d_in), &di, h->scen_order != 0);
     // small calls (latency path): the output slab is the page-locked host buffer itself (device-accessible under unified
     // addressing): the kernel's stores cross PCIe as posted writes, no D2H copy is enqueued
     const bool zc = h->zc_out && in->n_scen <= 8;
@@ -3820,7 +3848,7 @@ static void tick_bind_outputs(TickLayout* t, unsigned char* dob, double* planes)
 static int tick_pack(ltpl_handle* h, const ltpl_paths_in* in, const ltpl_tick_vel_in* vin, TickLayout* t,
                      unsigned char* hb, unsigned char* db, unsigned char* dob)
 {
-    pack_in(in, t->in, hb, db, &t->di);
+    pack_in(in, t->in, hb, db, &t->di, h->scen_order != 0);
     const int n = in->n_scen;
     memcpy(hb + t->axm, vin->params->ax_max_machines, sizeof(double) * 2 * (size_t)vin->params->n_ax_max_machines);
     memcpy(hb + t->vel_plan, vin->vel_plan, sizeof(double) * (size_t)n);

@@ -1290,6 +1290,7 @@ __device__ __forceinline__ WavePath team_paths_body(const DevLat& lat_, const De
     }
     Scen sc;
     sc.s = blockIdx.x;
+    if constexpr (NW == 1) { const int* ord = in.order; if (ord) sc.s = ord[blockIdx.x]; }     // large batches: scenarios in the order of their start layers (DevPathsIn::order)
     sc.sl = in.start_layer[sc.s]; sc.sn = in.start_node[sc.s]; sc.flags = in.flags[sc.s];
     sc.veh0 = in.veh_off[sc.s]; sc.n_veh = in.veh_off[sc.s + 1] - sc.veh0;
     sc.n_fac = min(in.n_last[sc.s] - 1, in.n_w_last);

@@ -21,6 +21,7 @@
  *   LTPL_FORCE_LONG_HORIZON=1   parent tables in global memory (the mode lattices with very long planning ranges get automatically)
  *   LTPL_BATCH_NW=4             four-wave teams also for batches; LTPL_NW1_MIN_SCEN=<n>: smallest batch that uses one-wave teams (64)
  *   LTPL_FORCE_FUSED=1          fused k_tick also for batches; LTPL_NO_OVERLAP=1: resident batches on one stream (no pipelining)
+ *   LTPL_NO_SCEN_ORDER=1        batches of >= 2048 scenarios planned in the caller's order instead of sorted by start layer (identical results)
  *   LTPL_FOLLOW_EMIT_MIN_SCEN=<n>  smallest pipeline batch whose follow jobs are finished by the lane kernel instead of k_vel_final (8192)
  *   LTPL_PIPELINE_MIN_SCEN=<n>  smallest tick batch that runs the one-wave pipeline instead of the fused tick kernel (default: more than two
  *                               fused workgroups per compute unit -- 513 on the MI355X; rounds 1-5: 64)

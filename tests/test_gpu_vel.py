@@ -213,3 +213,28 @@ def test_follow_jobs_finished_by_the_lane_kernel_or_by_the_final_kernel(montebla
                 assert np.array_equal(va.vx[s, k, :m], vb.vx[s, k, :m]) and np.array_equal(va.ax[s, k, :m], vb.ax[s, k, :m]), (s, k)
     assert n_follow >= n // 2, n_follow
     other.close()
+
+
+def test_large_batches_are_planned_in_the_order_of_their_start_layers_with_identical_results(monteblanco, hip_backend, monkeypatch):
+    """Round 6: batches of >= 2 048 scenarios are planned sorted by start layer (block b -> scenario order[b]); outputs are indexed by scenario,
+    so every output must be IDENTICAL bit for bit to a handle that plans them in the caller's order (LTPL_NO_SCEN_ORDER=1) -- 2 500 scenarios
+    with shuffled start layers, a zero-vehicle scenario and repeated start layers among them."""
+    n = 2500
+    batch, vel = make_tick_inputs(monteblanco, n, seed=41)
+    monkeypatch.setenv("LTPL_NO_SCEN_ORDER", "1")
+    other = _capi.HipBackend(monteblanco)
+    (ra, va), (rb, vb) = hip_backend.tick_batch(batch, vel), other.tick_batch(batch, vel)
+    for name in ("n_actions", "end_layer", "closest_obj_index", "closest_obj_node"):
+        assert np.array_equal(getattr(ra, name), getattr(rb, name)), name
+    assert np.array_equal(va.vel_bound, vb.vel_bound) and np.array_equal(va.too_close, vb.too_close)
+    for s in range(n):
+        na = int(ra.n_actions[s])
+        for name in ("action_id", "valid", "reduced", "goal_layer", "n_nodes", "n_pts", "n_ties"):
+            assert np.array_equal(getattr(ra, name)[s, :na], getattr(rb, name)[s, :na]), (s, name)
+        for k in range(na):
+            if ra.valid[s, k]:
+                m, nn = int(ra.n_pts[s, k]), int(ra.n_nodes[s, k])
+                assert np.array_equal(ra.nodes[s, k, :nn], rb.nodes[s, k, :nn]) and np.array_equal(ra.coeff[s, k, :nn - 1], rb.coeff[s, k, :nn - 1]), (s, k)
+                assert np.array_equal(ra.path_param[s, k, :m], rb.path_param[s, k, :m]), (s, k)
+                assert np.array_equal(va.vx[s, k, :m], vb.vx[s, k, :m]) and np.array_equal(va.ax[s, k, :m], vb.ax[s, k, :m]), (s, k)
+    other.close()
